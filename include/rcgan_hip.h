@@ -1,0 +1,263 @@
+/*
+ * rcgan_hip.h -- flat C ABI of librcgan_hip.so: the MI355X (gfx950) kernels behind the RCGAN
+ * generator/discriminator training step.
+ *
+ * The reference (tkkiran/Robust-Conditional-GAN) has no FFI / custom-op seam: every FLOP is a stock
+ * TensorFlow-1.5 kernel reached through its L1 Python op wrappers.  This ABI sits directly under an
+ * L1-compatible Python shim (robust-conditional-gan_amd/ops_mnist.py, ops_cifar.py); each entry point
+ * names the reference call site whose TF kernel it replaces (paths relative to the reference root).
+ *
+ * Conventions:
+ *   - every entry returns int: 0 = ok, <0 = RCGAN_E*; rcgan_last_error(ctx) gives the message.
+ *     No exceptions or aborts cross the ABI.
+ *   - all buffers are caller-owned DEVICE pointers; the library never frees or retains them past the
+ *     call.  Scratch is a caller-provided workspace (see the *_workspace_bytes helpers).
+ *   - one hipStream_t per ctx; every call is asynchronous on that stream; a ctx is not thread-safe;
+ *     distinct ctxs are independent (one ctx per rank/process).
+ *   - activations are NHWC; conv filters HWIO ([kh][kw][Cin][Cout]); transposed-conv filters
+ *     [kh][kw][Cout][Cin] (mnist/ops.py:74).  Parameters, their gradients and optimiser state are
+ *     always fp32; activations / activation gradients are fp32 or bf16 (desc.dtype).
+ */
+#ifndef RCGAN_HIP_H
+#define RCGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCGAN_OK 0
+#define RCGAN_EINVALID_ARG (-1)
+#define RCGAN_EUNSUPPORTED_SHAPE (-2)
+#define RCGAN_EWORKSPACE_TOO_SMALL (-3)
+#define RCGAN_EHIP (-4)
+#define RCGAN_ERCCL (-5)
+
+#define RCGAN_F32 0
+#define RCGAN_BF16 1
+
+/* activation codes shared by several entry points */
+#define RCGAN_ACT_NONE 0
+#define RCGAN_ACT_RELU 1
+#define RCGAN_ACT_LRELU 2   /* tf.maximum(x, 0.2x): mnist/ops.py:94-95 */
+#define RCGAN_ACT_TANH 3
+#define RCGAN_ACT_SIGMOID 4
+
+typedef struct rcgan_ctx rcgan_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* stream: a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream) or NULL
+ * for the null stream.  Replaces: tf.Session(config) at cifar10/gan_resnet.py:494-496, mnist/main.py:100. */
+int rcgan_create(rcgan_ctx** out, int device, void* stream);
+int rcgan_destroy(rcgan_ctx* ctx);
+const char* rcgan_last_error(rcgan_ctx* ctx);
+const char* rcgan_version(void);
+int rcgan_set_stream(rcgan_ctx* ctx, void* stream);
+int rcgan_stream_sync(rcgan_ctx* ctx);
+/* HIP-event timing on the ctx stream (bench.py roofline leg): slot in [0,64). */
+int rcgan_event_record(rcgan_ctx* ctx, int slot);
+int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* ms);
+/* hipGraph capture of everything launched on the ctx stream between begin/end; replay with launch.
+ * Replaces the per-step sess.run dispatch (gan_resnet.py:931,938; mnist/model.py:347-372). */
+int rcgan_graph_begin(rcgan_ctx* ctx);
+int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id);
+int rcgan_graph_launch(rcgan_ctx* ctx, int graph_id);
+int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
+
+/* ---- convolution ---------------------------------------------------------------------------- */
+#define RCGAN_CONV_IN_UPSAMPLE2X 1  /* conv reads nearest-2x-upsampled input (gan_resnet.py:263-264 folded in) */
+#define RCGAN_CONV_IN_RELU 2        /* relu applied to the input on load (gan_resnet.py:305,317,347) */
+#define RCGAN_CONV_ACCUMULATE 4     /* out += result (residual add, gan_resnet.py:328,353) */
+#define RCGAN_CONV_FORCE_DIRECT 8   /* testing: bypass the MFMA path */
+
+typedef struct rcgan_conv_desc {
+  int n, h, w, cin;   /* logical conv input: after the 2x upsample when IN_UPSAMPLE2X is set */
+  int cout, kh, kw, stride;
+  int dtype;          /* RCGAN_F32 / RCGAN_BF16: activations and activation gradients */
+  int flags;
+} rcgan_conv_desc;
+
+/* Filter preparation: master fp32 HWIO filter (optionally divided by *sigma, the spectral norm) ->
+ * the layouts the conv kernels consume.  `prepared` must hold rcgan_conv_prepared_bytes(desc).
+ * Replaces the W_bar = W / sigma reshape (mnist/sn.py:55-62) + the filter argument of tf.nn.conv2d. */
+size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d);
+int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w_hwio,
+                       const float* sigma /* device scalar or NULL */, void* prepared);
+
+size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
+/* y = conv2d_SAME(x, w) (+bias).  Replaces tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
+ * cifar10/common/ops/conv2d.py:181-216.  x: [n, h(/2), w(/2), cin]; y: [n, oh, ow, cout]. */
+int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
+                     const float* bias /* or NULL */, void* y);
+/* dx = d(conv)/dx.  With IN_RELU, dx is masked by x>0 (x = the pre-activation input).  With
+ * IN_UPSAMPLE2X dx is the gradient w.r.t. the low-resolution input.  ACCUMULATE: dx += ...
+ * Replaces tf.nn.conv2d_backprop_input (autodiff of the above).  ws: rcgan_conv_workspace_bytes. */
+int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared,
+                          const void* x /* needed with IN_RELU */, void* dx, void* ws, size_t ws_bytes);
+/* dw (fp32 HWIO) = d(conv)/dw (dw = or += by accumulate), dbias = sum dy (if non-NULL).
+ * Replaces tf.nn.conv2d_backprop_filter + BiasAddGrad. */
+int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
+                            float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
+
+/* Transposed convolution, filter [kh][kw][Cout][Cin] used as-is (no preparation, fp32).
+ * d describes the *forward conv* it is the gradient of: n,h,w,cin = deconv OUTPUT (n,H,W,Cout_deconv),
+ * d.cout = deconv input channels.  Replaces tf.nn.conv2d_transpose at mnist/ops.py:78-79. */
+int rcgan_deconv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const float* w,
+                       const float* bias, void* y);
+int rcgan_deconv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx);
+int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
+                              float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
+
+/* ---- dense ----------------------------------------------------------------------------------- */
+/* y[m,n] = x[m,k] @ w[k,n] (+bias).  w fp32 row-major, optionally divided by *sigma.
+ * Replaces tf.matmul + bias: mnist/ops.py:114-116, cifar10/common/ops/linear.py:161-180. */
+int rcgan_linear_fwd(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const float* w,
+                     const float* sigma, const float* bias, void* y);
+int rcgan_linear_bwd_data(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* dy, const float* w,
+                          const float* sigma, void* dx, int accumulate);
+/* dw is the gradient w.r.t. the matrix actually multiplied (W or W_bar). */
+int rcgan_linear_bwd_weight(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const void* dy,
+                            float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
+size_t rcgan_linear_workspace_bytes(int m, int k, int n);
+
+/* ---- normalisation ----------------------------------------------------------------------------- */
+/* Batch statistics over rows of x[rows][c]: mean, biased var -> rstd = rsqrt(var+eps).
+ * moving_mean / moving_var (may be NULL) get the TF fused-batch-norm update
+ * m -= (m - batch)*(1-decay) with the UNBIASED variance (mnist/ops.py:38-44).
+ * ws: rcgan_bn_workspace_bytes(rows, c). */
+size_t rcgan_bn_workspace_bytes(int rows, int c);
+int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, float eps,
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, float decay,
+                   void* ws, size_t ws_bytes);
+/* y = act( gamma[l]*(x-mean)*rstd + beta[l] ), l = labels[row / rows_per_sample] (labels NULL -> row 0
+ * of a [1][c] table = plain batch norm).  Replaces tf.nn.batch_normalization + embedding_lookup
+ * (cifar10/common/ops/normalization.py:47-57) and tf.contrib.layers.batch_norm (mnist/ops.py:38-44)
+ * fused with the following relu / lrelu (gan_resnet.py:305,317,366; mnist/model.py:661-719). */
+int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int dtype, const void* x,
+                       const int32_t* labels, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, int act, void* y);
+/* Backward of stats+apply (gradient flows through the batch statistics).  dgamma/dbeta: [n_labels][c]
+ * (= or += by accumulate).  y is the forward output (gives the activation mask). */
+int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype,
+                 const void* x, const void* y, const void* dy, const int32_t* labels,
+                 const float* gamma, const float* mean, const float* rstd, int act,
+                 void* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
+/* Inference-mode batch norm with moving statistics (gen_sampler, mnist/model.py:745-754). */
+int rcgan_bn_infer(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, const float* gamma,
+                   const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                   int act, void* y);
+
+/* ---- spectral normalisation (mnist/sn.py:31-75 == cifar10/common/ops/sn.py:31-75) --------------- */
+typedef struct rcgan_sn_item {
+  const float* w;   /* [k][c] (any filter reshaped to [-1, c]) */
+  float* u;         /* [c] persistent; overwritten with u' iff update != 0 */
+  float* sigma;     /* [1] out */
+  float* save;      /* scratch kept for the backward: rcgan_sn_save_floats(k,c) floats */
+  int k, c, update;
+} rcgan_sn_item;
+size_t rcgan_sn_save_floats(int k, int c);
+/* One power iteration for every item in one launch (items: HOST array, copied into the launch). */
+int rcgan_sn_power_iter(rcgan_ctx* ctx, const rcgan_sn_item* items, int n_items);
+typedef struct rcgan_sn_bwd_item {
+  const float* w; const float* dwbar; float* dw; const float* save; int k, c, accumulate;
+} rcgan_sn_bwd_item;
+/* dW from dW_bar, differentiating THROUGH the power iteration (no stop_gradient in the reference). */
+int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items);
+
+/* ---- elementwise / resampling -------------------------------------------------------------------- */
+int rcgan_act_fwd(rcgan_ctx* ctx, size_t count, int dtype, int act, const void* x, void* y);
+/* dx = dy * act'(.)  (mask/derivative taken from y for tanh/sigmoid, from x for relu/lrelu). */
+int rcgan_act_bwd(rcgan_ctx* ctx, size_t count, int dtype, int act, const void* x_or_y, const void* dy,
+                  void* dx, int accumulate);
+int rcgan_add(rcgan_ctx* ctx, size_t count, int dtype, const void* a, const void* b, void* y);
+int rcgan_axpby(rcgan_ctx* ctx, size_t count, int dtype, float alpha, const void* a, float beta, void* y);
+int rcgan_cast(rcgan_ctx* ctx, size_t count, int src_dtype, const void* src, int dst_dtype, void* dst);
+/* 2x2 mean pool (gan_resnet.py:239-240) and its adjoint; nearest 2x upsample (:263-264) and its adjoint. */
+int rcgan_meanpool2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y);
+int rcgan_meanpool2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate);
+int rcgan_upsample2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y);
+int rcgan_upsample2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate);
+/* y[n,h,w,:c1] = x ; y[n,h,w,c1:] = onehot rows yb[n,:c2]  (conv_cond_concat, mnist/ops.py:46-51);
+ * the adjoint copies the first c1 channels back. */
+int rcgan_concat_channels_fwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* x,
+                              const float* yb, void* y);
+int rcgan_concat_channels_bwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* dy, void* dx);
+/* uint8-as-int32 CHW [n][3][32][32] + dequantisation noise (fp32, CHW order) -> NHWC in [-1,1):
+ * 2*(x/256-.5)+noise (gan_resnet.py:548-551). */
+int rcgan_preprocess_cifar(rcgan_ctx* ctx, int n, const int32_t* images_chw, const float* noise_chw,
+                           int dtype, void* y_nhwc);
+
+/* Counter-based device RNG (Philox4x32-10).  kind 0: uniform [lo,hi); kind 1: normal(mean=lo, std=hi).
+ * state: DEVICE uint64[1] stream offset, advanced on the stream after the draw (so a replayed graph
+ * draws fresh numbers), or NULL for offset 0.  Replaces tf.random_normal (gan_resnet.py:359) and the
+ * tf.random_uniform dequantisation noise (gan_resnet.py:549); the TF Philox stream itself is not
+ * reproducible, parity tests feed explicit noise instead. */
+int rcgan_rng_fill(rcgan_ctx* ctx, size_t count, int dtype, int kind, float lo, float hi, uint64_t seed,
+                   void* state, void* y);
+
+/* ---- discriminator head + losses -------------------------------------------------------------------- */
+/* feat[n][c] = mean_hw(relu(x)) (gan_resnet.py:405-407; act = RCGAN_ACT_NONE gives the plain spatial
+ * mean of mnist/model.py:679) and its adjoint. */
+int rcgan_act_meanhw_fwd(rcgan_ctx* ctx, int n, int hw, int c, int dtype, int act, const void* x, float* feat);
+int rcgan_act_meanhw_bwd(rcgan_ctx* ctx, int n, int hw, int c, int dtype, int act, const void* x,
+                         const float* dfeat, void* dx);
+/* rows gathered from a [v][d] table / scatter-added back (tf.nn.embedding_lookup, embedding.py:51). */
+int rcgan_gather_rows(rcgan_ctx* ctx, int n, int d, const float* table, const int32_t* idx, float* out);
+int rcgan_scatter_add_rows(rcgan_ctx* ctx, int n, int d, int v, const float* src, const int32_t* idx,
+                           float* table_grad, int accumulate);
+/* logit[n] = psi[n] + <feat[n,:], emb[n,:]>  (gan_resnet.py:588,763; mnist/model.py:685) + adjoint. */
+int rcgan_proj_logit_fwd(rcgan_ctx* ctx, int n, int d, const float* feat, const float* psi, const float* emb,
+                         float* logit);
+int rcgan_proj_logit_bwd(rcgan_ctx* ctx, int n, int d, const float* feat, const float* emb, const float* dlogit,
+                         float* dfeat, float* dpsi, float* demb, int acc_feat);
+/* logits[n][v] = psi[n] + <feat[n,:], E[v,:]> for every label v (rcgan-u: gan_resnet.py:654-660, 737-740;
+ * the reference re-runs the projection for all 10 labels -- features are computed once here) + adjoint. */
+int rcgan_proj_logit_all_fwd(rcgan_ctx* ctx, int n, int d, int v, const float* feat, const float* psi,
+                             const float* E, float* logits);
+int rcgan_proj_logit_all_bwd(rcgan_ctx* ctx, int n, int d, int v, const float* feat, const float* E,
+                             const float* dlogits, float* dfeat, float* dpsi, float* dE, int acc_feat);
+/* Loss terms.  Each adds weight*L to *loss_acc (device scalar) and WRITES dlogit = weight * dL/dlogit.
+ *   kind HINGE_REAL: mean relu(1-x)   HINGE_FAKE: mean relu(1+x)   NEG_MEAN: -mean x  (gan_resnet.py:604-605,773)
+ *   CE_ONES / CE_ZEROS: mean sigmoid_ce(x, 1|0) (mnist/model.py:139-145)
+ * x: [rows][cols]; optional row weights wts[rows][cols] turn the inner mean into
+ * mean_rows( sum_cols( term * wts ) )  (unbiased :647, rcgan-u :684,759; mnist/model.py:201-204);
+ * dwts (may be NULL) receives weight * dL/dwts (needed for the learned confusion matrix). */
+#define RCGAN_LOSS_HINGE_REAL 0
+#define RCGAN_LOSS_HINGE_FAKE 1
+#define RCGAN_LOSS_NEG_MEAN 2
+#define RCGAN_LOSS_CE_ONES 3
+#define RCGAN_LOSS_CE_ZEROS 4
+int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float* x, const float* wts,
+                       float weight, float* loss_acc, float* dlogit, float* dwts);
+/* weight * mean over all rows*cols of sigmoid_cross_entropy_with_logits(x, onehot(labels))
+ * (perm regulariser: gan_resnet.py:693-694,782-783; mnist/model.py:218-221). */
+int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels,
+                             float weight, float* loss_acc, float* dx);
+/* C = softmax(logits) row-wise and its adjoint (gan_resnet.py:522, mnist/model.py:106). */
+int rcgan_softmax_rows_fwd(rcgan_ctx* ctx, int rows, int cols, const float* logits, float* p);
+int rcgan_softmax_rows_bwd(rcgan_ctx* ctx, int rows, int cols, const float* p, const float* dp, float* dlogits,
+                           int accumulate);
+
+/* ---- optimiser ---------------------------------------------------------------------------------------- */
+/* tf.train.AdamOptimizer on a flat fp32 range (model.py:250-262, gan_resnet.py:802-817):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; w -= lr_t*m/(sqrt(v)+eps); optional clip to [-clip,clip]
+ * (variable constraint of mnist/ops.py:102-111; clip<=0 disables).  hyper: DEVICE float[2] = {lr, t}
+ * so a captured graph can be replayed with new values.  grad_scale multiplies g first (1/world_size). */
+int rcgan_adam_tf(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v,
+                  const float* hyper, float beta1, float beta2, float eps, float clip, float grad_scale);
+int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float value);
+
+/* ---- self test ---------------------------------------------------------------------------------------- */
+/* Runs the MFMA / ds_read_b64_tr_b16 fragment-layout probes on the device (call once, outside graph
+ * capture).  Fails iff the MFMA operand layout this library assumes does not hold; a failed
+ * transpose-read probe only switches the filter-gradient kernel to its slower scalar LDS reads. */
+int rcgan_selftest(rcgan_ctx* ctx);
+#define RCGAN_QUERY_TR_READ 0   /* 1 = ds_read_b64_tr_b16 path in use, 0 = scalar fallback, -1 = not probed */
+int rcgan_query(rcgan_ctx* ctx, int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCGAN_HIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of librcgan_hip.so (the C ABI declared in include/rcgan_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module
+raises.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librcgan_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+CONV_IN_UPSAMPLE2X, CONV_IN_RELU, CONV_ACCUMULATE, CONV_FORCE_DIRECT = 1, 2, 4, 8
+LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_CE_ONES, LOSS_CE_ZEROS = 0, 1, 2, 3, 4
+QUERY_TR_READ = 0
+
+ERRORS = {-1: "RCGAN_EINVALID_ARG", -2: "RCGAN_EUNSUPPORTED_SHAPE", -3: "RCGAN_EWORKSPACE_TOO_SMALL",
+          -4: "RCGAN_EHIP", -5: "RCGAN_ERCCL"}
+
+
+class RcganError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "RCGAN_E?"), code, msg))
+        self.code = code
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int),
+                ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
+                ("dtype", C.c_int), ("flags", C.c_int)]
+
+
+class SnItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("sigma", C.c_void_p), ("save", C.c_void_p),
+                ("k", C.c_int), ("c", C.c_int), ("update", C.c_int)]
+
+
+class SnBwdItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dwbar", C.c_void_p), ("dw", C.c_void_p), ("save", C.c_void_p),
+                ("k", C.c_int), ("c", C.c_int), ("accumulate", C.c_int)]
+
+
+P, I, F, SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/rcgan_hip.h declares
+SIGNATURES = {
+    "rcgan_create": (I, [C.POINTER(P), I, P]),
+    "rcgan_destroy": (I, [P]),
+    "rcgan_last_error": (C.c_char_p, [P]),
+    "rcgan_version": (C.c_char_p, []),
+    "rcgan_set_stream": (I, [P, P]),
+    "rcgan_stream_sync": (I, [P]),
+    "rcgan_event_record": (I, [P, I]),
+    "rcgan_event_elapsed_ms": (I, [P, I, I, C.POINTER(F)]),
+    "rcgan_graph_begin": (I, [P]),
+    "rcgan_graph_end": (I, [P, C.POINTER(I)]),
+    "rcgan_graph_launch": (I, [P, I]),
+    "rcgan_graph_destroy": (I, [P, I]),
+    "rcgan_conv_prepared_bytes": (SZ, [DP]),
+    "rcgan_conv_prepare": (I, [P, DP, P, P, P]),
+    "rcgan_conv_workspace_bytes": (SZ, [DP]),
+    "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
+    "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),
+    "rcgan_conv2d_bwd_weight": (I, [P, DP, P, P, P, P, I, P, SZ]),
+    "rcgan_deconv2d_fwd": (I, [P, DP, P, P, P, P]),
+    "rcgan_deconv2d_bwd_data": (I, [P, DP, P, P, P]),
+    "rcgan_deconv2d_bwd_weight": (I, [P, DP, P, P, P, P, I, P, SZ]),
+    "rcgan_linear_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
+    "rcgan_linear_bwd_data": (I, [P, I, I, I, I, P, P, P, P, I]),
+    "rcgan_linear_bwd_weight": (I, [P, I, I, I, I, P, P, P, P, I, P, SZ]),
+    "rcgan_linear_workspace_bytes": (SZ, [I, I, I]),
+    "rcgan_bn_workspace_bytes": (SZ, [I, I]),
+    "rcgan_bn_stats": (I, [P, I, I, I, P, F, P, P, P, P, F, P, SZ]),
+    "rcgan_bn_apply_fwd": (I, [P, I, I, I, I, P, P, P, P, P, P, I, P]),
+    "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, I, P, SZ]),
+    "rcgan_bn_infer": (I, [P, I, I, I, P, P, P, P, P, F, I, P]),
+    "rcgan_sn_save_floats": (SZ, [I, I]),
+    "rcgan_sn_power_iter": (I, [P, C.POINTER(SnItem), I]),
+    "rcgan_sn_bwd": (I, [P, C.POINTER(SnBwdItem), I]),
+    "rcgan_act_fwd": (I, [P, SZ, I, I, P, P]),
+    "rcgan_act_bwd": (I, [P, SZ, I, I, P, P, P, I]),
+    "rcgan_add": (I, [P, SZ, I, P, P, P]),
+    "rcgan_axpby": (I, [P, SZ, I, F, P, F, P]),
+    "rcgan_cast": (I, [P, SZ, I, P, I, P]),
+    "rcgan_meanpool2_fwd": (I, [P, I, I, I, I, I, P, P]),
+    "rcgan_meanpool2_bwd": (I, [P, I, I, I, I, I, P, P, I]),
+    "rcgan_upsample2_fwd": (I, [P, I, I, I, I, I, P, P]),
+    "rcgan_upsample2_bwd": (I, [P, I, I, I, I, I, P, P, I]),
+    "rcgan_concat_channels_fwd": (I, [P, I, I, I, I, I, P, P, P]),
+    "rcgan_concat_channels_bwd": (I, [P, I, I, I, I, I, P, P]),
+    "rcgan_preprocess_cifar": (I, [P, I, P, P, I, P]),
+    "rcgan_rng_fill": (I, [P, SZ, I, I, F, F, C.c_uint64, P, P]),
+    "rcgan_act_meanhw_fwd": (I, [P, I, I, I, I, I, P, P]),
+    "rcgan_act_meanhw_bwd": (I, [P, I, I, I, I, I, P, P, P]),
+    "rcgan_gather_rows": (I, [P, I, I, P, P, P]),
+    "rcgan_scatter_add_rows": (I, [P, I, I, I, P, P, P, I]),
+    "rcgan_proj_logit_fwd": (I, [P, I, I, P, P, P, P]),
+    "rcgan_proj_logit_bwd": (I, [P, I, I, P, P, P, P, P, P, I]),
+    "rcgan_proj_logit_all_fwd": (I, [P, I, I, I, P, P, P, P]),
+    "rcgan_proj_logit_all_bwd": (I, [P, I, I, I, P, P, P, P, P, P, I]),
+    "rcgan_loss_fwd_bwd": (I, [P, I, I, I, P, P, F, P, P, P]),
+    "rcgan_bce_onehot_fwd_bwd": (I, [P, I, I, P, P, F, P, P]),
+    "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),
+    "rcgan_softmax_rows_bwd": (I, [P, I, I, P, P, P, I]),
+    "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),
+    "rcgan_fill_f32": (I, [P, SZ, P, F]),
+    "rcgan_selftest": (I, [P]),
+    "rcgan_query": (I, [P, I]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Loading needs no GPU; compute calls do."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "librcgan_hip.so is missing (%s): build it with robust-conditional-gan_amd/csrc/build.sh "
+            "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,482 @@
+"""CIFAR-10 SNGAN-projection RCGAN / RCGAN-U on the gfx950 kernels: model, losses, step functions.
+
+Host-side mirror of /root/reference cifar10/gan_resnet.py: the block/model functions keep the
+reference's names and structure (:199-421, :458-483), the loss assembly follows :557-695 / :715-786,
+the optimisers :700-705 / :802-817 and the step order :919-947.  What differs is *how* it runs:
+one process per GPU, eager hand-written HIP kernels recorded on a tape, the whole D-step / G-step
+captured into a hipGraph, gradients all-reduced over RCCL on flat slabs.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops as O
+from .ops_cifar import NO_OPS, Conv2D, Linear, cond_batchnorm, embed_y
+from .runtime import Context, ParamGroup
+from .variables import Graph, variable_scope
+
+Z_DIM = 128
+DIM_G = 128
+DIM_D = 128
+VOCAB_SIZE = 10
+EMBEDDING_DIM = 300
+IMG_SIZE = 32
+IMG_DIM = 3
+OUTPUT_DIM = 3072
+N_CRITIC = 5
+GEN_BS_MULTIPLE = 2
+ALGORITHMS = ("rcgan", "rcgan-u", "biased", "unbiased")
+
+
+# ------------------------------------------------------------------------------------------------------
+# variable creation (reference initialisers, reference creation order -- SURVEY.md Appendix A)
+# ------------------------------------------------------------------------------------------------------
+class _Init:
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.G, self.D, self.Cm, self.U = [], [], [], {}
+
+    def uniform(self, stdev, shape):          # conv2d.py:83-88, linear.py:54-61
+        return self.rs.uniform(low=-stdev * np.sqrt(3), high=stdev * np.sqrt(3), size=shape).astype("float32")
+
+    def trunc_normal(self, shape):            # tf.truncated_normal_initializer() for u (sn.py:36)
+        x = self.rs.normal(0.0, 1.0, size=shape)
+        while True:
+            bad = np.abs(x) > 2.0
+            if not bad.any():
+                return x.astype("float32")
+            x[bad] = self.rs.normal(0.0, 1.0, size=int(bad.sum()))
+
+    def conv(self, dst, name, cin, cout, k, he, sn):
+        fan_in, fan_out = cin * k * k, cout * k * k
+        sd = np.sqrt((4. if he else 2.) / (fan_in + fan_out))      # conv2d.py:103-106
+        dst.append((name + "/Filters", (k, k, cin, cout), self.uniform(sd, (k, k, cin, cout))))
+        if sn:
+            self.U[name + "/filters/spectral_norm/u"] = self.trunc_normal((1, cout))
+        dst.append((name + "/Biases", (cout,), np.zeros(cout, "float32")))
+
+    def linear(self, dst, name, cin, cout, sn):
+        dst.append((name + "/W", (cin, cout), self.uniform(np.sqrt(2. / (cin + cout)), (cin, cout))))   # linear.py:76-80
+        if sn:
+            self.U[name + "/spectral_norm/u"] = self.trunc_normal((1, cout))
+        dst.append((name + "/b", (cout,), np.zeros(cout, "float32")))
+
+    def condbn(self, dst, name, c):           # normalization.py:49-52
+        dst.append((name + "/CondBatchNorm/offset", (VOCAB_SIZE, c), np.zeros((VOCAB_SIZE, c), "float32")))
+        dst.append((name + "/CondBatchNorm/scale", (VOCAB_SIZE, c), np.ones((VOCAB_SIZE, c), "float32")))
+
+
+def confusion_logits_initial(confuse_init, confuse_init_diag, rs):
+    """gan_resnet.py:499-520."""
+    if not confuse_init:
+        lim = np.sqrt(6.0 / (2 * VOCAB_SIZE))      # TF default get_variable initialiser: glorot_uniform
+        return rs.uniform(-lim, lim, size=(VOCAB_SIZE, VOCAB_SIZE)).astype("float32")
+    if confuse_init_diag > 0.99 and VOCAB_SIZE == 10.:
+        aa = 7.0
+    else:
+        aa = np.log(VOCAB_SIZE * confuse_init_diag / (1. - confuse_init_diag))
+    aa = min(7.0, aa)
+    m = (0 - aa / VOCAB_SIZE) * np.ones([VOCAB_SIZE, VOCAB_SIZE], dtype=np.float32)
+    np.fill_diagonal(m, (aa - (aa / VOCAB_SIZE)))
+    return m
+
+
+def create_variables(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="linear",
+                     confuse_init=False, confuse_init_diag=0.2):
+    """-> (G specs, D specs, C specs, U dict); specs are (name, shape, initial value)."""
+    it = _Init(seed)
+    if algorithm == "rcgan-u":
+        it.Cm.append(("confusion_logits", (VOCAB_SIZE, VOCAB_SIZE),
+                      confusion_logits_initial(confuse_init, confuse_init_diag, it.rs)))
+    it.linear(it.G, "Generator/G.Input", Z_DIM, 4 * 4 * DIM_G * 8, False)
+    for blk, cin in ((1, DIM_G * 8), (2, DIM_G * 2), (3, DIM_G * 2)):
+        nm = "Generator/G.Block.%d" % blk
+        it.conv(it.G, nm + ".Shortcut", cin, DIM_G * 2, 1, False, False)
+        it.condbn(it.G, nm + ".N1", cin)
+        it.conv(it.G, nm + ".Conv1", cin, DIM_G * 2, 3, True, False)
+        it.condbn(it.G, nm + ".N2", DIM_G * 2)
+        it.conv(it.G, nm + ".Conv2", DIM_G * 2, DIM_G * 2, 3, True, False)
+    it.condbn(it.G, "Generator/G.OutputNorm", DIM_G * 2)
+    it.conv(it.G, "Generator/G.Output", DIM_G * 2, IMG_DIM, 3, False, False)
+    d = "Discriminator/"
+    it.conv(it.D, d + "D.Block.1.Shortcut", IMG_DIM, DIM_D, 1, False, True)
+    it.conv(it.D, d + "D.Block.1.Conv1", IMG_DIM, DIM_D, 3, True, True)
+    it.conv(it.D, d + "D.Block.1.Conv2", DIM_D, DIM_D, 3, True, True)
+    it.conv(it.D, d + "D.Block.2.Shortcut", DIM_D, DIM_D, 1, False, True)
+    it.conv(it.D, d + "D.Block.2.Conv1", DIM_D, DIM_D, 3, True, True)
+    it.conv(it.D, d + "D.Block.2.Conv2", DIM_D, DIM_D, 3, True, True)
+    for blk in (3, 4, 5, 6):
+        it.conv(it.D, d + "D.Block.%d.Conv1" % blk, DIM_D, DIM_D, 3, True, True)
+        it.conv(it.D, d + "D.Block.%d.Conv2" % blk, DIM_D, DIM_D, 3, True, True)
+    it.linear(it.D, d + "D.Output", DIM_D, 1, True)
+    it.D.append((d + "Embedding.Label/embedding_map", (VOCAB_SIZE, EMBEDDING_DIM),
+                 it.rs.uniform(-0.08, 0.08, size=(VOCAB_SIZE, EMBEDDING_DIM)).astype("float32")))   # embedding.py:29-34
+    it.linear(it.D, d + "D.Embedding_y", EMBEDDING_DIM, DIM_D, True)
+    if perm_classifier:
+        if perm_type == "linear":
+            it.linear(it.D, d + "D.d_perm_classifier_h1", OUTPUT_DIM, VOCAB_SIZE, True)
+        elif perm_type == "2layer":
+            it.linear(it.D, d + "D.d_perm_classifier_h1", OUTPUT_DIM, 128, True)
+            it.linear(it.D, d + "D.d_perm_classifier_h2", 128, VOCAB_SIZE, True)
+        else:
+            raise ValueError('Unknown perm_type {}'.format(perm_type))
+    return it.G, it.D, it.Cm, it.U
+
+
+def C_ALPHA(alpha):
+    """gan_resnet.py:106."""
+    return ((1 - alpha) / 9.0) * np.ones((10, 10)) + (alpha - (1 - alpha) / 9.0) * np.eye(10)
+
+
+def lr_decay(iteration):
+    """gan_resnet.py:700-705."""
+    return max(0., 1. - iteration / 100000.) if iteration < 50000 else 0.5
+
+
+# ------------------------------------------------------------------------------------------------------
+# model blocks (gan_resnet.py:199-421).  Fusions relative to the reference graph, all algebraic identities:
+#   * Normalize + nonlinearity -> one fused condBN+ReLU kernel;   * nonlinearity before a conv in D ->
+#     folded into the conv operand load;   * UpsampleConv -> upsample folded into the conv's input indexing;
+#   * shortcut + ConvMeanPool(...) with a pooled 1x1 shortcut -> both convs accumulate into one buffer that
+#     is pooled once (mean-pool and 1x1 conv commute; pooling is linear).
+# ------------------------------------------------------------------------------------------------------
+def _ctx():
+    return Graph.current.ctx
+
+
+def UpsampleConv(inputs, output_dim, filter_size=3, name=None, spectral_normed=False, update_collection=None,
+                 he_init=True, biases=True, _in_relu=False, _accumulate_into=None):
+    return Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, 1, name, spectral_normed=spectral_normed,
+                  update_collection=update_collection, he_init=he_init, biases=biases,
+                  _in_upsample=True, _in_relu=_in_relu, _accumulate_into=_accumulate_into)
+
+
+def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels):
+    """ResidualBlock(resample='up') with conditional batch norm (gan_resnet.py:275-328)."""
+    shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
+    with variable_scope(name + '.N1'):
+        out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU)
+    out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1')
+    with variable_scope(name + '.N2'):
+        out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU)
+    return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _accumulate_into=shortcut)
+
+
+def Generator(n_samples, labels, noise, out=None):
+    """gan_resnet.py:356-371.  noise: [n,128] device tensor; returns [n, 3072] (NHWC flattened) in (-1,1)."""
+    ctx = _ctx()
+    with variable_scope("Generator"):
+        output = Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
+        output = O.reshape(ctx, output, (-1, 4, 4, DIM_G * 8))
+        output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels)
+        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels)
+        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels)
+        with variable_scope('G.OutputNorm'):
+            output = cond_batchnorm('G.OutputNorm', [0, 1, 2], output, labels=labels, n_labels=10, _act=L.ACT_RELU)
+        output = Conv2D(output, DIM_G * 2, IMG_DIM, 3, 1, 'G.Output', he_init=False)
+        output = O.act(ctx, output, L.ACT_TANH, out=out.reshape(output.shape) if out is not None else None)
+        return O.reshape(ctx, output, (-1, OUTPUT_DIM))
+
+
+def Discriminator(inputs, labels, update_collection=None):
+    """gan_resnet.py:374-412 (+ OptimizedResBlockDisc1 :331-353, ResidualBlock :275-328).  No norm in D
+    (NORMALIZATION_D=False), so ``labels`` is unused exactly as in the reference."""
+    ctx = _ctx()
+    kw = dict(spectral_normed=True, update_collection=update_collection)
+    with variable_scope("Discriminator"):
+        x = O.reshape(ctx, inputs, (-1, IMG_SIZE, IMG_SIZE, IMG_DIM))
+        # D.Block.1: shortcut = conv1x1(meanpool(x)) == meanpool(conv1x1(x)); pooled together with Conv2
+        t = Conv2D(x, IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
+        h = Conv2D(x, IMG_DIM, DIM_D, 3, 1, 'D.Block.1.Conv1', **kw)
+        t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.1.Conv2', _in_relu=True, _accumulate_into=t, **kw)
+        x = O.meanpool2(ctx, t)
+        # D.Block.2 (down)
+        t = Conv2D(x, DIM_D, DIM_D, 1, 1, 'D.Block.2.Shortcut', he_init=False, **kw)
+        h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
+        t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
+        x = O.meanpool2(ctx, t)
+        for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
+            h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
+            h = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv2' % blk, _in_relu=True, **kw)
+            x = O.add(ctx, x, h)
+        output = O.act_meanhw(ctx, x, L.ACT_RELU)                       # relu + reduce_mean over (1,2)
+        output_wgan = Linear(output, DIM_D, 1, 'D.Output', **kw)
+        return output, O.reshape(ctx, output_wgan, (-1,))
+
+
+def Discriminator_projection(labels, update_collection=None):
+    """gan_resnet.py:414-421."""
+    with variable_scope("Discriminator"):
+        e = embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
+        return Linear(e, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                      update_collection=update_collection, biases=True)
+
+
+def perm_classifier(x, perm_type='linear'):
+    """gan_resnet.py:458-483."""
+    ctx = _ctx()
+    with variable_scope("Discriminator"):
+        x = O.cast(ctx, O.reshape(ctx, x, (-1, OUTPUT_DIM)), L.F32)
+        if perm_type == 'linear':
+            return Linear(x, OUTPUT_DIM, VOCAB_SIZE, 'D.d_perm_classifier_h1', spectral_normed=True, biases=True)
+        elif perm_type == '2layer':
+            h = Linear(x, OUTPUT_DIM, 128, 'D.d_perm_classifier_h1', spectral_normed=True, biases=True)
+            return Linear(h, 128, VOCAB_SIZE, 'D.d_perm_classifier_h2', spectral_normed=True, biases=True)
+        raise ValueError('Unknown perm_type {}'.format(perm_type))
+
+
+# ------------------------------------------------------------------------------------------------------
+# trainer
+# ------------------------------------------------------------------------------------------------------
+class CifarRCGAN:
+    """One rank of the data-parallel RCGAN engine.  ``batch_size`` is the per-rank critic batch
+    (the reference's BATCH_SIZE / len(DEVICES) tower batch, gan_resnet.py:190-192,544)."""
+
+    def __init__(self, algorithm="rcgan", alpha=0.6, batch_size=64, lr=2e-4, dtype="bf16", seed=0,
+                 perm_classifier=False, perm_multiplier=1.0, perm_type="linear",
+                 confuse_init=False, confuse_init_diag=0.2, confuse_multiplier=1.0, confuse_lr_decay=False,
+                 device=0, use_graphs=True, device_rng=True, arena_bytes=None, world_size=1, rank=0,
+                 variables=None):
+        if algorithm not in ALGORITHMS:
+            raise ValueError("Unknown algorithm %s" % algorithm)
+        self.alg, self.alpha, self.B, self.lr = algorithm, alpha, int(batch_size), lr
+        self.perm, self.perm_mult, self.perm_type = perm_classifier, perm_multiplier, perm_type
+        self.confuse_multiplier, self.confuse_lr_decay = confuse_multiplier, confuse_lr_decay
+        self.world, self.rank = world_size, rank
+        self.use_graphs, self.device_rng = use_graphs, device_rng
+        if arena_bytes is None:
+            arena_bytes = int(2.5e6 * 4 * self.B * 2) + (1 << 30)      # ~20 MB/sample fp32-equivalent + slack
+        self.ctx = Context(device, dtype, arena_bytes=arena_bytes)
+        ctx = self.ctx
+        if variables is None:
+            variables = create_variables(seed, algorithm, perm_classifier, perm_type, confuse_init, confuse_init_diag)
+        gs, ds, cs, U = variables
+        self.PG, self.PD = ParamGroup(ctx, gs), ParamGroup(ctx, ds)
+        self.PC = ParamGroup(ctx, cs) if cs else None
+        self.groups = [self.PG, self.PD] + ([self.PC] if self.PC else [])
+        self.state = {}
+        for k, v in U.items():
+            t = ctx.persistent((v.size,), L.F32)
+            ctx.view(t).copy_(torch.from_numpy(np.ascontiguousarray(v.reshape(-1))))
+            self.state[k] = t
+        self.graph = Graph(ctx, self.groups, self.state)
+        B = self.B
+        f32, i32, act = L.F32, "i32", ctx.act_dtype
+        P = ctx.persistent
+        # static step inputs (graph replays read these addresses)
+        self.inp = dict(
+            images=P((B, OUTPUT_DIM), i32), noise=P((B, OUTPUT_DIM), f32), labels=P((B,), i32),
+            labels_random=P((B,), i32), labels_biased=P((B,), i32), inv_weights=P((B, VOCAB_SIZE), f32),
+            z=P((B, Z_DIM), act), labels_all=P((2 * B,), i32),
+            labels_random_G=P((2 * B,), i32), labels_biased_G=P((2 * B,), i32), z_G=P((2 * B, Z_DIM), act),
+            arange=P((VOCAB_SIZE,), i32), C_const=P((VOCAB_SIZE, VOCAB_SIZE), f32))
+        ctx.view(self.inp["arange"]).copy_(torch.arange(VOCAB_SIZE, dtype=torch.int32))
+        ctx.view(self.inp["C_const"]).copy_(torch.from_numpy(C_ALPHA(alpha).astype(np.float32)))
+        self.loss_d = P((1,), f32, fill=0.0)
+        self.loss_g = P((1,), f32, fill=0.0)
+        self.rng_state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+        self.seed = seed
+        self._graphs = {}
+        self.iteration = 0
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------------------------- helpers
+    def set_inputs(self, **arrays):
+        """Copy host arrays into the static device inputs (int arrays -> int32, floats -> buffer dtype)."""
+        ctx = self.ctx
+        with torch.cuda.stream(ctx.stream):
+            for k, a in arrays.items():
+                dst = ctx.view(self.inp[k])
+                src = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+                dst.copy_(src.reshape(dst.shape).to(dst.dtype), non_blocking=False)
+
+    def _rng(self, t, kind, lo, hi):
+        ctx = self.ctx
+        ctx.check(ctx.lib.rcgan_rng_fill(ctx.h, t.size, t.dtype, kind, lo, hi, self.seed * 1000003 + self.rank,
+                                         C.c_void_p(self.rng_state.data_ptr()), C.c_void_p(t.ptr)))
+
+    def _sn_entries(self, conv_update, proj_update):
+        ents = []
+        for name in self.PD.names:
+            if name.endswith("/Filters"):
+                ents.append((name, name[:-len("Filters")] + "filters/spectral_norm/u", conv_update))
+            elif name.endswith("/W"):
+                base = name[:-2]
+                upd = conv_update if base.endswith("D.Output") else proj_update
+                ents.append((name, base + "/spectral_norm/u", upd))
+        return ents
+
+    def confusion_matrix(self):
+        ctx = self.ctx
+        if self.PC is not None:
+            return O.softmax_rows(ctx, self.graph.param("confusion_logits"))      # gan_resnet.py:522
+        return self.inp["C_const"]                                               # gan_resnet.py:524
+
+    # ---------------------------------------------------------------------------------- D step
+    def _d_body(self):
+        """Forward + backward of disc_cost (gan_resnet.py:557-697) on this rank's shard."""
+        ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
+        ctx.new_step()
+        g.begin_step({1})
+        self.PD.zero_grad()
+        ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss_d.ptr, 0.0))
+        if self.device_rng:
+            self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
+            self._rng(inp["z"], 1, 0.0, 1.0)
+        g.prefetch_sn(self._sn_entries(True, True))
+        fake_dst = None
+        if self.alg == "rcgan-u":
+            real = ctx.empty((B, OUTPUT_DIM))
+        else:
+            x_all = ctx.empty((2 * B, OUTPUT_DIM))
+            real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
+        ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
+        fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)                 # :540-546
+        w = 1.0
+        if self.alg == "rcgan-u":
+            feat, wgan = Discriminator(real, inp["labels"], update_collection=None)
+            emb = Discriminator_projection(inp["labels"], update_collection=None)
+            disc_real = O.proj_logit(ctx, feat, wgan, emb)
+            feat_f, wgan_f = Discriminator(fake, inp["labels_random"], update_collection=None)
+            E = Discriminator_projection(inp["arange"], update_collection=None)
+            disc_fake = O.proj_logit_all(ctx, feat_f, wgan_f, E)                         # :654-660
+            y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random"], B)   # :682-683
+            O.loss_term(ctx, L.LOSS_HINGE_FAKE, disc_fake, w, self.loss_d, wts=y_conf)   # :673,684
+            O.loss_term(ctx, L.LOSS_HINGE_REAL, disc_real, w, self.loss_d)               # :674
+        else:
+            feat, wgan = Discriminator(x_all, None, update_collection=None)              # :584
+            if self.alg in ("biased", "rcgan"):
+                emb = Discriminator_projection(inp["labels_all"], update_collection=None)    # :585
+                disc_all = O.proj_logit(ctx, feat, wgan, emb)                            # :588
+                O.loss_term(ctx, L.LOSS_HINGE_REAL, O.rows(ctx, disc_all, 0, B), w, self.loss_d)       # :604
+                O.loss_term(ctx, L.LOSS_HINGE_FAKE, O.rows(ctx, disc_all, B, 2 * B), w, self.loss_d)   # :605
+            else:   # unbiased (:613-648): every label's projection once, real loss weighted by C^-1 rows
+                E = Discriminator_projection(inp["arange"], update_collection=None)
+                feat_r, wgan_r = O.rows(ctx, feat, 0, B), O.rows(ctx, wgan, 0, B)
+                feat_f, wgan_f = O.rows(ctx, feat, B, 2 * B), O.rows(ctx, wgan, B, 2 * B)
+                disc_real_all = O.proj_logit_all(ctx, feat_r, wgan_r, E)                 # [B,10]
+                O.loss_term(ctx, L.LOSS_HINGE_REAL, disc_real_all, w, self.loss_d, wts=inp["inv_weights"])   # :647
+                emb_f = Discriminator_projection(inp["labels_random"], update_collection=None)
+                disc_fake = O.proj_logit(ctx, feat_f, wgan_f, emb_f)
+                O.loss_term(ctx, L.LOSS_HINGE_FAKE, disc_fake, w, self.loss_d)           # :639,648
+        if self.perm:
+            logits = perm_classifier(real, self.perm_type)                               # :692
+            O.bce_onehot_term(ctx, logits, inp["labels"], 1.0, self.loss_d)              # :693-695
+        ctx.backward()
+
+    # ---------------------------------------------------------------------------------- G step
+    def _g_body(self):
+        """Forward + backward of gen_cost (gan_resnet.py:715-786) on this rank's shard."""
+        ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
+        n = GEN_BS_MULTIPLE * B
+        ctx.new_step()
+        g.begin_step({0, 2} if self.PC is not None else {0})
+        self.PG.zero_grad()
+        if self.PC is not None:
+            self.PC.zero_grad()
+        ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss_g.ptr, 0.0))
+        if self.device_rng:
+            self._rng(inp["z_G"], 1, 0.0, 1.0)
+        g.prefetch_sn(self._sn_entries(False, True))        # D convs + D.Output: NO_OPS; projection / perm: update
+        fake = Generator(n, inp["labels_random_G"], inp["z_G"])                                      # :719
+        lab = inp["labels_random_G"] if self.alg in ("biased", "unbiased") else inp["labels_biased_G"]
+        feat, wgan = Discriminator(fake, lab, update_collection=NO_OPS)                              # :721-730
+        if self.alg == "rcgan-u":
+            E = Discriminator_projection(inp["arange"], update_collection=None)                      # :736
+            disc_fake = O.proj_logit_all(ctx, feat, wgan, E)
+            y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random_G"], n)          # :757-758
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g, wts=y_conf)               # :751,759
+        else:
+            emb = Discriminator_projection(lab, update_collection=None)                              # :725,731
+            disc_fake = O.proj_logit(ctx, feat, wgan, emb)                                           # :763
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g)                           # :773
+        if self.perm:
+            logits = perm_classifier(fake, self.perm_type)                                           # :781
+            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult, self.loss_g)      # :782-784
+        ctx.backward()
+
+    # ---------------------------------------------------------------------------------- stepping
+    def _run(self, key, body):
+        ctx = self.ctx
+        if not self.use_graphs:
+            body()
+            return
+        if key not in self._graphs:
+            body()                      # eager warm-up (module loads, LDS attributes, self test)
+            ctx.sync()
+            ctx.graph_begin()
+            try:
+                body()
+            finally:
+                gid = ctx.graph_end()
+            self._graphs[key] = gid
+            return                      # the warm-up execution already did this step's work
+        ctx.graph_launch(self._graphs[key])
+
+    def _allreduce(self, group):
+        if self.world > 1:
+            import torch.distributed as dist
+            with torch.cuda.stream(self.ctx.stream):
+                dist.all_reduce(group.grad)
+
+    def d_step(self, iteration=None):
+        """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""
+        it = self.iteration if iteration is None else iteration
+        self._run("d", self._d_body)
+        self._allreduce(self.PD)
+        self.PD.t += 1
+        self.PD.set_hyper(self.lr * lr_decay(it), self.PD.t)
+        self.PD.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+
+    def g_step(self, iteration=None):
+        """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op
+        (gan_resnet.py:806-817)."""
+        it = self.iteration if iteration is None else iteration
+        self._run("g", self._g_body)
+        self._allreduce(self.PG)
+        self.PG.t += 1
+        self.PG.set_hyper(self.lr * lr_decay(it), self.PG.t)
+        self.PG.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+        if self.PC is not None:
+            self._allreduce(self.PC)
+            self.PC.t += 1
+            clr = self.lr * self.confuse_multiplier * (lr_decay(it) if self.confuse_lr_decay else 1.0)
+            self.PC.set_hyper(clr, self.PC.t)
+            self.PC.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+
+    def losses(self):
+        ctx = self.ctx
+        d = float(ctx.download(self.loss_d)[0])
+        g = float(ctx.download(self.loss_g)[0])
+        return d, g
+
+    # ---------------------------------------------------------------------------------- inspection
+    def get_params(self):
+        out = {}
+        for grp in self.groups:
+            for n in grp.names:
+                out[n] = grp.get(n)
+        return out
+
+    def get_grads(self, group):
+        return {n: group.get(n, "grad") for n in group.names}
+
+    def get_state(self):
+        return {k: self.ctx.download(v).reshape(1, -1) for k, v in self.state.items()}
+
+    def sample(self, labels, z):
+        """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32."""
+        ctx, g = self.ctx, self.graph
+        ctx.new_step()
+        g.begin_step(set())
+        rec, ctx.recording = ctx.recording, False
+        try:
+            lab = ctx.upload(np.asarray(labels, np.int32))
+            zz = ctx.upload(np.asarray(z, np.float32))
+            out = Generator(len(labels), lab, zz)
+            res = ctx.download(out)
+        finally:
+            ctx.recording = rec
+        return res

@@ -1,0 +1,384 @@
+// extern "C" entry points: context, conv / dense dispatch (MFMA vs direct), optimiser, graphs.
+#include "conv_mfma.h"
+
+// ---- provided by the other translation units ------------------------------------------------------
+
+size_t direct_wgrad_ws_bytes(const rcgan_conv_desc* d);
+template <typename T> int direct_fwd(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, T*);
+template <typename T> int direct_dgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, const T*, T*, int);
+template <typename T> int direct_wgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, float*, float*, int, void*, size_t);
+template <typename T> int colsum_launch(rcgan_ctx*, const T*, long, int, float*, int, float*);
+template <typename T> int sumpool2_masked_launch(rcgan_ctx*, int, int, int, int, const T*, const T*, T*, int);
+
+__global__ void slab_reduce2_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += slab[(long)z * count + i];
+  if (accumulate) s += out[i];
+  out[i] = s;
+}
+
+__global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
+                               float beta2, float eps, float clip, float grad_scale) {
+  const float lr = hyper[0], t = hyper[1];
+  const float lr_t = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * grad_scale;
+    float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    float wi = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+    if (clip > 0.f) wi = fminf(fmaxf(wi, -clip), clip);
+    m[i] = mi; v[i] = vi; w[i] = wi;
+  }
+}
+
+static int g_use_tr = -1;   // -1 unknown, 0 no, 1 yes (decided by the self test)
+
+static int ensure_selftest(rcgan_ctx* ctx) {
+  if (g_use_tr >= 0) return RCGAN_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ctx->stream, &st);
+  if (st != hipStreamCaptureStatusNone) RC_FAIL(ctx, RCGAN_EINVALID_ARG, "first MFMA wgrad call must happen outside graph capture");
+  int res[2] = {0, 0};
+  int rc = mfma_selftest(ctx, res);
+  if (rc) return rc;
+  if (res[0] != 0) RC_FAIL(ctx, RCGAN_EHIP, "MFMA 16x16x32 bf16 fragment layout probe failed (%d mismatches)", res[0]);
+  g_use_tr = (res[1] == 0) ? 1 : 0;
+  const char* e = getenv("RCGAN_NO_TR");
+  if (e && e[0] == '1') g_use_tr = 0;
+  return RCGAN_OK;
+}
+
+extern "C" {
+
+const char* rcgan_version(void) { return "rcgan_hip 0.1 (gfx950)"; }
+
+int rcgan_create(rcgan_ctx** out, int device, void* stream) {
+  if (!out) return RCGAN_EINVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RCGAN_EHIP;
+  if (hipSetDevice(device) != hipSuccess) return RCGAN_EHIP;
+  rcgan_ctx* c = new rcgan_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->capturing = false;
+  c->devtmp = nullptr;
+  c->devtmp_bytes = 0;
+  for (int i = 0; i < 64; ++i) c->event_made[i] = false;
+  *out = c;
+  return RCGAN_OK;
+}
+
+int rcgan_destroy(rcgan_ctx* ctx) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  for (int i = 0; i < 64; ++i)
+    if (ctx->event_made[i]) (void)hipEventDestroy(ctx->events[i]);
+  for (auto g : ctx->graphs)
+    if (g) (void)hipGraphExecDestroy(g);
+  delete ctx;
+  return RCGAN_OK;
+}
+
+const char* rcgan_last_error(rcgan_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int rcgan_set_stream(rcgan_ctx* ctx, void* stream) { ctx->stream = (hipStream_t)stream; return RCGAN_OK; }
+
+int rcgan_stream_sync(rcgan_ctx* ctx) {
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RCGAN_OK;
+}
+
+int rcgan_event_record(rcgan_ctx* ctx, int slot) {
+  RC_REQUIRE(ctx, slot >= 0 && slot < 64, "slot %d", slot);
+  if (!ctx->event_made[slot]) {
+    RC_HIP(ctx, hipEventCreate(&ctx->events[slot]));
+    ctx->event_made[slot] = true;
+  }
+  RC_HIP(ctx, hipEventRecord(ctx->events[slot], ctx->stream));
+  return RCGAN_OK;
+}
+
+int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int s0, int s1, float* ms) {
+  RC_REQUIRE(ctx, s0 >= 0 && s0 < 64 && s1 >= 0 && s1 < 64 && ctx->event_made[s0] && ctx->event_made[s1], "bad slots");
+  RC_HIP(ctx, hipEventSynchronize(ctx->events[s1]));
+  RC_HIP(ctx, hipEventElapsedTime(ms, ctx->events[s0], ctx->events[s1]));
+  return RCGAN_OK;
+}
+
+int rcgan_graph_begin(rcgan_ctx* ctx) {
+  RC_REQUIRE(ctx, !ctx->capturing, "already capturing");
+  RC_REQUIRE(ctx, ctx->stream != nullptr, "graph capture needs a non-null stream");
+  RC_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return RCGAN_OK;
+}
+
+int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id) {
+  RC_REQUIRE(ctx, ctx->capturing, "not capturing");
+  hipGraph_t g = nullptr;
+  ctx->capturing = false;
+  RC_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) RC_FAIL(ctx, RCGAN_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
+  ctx->graphs.push_back(ge);
+  *graph_id = (int)ctx->graphs.size() - 1;
+  return RCGAN_OK;
+}
+
+int rcgan_graph_launch(rcgan_ctx* ctx, int id) {
+  RC_REQUIRE(ctx, id >= 0 && id < (int)ctx->graphs.size() && ctx->graphs[id], "graph id %d", id);
+  RC_HIP(ctx, hipGraphLaunch(ctx->graphs[id], ctx->stream));
+  return RCGAN_OK;
+}
+
+int rcgan_graph_destroy(rcgan_ctx* ctx, int id) {
+  RC_REQUIRE(ctx, id >= 0 && id < (int)ctx->graphs.size() && ctx->graphs[id], "graph id %d", id);
+  (void)hipGraphExecDestroy(ctx->graphs[id]);
+  ctx->graphs[id] = nullptr;
+  return RCGAN_OK;
+}
+
+int rcgan_selftest(rcgan_ctx* ctx) {
+  g_use_tr = -1;
+  return ensure_selftest(ctx);
+}
+
+int rcgan_query(rcgan_ctx* ctx, int what) {
+  (void)ctx;
+  if (what == RCGAN_QUERY_TR_READ) return g_use_tr;
+  return RCGAN_EINVALID_ARG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolution
+// ------------------------------------------------------------------------------------------------
+static int check_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d) {
+  RC_REQUIRE(ctx, d != nullptr, "null desc");
+  RC_REQUIRE(ctx, d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad dims");
+  RC_REQUIRE(ctx, d->kh > 0 && d->kw > 0 && d->stride > 0, "bad kernel/stride");
+  RC_REQUIRE(ctx, d->dtype == RCGAN_F32 || d->dtype == RCGAN_BF16, "bad dtype");
+  if (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) RC_REQUIRE(ctx, d->h % 2 == 0 && d->w % 2 == 0, "upsampled size must be even");
+  return RCGAN_OK;
+}
+
+size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d) {
+  size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+  if (mfma_eligible(d)) return 2 * elems * sizeof(bf16_t) + 256;
+  return elems * sizeof(float) + 256;
+}
+
+int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w, const float* sigma, void* prepared) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  const int T = d->kh * d->kw;
+  size_t elems = (size_t)T * d->cin * d->cout;
+  if (mfma_eligible(d)) {
+    bf16_t* wt = (bf16_t*)prepared;
+    return mfma_prepare_launch(ctx, w, sigma, wt, wt + elems, T, d->cin, d->cout);
+  }
+  return direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
+}
+
+size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {
+  int oh, ow, p;
+  same_pad(d->h, d->kh, d->stride, &oh, &p);
+  same_pad(d->w, d->kw, d->stride, &ow, &p);
+  long M = (long)d->n * oh * ow;
+  size_t ws = direct_wgrad_ws_bytes(d);
+  if (mfma_wgrad_eligible(d)) {
+    size_t s = (size_t)mfma_wgrad_splits(d, M) * d->kh * d->kw * d->cin * d->cout * sizeof(float) + (size_t)cdiv(M, 2048) * d->cout * sizeof(float) + 256;
+    if (s > ws) ws = s;
+  }
+  // upsample-folded data gradient: full-resolution dx scratch
+  if (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) {
+    size_t s = (size_t)d->n * d->h * d->w * d->cin * dtype_size(d->dtype) + 256;
+    if (s > ws) ws = s;
+  }
+  return ws;
+}
+
+static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
+  int oh, ow, pt, pl;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  a.N = d->n; a.H = d->h; a.W = d->w; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
+  a.M = (long)d->n * d->h * d->w;
+}
+
+int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  if (mfma_eligible(d)) {
+    MfmaConvArgs a;
+    fill_mfma_args(d, a);
+    a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+    a.Cin = d->cin; a.Cout = d->cout;
+    a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+    return mfma_conv_launch(ctx, a);
+  }
+  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_fwd<T>(ctx, d, (const T*)x, (const float*)prepared, nullptr, bias, (T*)y));
+  return RCGAN_OK;
+}
+
+int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, const void* x, void* dx,
+                          void* ws, size_t ws_bytes) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  const bool up = d->flags & RCGAN_CONV_IN_UPSAMPLE2X;
+  const bool relu = d->flags & RCGAN_CONV_IN_RELU;
+  const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  RC_REQUIRE(ctx, !relu || x != nullptr, "IN_RELU needs x for the mask");
+  void* target = dx;
+  if (up) {
+    size_t need = (size_t)d->n * d->h * d->w * d->cin * dtype_size(d->dtype);
+    if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+    target = ws;
+  }
+  const void* mask = (relu && !up) ? x : nullptr;
+  const int acc_now = up ? 0 : acc;
+  if (mfma_eligible(d)) {
+    MfmaConvArgs a;
+    fill_mfma_args(d, a);
+    size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared + elems; a.bias = nullptr; a.mask = (const bf16_t*)mask;
+    a.out = (bf16_t*)target;
+    a.Cin = d->cout; a.Cout = d->cin;          // reduction over cout, output channels = cin
+    a.PT = d->kh - 1 - a.PT; a.PL = d->kw - 1 - a.PL;
+    a.up = 0; a.relu_in = 0; a.accumulate = acc_now;
+    rc = mfma_conv_launch(ctx, a);
+    if (rc) return rc;
+  } else {
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = direct_dgrad<T>(ctx, d, (const T*)dy, (const float*)prepared, nullptr, nullptr, (const T*)mask, (T*)target, acc_now));
+    if (rc) return rc;
+  }
+  if (up) {
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = sumpool2_masked_launch<T>(ctx, d->n, d->h, d->w, d->cin, (const T*)ws, relu ? (const T*)x : (const T*)nullptr, (T*)dx, acc));
+    if (rc) return rc;
+  }
+  return RCGAN_OK;
+}
+
+int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                            int accumulate, void* ws, size_t ws_bytes) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  if (mfma_wgrad_eligible(d)) {
+    rc = ensure_selftest(ctx);
+    if (rc) return rc;
+    MfmaWgradArgs a;
+    int oh, ow, pt, pl;
+    same_pad(d->h, d->kh, 1, &oh, &pt);
+    same_pad(d->w, d->kw, 1, &ow, &pl);
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
+    a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    a.use_tr = g_use_tr;
+    a.M = (long)d->n * d->h * d->w;
+    int nz = mfma_wgrad_splits(d, a.M);
+    long cnt = (long)d->kh * d->kw * d->cin * d->cout;
+    size_t need = (size_t)nz * cnt * sizeof(float) + (size_t)cdiv(a.M, 2048) * d->cout * sizeof(float);
+    if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+    int nzz = mfma_wgrad_launch(ctx, a, nz);
+    if (nzz < 0) return nzz;
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)a.slab, dw, cnt, nzz, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    if (dbias) {
+      float* part = (float*)((char*)ws + (size_t)nz * cnt * sizeof(float));
+      rc = colsum_launch<bf16_t>(ctx, (const bf16_t*)dy, a.M, d->cout, dbias, accumulate, part);
+      if (rc) return rc;
+    }
+    return RCGAN_OK;
+  }
+  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_wgrad<T>(ctx, d, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
+  return RCGAN_OK;
+}
+
+// transposed conv: d describes the forward conv whose data-gradient it is (see header)
+int rcgan_deconv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const float* w, const float* bias, void* y) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_dgrad<T>(ctx, d, (const T*)x, w, nullptr, bias, (const T*)nullptr, (T*)y, 0));
+  return RCGAN_OK;
+}
+
+int rcgan_deconv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_fwd<T>(ctx, d, (const T*)dy, w, nullptr, nullptr, (T*)dx));
+  return RCGAN_OK;
+}
+
+int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                              int accumulate, void* ws, size_t ws_bytes) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  // forward-conv input = deconv output gradient dy; forward-conv output gradient = deconv input x
+  RC_DISPATCH_DTYPE(ctx, d->dtype, rc = direct_wgrad<T>(ctx, d, (const T*)dy, (const T*)x, dw, nullptr, accumulate, ws, ws_bytes));
+  if (rc) return rc;
+  if (dbias) {
+    int oh, ow, p;
+    same_pad(d->h, d->kh, d->stride, &oh, &p);
+    same_pad(d->w, d->kw, d->stride, &ow, &p);
+    (void)oh; (void)ow;
+    long rows = (long)d->n * d->h * d->w;
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = colsum_launch<T>(ctx, (const T*)dy, rows, d->cin, dbias, accumulate, (float*)nullptr));
+    if (rc) return rc;
+  }
+  return RCGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense layers as 1x1 convolutions on an [m,1,1,k] tensor
+// ------------------------------------------------------------------------------------------------
+static rcgan_conv_desc lin_desc(int m, int k, int n, int dtype) {
+  rcgan_conv_desc d;
+  d.n = m; d.h = 1; d.w = 1; d.cin = k; d.cout = n; d.kh = 1; d.kw = 1; d.stride = 1; d.dtype = dtype; d.flags = RCGAN_CONV_FORCE_DIRECT;
+  return d;
+}
+
+size_t rcgan_linear_workspace_bytes(int m, int k, int n) {
+  rcgan_conv_desc d = lin_desc(m, k, n, RCGAN_F32);
+  return direct_wgrad_ws_bytes(&d);
+}
+
+int rcgan_linear_fwd(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const float* w, const float* sigma,
+                     const float* bias, void* y) {
+  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
+  RC_DISPATCH_DTYPE(ctx, dtype, return direct_fwd<T>(ctx, &d, (const T*)x, w, sigma, bias, (T*)y));
+  return RCGAN_OK;
+}
+
+int rcgan_linear_bwd_data(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* dy, const float* w, const float* sigma,
+                          void* dx, int accumulate) {
+  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
+  RC_DISPATCH_DTYPE(ctx, dtype, return direct_dgrad<T>(ctx, &d, (const T*)dy, w, sigma, nullptr, (const T*)nullptr, (T*)dx, accumulate));
+  return RCGAN_OK;
+}
+
+int rcgan_linear_bwd_weight(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const void* dy, float* dw, float* dbias,
+                            int accumulate, void* ws, size_t ws_bytes) {
+  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
+  RC_DISPATCH_DTYPE(ctx, dtype, return direct_wgrad<T>(ctx, &d, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
+  return RCGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser
+// ------------------------------------------------------------------------------------------------
+int rcgan_adam_tf(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
+                  float beta2, float eps, float clip, float grad_scale) {
+  if (count == 0) return RCGAN_OK;
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, w, g, m, v, hyper, beta1, beta2, eps, clip, grad_scale);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+}  // extern "C"

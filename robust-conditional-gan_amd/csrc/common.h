@@ -1,0 +1,144 @@
+// Shared helpers for the gfx950 kernels of librcgan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rcgan_hip.h"
+
+struct rcgan_ctx {
+  int device;
+  hipStream_t stream;
+  std::string err;
+  hipEvent_t events[64];
+  bool event_made[64];
+  std::vector<hipGraphExec_t> graphs;
+  bool capturing;
+  void* devtmp;        // small persistent device scratch (descriptor tables for batched launches)
+  size_t devtmp_bytes;
+};
+
+#define RC_FAIL(ctx, code, ...)                         \
+  do {                                                  \
+    char _b[512];                                       \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);              \
+    (ctx)->err = std::string(__func__) + ": " + _b;     \
+    return (code);                                      \
+  } while (0)
+
+#define RC_HIP(ctx, expr)                                                           \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) RC_FAIL(ctx, RCGAN_EHIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define RC_LAUNCH_CHECK(ctx)                                                        \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) RC_FAIL(ctx, RCGAN_EHIP, "launch -> %s", hipGetErrorString(_e)); \
+  } while (0)
+
+#define RC_REQUIRE(ctx, cond, ...)                                  \
+  do {                                                              \
+    if (!(cond)) RC_FAIL(ctx, RCGAN_EINVALID_ARG, __VA_ARGS__);     \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage helpers (round-to-nearest-even, as v_cvt_pk_bf16_f32 does)
+// ---------------------------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __float_as_uint(f);
+#else
+  memcpy(&u, &f, 4);
+#endif
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+static inline size_t dtype_size(int dtype) { return dtype == RCGAN_BF16 ? 2 : 4; }
+
+// dispatch a templated launcher over the activation dtype
+#define RC_DISPATCH_DTYPE(ctx, dtype, ...)                              \
+  do {                                                                  \
+    if ((dtype) == RCGAN_F32) { typedef float T; __VA_ARGS__; }         \
+    else if ((dtype) == RCGAN_BF16) { typedef bf16_t T; __VA_ARGS__; }  \
+    else RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtype %d", (int)(dtype)); \
+  } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0] + red[1] + red[2] + red[3];
+  return r;
+}
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case RCGAN_ACT_RELU: return x > 0.f ? x : 0.f;
+    case RCGAN_ACT_LRELU: return fmaxf(x, 0.2f * x);
+    case RCGAN_ACT_TANH: return tanhf(x);
+    case RCGAN_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    default: return x;
+  }
+}
+
+// derivative factor: for relu/lrelu `s` is the pre-activation input (or the output: same sign);
+// for tanh/sigmoid `s` is the OUTPUT y.
+__device__ __forceinline__ float act_grad(int act, float s) {
+  switch (act) {
+    case RCGAN_ACT_RELU: return s > 0.f ? 1.f : 0.f;
+    case RCGAN_ACT_LRELU: return s > 0.f ? 1.f : 0.2f;
+    case RCGAN_ACT_TANH: return 1.f - s * s;
+    case RCGAN_ACT_SIGMOID: return s * (1.f - s);
+    default: return 1.f;
+  }
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// TF SAME padding (tf.nn.conv2d padding='SAME')
+static inline void same_pad(int in, int k, int s, int* out, int* before) {
+  int o = (in + s - 1) / s;
+  int tot = (o - 1) * s + k - in;
+  if (tot < 0) tot = 0;
+  *out = o;
+  *before = tot / 2;
+}

@@ -1,0 +1,316 @@
+// Generic fp32-accumulate implicit-GEMM convolution on the vector ALUs ("direct" path).
+//
+// One LDS-tiled 64x64x16 GEMM skeleton, C[i][j] = sum_r A(i,r) * B(r,j), with the operand fetch
+// expressed as gather functors.  It serves every shape the MFMA path does not take: fp32 parity
+// mode, the 3-channel ends of the CIFAR nets (Cin=3 / Cout=3), the MNIST 5x5 stride-2 convs and
+// transposed convs, and all dense layers.  Same math as tf.nn.conv2d / conv2d_backprop_input /
+// conv2d_backprop_filter with SAME padding (reference call sites: mnist/ops.py:62,78;
+// cifar10/common/ops/conv2d.py:181-187).
+#include "common.h"
+
+struct ConvGeom {
+  int N, H, W, Cin;      // logical conv input (post-upsample)
+  int OH, OW, Cout;
+  int KH, KW, S, PT, PL;
+  int up;                // input tensor is stored at (H/2, W/2) and read through nearest upsample
+  int relu_in;
+};
+
+static ConvGeom make_geom(const rcgan_conv_desc* d) {
+  ConvGeom g;
+  g.N = d->n; g.H = d->h; g.W = d->w; g.Cin = d->cin; g.Cout = d->cout;
+  g.KH = d->kh; g.KW = d->kw; g.S = d->stride;
+  same_pad(d->h, d->kh, d->stride, &g.OH, &g.PT);
+  same_pad(d->w, d->kw, d->stride, &g.OW, &g.PL);
+  g.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+  g.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+  return g;
+}
+
+// value of the (virtually padded / upsampled / relu'd) conv input at pixel m=(n,oh,ow), tap index k=(kh,kw,ci)
+template <typename T>
+__device__ __forceinline__ float gather_in(const ConvGeom& g, const T* x, long m, long k) {
+  int ow = (int)(m % g.OW);
+  long t = m / g.OW;
+  int oh = (int)(t % g.OH);
+  int n = (int)(t / g.OH);
+  int ci = (int)(k % g.Cin);
+  int kk = (int)(k / g.Cin);
+  int kw = kk % g.KW, kh = kk / g.KW;
+  int ih = oh * g.S + kh - g.PT, iw = ow * g.S + kw - g.PL;
+  if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
+  long off;
+  if (g.up) off = (((long)n * (g.H >> 1) + (ih >> 1)) * (g.W >> 1) + (iw >> 1)) * g.Cin + ci;
+  else off = (((long)n * g.H + ih) * g.W + iw) * g.Cin + ci;
+  float v = Elem<T>::ld(x + off);
+  if (g.relu_in) v = v > 0.f ? v : 0.f;
+  return v;
+}
+
+// ---- forward: i = output pixel, j = cout, r = (kh,kw,ci) ---------------------------------------
+template <typename T> struct FwdOp {
+  ConvGeom g; const T* x; const float* w; const float* bias; T* y; int accumulate;
+  const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
+  long M, N, R, r_chunk;
+  __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, i, r); }
+  __device__ __forceinline__ float b(long r, long j) const {
+    float v = w[r * g.Cout + j];
+    return wscale ? v / *wscale : v;
+  }
+  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+    if (bias) v += bias[j];
+    T* p = y + i * g.Cout + j;
+    if (accumulate) v += Elem<T>::ld(p);
+    Elem<T>::st(p, v);
+  }
+};
+
+// ---- data gradient: i = input pixel (n,ih,iw) at the logical resolution, j = ci, r = (kh,kw,co) ---
+template <typename T> struct DgradOp {
+  ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
+  const float* wscale;
+  long M, N, R, r_chunk;
+  __device__ __forceinline__ float a(long i, long r) const {
+    int iw = (int)(i % g.W);
+    long t = i / g.W;
+    int ih = (int)(t % g.H);
+    int n = (int)(t / g.H);
+    int co = (int)(r % g.Cout);
+    int kk = (int)(r / g.Cout);
+    int kw = kk % g.KW, kh = kk / g.KW;
+    int th = ih + g.PT - kh, tw = iw + g.PL - kw;
+    if (th < 0 || tw < 0) return 0.f;
+    if (g.S > 1 && ((th % g.S) || (tw % g.S))) return 0.f;
+    int oh = th / g.S, ow = tw / g.S;
+    if (oh >= g.OH || ow >= g.OW) return 0.f;
+    return Elem<T>::ld(dy + (((long)n * g.OH + oh) * g.OW + ow) * g.Cout + co);
+  }
+  __device__ __forceinline__ float b(long r, long j) const {
+    long co = r % g.Cout, kk = r / g.Cout;
+    float v = w[(kk * g.Cin + j) * g.Cout + co];
+    return wscale ? v / *wscale : v;
+  }
+  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+    if (bias) v += bias[j];          // used by the transposed-conv forward
+    long off = i * g.Cin + j;
+    if (xmask) { float xv = Elem<T>::ld(xmask + off); if (!(xv > 0.f)) v = 0.f; }
+    T* p = dx + off;
+    if (accumulate) v += Elem<T>::ld(p);
+    Elem<T>::st(p, v);
+  }
+};
+
+// ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs ----
+template <typename T> struct WgradOp {
+  ConvGeom g; const T* x; const T* dy; float* slab;
+  long M, N, R, r_chunk;
+  __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, r, i); }
+  __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * g.Cout + j); }
+  __device__ __forceinline__ void store(long i, long j, float v, int z) const {
+    slab[(long)z * M * N + i * N + j] = v;
+  }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
+  const long r_begin = (long)blockIdx.z * op.r_chunk;
+  long r_end = r_begin + op.r_chunk;
+  if (r_end > op.R) r_end = op.R;
+  float acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = 0.f;
+
+  const long ai = i0 + (tid >> 2);
+  const int ar = (tid & 3) * 4;
+  const int br = tid >> 4;
+  const long bj = j0 + (tid & 15) * 4;
+  for (long r0 = r_begin; r0 < r_end; r0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      long r = r0 + ar + q;
+      float v = 0.f;
+      if (ai < op.M && r < r_end) v = op.a(ai, r);
+      As[ar + q][tid >> 2] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      long r = r0 + br, j = bj + q;
+      float v = 0.f;
+      if (r < r_end && j < op.N) v = op.b(r, j);
+      Bs[br][(tid & 15) * 4 + q] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a4[4], b4[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) a4[p] = As[kk][ty * 4 + p];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = Bs[kk][tx * 4 + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = fmaf(a4[p], b4[q], acc[p][q]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    long i = i0 + ty * 4 + p;
+    if (i >= op.M) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      long j = j0 + tx * 4 + q;
+      if (j < op.N) op.store(i, j, acc[p][q], blockIdx.z);
+    }
+  }
+}
+
+// out[i] (= or +=) sum_z slab[z][i]
+__global__ void slab_reduce_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += slab[(long)z * count + i];
+  if (accumulate) s += out[i];
+  out[i] = s;
+}
+
+// column sums of a [rows][c] matrix, one block per 64 columns; deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long rows, int c, float* out, int accumulate) {
+  __shared__ float red[4][64];
+  int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  int lane_r = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < c)
+    for (long r = lane_r; r < rows; r += 4) s += Elem<T>::ld(x + r * c + col);
+  red[lane_r][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && col < c) {
+    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (accumulate) t += out[col];
+    out[col] = t;
+  }
+}
+
+// two-level column sum for tall matrices: partial[blk][c] then reduce
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, long rows, int c, long rows_per_blk, float* partial) {
+  __shared__ float red[4][64];
+  int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  int lane_r = threadIdx.x >> 6;
+  long rb = (long)blockIdx.y * rows_per_blk;
+  long re = rb + rows_per_blk;
+  if (re > rows) re = rows;
+  float s = 0.f;
+  if (col < c)
+    for (long r = rb + lane_r; r < re; r += 4) s += Elem<T>::ld(x + r * c + col);
+  red[lane_r][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && col < c)
+    partial[(long)blockIdx.y * c + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <class Op>
+static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz) {
+  dim3 grid(cdiv(op.N, 64), cdiv(op.M, 64), nz);
+  if (grid.y > 65535u || grid.z > 65535u) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "M too large");
+  hipLaunchKernelGGL(gemm_gather_kernel<Op>, grid, dim3(256), 0, ctx->stream, op);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// pick the number of r-splits for a filter-gradient GEMM so the grid fills the chip
+static int wgrad_splits(long K, long Cout, long M) {
+  long tiles = (long)cdiv(K, 64) * cdiv(Cout, 64);
+  long want = (1024 + tiles - 1) / tiles;
+  long maxs = (M + 255) / 256;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return (int)want;
+}
+
+size_t direct_wgrad_ws_bytes(const rcgan_conv_desc* d) {
+  ConvGeom g = make_geom(d);
+  long K = (long)g.KH * g.KW * g.Cin, M = (long)g.N * g.OH * g.OW;
+  int nz = wgrad_splits(K, g.Cout, M);
+  size_t bias_part = (size_t)cdiv(M, 2048) * g.Cout * sizeof(float);
+  return (size_t)nz * K * g.Cout * sizeof(float) + bias_part + 256;
+}
+
+template <typename T>
+int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int accumulate, float* partial_ws) {
+  if (rows <= 4096 || partial_ws == nullptr) {
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, x, rows, c, out, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
+  int nb = cdiv(rows, 2048);
+  hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(cdiv(c, 64), nb), dim3(256), 0, ctx->stream, x, rows, c, (long)2048, partial_ws);
+  RC_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, (const float*)partial_ws, (long)nb, c, out, accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+template int colsum_launch<float>(rcgan_ctx*, const float*, long, int, float*, int, float*);
+template int colsum_launch<bf16_t>(rcgan_ctx*, const bf16_t*, long, int, float*, int, float*);
+
+template <typename T>
+int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float* w, const float* wscale, const float* bias, T* y) {
+  FwdOp<T> op;
+  op.g = make_geom(d); op.x = x; op.w = w; op.wscale = wscale; op.bias = bias; op.y = y;
+  op.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  op.M = (long)op.g.N * op.g.OH * op.g.OW; op.N = op.g.Cout; op.R = (long)op.g.KH * op.g.KW * op.g.Cin; op.r_chunk = op.R;
+  return launch_gemm(ctx, op, 1);
+}
+template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*);
+template int direct_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const float*, const float*, const float*, bf16_t*);
+
+// dgrad at the LOGICAL input resolution (no upsample folding here; the caller pools afterwards).
+template <typename T>
+int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const float* w, const float* wscale, const float* bias,
+                 const T* xmask, T* dx, int accumulate) {
+  DgradOp<T> op;
+  op.g = make_geom(d); op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
+  op.M = (long)op.g.N * op.g.H * op.g.W; op.N = op.g.Cin; op.R = (long)op.g.KH * op.g.KW * op.g.Cout; op.r_chunk = op.R;
+  return launch_gemm(ctx, op, 1);
+}
+template int direct_dgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, const float*, float*, int);
+template int direct_dgrad<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const float*, const float*, const float*, const bf16_t*, bf16_t*, int);
+
+template <typename T>
+int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* dy, float* dw, float* dbias,
+                 int accumulate, void* ws, size_t ws_bytes) {
+  WgradOp<T> op;
+  op.g = make_geom(d); op.x = x; op.dy = dy;
+  long K = (long)op.g.KH * op.g.KW * op.g.Cin, M = (long)op.g.N * op.g.OH * op.g.OW;
+  int nz = wgrad_splits(K, op.g.Cout, M);
+  size_t need = direct_wgrad_ws_bytes(d);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  op.slab = (float*)ws;
+  op.M = K; op.N = op.g.Cout; op.R = M;
+  op.r_chunk = ((M + nz - 1) / nz + 15) / 16 * 16;
+  nz = cdiv(M, op.r_chunk);
+  int rc = launch_gemm(ctx, op, nz);
+  if (rc) return rc;
+  long cnt = K * op.g.Cout;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)op.slab, dw, cnt, nz, accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  if (dbias) {
+    float* part = (float*)((char*)ws + (size_t)wgrad_splits(K, op.g.Cout, M) * K * op.g.Cout * sizeof(float));
+    rc = colsum_launch<T>(ctx, dy, M, op.g.Cout, dbias, accumulate, part);
+    if (rc) return rc;
+  }
+  return RCGAN_OK;
+}
+template int direct_wgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, float*, float*, int, void*, size_t);
+template int direct_wgrad<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const bf16_t*, float*, float*, int, void*, size_t);

@@ -1,0 +1,32 @@
+// Argument blocks shared by conv_mfma.hip (kernels) and api.hip (dispatch).
+#pragma once
+#include "common.h"
+
+struct MfmaConvArgs {
+  const bf16_t* in;       // [N][H(/2)][W(/2)][Cin]
+  const bf16_t* wt;       // [Cout][T*Cin]
+  const float* bias;      // [Cout] or null
+  const bf16_t* mask;     // [M][Cout] or null: output zeroed where mask <= 0 (ReLU backward)
+  bf16_t* out;            // [M][Cout]
+  int N, H, W, Cin, Cout, KH, KW, PT, PL;
+  int up, relu_in, accumulate;
+  long M;
+};
+
+struct MfmaWgradArgs {
+  const bf16_t* x;        // [N][H(/2)][W(/2)][Cin]
+  const bf16_t* dy;       // [M][Cout]
+  float* slab;            // [nz][T*Cin*Cout]
+  int N, H, W, Cin, Cout, KH, KW, PT, PL;
+  int up, relu_in, use_tr;
+  long M, m_chunk;
+};
+
+bool mfma_eligible(const rcgan_conv_desc* d);
+bool mfma_wgrad_eligible(const rcgan_conv_desc* d);
+int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
+int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz);
+int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
+int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);
+int mfma_selftest(rcgan_ctx* ctx, int* host_result);

@@ -1,0 +1,441 @@
+// bf16 MFMA implicit-GEMM convolution for gfx950 (CDNA4): the hot path of the CIFAR ResNet G/D.
+//
+// Forward / data-gradient kernel  (3x3 or 1x1, stride 1, SAME, NHWC, Cin % 64 == 0, Cout % 64 == 0):
+//   Out[m][co] = sum_{tap,ci} In[pix(m,tap)][ci] * Wt[co][tap*Cin+ci]
+//   * 256 threads = 4 wavefronts (2 pixel-halves x 2 cout-halves), block tile BM pixels x BN couts,
+//     K-step 64 (one filter tap, 64 contiguous NHWC channels = 128 B per pixel row -> coalesced).
+//   * register-staged double-buffered LDS pipeline: the global loads of K-tile t+1 are issued before
+//     the MFMAs of tile t and written to the other LDS buffer after them (one barrier per tile).
+//     Staging through registers lets the loader zero-fill the SAME-padding halo, read through a
+//     nearest-2x upsample and apply the input ReLU for free.
+//   * LDS rows are [row][64 + 8 pad] bf16 (144 B pitch): 16 consecutive rows land on 16 distinct
+//     16-B bank slots, so the ds_read_b128 fragment reads of one 16-lane group do not collide.
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and the pixels as B, so every lane
+//     ends up with 4 consecutive output channels of one pixel: the epilogue (bias, residual
+//     accumulate, ReLU-mask of the data gradient) writes 8-byte packed bf16 stores.
+//   The data gradient is the same kernel run on dy with the 180-degree-rotated, in/out-swapped filter
+//   prepared by conv_prepare_kernel.
+//
+// Filter-gradient kernel: dW[tap][ci][co] = sum_m X[pix(m,tap)][ci] * dY[m][co], a GEMM whose
+//   reduction runs over pixels.  Both operands are channel-contiguous in HBM but the MFMA wants
+//   them pixel(k)-contiguous per lane; tiles are staged as [pixel][channel] and the fragments are
+//   read with ds_read_b64_tr_b16 (the gfx950 LDS transpose read).  Pixel ranges are split across
+//   blocks into fp32 slabs that a second kernel reduces (deterministic, no atomics).
+#include "conv_mfma.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define LDS_PITCH 72          // elements per LDS row in the fwd kernel (64 + 8 pad)
+#define WG_PITCH 144          // elements per LDS row in the wgrad kernel (128 + 16 pad = 288 B)
+
+
+
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
+  uint32_t neg = ((w >> 15) & 0x00010001u) * 0xFFFFu;
+  return w & ~neg;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* As = (bf16_t*)smem;                                  // [2][BM][LDS_PITCH]
+  bf16_t* Bs = As + 2 * BM * LDS_PITCH;                        // [2][BN][LDS_PITCH]
+  constexpr int AR = BM / 32, BR = BN / 32;                    // 16-B chunks per thread per tile
+  constexpr int TM = BM / 2, TN = BN / 2;                      // wave tile
+  constexpr int NI = TN / 16, NJ = TM / 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const long m0 = (long)blockIdx.x * BM;
+  const int co0 = blockIdx.y * BN;
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int K = a.KH * a.KW * a.Cin;
+  const int KT = K / 64;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+
+  // per-thread pixel decode for the A rows it stages
+  int p_n[AR], p_oh[AR], p_ow[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    long m = m0 + lrow + 32 * i;
+    if (m < a.M) {
+      p_ow[i] = (int)(m % a.W);
+      long t = m / a.W;
+      p_oh[i] = (int)(t % a.H);
+      p_n[i] = (int)(t / a.H);
+    } else {
+      p_n[i] = 0; p_oh[i] = -100000; p_ow[i] = 0;
+    }
+  }
+  const bf16_t* wrow[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) wrow[i] = a.wt + (long)(co0 + lrow + 32 * i) * K + chunk * 8;
+
+  uint4 ra[AR], rb[BR];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * 64;
+    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        if (a.up) { ih >>= 1; iw >>= 1; }
+        const bf16_t* p = a.in + (((long)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + c0 + chunk * 8;
+        v = *(const uint4*)p;
+        if (a.relu_in) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) rb[i] = *(const uint4*)(wrow[i] + k0);
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *(uint4*)(As + ((long)buf * BM + lrow + 32 * i) * LDS_PITCH + chunk * 8) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      *(uint4*)(Bs + ((long)buf * BN + lrow + 32 * i) * LDS_PITCH + chunk * 8) = rb[i];
+  };
+
+  f32x4_t acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int frow = lane & 15, fk = (lane >> 4) * 8;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const bf16_t* Ab = As + (long)buf * BM * LDS_PITCH + (wm * TM + frow) * LDS_PITCH + fk;
+    const bf16_t* Bb = Bs + (long)buf * BN * LDS_PITCH + (wn * TN + frow) * LDS_PITCH + fk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t wf[NI], xf[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * LDS_PITCH + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf[j] = *(const bf16x8_t*)(Ab + j * 16 * LDS_PITCH + ks * 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds out[m][co..co+3], m = pixel (lane&15), co = 4*(lane>>4)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long m = m0 + wm * TM + j * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int co = co0 + wn * TN + i * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) {
+        const float4 b = *(const float4*)(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const long off = m * a.Cout + co;
+      if (a.mask) {
+        const uint2 mk = *(const uint2*)(a.mask + off);
+        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+      }
+      if (a.accumulate) {
+        const uint2 o = *(const uint2*)(a.out + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *(uint2*)(a.out + off) = pk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter gradient
+// ---------------------------------------------------------------------------------------------
+
+
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* base /* &tile[row0][ch0] */, int lane, int use_tr) {
+  // returns, for lane (g = lane>>4, i = lane&15), channel ch0+i at k-slots {g*4+e} U {16+g*4+e}, e=0..3
+  const int g = lane >> 4, i = lane & 15;
+  s16x8_t r;
+  if (use_tr) {
+    const bf16_t* p = base + (g * 4 + (i >> 2)) * WG_PITCH + (i & 3) * 4;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * WG_PITCH));
+    r = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = (e < 4) ? (g * 4 + e) : (16 + g * 4 + (e - 4));
+      r[e] = (short)base[row * WG_PITCH + i];
+    }
+  }
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// block tile: 128 ci x 128 co for one tap; 4 waves as 2 (ci) x 2 (co), wave tile 64 x 64
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Xs = (bf16_t*)smem;                    // [2][64][WG_PITCH]
+  bf16_t* Ys = Xs + 2 * 64 * WG_PITCH;           // [2][64][WG_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wo = wave >> 1;
+  const int nci = a.Cin / 128, nco = a.Cout / 128;
+  int b = blockIdx.x;
+  const int cot = b % nco; b /= nco;
+  const int cit = b % nci; b /= nci;
+  const int tap = b;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int ci0 = cit * 128, co0 = cot * 128;
+  const long mb = (long)blockIdx.y * a.m_chunk;
+  long me = mb + a.m_chunk;
+  if (me > a.M) me = a.M;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int chunk = tid & 15, lrow = tid >> 4;   // 16 chunks of 8 channels, 16 rows per pass, 4 passes
+
+  uint4 rx[4], ry[4];
+  auto load_tile = [&](long p0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = p0 + lrow + 16 * i;
+      uint4 vx = make_uint4(0, 0, 0, 0), vy = make_uint4(0, 0, 0, 0);
+      if (m < me) {
+        int ow = (int)(m % a.W);
+        long t = m / a.W;
+        int oh = (int)(t % a.H);
+        int n = (int)(t / a.H);
+        int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+          if (a.up) { ih >>= 1; iw >>= 1; }
+          vx = *(const uint4*)(a.x + (((long)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + chunk * 8);
+          if (a.relu_in) { vx.x = relu_bf16x2(vx.x); vx.y = relu_bf16x2(vx.y); vx.z = relu_bf16x2(vx.z); vx.w = relu_bf16x2(vx.w); }
+        }
+        vy = *(const uint4*)(a.dy + m * a.Cout + co0 + chunk * 8);
+      }
+      rx[i] = vx; ry[i] = vy;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(Xs + ((long)buf * 64 + lrow + 16 * i) * WG_PITCH + chunk * 8) = rx[i];
+      *(uint4*)(Ys + ((long)buf * 64 + lrow + 16 * i) * WG_PITCH + chunk * 8) = ry[i];
+    }
+  };
+
+  f32x4_t acc[4][4];   // [co tile][ci tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const long ntile = (me - mb + 63) / 64;
+  if (ntile > 0) {
+    load_tile(mb);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (long t = 0; t < ntile; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntile) load_tile(mb + (t + 1) * 64);
+    const bf16_t* Xb = Xs + (long)buf * 64 * WG_PITCH + wi * 64;
+    const bf16_t* Yb = Ys + (long)buf * 64 * WG_PITCH + wo * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yf[i] = frag_tr(Yb + ks * 32 * WG_PITCH + i * 16, lane, a.use_tr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = frag_tr(Xb + ks * 32 * WG_PITCH + j * 16, lane, a.use_tr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < ntile) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
+  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + wo * 64 + i * 16 + (lane >> 4) * 4;
+      const int ci = ci0 + wi * 64 + j * 16 + (lane & 15);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      *(float4*)(slab + ((long)tap * a.Cin + ci) * a.Cout + co) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter preparation: fp32 HWIO (optionally / sigma) -> bf16 [Cout][T*Cin] and the rotated
+// in/out-swapped [Cin][T*Cout] used by the data gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)T * Cin * Cout;
+  if (idx >= total) return;
+  const float inv = sigma ? 1.f / *sigma : 1.f;
+  int co = (int)(idx % Cout);
+  long r = idx / Cout;
+  int ci = (int)(r % Cin);
+  int t = (int)(r / Cin);
+  bf16_t v = f32_to_bf16(w[idx] * inv);
+  wt[(long)co * T * Cin + (long)t * Cin + ci] = v;
+  wd[(long)ci * T * Cout + (long)(T - 1 - t) * Cout + co] = v;
+}
+
+__global__ void conv_prepare_direct_kernel(const float* w, const float* sigma, float* out, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const float inv = sigma ? 1.f / *sigma : 1.f;
+  out[idx] = w[idx] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool mfma_eligible(const rcgan_conv_desc* d) {
+  if (d->dtype != RCGAN_BF16) return false;
+  if (d->flags & RCGAN_CONV_FORCE_DIRECT) return false;
+  if (d->stride != 1) return false;
+  if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return false;
+  if (d->cin % 64 || d->cout % 64) return false;
+  return true;
+}
+
+bool mfma_wgrad_eligible(const rcgan_conv_desc* d) {
+  return mfma_eligible(d) && d->cin % 128 == 0 && d->cout % 128 == 0;
+}
+
+template <int BM, int BN>
+static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(bf16_t);
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM), a.Cout / BN);
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
+  long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
+  if (a.Cout % 128 == 0 && blocks128 >= 384) return launch_conv_mfma<128, 128>(ctx, a);
+  return launch_conv_mfma<64, 64>(ctx, a);
+}
+
+int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
+  long tiles = (long)d->kh * d->kw * (d->cin / 128) * (d->cout / 128);
+  long want = (768 + tiles - 1) / tiles;
+  long maxs = (M + 511) / 512;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 128) want = 128;
+  return (int)want;
+}
+
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
+  static bool attr_set = false;
+  size_t lds = (size_t)4 * 64 * WG_PITCH * sizeof(bf16_t);
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  a.m_chunk = ((a.M + nz - 1) / nz + 63) / 64 * 64;
+  int nzz = cdiv(a.M, a.m_chunk);
+  dim3 grid(a.KH * a.KW * (a.Cin / 128) * (a.Cout / 128), nzz);
+  hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
+  RC_LAUNCH_CHECK(ctx);
+  return nzz;
+}
+
+int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout) {
+  long total = (long)T * Cin * Cout;
+  hipLaunchKernelGGL(conv_prepare_mfma_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, w, sigma, wt, wd, T, Cin, Cout);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total) {
+  hipLaunchKernelGGL(conv_prepare_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, w, sigma, out, total);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// self test of the fragment layouts this file assumes
+// ---------------------------------------------------------------------------------------------
+__global__ void selftest_kernel(int* result /* [0]=mfma mismatches, [1]=tr mismatches */) {
+  __shared__ __attribute__((aligned(16))) bf16_t A[16 * 32];     // A[row][k]
+  __shared__ __attribute__((aligned(16))) bf16_t B[16 * 32];     // B^T[col][k]
+  __shared__ __attribute__((aligned(16))) bf16_t Tm[32 * 16];    // [row][col] for the transpose read
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 512; i += 64) {
+    int r = i / 32, k = i % 32;
+    A[i] = f32_to_bf16((float)((r * 7 + k * 3) % 11) - 5.f);
+    B[i] = f32_to_bf16((float)((r * 5 + k * 2 + 1) % 13) - 6.f);
+    Tm[i] = f32_to_bf16((float)(i % 256));
+  }
+  __syncthreads();
+  bf16x8_t af = *(const bf16x8_t*)(A + (lane & 15) * 32 + (lane >> 4) * 8);
+  bf16x8_t bf = *(const bf16x8_t*)(B + (lane & 15) * 32 + (lane >> 4) * 8);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+  int bad = 0;
+  for (int r = 0; r < 4; ++r) {
+    int row = (lane >> 4) * 4 + r, col = lane & 15;
+    float ref = 0.f;
+    for (int k = 0; k < 32; ++k) ref += bf16_to_f32(A[row * 32 + k]) * bf16_to_f32(B[col * 32 + k]);
+    if (fabsf(ref - acc[r]) > 1e-3f) bad++;
+  }
+  if (bad) atomicAdd(&result[0], bad);
+  // transpose read: 16-lane group g, lane i supplies &Tm[g*4 + (i>>2)][(i&3)*4]; expects column i, rows g*4+e
+  const int g = lane >> 4, i = lane & 15;
+  const bf16_t* p = Tm + (g * 4 + (i >> 2)) * 16 + (i & 3) * 4;
+  s16x4_t tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  int badt = 0;
+  for (int e = 0; e < 4; ++e) {
+    bf16_t expect = Tm[(g * 4 + e) * 16 + i];
+    if ((bf16_t)tr[e] != expect) badt++;
+  }
+  if (badt) atomicAdd(&result[1], badt);
+}
+
+int mfma_selftest(rcgan_ctx* ctx, int* host_result /* [2] */) {
+  int* d;
+  RC_HIP(ctx, hipMalloc(&d, 2 * sizeof(int)));
+  RC_HIP(ctx, hipMemsetAsync(d, 0, 2 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+  RC_LAUNCH_CHECK(ctx);
+  RC_HIP(ctx, hipMemcpyAsync(host_result, d, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RC_HIP(ctx, hipFree(d));
+  return RCGAN_OK;
+}

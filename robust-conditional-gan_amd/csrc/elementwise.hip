@@ -1,0 +1,311 @@
+// HBM-bound elementwise / resampling kernels (grid-stride, 4 elements per thread).
+#include "common.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(size_t count, int per_thread = 1) {
+  size_t b = (count + (size_t)EW_BLOCK * per_thread - 1) / ((size_t)EW_BLOCK * per_thread);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename T>
+__global__ void act_fwd_kernel(size_t count, int act, const T* x, T* y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    Elem<T>::st(y + i, act_apply(act, Elem<T>::ld(x + i)));
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(size_t count, int act, const T* s, const T* dy, T* dx, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float v = Elem<T>::ld(dy + i) * act_grad(act, Elem<T>::ld(s + i));
+    if (accumulate) v += Elem<T>::ld(dx + i);
+    Elem<T>::st(dx + i, v);
+  }
+}
+
+template <typename T>
+__global__ void axpby_kernel(size_t count, float alpha, const T* a, float beta, const T* b, T* y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float v = alpha * Elem<T>::ld(a + i);
+    if (beta != 0.f) v += beta * Elem<T>::ld(b + i);
+    Elem<T>::st(y + i, v);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(size_t count, const S* s, D* d) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    Elem<D>::st(d + i, Elem<S>::ld(s + i));
+}
+
+__global__ void fill_kernel(size_t count, float* p, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// y[n][h/2][w/2][c] = mean of the 2x2 window
+template <typename T>
+__global__ void meanpool2_fwd_kernel(int n, int h, int w, int c, const T* x, T* y) {
+  const int oh = h >> 1, ow = w >> 1;
+  size_t total = (size_t)n * oh * ow * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    size_t p = i / c;
+    int x2 = (int)(p % ow);
+    size_t q = p / ow;
+    int y2 = (int)(q % oh);
+    int b = (int)(q / oh);
+    const T* s = x + (((size_t)b * h + 2 * y2) * w + 2 * x2) * c + ch;
+    // add_n order of gan_resnet.py:239-240: [::2,::2] + [1::2,::2] + [::2,1::2] + [1::2,1::2]
+    float v = Elem<T>::ld(s) + Elem<T>::ld(s + (size_t)w * c) + Elem<T>::ld(s + c) + Elem<T>::ld(s + (size_t)w * c + c);
+    Elem<T>::st(y + i, v * 0.25f);
+  }
+}
+
+// dx[n][h][w][c] (=|+=) scale * dy[n][h/2][w/2][c]    (adjoint of meanpool with scale .25; nearest upsample with scale 1)
+template <typename T>
+__global__ void expand2_kernel(int n, int h, int w, int c, float scale, const T* dy, T* dx, int accumulate) {
+  size_t total = (size_t)n * h * w * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    size_t p = i / c;
+    int xx = (int)(p % w);
+    size_t q = p / w;
+    int yy = (int)(q % h);
+    int b = (int)(q / h);
+    float v = scale * Elem<T>::ld(dy + (((size_t)b * (h >> 1) + (yy >> 1)) * (w >> 1) + (xx >> 1)) * c + ch);
+    if (accumulate) v += Elem<T>::ld(dx + i);
+    Elem<T>::st(dx + i, v);
+  }
+}
+
+// dx[n][h/2][w/2][c] (=|+=) sum of the 2x2 window of dy[n][h][w][c], optionally masked by xmask>0 (fused ReLU backward)
+template <typename T>
+__global__ void sumpool2_kernel(int n, int h, int w, int c, const T* dy, const T* xmask, T* dx, int accumulate) {
+  const int oh = h >> 1, ow = w >> 1;
+  size_t total = (size_t)n * oh * ow * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    size_t p = i / c;
+    int x2 = (int)(p % ow);
+    size_t q = p / ow;
+    int y2 = (int)(q % oh);
+    int b = (int)(q / oh);
+    const T* s = dy + (((size_t)b * h + 2 * y2) * w + 2 * x2) * c + ch;
+    float v = Elem<T>::ld(s) + Elem<T>::ld(s + (size_t)w * c) + Elem<T>::ld(s + c) + Elem<T>::ld(s + (size_t)w * c + c);
+    if (xmask && !(Elem<T>::ld(xmask + i) > 0.f)) v = 0.f;
+    if (accumulate) v += Elem<T>::ld(dx + i);
+    Elem<T>::st(dx + i, v);
+  }
+}
+
+template <typename T>
+__global__ void concat_channels_fwd_kernel(int n, int hw, int c1, int c2, const T* x, const float* yb, T* y) {
+  const int c = c1 + c2;
+  size_t total = (size_t)n * hw * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    size_t p = i / c;
+    int b = (int)(p / hw);
+    float v = ch < c1 ? Elem<T>::ld(x + p * c1 + ch) : yb[(size_t)b * c2 + (ch - c1)];
+    Elem<T>::st(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ void concat_channels_bwd_kernel(int n, int hw, int c1, int c2, const T* dy, T* dx) {
+  const int c = c1 + c2;
+  size_t total = (size_t)n * hw * c1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c1);
+    size_t p = i / c1;
+    Elem<T>::st(dx + i, Elem<T>::ld(dy + p * c + ch));
+  }
+}
+
+// gan_resnet.py:548-551
+template <typename T>
+__global__ void preprocess_cifar_kernel(int n, const int32_t* img, const float* noise, T* y) {
+  size_t total = (size_t)n * 3072;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % 3);
+    size_t p = i / 3;
+    int px = (int)(p % 1024);
+    int b = (int)(p / 1024);
+    size_t src = (size_t)b * 3072 + (size_t)ch * 1024 + px;
+    float v = 2.f * ((float)img[src] / 256.f - .5f);
+    v += noise[src];
+    Elem<T>::st(y + i, v);
+  }
+}
+
+// ---- counter-based RNG (Philox4x32-10): stands in for tf.random_normal (gan_resnet.py:359) and
+// tf.random_uniform (gan_resnet.py:549).  state[0..1] = 64-bit stream offset kept on the device so a
+// captured graph draws fresh numbers on every replay; rng_advance_kernel bumps it after each use.
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox4(uint64_t ctr, uint32_t seed_lo, uint32_t seed_hi, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5eed5eedu, c3 = 0;
+  uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// kind 0: uniform [lo, hi)   kind 1: normal(mean=lo, std=hi)
+template <typename T>
+__global__ void rng_fill_kernel(size_t count, int kind, float lo, float hi, uint64_t seed, const uint64_t* state, T* y) {
+  const uint64_t base = state ? state[0] : 0;
+  const size_t nquad = (count + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (size_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(base + q, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float v[4];
+    if (kind == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = lo + (hi - lo) * ((float)(r[i] >> 8) * (1.0f / 16777216.0f));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        float u1 = ((float)(r[i] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float u2 = ((float)(r[i + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float rad = sqrtf(-2.f * logf(u1));
+        v[i] = lo + hi * rad * cosf(6.28318530718f * u2);
+        v[i + 1] = lo + hi * rad * sinf(6.28318530718f * u2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (q * 4 + i < count) Elem<T>::st(y + q * 4 + i, v[i]);
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* state, uint64_t n) { state[0] += n; }
+
+extern "C" {
+
+int rcgan_rng_fill(rcgan_ctx* ctx, size_t count, int dtype, int kind, float lo, float hi, uint64_t seed, void* state, void* y) {
+  RC_REQUIRE(ctx, kind == 0 || kind == 1, "kind %d", kind);
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(rng_fill_kernel<T>, dim3(ew_grid((count + 3) / 4)), dim3(EW_BLOCK), 0, ctx->stream, count, kind, lo, hi, seed, (const uint64_t*)state, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  if (state) {
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, (uint64_t*)state, (uint64_t)((count + 3) / 4));
+    RC_LAUNCH_CHECK(ctx);
+  }
+  return RCGAN_OK;
+}
+
+int rcgan_act_fwd(rcgan_ctx* ctx, size_t count, int dtype, int act, const void* x, void* y) {
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(act_fwd_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, act, (const T*)x, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_act_bwd(rcgan_ctx* ctx, size_t count, int dtype, int act, const void* s, const void* dy, void* dx, int accumulate) {
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, act, (const T*)s, (const T*)dy, (T*)dx, accumulate));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_add(rcgan_ctx* ctx, size_t count, int dtype, const void* a, const void* b, void* y) {
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, 1.f, (const T*)a, 1.f, (const T*)b, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// y = alpha*a + beta*y
+int rcgan_axpby(rcgan_ctx* ctx, size_t count, int dtype, float alpha, const void* a, float beta, void* y) {
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, alpha, (const T*)a, beta, (const T*)y, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_cast(rcgan_ctx* ctx, size_t count, int sd, const void* s, int dd, void* d) {
+  dim3 g(ew_grid(count)), b(EW_BLOCK);
+  if (sd == RCGAN_F32 && dd == RCGAN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, ctx->stream, count, (const float*)s, (bf16_t*)d);
+  else if (sd == RCGAN_BF16 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (float*)d);
+  else if (sd == RCGAN_F32 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, ctx->stream, count, (const float*)s, (float*)d);
+  else if (sd == RCGAN_BF16 && dd == RCGAN_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (bf16_t*)d);
+  else RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtypes %d %d", sd, dd);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float v) {
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, p, v);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_meanpool2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y) {
+  RC_REQUIRE(ctx, (h % 2 == 0) && (w % 2 == 0), "odd spatial size %dx%d", h, w);
+  size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(meanpool2_fwd_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, (const T*)x, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_meanpool2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate) {
+  size_t cnt = (size_t)n * h * w * c;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(expand2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, 0.25f, (const T*)dy, (T*)dx, accumulate));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// h, w: OUTPUT (upsampled) size
+int rcgan_upsample2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y) {
+  size_t cnt = (size_t)n * h * w * c;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(expand2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, 1.f, (const T*)x, (T*)y, 0));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_upsample2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate) {
+  size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, (const T*)dy, (const T*)nullptr, (T*)dx, accumulate));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_concat_channels_fwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* x, const float* yb, void* y) {
+  size_t cnt = (size_t)n * hw * (c1 + c2);
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(concat_channels_fwd_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, hw, c1, c2, (const T*)x, yb, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_concat_channels_bwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* dy, void* dx) {
+  size_t cnt = (size_t)n * hw * c1;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(concat_channels_bwd_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, hw, c1, c2, (const T*)dy, (T*)dx));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_preprocess_cifar(rcgan_ctx* ctx, int n, const int32_t* img, const float* noise, int dtype, void* y) {
+  size_t cnt = (size_t)n * 3072;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(preprocess_cifar_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, img, noise, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+}  // extern "C"
+
+// used by the conv API for the upsample-folded data gradient
+template <typename T>
+int sumpool2_masked_launch(rcgan_ctx* ctx, int n, int h, int w, int c, const T* dy, const T* xmask, T* dx, int accumulate) {
+  size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, dy, xmask, dx, accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+template int sumpool2_masked_launch<float>(rcgan_ctx*, int, int, int, int, const float*, const float*, float*, int);
+template int sumpool2_masked_launch<bf16_t>(rcgan_ctx*, int, int, int, int, const bf16_t*, const bf16_t*, bf16_t*, int);

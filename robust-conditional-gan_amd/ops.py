@@ -1,0 +1,515 @@
+"""Differentiable device ops: each forward is one (or a few) C-ABI calls into the gfx950 kernels and
+records a closure that runs the matching hand-written backward kernels.  This tape takes the place of
+``tf.gradients`` in the reference (``compute_gradients`` at cifar10/gan_resnet.py:803,807; ``minimize``
+at mnist/model.py:250-262).  No arithmetic happens in Python or in PyTorch.
+"""
+import ctypes as C
+
+from . import _lib as L
+from .runtime import DT
+
+
+def _p(t):
+    return C.c_void_p(t.ptr) if t is not None else None
+
+
+def same_pad(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return out, tot // 2
+
+
+def zeros_like_grad(ctx, t):
+    g = ctx.empty(t.shape, t.dtype)
+    ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, (g.nbytes + 3) // 4, g.ptr, 0.0))
+    return g
+
+
+def grad_of(ctx, t):
+    """(gradient buffer of t, accumulate flag)."""
+    if t.grad is None:
+        t.grad = ctx.empty(t.shape, t.dtype)
+        return t.grad, 0
+    return t.grad, 1
+
+
+def _track(ctx, out, *ins):
+    out.req = ctx.recording and any(i is not None and i.req for i in ins)
+    return out.req
+
+
+# ----------------------------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------------------------
+class Weight:
+    """A filter / matrix as the conv and dense ops consume it: the fp32 master parameter plus, when
+    spectrally normalised, the device scalar sigma (W_bar = W / sigma is never materialised in fp32:
+    the division is fused into the filter-preparation / operand-load)."""
+
+    def __init__(self, ctx, param, sigma=None):
+        self.ctx, self.param, self.sigma = ctx, param, sigma
+        self._prepared = {}
+        self.dwbar = None
+
+    @property
+    def req(self):
+        return self.param.req
+
+    def prepared(self, desc):
+        key = (desc.kh, desc.kw, desc.cin, desc.cout, desc.dtype, desc.stride, desc.flags & L.CONV_FORCE_DIRECT)
+        # the prepared layout depends only on whether the MFMA path takes this shape
+        ctx = self.ctx
+        nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
+        key = key + (nbytes,)
+        if key not in self._prepared:
+            buf = DT(ctx.arena.alloc(nbytes), (nbytes,), "u8", ctx.arena.buf)
+            ctx.check(ctx.lib.rcgan_conv_prepare(ctx.h, C.byref(desc), _p(self.param), _p(self.sigma), _p(buf)))
+            self._prepared[key] = buf
+        return self._prepared[key]
+
+    def grad_target(self):
+        """Where d/dW (or d/dW_bar for SN weights) is accumulated."""
+        if self.sigma is None:
+            return self.param.grad
+        if self.dwbar is None:
+            self.dwbar = DT(self.ctx.arena.alloc(self.param.nbytes), self.param.shape, L.F32, self.ctx.arena.buf)
+            self.ctx.check(self.ctx.lib.rcgan_fill_f32(self.ctx.h, self.param.size, self.dwbar.ptr, 0.0))
+        return self.dwbar
+
+
+def spectral_norm_batch(ctx, entries):
+    """entries: list of (param DT [.., c], u DT [c] persistent, update flag).  One launch runs the power
+    iteration of every weight (mnist/sn.py:37-62); returns a Weight per entry.  Records ONE tape entry
+    that, at the very end of the backward pass, turns every accumulated dW_bar into dW -- through the
+    power iteration, as TF does (no stop_gradient in the reference)."""
+    n = len(entries)
+    if n == 0:
+        return []
+    items = (L.SnItem * n)()
+    weights = []
+    saves = []
+    for i, (param, u, update) in enumerate(entries):
+        c = param.shape[-1]
+        k = param.size // c
+        sigma = ctx.empty((1,), L.F32)
+        save = ctx.empty((ctx.lib.rcgan_sn_save_floats(k, c),), L.F32)
+        items[i] = L.SnItem(param.ptr, u.ptr, sigma.ptr, save.ptr, k, c, 1 if update else 0)
+        weights.append(Weight(ctx, param, sigma))
+        saves.append((save, k, c))
+    ctx.check(ctx.lib.rcgan_sn_power_iter(ctx.h, items, n))
+
+    def bw():
+        todo = [(w, s) for w, s in zip(weights, saves) if w.dwbar is not None and w.param.req]
+        if not todo:
+            return
+        bi = (L.SnBwdItem * len(todo))()
+        for i, (w, (save, k, c)) in enumerate(todo):
+            bi[i] = L.SnBwdItem(w.param.ptr, w.dwbar.ptr, w.param.grad.ptr, save.ptr, k, c, 1)
+        ctx.check(ctx.lib.rcgan_sn_bwd(ctx.h, bi, len(todo)))
+    if any(p.req for p, _, _ in entries):
+        ctx.record(bw)
+    return weights
+
+
+# ----------------------------------------------------------------------------------------------------
+# convolution / dense
+# ----------------------------------------------------------------------------------------------------
+def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumulate_into=None, force_direct=False):
+    """SAME conv on NHWC x with HWIO weight [k,k,cin,cout] (tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
+    cifar10/common/ops/conv2d.py:181-216).  in_up / in_relu fold the preceding nearest-2x upsample
+    (gan_resnet.py:263-264) and ReLU into the operand load; accumulate_into adds the result into an
+    existing tensor (the residual sum of gan_resnet.py:328)."""
+    n, hs, ws_, cin = x.shape
+    h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
+    cout = weight.param.shape[-1]
+    assert weight.param.shape == (k, k, cin, cout), (weight.param.shape, (k, k, cin, cout))
+    flags = (L.CONV_IN_UPSAMPLE2X if in_up else 0) | (L.CONV_IN_RELU if in_relu else 0) | (L.CONV_FORCE_DIRECT if force_direct else 0)
+    oh, _ = same_pad(h, k, stride)
+    ow, _ = same_pad(w, k, stride)
+    desc = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags)
+    prep = weight.prepared(desc)
+    if accumulate_into is not None:
+        y = accumulate_into
+        assert y.shape == (n, oh, ow, cout)
+        fdesc = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | L.CONV_ACCUMULATE)
+    else:
+        y = ctx.empty((n, oh, ow, cout), x.dtype)
+        fdesc = desc
+    ctx.check(ctx.lib.rcgan_conv2d_fwd(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(y)))
+    prev_req = y.req if accumulate_into is not None else False
+    if _track(ctx, y, x, weight.param, bias) or prev_req:
+        y.req = True
+        xr, wr, br = x.req, weight.req, (bias is not None and bias.req)
+
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            if xr:
+                dx, acc = grad_of(ctx, x)
+                d2 = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_ACCUMULATE if acc else 0))
+                ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
+                                                        _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            if wr or br:
+                dw = weight.grad_target() if wr else None
+                if wr:
+                    ctx.check(ctx.lib.rcgan_conv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(dw),
+                                                              _p(bias.grad) if br else None, 1,
+                                                              C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                else:
+                    raise NotImplementedError("bias-only gradient")
+        ctx.record(bw)
+    return y
+
+
+def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
+    """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], out_shape, strides) + bias (mnist/ops.py:78-86)."""
+    n, oh, ow, cout = out_shape
+    cin = x.shape[-1]
+    assert w.shape == (k, k, cout, cin), (w.shape, (k, k, cout, cin))
+    desc = L.ConvDesc(n, oh, ow, cout, cin, k, k, stride, x.dtype, 0)     # the forward conv it transposes
+    y = ctx.empty(out_shape, x.dtype)
+    ctx.check(ctx.lib.rcgan_deconv2d_fwd(ctx.h, C.byref(desc), _p(x), _p(w), _p(bias), _p(y)))
+    if _track(ctx, y, x, w, bias):
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            if x.req:
+                assert x.grad is None, "deconv input gradient is written once"
+                dx, _ = grad_of(ctx, x)
+                ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(dx)))
+            if w.req:
+                ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(w.grad),
+                                                            _p(bias.grad) if (bias is not None and bias.req) else None, 1,
+                                                            C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        ctx.record(bw)
+    return y
+
+
+def linear(ctx, x, weight, bias, out_dtype=None):
+    """x[m,k] @ W[k,n] + b with W a Weight (optionally / sigma).  tf.matmul + bias: mnist/ops.py:114-116,
+    cifar10/common/ops/linear.py:161-180."""
+    m, kk = x.shape
+    n = weight.param.shape[-1]
+    assert weight.param.shape == (kk, n), (weight.param.shape, (kk, n))
+    y = ctx.empty((m, n), x.dtype)
+    ctx.check(ctx.lib.rcgan_linear_fwd(ctx.h, m, kk, n, x.dtype, _p(x), _p(weight.param), _p(weight.sigma), _p(bias), _p(y)))
+    if _track(ctx, y, x, weight.param, bias):
+        xr, wr, br = x.req, weight.req, (bias is not None and bias.req)
+
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            if xr:
+                dx, acc = grad_of(ctx, x)
+                ctx.check(ctx.lib.rcgan_linear_bwd_data(ctx.h, m, kk, n, x.dtype, _p(dy), _p(weight.param), _p(weight.sigma), _p(dx), acc))
+            if wr:
+                dw = weight.grad_target()
+                ctx.check(ctx.lib.rcgan_linear_bwd_weight(ctx.h, m, kk, n, x.dtype, _p(x), _p(dy), _p(dw),
+                                                          _p(bias.grad) if br else None, 1, C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        ctx.record(bw)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------------
+def _rows(x):
+    if len(x.shape) == 4:
+        return x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    return x.shape[0], 1, x.shape[1]
+
+
+def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1, moving=None, decay=0.9, eps=1e-5):
+    """Batch statistics + (conditional) affine + activation, one fused op.
+    labels=None: tf.contrib.layers.batch_norm (mnist/ops.py:38-44), ``moving`` = (moving_mean, moving_var)
+    DTs updated in place.  labels=int32 DT [n]: cond_batchnorm (cifar10/common/ops/normalization.py:27-59),
+    gamma/beta are [n_labels, c] tables."""
+    n, rps, c = _rows(x)
+    rows = n * rps
+    mean = ctx.empty((c,), L.F32)
+    rstd = ctx.empty((c,), L.F32)
+    mm, mv = moving if moving is not None else (None, None)
+    ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), _p(mm), _p(mv), decay,
+                                     C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+    y = ctx.empty(x.shape, x.dtype)
+    ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, n, rps, c, x.dtype, _p(x), _p(labels), _p(gamma), _p(beta), _p(mean), _p(rstd), act, _p(y)))
+    if _track(ctx, y, x, gamma, beta):
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            assert x.grad is None, "batch-norm input gradient is written once"
+            dx, _ = grad_of(ctx, x)
+            # parameter gradients always accumulate into the (zeroed) slab; frozen params get a scratch
+            if gamma.req:
+                dg, db = gamma.grad, beta.grad
+            else:
+                dg = zeros_like_grad(ctx, gamma)
+                db = zeros_like_grad(ctx, beta)
+            ctx.check(ctx.lib.rcgan_bn_bwd(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(y), _p(dy), _p(labels), _p(gamma),
+                                           _p(mean), _p(rstd), act, _p(dx), _p(dg), _p(db), 1,
+                                           C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        ctx.record(bw)
+    return y
+
+
+def batch_norm_infer(ctx, x, gamma, beta, mm, mv, act=L.ACT_NONE, eps=1e-5):
+    n, rps, c = _rows(x)
+    y = ctx.empty(x.shape, x.dtype)
+    ctx.check(ctx.lib.rcgan_bn_infer(ctx.h, n * rps, c, x.dtype, _p(x), _p(gamma), _p(beta), _p(mm), _p(mv), eps, act, _p(y)))
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# elementwise / resampling
+# ----------------------------------------------------------------------------------------------------
+def act(ctx, x, kind, out=None):
+    y = out if out is not None else ctx.empty(x.shape, x.dtype)
+    ctx.check(ctx.lib.rcgan_act_fwd(ctx.h, x.size, x.dtype, kind, _p(x), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            s = y if kind in (L.ACT_TANH, L.ACT_SIGMOID) else x
+            ctx.check(ctx.lib.rcgan_act_bwd(ctx.h, x.size, x.dtype, kind, _p(s), _p(y.grad), _p(dx), acc))
+        ctx.record(bw)
+    return y
+
+
+def add(ctx, a, b):
+    y = ctx.empty(a.shape, a.dtype)
+    assert a.shape == b.shape
+    ctx.check(ctx.lib.rcgan_add(ctx.h, a.size, a.dtype, _p(a), _p(b), _p(y)))
+    if _track(ctx, y, a, b):
+        def bw():
+            if y.grad is None:
+                return
+            for t in (a, b):
+                if t.req:
+                    dx, acc = grad_of(ctx, t)
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, t.size, t.dtype, 1.0, _p(y.grad), float(acc), _p(dx)))
+        ctx.record(bw)
+    return y
+
+
+def meanpool2(ctx, x):
+    n, h, w, c = x.shape
+    y = ctx.empty((n, h // 2, w // 2, c), x.dtype)
+    ctx.check(ctx.lib.rcgan_meanpool2_fwd(ctx.h, n, h, w, c, x.dtype, _p(x), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_meanpool2_bwd(ctx.h, n, h, w, c, x.dtype, _p(y.grad), _p(dx), acc))
+        ctx.record(bw)
+    return y
+
+
+def upsample2(ctx, x):
+    n, h, w, c = x.shape
+    y = ctx.empty((n, h * 2, w * 2, c), x.dtype)
+    ctx.check(ctx.lib.rcgan_upsample2_fwd(ctx.h, n, h * 2, w * 2, c, x.dtype, _p(x), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_upsample2_bwd(ctx.h, n, h * 2, w * 2, c, x.dtype, _p(y.grad), _p(dx), acc))
+        ctx.record(bw)
+    return y
+
+
+def concat_channels(ctx, x, yb):
+    """conv_cond_concat (mnist/ops.py:46-51): append the one-hot label yb[n,c2] (fp32) to every pixel."""
+    if len(x.shape) == 4:
+        n, h, w, c1 = x.shape
+        hw = h * w
+        oshape = (n, h, w, c1 + yb.shape[1])
+    else:
+        n, c1 = x.shape
+        hw = 1
+        oshape = (n, c1 + yb.shape[1])
+    c2 = yb.shape[1]
+    y = ctx.empty(oshape, x.dtype)
+    ctx.check(ctx.lib.rcgan_concat_channels_fwd(ctx.h, n, hw, c1, c2, x.dtype, _p(x), _p(yb), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            assert x.grad is None
+            dx, _ = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_concat_channels_bwd(ctx.h, n, hw, c1, c2, x.dtype, _p(y.grad), _p(dx)))
+        ctx.record(bw)
+    return y
+
+
+def reshape(ctx, x, shape):
+    y = x.reshape(shape)
+    y.req = x.req
+    if x.req and ctx.recording:
+        if x.grad is None:
+            x.grad = zeros_like_grad(ctx, x)
+        y.grad = x.grad.reshape(y.shape)
+    return y
+
+
+def rows(ctx, x, lo, hi):
+    y = x.rows(lo, hi)
+    y.req = x.req
+    if x.req and ctx.recording:
+        if x.grad is None:
+            x.grad = zeros_like_grad(ctx, x)
+        y.grad = x.grad.rows(lo, hi)
+    return y
+
+
+def cast(ctx, x, dtype):
+    if x.dtype == dtype:
+        return x
+    y = ctx.empty(x.shape, dtype)
+    ctx.check(ctx.lib.rcgan_cast(ctx.h, x.size, x.dtype, _p(x), dtype, _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            assert x.grad is None
+            dx, _ = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_cast(ctx.h, x.size, dtype, _p(y.grad), x.dtype, _p(dx)))
+        ctx.record(bw)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# discriminator head / losses (all fp32)
+# ----------------------------------------------------------------------------------------------------
+def act_meanhw(ctx, x, kind):
+    """mean over (H,W) of act(x) -> fp32 [n,c]  (gan_resnet.py:405-407; mnist/model.py:679 with ACT_NONE)."""
+    n, h, w, c = x.shape
+    y = ctx.empty((n, c), L.F32)
+    ctx.check(ctx.lib.rcgan_act_meanhw_fwd(ctx.h, n, h * w, c, x.dtype, kind, _p(x), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            assert x.grad is None
+            dx, _ = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_act_meanhw_bwd(ctx.h, n, h * w, c, x.dtype, kind, _p(x), _p(y.grad), _p(dx)))
+        ctx.record(bw)
+    return y
+
+
+def gather_rows(ctx, table, idx, n):
+    """tf.nn.embedding_lookup(table, idx) (embedding.py:51); idx: int32 DT [n]."""
+    v, d = table.shape
+    y = ctx.empty((n, d), L.F32)
+    ctx.check(ctx.lib.rcgan_gather_rows(ctx.h, n, d, _p(table), _p(idx), _p(y)))
+    if _track(ctx, y, table):
+        def bw():
+            if y.grad is None:
+                return
+            if table.grad is None:
+                table.grad = zeros_like_grad(ctx, table)
+            ctx.check(ctx.lib.rcgan_scatter_add_rows(ctx.h, n, d, v, _p(y.grad), _p(idx), _p(table.grad), 1))
+        ctx.record(bw)
+    return y
+
+
+def proj_logit(ctx, feat, psi, emb):
+    """psi[n] + sum(feat*emb, axis=1)  (gan_resnet.py:588; mnist/model.py:685)."""
+    n, d = feat.shape
+    y = ctx.empty((n,), L.F32)
+    ctx.check(ctx.lib.rcgan_proj_logit_fwd(ctx.h, n, d, _p(feat), _p(psi), _p(emb), _p(y)))
+    if _track(ctx, y, feat, psi, emb):
+        def bw():
+            if y.grad is None:
+                return
+            dfeat = dpsi = demb = None
+            accf = 0
+            if feat.req:
+                dfeat, accf = grad_of(ctx, feat)
+            if psi is not None and psi.req:
+                assert psi.grad is None or psi.grad.ptr != 0
+                if psi.grad is None:
+                    psi.grad = ctx.empty(psi.shape, L.F32)
+                    dpsi = psi.grad
+                else:
+                    # psi gradient already holds another consumer's contribution: go through a scratch
+                    dpsi = ctx.empty(psi.shape, L.F32)
+            if emb.req:
+                assert emb.grad is None
+                demb, _ = grad_of(ctx, emb)
+            ctx.check(ctx.lib.rcgan_proj_logit_bwd(ctx.h, n, d, _p(feat), _p(emb), _p(y.grad), _p(dfeat), _p(dpsi), _p(demb), accf))
+            if dpsi is not None and dpsi is not psi.grad:
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, psi.size, L.F32, 1.0, _p(dpsi), 1.0, _p(psi.grad)))
+        ctx.record(bw)
+    return y
+
+
+def proj_logit_all(ctx, feat, psi, E):
+    """logits[n,v] = psi[n] + feat @ E^T for every label (gan_resnet.py:654-660)."""
+    n, d = feat.shape
+    v = E.shape[0]
+    y = ctx.empty((n, v), L.F32)
+    ctx.check(ctx.lib.rcgan_proj_logit_all_fwd(ctx.h, n, d, v, _p(feat), _p(psi), _p(E), _p(y)))
+    if _track(ctx, y, feat, psi, E):
+        def bw():
+            if y.grad is None:
+                return
+            dfeat, accf = grad_of(ctx, feat)
+            if psi.grad is None:
+                psi.grad = ctx.empty(psi.shape, L.F32)
+                dpsi = psi.grad
+            else:
+                dpsi = ctx.empty(psi.shape, L.F32)
+            assert E.grad is None
+            dE, _ = grad_of(ctx, E)
+            ctx.check(ctx.lib.rcgan_proj_logit_all_bwd(ctx.h, n, d, v, _p(feat), _p(E), _p(y.grad), _p(dfeat), _p(dpsi), _p(dE), accf))
+            if dpsi is not psi.grad:
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, psi.size, L.F32, 1.0, _p(dpsi), 1.0, _p(psi.grad)))
+        ctx.record(bw)
+    return y
+
+
+def loss_term(ctx, kind, x, weight, loss_acc, wts=None):
+    """Adds weight * L(x) to the device scalar loss_acc; the gradient weight*dL/dx is computed in the
+    same launch (the total cost is a weighted sum of such terms, so no upstream gradient is needed)."""
+    if len(x.shape) == 1:
+        r, c = x.shape[0], 1
+    else:
+        r, c = x.shape
+    need = x.req and ctx.recording
+    # the kernel WRITES its gradients: x (and wts) must have this loss term as their only consumer
+    dx = None
+    if need:
+        dx, _ = grad_of(ctx, x)
+    dw = None
+    if wts is not None and wts.req and ctx.recording:
+        dw, _ = grad_of(ctx, wts)
+    ctx.check(ctx.lib.rcgan_loss_fwd_bwd(ctx.h, kind, r, c, _p(x), _p(wts), float(weight), _p(loss_acc), _p(dx), _p(dw)))
+
+
+def bce_onehot_term(ctx, x, labels, weight, loss_acc):
+    """weight * reduce_mean(sigmoid_cross_entropy_with_logits(x, one_hot(labels))) (gan_resnet.py:693-694)."""
+    r, c = x.shape
+    dx = None
+    if x.req and ctx.recording:
+        dx, _ = grad_of(ctx, x)
+    ctx.check(ctx.lib.rcgan_bce_onehot_fwd_bwd(ctx.h, r, c, _p(x), _p(labels), float(weight), _p(loss_acc), _p(dx)))
+
+
+def softmax_rows(ctx, logits):
+    r, c = logits.shape
+    p = ctx.empty((r, c), L.F32)
+    ctx.check(ctx.lib.rcgan_softmax_rows_fwd(ctx.h, r, c, _p(logits), _p(p)))
+    if _track(ctx, p, logits):
+        def bw():
+            if p.grad is None:
+                return
+            ctx.check(ctx.lib.rcgan_softmax_rows_bwd(ctx.h, r, c, _p(p), _p(p.grad), _p(logits.grad), 1))
+        ctx.record(bw)
+    return p

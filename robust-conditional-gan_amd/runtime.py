@@ -1,0 +1,308 @@
+"""Device runtime for the RCGAN engine: context, stream, arena allocator, device tensors.
+
+PyTorch-ROCm is used only as plumbing: it owns the HIP stream, allocates the few large buffers
+(parameter/gradient/optimiser slabs, the activation arena, the kernel workspace), moves host data and
+bootstraps RCCL.  Every arithmetic op goes through the C ABI in ``_lib`` to the hand-written gfx950
+kernels.  Layout in HBM (one process per GPU, sized for 288 GB):
+
+  params   : one flat fp32 slab per optimiser group (Generator / Discriminator / confusion_logits),
+             each variable 256-byte aligned; gradients and Adam m, v are slabs of the same shape so the
+             optimiser and the RCCL all-reduce are single launches over contiguous memory.
+  state    : SN ``u`` vectors, BN moving statistics (non-trainable, checkpointed, never all-reduced).
+  arena    : bump allocator for activations / activation gradients / per-step scratch; reset at the
+             start of every step so captured hipGraphs see identical addresses on replay.
+  workspace: split-K slabs of the filter-gradient kernels and the upsample-folded dgrad scratch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+ALIGN = 256
+
+
+def _np_dtype(code):
+    return np.float32 if code == L.F32 else np.uint16
+
+
+class DT:
+    """A device tensor: raw pointer + shape + dtype code.  ``base`` keeps the owning torch storage alive."""
+    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name")
+
+    def __init__(self, ptr, shape, dtype, base=None, name=None):
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = dtype
+        self.base = base
+        self.grad = None
+        self.req = False
+        self.name = name
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def itemsize(self):
+        if self.dtype == "u8":
+            return 1
+        return 4 if self.dtype in (L.F32, "i32") else 2
+
+    @property
+    def nbytes(self):
+        return self.size * self.itemsize
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            known = 1
+            for s in shape:
+                if s != -1:
+                    known *= s
+            shape[shape.index(-1)] = self.size // known
+        t = DT(self.ptr, shape, self.dtype, self.base, self.name)
+        assert t.size == self.size, (self.shape, shape)
+        return t
+
+    def rows(self, lo, hi):
+        """Contiguous leading-dimension slice (a view)."""
+        stride = self.size // self.shape[0]
+        return DT(self.ptr + lo * stride * self.itemsize, (hi - lo,) + self.shape[1:], self.dtype, self.base, self.name)
+
+
+class Arena:
+    def __init__(self, nbytes, device):
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.base = self.buf.data_ptr()
+        self.cap = int(nbytes)
+        self.off = 0
+        self.peak = 0
+
+    def reset(self):
+        self.off = 0
+
+    def alloc(self, nbytes):
+        off = (self.off + ALIGN - 1) // ALIGN * ALIGN
+        if off + nbytes > self.cap:
+            raise MemoryError("activation arena exhausted: need %d more bytes (capacity %d); raise arena_bytes"
+                              % (off + nbytes - self.cap, self.cap))
+        self.off = off + int(nbytes)
+        self.peak = max(self.peak, self.off)
+        return self.base + off
+
+
+class Context:
+    """One per process / GPU.  Wraps rcgan_ctx, the stream, the arena and the workspace."""
+
+    def __init__(self, device=0, dtype="bf16", arena_bytes=6 << 30, ws_bytes=1 << 30):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the RCGAN engine has no CPU fallback")
+        self.lib = L.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        h = C.c_void_p()
+        rc = self.lib.rcgan_create(C.byref(h), device, C.c_void_p(self.stream.cuda_stream))
+        if rc != 0:
+            raise L.RcganError(rc, "rcgan_create failed")
+        self.h = h
+        self.act_dtype = L.BF16 if dtype in ("bf16", L.BF16) else L.F32
+        self.arena = Arena(arena_bytes, self.device)
+        self.ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device)
+        self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), int(ws_bytes)
+        self.tape = []
+        self.recording = True
+        self._keep = []
+        self.check(self.lib.rcgan_selftest(self.h))
+        self.uses_tr_read = self.lib.rcgan_query(self.h, L.QUERY_TR_READ)
+
+    # ------------------------------------------------------------------ errors
+    def check(self, rc):
+        if rc != 0:
+            raise L.RcganError(rc, self.lib.rcgan_last_error(self.h).decode())
+
+    def close(self):
+        if self.h is not None:
+            self.lib.rcgan_destroy(self.h)
+            self.h = None
+
+    # ------------------------------------------------------------------ memory
+    def empty(self, shape, dtype=None, name=None):
+        dtype = self.act_dtype if dtype is None else dtype
+        n = 1
+        for s in shape:
+            n *= int(s)
+        isz = 4 if dtype in (L.F32, "i32") else 2
+        return DT(self.arena.alloc(max(n, 1) * isz), shape, dtype, self.arena.buf, name)
+
+    def persistent(self, shape, dtype=L.F32, fill=None):
+        """A buffer outside the arena (survives arena resets)."""
+        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, "i32": torch.int32}[dtype]
+        t = torch.empty(tuple(int(s) for s in shape) or (1,), dtype=tdt, device=self.device)
+        if fill is not None:
+            with torch.cuda.stream(self.stream):
+                t.fill_(fill)
+        self._keep.append(t)
+        return DT(t.data_ptr(), shape, dtype, t)
+
+    def view(self, t):
+        """torch tensor aliasing a DT (for uploads, downloads and RCCL)."""
+        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, "i32": torch.int32}[t.dtype]
+        if isinstance(t.base, torch.Tensor):
+            base = t.base
+            off = t.ptr - base.data_ptr()
+            raw = base.view(torch.uint8).reshape(-1)[off:off + t.nbytes]
+            return raw.view(tdt).reshape(t.shape if t.shape else (1,))
+        raise ValueError("DT has no torch base")
+
+    def upload(self, arr, dtype=None, out=None):
+        """numpy -> device (into ``out`` or a fresh arena tensor); float arrays go to the activation dtype
+        unless ``dtype`` says otherwise, integer arrays to int32."""
+        arr = np.asarray(arr)
+        if arr.dtype.kind in "iub":
+            dtype = "i32"
+            src = torch.from_numpy(np.ascontiguousarray(arr.astype(np.int32)))
+        else:
+            dtype = self.act_dtype if dtype is None else dtype
+            src = torch.from_numpy(np.ascontiguousarray(arr.astype(np.float32)))
+        if out is None:
+            out = self.empty(arr.shape, dtype)
+        with torch.cuda.stream(self.stream):
+            self.view(out).copy_(src.reshape(out.shape if out.shape else (1,)), non_blocking=False)
+        return out
+
+    def download(self, t):
+        with torch.cuda.stream(self.stream):
+            v = self.view(t).float() if t.dtype != "i32" else self.view(t)
+            out = v.cpu()
+        self.stream.synchronize()
+        return out.numpy().reshape(t.shape)
+
+    def sync(self):
+        self.check(self.lib.rcgan_stream_sync(self.h))
+
+    def zeros(self, shape, dtype=None):
+        t = self.empty(shape, dtype)
+        with torch.cuda.stream(self.stream):
+            self.view(t).zero_()
+        return t
+
+    # ------------------------------------------------------------------ tape
+    def record(self, fn):
+        if self.recording:
+            self.tape.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    def new_step(self):
+        self.tape = []
+        self.arena.reset()
+
+    # ------------------------------------------------------------------ graphs
+    def graph_begin(self):
+        self.check(self.lib.rcgan_graph_begin(self.h))
+
+    def graph_end(self):
+        gid = C.c_int(-1)
+        self.check(self.lib.rcgan_graph_end(self.h, C.byref(gid)))
+        return gid.value
+
+    def graph_launch(self, gid):
+        self.check(self.lib.rcgan_graph_launch(self.h, gid))
+
+    def event_record(self, slot):
+        self.check(self.lib.rcgan_event_record(self.h, slot))
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float(0)
+        self.check(self.lib.rcgan_event_elapsed_ms(self.h, a, b, C.byref(ms)))
+        return ms.value
+
+
+class ParamGroup:
+    """Flat fp32 slabs (value, grad, Adam m, Adam v) for one optimiser group."""
+
+    def __init__(self, ctx, specs):
+        """specs: list of (name, shape, init ndarray)."""
+        self.ctx = ctx
+        self.names, self.offsets, self.shapes = [], {}, {}
+        off = 0
+        for name, shape, _ in specs:
+            off = (off + 63) // 64 * 64
+            self.names.append(name)
+            self.offsets[name] = off
+            self.shapes[name] = tuple(shape)
+            n = 1
+            for s in shape:
+                n *= int(s)
+            off += n
+        self.count = max((off + 63) // 64 * 64, 64)
+        dev = ctx.device
+        self.value = torch.zeros(self.count, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.count, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self.count, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.count, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)      # {lr, t} read by the Adam kernel
+        self.hyper_host = torch.zeros(256, 2, dtype=torch.float32).pin_memory()   # ring: async H2D sources
+        self._hslot = 0
+        self.t = 0
+        host = np.zeros(self.count, np.float32)
+        for name, shape, init in specs:
+            o = self.offsets[name]
+            a = np.asarray(init, np.float32).reshape(-1)
+            host[o:o + a.size] = a
+        self.value.copy_(torch.from_numpy(host))
+        torch.cuda.synchronize()
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.ctx.stream)
+
+    def param(self, name):
+        o = self.offsets[name] * 4
+        p = DT(self.value.data_ptr() + o, self.shapes[name], L.F32, self.value, name)
+        p.grad = DT(self.grad.data_ptr() + o, self.shapes[name], L.F32, self.grad, name + ":grad")
+        return p
+
+    def get(self, name, which="value"):
+        o = self.offsets[name]
+        n = int(np.prod(self.shapes[name])) if self.shapes[name] else 1
+        with self._on_stream():
+            out = getattr(self, which)[o:o + n].detach().cpu()
+        self.ctx.stream.synchronize()
+        return out.numpy().reshape(self.shapes[name])
+
+    def set(self, name, arr, which="value"):
+        o = self.offsets[name]
+        a = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, np.float32).reshape(-1)))
+        with self._on_stream():
+            getattr(self, which)[o:o + a.numel()].copy_(a)
+
+    def zero_grad(self):
+        c = self.ctx
+        c.check(c.lib.rcgan_fill_f32(c.h, self.count, self.grad.data_ptr(), 0.0))
+
+    def set_hyper(self, lr, t):
+        self._hslot = (self._hslot + 1) % 256
+        src = self.hyper_host[self._hslot]
+        src[0] = float(lr)
+        src[1] = float(t)
+        with torch.cuda.stream(self.ctx.stream):
+            self.hyper.copy_(src, non_blocking=True)
+
+    def adam(self, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0, lo=0, hi=None):
+        c = self.ctx
+        hi = self.count if hi is None else hi
+        o = lo * 4
+        c.check(c.lib.rcgan_adam_tf(c.h, hi - lo, self.value.data_ptr() + o, self.grad.data_ptr() + o,
+                                    self.m.data_ptr() + o, self.v.data_ptr() + o, self.hyper.data_ptr(),
+                                    beta1, beta2, eps, clip, grad_scale))

@@ -1,0 +1,84 @@
+"""Variable store + name scopes: the host-side stand-in for tf.get_variable / tf.variable_scope.
+
+Variables are created up-front in the reference's creation order so that the
+flat parameter slabs can be laid out once; the L1 op shims then look them up by their TF name
+(``Discriminator/D.Block.1.Conv1/Filters`` ...), which is also the name used in checkpoints.
+"""
+import contextlib
+
+from . import ops as O
+
+_scope_stack = []
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    _scope_stack.append(name)
+    try:
+        yield "/".join(_scope_stack)
+    finally:
+        _scope_stack.pop()
+
+
+def scoped(name):
+    return "/".join(_scope_stack + [name])
+
+
+class Graph:
+    """What the L1 shims need to resolve a variable during one step: the parameter groups, the
+    non-trainable state (SN u, BN moving stats) and the spectral-norm results prefetched for this step."""
+
+    current = None
+
+    def __init__(self, ctx, groups, state):
+        self.ctx = ctx
+        self.groups = groups            # list of ParamGroup
+        self.state = state              # name -> persistent DT
+        self.trainable = set()          # group indices whose params require grad this step
+        self._params = {}
+        self.sn = {}                    # param name -> (Weight, update flag) prefetched this step
+        self.plain = {}                 # param name -> Weight (no SN), per step
+        self.index = {}
+        for gi, g in enumerate(groups):
+            for n in g.names:
+                self.index[n] = gi
+
+    def begin_step(self, trainable_groups):
+        self.trainable = set(trainable_groups)
+        self._params = {}
+        self.sn = {}
+        self.plain = {}
+        Graph.current = self
+
+    def param(self, name):
+        if name not in self._params:
+            if name not in self.index:
+                raise KeyError("Variable %s does not exist (variables are created up-front)" % name)
+            gi = self.index[name]
+            p = self.groups[gi].param(name)
+            p.req = gi in self.trainable
+            self._params[name] = p
+        return self._params[name]
+
+    def has(self, name):
+        return name in self.index
+
+    def prefetch_sn(self, entries):
+        """entries: list of (param name, u-state name, update).  One batched launch for all of them."""
+        ents = [(self.param(pn), self.state[un], upd) for pn, un, upd in entries]
+        ws = O.spectral_norm_batch(self.ctx, ents)
+        for (pn, _, upd), w in zip(entries, ws):
+            self.sn[pn] = (w, upd)
+
+    def sn_weight(self, pname, uname, update):
+        if pname not in self.sn:
+            self.prefetch_sn([(pname, uname, update)])
+        w, upd = self.sn[pname]
+        if bool(upd) != bool(update):
+            raise ValueError("spectral norm of %s was prefetched with update=%s but used with update=%s" % (pname, upd, update))
+        return w
+
+    def weight(self, pname):
+        if pname not in self.plain:
+            self.plain[pname] = O.Weight(self.ctx, self.param(pname), None)
+        return self.plain[pname]

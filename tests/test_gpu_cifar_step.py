@@ -1,0 +1,193 @@
+"""Step-level parity of the CIFAR RCGAN engine (HIP, through the C ABI) against the numpy oracle:
+identical initial weights, identical fed batch -> loss, every parameter gradient, SN ``u`` state and the
+Adam-updated weights after a D step and a G step.
+
+fp32 activations: per-tensor max error <= 2e-3 of that gradient's max magnitude (deep fp32 chains:
+~30 layers of accumulation-order noise; typical observed error is 1e-5..1e-4).
+bf16 activations (fp32 master weights / accumulation): norm-relative error <= 8e-2 per tensor -- bf16
+rounding (2^-9 per stored activation) random-walks through ~30 layers of forward and backward.
+"""
+import numpy as np
+import pytest
+
+from oracle import cifar as oc
+from tests.gpu_util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(rs, B, alpha=0.6):
+    C = oc.c_alpha(alpha)
+    Cinv = np.linalg.inv(C)
+    lab = rs.randint(10, size=B)
+    raw = dict(images=rs.randint(0, 256, size=(B, 3072)), noise=rs.uniform(0, 1 / 128., size=(B, 3072)).astype(np.float32),
+               labels=lab, labels_random=rs.randint(10, size=B), labels_biased=rs.randint(10, size=B),
+               inv_weights=Cinv[lab].astype(np.float32), z=rs.randn(B, 128).astype(np.float32))
+    g = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B),
+             z_G=rs.randn(2 * B, 128).astype(np.float32))
+    return C, raw, g
+
+
+def _make(alg, perm, B, dtype, use_graphs=False):
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN, create_variables
+    variables = create_variables(0, alg, perm, "linear", True, 0.2)
+    rs = np.random.RandomState(3)
+    # de-trivialise zero-initialised tensors (biases, condBN tables) so their gradients matter
+    gs, ds, cs, U = variables
+    def jitter(specs):
+        out = []
+        for n, shp, v in specs:
+            if n.endswith("/Biases") or n.endswith("/b") or "CondBatchNorm" in n:
+                v = (v + 0.1 * rs.randn(*shp)).astype(np.float32)
+            out.append((n, shp, v))
+        return out
+    variables = (jitter(gs), jitter(ds), cs, U)
+    m = CifarRCGAN(algorithm=alg, alpha=0.6, batch_size=B, dtype=dtype, perm_classifier=perm, perm_multiplier=1.0,
+                   use_graphs=use_graphs, device_rng=False, variables=variables, arena_bytes=2 << 30)
+    P = {n: v.copy() for n, _, v in variables[0] + variables[1] + variables[2]}
+    Uo = {k: v.copy() for k, v in U.items()}
+    return m, P, Uo
+
+
+def _labels_all(alg, raw):
+    second = raw["labels_random"] if alg in ("biased", "unbiased") else raw["labels_biased"]
+    return np.concatenate([raw["labels"], second])
+
+
+def _check(m, P, Uo, alg, perm, raw, gb, C, tol_kind):
+    from rcgan_amd import _lib as L
+    cfg = dict(algorithm=alg, C=C, perm_classifier=perm, perm_multiplier=1.0)
+    bf16 = m.ctx.act_dtype == L.BF16
+
+    def cmp(name, a, ref):
+        if bf16:
+            e = rel_err(a, ref)
+            assert np.isfinite(a).all() and e <= 8e-2, "%s: norm-rel err %.3e" % (name, e)
+        else:
+            assert_close(a, ref, 2e-3, name)
+
+    # ---- D step
+    m.set_inputs(labels_all=_labels_all(alg, raw), **raw)
+    m.d_step(iteration=0)
+    ob = dict(real=oc.preprocess_real(raw["images"], raw["noise"]), labels=raw["labels"], labels_random=raw["labels_random"],
+              labels_biased=raw["labels_biased"], inv_weights=raw["inv_weights"], z=raw["z"])
+    tr = oc.Trainer(P, Uo, cfg, lr=2e-4)
+    cost, grads = tr.d_step(0, ob)
+    d_loss, _ = m.losses()
+    assert abs(d_loss - cost) <= (5e-2 if bf16 else 2e-4) * max(1.0, abs(cost)), (d_loss, cost)
+    got = m.get_grads(m.PD)
+    for k, gref in grads.items():
+        cmp("D grad " + k, got[k], gref)
+    st = m.get_state()
+    for k in Uo:
+        assert_close(st[k], Uo[k], 2e-2 if bf16 else 1e-4, "u " + k)
+    newp = m.get_params()
+    for k in grads:
+        # Adam(beta1=0) moves each weight by ~lr*sign(g): compare the update, not the weight
+        upd, uref = newp[k] - m_init[k], P[k] - m_init[k]
+        if not bf16:
+            # a near-zero gradient can flip sign under fp32 noise and move that weight by 2*lr: allow a few
+            bad = np.mean(np.abs(upd - uref) > 0.1 * 2e-4)
+            assert bad < 0.02, "D update %s: %.3f of elements differ" % (k, bad)
+    # ---- G step
+    m.set_inputs(**gb)
+    m.g_step(iteration=1)
+    og = dict(labels_random_G=gb["labels_random_G"], labels_biased_G=gb["labels_biased_G"], z=gb["z_G"])
+    cost, grads = tr.g_step(1, og)
+    _, g_loss = m.losses()
+    assert abs(g_loss - cost) <= (5e-2 if bf16 else 2e-4) * max(1.0, abs(cost)), (g_loss, cost)
+    got = m.get_grads(m.PG)
+    if m.PC is not None:
+        got.update(m.get_grads(m.PC))
+    for k, gref in grads.items():
+        cmp("G grad " + k, got[k], gref)
+    st = m.get_state()
+    for k in Uo:
+        assert_close(st[k], Uo[k], 2e-2 if bf16 else 1e-4, "u(after G) " + k)
+
+
+m_init = {}
+
+
+@pytest.mark.parametrize("alg,perm", [("rcgan", False), ("rcgan-u", True), ("biased", False), ("unbiased", False)])
+def test_step_parity_fp32(alg, perm):
+    global m_init
+    rs = np.random.RandomState(21)
+    B = 4
+    C, raw, gb = _batches(rs, B)
+    m, P, Uo = _make(alg, perm, B, "f32")
+    m_init = {k: v.copy() for k, v in P.items()}
+    try:
+        _check(m, P, Uo, alg, perm, raw, gb, C, "f32")
+    finally:
+        m.ctx.close()
+
+
+@pytest.mark.parametrize("alg,perm", [("rcgan", False), ("rcgan-u", True)])
+def test_step_parity_bf16(alg, perm):
+    global m_init
+    rs = np.random.RandomState(22)
+    B = 8
+    C, raw, gb = _batches(rs, B)
+    m, P, Uo = _make(alg, perm, B, "bf16")
+    m_init = {k: v.copy() for k, v in P.items()}
+    try:
+        _check(m, P, Uo, alg, perm, raw, gb, C, "bf16")
+    finally:
+        m.ctx.close()
+
+
+def test_graph_replay_matches_eager():
+    """The captured hipGraph of a D step / G step must reproduce the eager launches bit for bit."""
+    rs = np.random.RandomState(23)
+    B = 4
+    C, raw, gb = _batches(rs, B)
+    outs = []
+    for graphs in (False, True):
+        m, P, Uo = _make("rcgan", False, B, "bf16", use_graphs=graphs)
+        try:
+            for it in range(3):      # graph mode: warm-up+capture on call 1, replays on calls 2 and 3
+                m.set_inputs(labels_all=_labels_all("rcgan", raw), **raw)
+                m.d_step(iteration=it)
+                m.set_inputs(**gb)
+                m.g_step(iteration=it)
+            outs.append((m.get_params(), m.losses()))
+        finally:
+            m.ctx.close()
+    (pa, la), (pb, lb) = outs
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+
+
+def test_multi_step_trajectory_fp32():
+    """3 iterations of [G step, 2 D steps] track the oracle (weights after Adam)."""
+    rs = np.random.RandomState(24)
+    B = 4
+    m, P, Uo = _make("rcgan", False, B, "f32")
+    C = oc.c_alpha(0.6)
+    tr = oc.Trainer(P, Uo, dict(algorithm="rcgan", C=C), lr=2e-4)
+    try:
+        for it in range(2):
+            _, raw, gb = _batches(rs, B)
+            if it > 0:
+                m.set_inputs(**gb)
+                m.g_step(iteration=it)
+                tr.g_step(it, dict(labels_random_G=gb["labels_random_G"], labels_biased_G=gb["labels_biased_G"], z=gb["z_G"]))
+            for _ in range(2):
+                m.set_inputs(labels_all=_labels_all("rcgan", raw), **raw)
+                m.d_step(iteration=it)
+                tr.d_step(it, dict(real=oc.preprocess_real(raw["images"], raw["noise"]), labels=raw["labels"],
+                                   labels_random=raw["labels_random"], labels_biased=raw["labels_biased"],
+                                   inv_weights=raw["inv_weights"], z=raw["z"]))
+        newp = m.get_params()
+        worst = 0.0
+        for k in P:
+            worst = max(worst, float(np.abs(newp[k] - P[k]).max()))
+        # lr = 2e-4, <= 4 Adam updates per tensor: a sign flip of a near-zero gradient moves a weight by 2*lr
+        assert worst <= 1e-3, worst
+        far = np.mean([np.mean(np.abs(newp[k] - P[k]) > 1e-4) for k in P])
+        assert far < 0.02, far
+    finally:
+        m.ctx.close()

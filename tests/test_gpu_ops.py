@@ -1,0 +1,479 @@
+"""Per-op parity: every HIP kernel, called through the C ABI, against the numpy oracle on the same
+seeded inputs.  fp32 activations: tolerance 2e-5 of the reference's scale (fp32 accumulation-order
+noise only).  bf16 activations: inputs are rounded to bf16 on the host first, so what remains is fp32
+accumulation order + one bf16 rounding of the stored result: tolerance 1e-2 (bf16 has 8 mantissa bits,
+half-ulp 2^-9 = 0.2 %; sums of a few roundings stay well under 1 %)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.gpu_util import FakeParam, assert_close, bf16_round, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-5, "bf16": 1e-2}
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16"])
+def dev(request):
+    ctx = make_ctx(request.param)
+    yield ctx, request.param
+    ctx.close()
+
+
+def _prep(a, mode):
+    return bf16_round(a) if mode == "bf16" else np.asarray(a, np.float32)
+
+
+def test_selftest_layouts(dev):
+    ctx, _ = dev
+    assert ctx.uses_tr_read in (0, 1)
+    print("ds_read_b64_tr_b16 path in use:", ctx.uses_tr_read)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, in_up, in_relu
+    (2, 9, 7, 3, 5, 3, 1, False, False),
+    (2, 28, 28, 1, 8, 5, 2, False, False),
+    (3, 7, 7, 6, 4, 5, 2, False, True),
+    (2, 4, 4, 5, 3, 5, 2, False, False),
+    (2, 8, 8, 16, 8, 1, 1, False, False),
+    (2, 8, 8, 4, 6, 3, 1, True, True),
+    (2, 8, 8, 64, 64, 3, 1, False, False),      # MFMA 64x64 tile (bf16)
+    (3, 5, 5, 64, 128, 3, 1, False, True),      # MFMA, M tail (75 pixels)
+    (2, 16, 16, 128, 128, 3, 1, False, True),   # MFMA + MFMA filter gradient
+    (1, 8, 8, 128, 256, 3, 1, True, False),     # MFMA with folded upsample
+    (2, 8, 8, 256, 128, 1, 1, False, False),    # MFMA 1x1
+    (5, 32, 32, 128, 128, 3, 1, False, True),   # MFMA 128x128 tile (M = 5120 -> 40 blocks < 384 -> 64 tile) ...
+    (48, 32, 32, 128, 128, 3, 1, False, False), # ... and M = 49152 -> 384 blocks of 128x128
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, case):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    n, h, w, cin, cout, k, s, up, relu = case
+    if mode == "f32" and n * h * w * cin > 2 ** 21:
+        pytest.skip("large case only exercises the MFMA tiles (bf16)")
+    rs = np.random.RandomState(hash(case) % 2 ** 31)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = _prep(rs.randn(n, hs, ws, cin), mode)
+    wgt = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    sigma = np.float32(1.7)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    wp, bp = FakeParam(ctx, wgt), FakeParam(ctx, b)
+    sg = ctx.upload(np.array([sigma], np.float32), L.F32)
+    W = O.Weight(ctx, wp.t, sg)
+    y = O.conv2d(ctx, xd, W, bp.t, k, s, in_up=up, in_relu=relu)
+    # oracle: same bf16-rounded filter the MFMA path uses (direct path keeps the filter in fp32)
+    mf = mode == "bf16" and s == 1 and k in (1, 3) and cin % 64 == 0 and cout % 64 == 0
+    w_eff = (wgt / sigma)
+    w_eff = bf16_round(w_eff) if mf else w_eff
+    xin = np.maximum(x, 0) if relu else x
+    xin = nn.upsample2(xin) if up else xin
+    ref = nn.conv2d_fwd(xin.astype(np.float64), w_eff.astype(np.float64), s) + b
+    assert_close(ctx.download(y), ref, TOL[mode], "conv fwd %s" % (case,))
+    dy = _prep(rs.randn(*ref.shape), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    dxin = nn.conv2d_bwd_input(dy.astype(np.float64), w_eff.astype(np.float64), xin.shape, s)
+    if up:
+        dxin = nn.upsample2_bwd(dxin)
+    if relu:
+        dxin = dxin * (x > 0)
+    assert_close(ctx.download(xd.grad), dxin, TOL[mode], "conv dgrad %s" % (case,))
+    dw_bar = nn.conv2d_bwd_filter(xin.astype(np.float64), dy.astype(np.float64), wgt.shape, s)
+    assert_close(ctx.download(W.dwbar), dw_bar, 2e-4 if mode == "bf16" else TOL[mode], "conv wgrad %s" % (case,))
+    assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "conv dbias %s" % (case,))
+
+
+def test_conv_accumulate_and_force_direct(dev):
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(5)
+    x = _prep(rs.randn(2, 8, 8, 64), mode)
+    w1 = (rs.randn(1, 1, 64, 64) / 8).astype(np.float32)
+    w3 = (rs.randn(3, 3, 64, 64) / 24).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    p1, p3 = FakeParam(ctx, w1), FakeParam(ctx, w3)
+    t = O.conv2d(ctx, xd, O.Weight(ctx, p1.t), None, 1)
+    t = O.conv2d(ctx, xd, O.Weight(ctx, p3.t), None, 3, accumulate_into=t)
+    t2 = O.conv2d(ctx, xd, O.Weight(ctx, p1.t), None, 1, force_direct=True)
+    t2 = O.conv2d(ctx, xd, O.Weight(ctx, p3.t), None, 3, accumulate_into=t2, force_direct=True)
+    ref = nn.conv2d_fwd(x.astype(np.float64), w1.astype(np.float64)) + nn.conv2d_fwd(x.astype(np.float64), w3.astype(np.float64))
+    assert_close(ctx.download(t2), ref, TOL[mode], "direct accumulate")
+    assert_close(ctx.download(t), ref, 2e-2 if mode == "bf16" else TOL[mode], "mfma accumulate")
+
+
+@pytest.mark.parametrize("hin,cin,cout", [(7, 10, 6), (14, 138, 1), (7, 138, 128)])
+def test_deconv(dev, hin, cin, cout):
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(hin + cin)
+    n = 3
+    x = _prep(rs.randn(n, hin, hin, cin), mode)
+    w = (rs.randn(5, 5, cout, cin) * 0.05).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    wp, bp = FakeParam(ctx, w), FakeParam(ctx, b)
+    oshape = (n, 2 * hin, 2 * hin, cout)
+    y = O.deconv2d(ctx, xd, wp.t, bp.t, oshape)
+    ref = nn.conv2d_transpose_fwd(x.astype(np.float64), w.astype(np.float64), oshape, 2) + b
+    assert_close(ctx.download(y), ref, TOL[mode], "deconv fwd")
+    dy = _prep(rs.randn(*oshape), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert_close(ctx.download(xd.grad), nn.conv2d_transpose_bwd_input(dy.astype(np.float64), w.astype(np.float64), 2), TOL[mode], "deconv dx")
+    assert_close(wp.grad(ctx), nn.conv2d_transpose_bwd_filter(x.astype(np.float64), dy.astype(np.float64), w.shape, 2), 2e-4, "deconv dw")
+    assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "deconv db")
+
+
+@pytest.mark.parametrize("m,k,n", [(5, 110, 1024), (64, 128, 16384), (7, 128, 1), (9, 300, 128), (4, 3072, 10)])
+def test_linear(dev, m, k, n):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(m * 7 + n)
+    x = _prep(rs.randn(m, k), mode)
+    w = (rs.randn(k, n) / np.sqrt(k)).astype(np.float32)
+    b = rs.randn(n).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    wp, bp = FakeParam(ctx, w), FakeParam(ctx, b)
+    sg = ctx.upload(np.array([0.8], np.float32), L.F32)
+    W = O.Weight(ctx, wp.t, sg)
+    y = O.linear(ctx, xd, W, bp.t)
+    we = w.astype(np.float64) / np.float32(0.8)
+    ref = x.astype(np.float64) @ we + b
+    assert_close(ctx.download(y), ref, TOL[mode], "linear fwd")
+    dy = _prep(rs.randn(m, n), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert_close(ctx.download(xd.grad), dy.astype(np.float64) @ we.T, TOL[mode], "linear dx")
+    assert_close(ctx.download(W.dwbar), x.astype(np.float64).T @ dy.astype(np.float64), 2e-4, "linear dw")
+    assert_close(bp.grad(ctx), dy.astype(np.float64).sum(0), 2e-4, "linear db")
+
+
+@pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False)])
+def test_batch_norm(dev, shape, cond):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(len(shape) * 100 + shape[-1])
+    c = shape[-1]
+    x = _prep(rs.randn(*shape) * 1.5 + 0.3, mode)
+    nl = 10 if cond else 1
+    gamma = (1 + 0.3 * rs.randn(nl, c)).astype(np.float32)
+    beta = (0.2 * rs.randn(nl, c)).astype(np.float32)
+    labels = rs.randint(nl, size=shape[0]).astype(np.int32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    gp, bp = FakeParam(ctx, gamma), FakeParam(ctx, beta)
+    act = L.ACT_RELU if cond else L.ACT_LRELU
+    mm = ctx.upload(np.zeros(c, np.float32), L.F32)
+    mv = ctx.upload(np.ones(c, np.float32), L.F32)
+    lab = ctx.upload(labels) if cond else None
+    y = O.batch_norm_act(ctx, xd, gp.t, bp.t, act=act, labels=lab, n_labels=nl, moving=None if cond else (mm, mv))
+    x64 = x.astype(np.float64)
+    x4 = x64 if x64.ndim == 4 else x64.reshape(shape[0], 1, 1, c)
+    if cond:
+        pre, st = nn.cond_batchnorm_fwd(x4, labels, gamma.astype(np.float64), beta.astype(np.float64))
+        ref = np.maximum(pre, 0)
+    else:
+        pre, st, mm2, mv2 = nn.batch_norm_train_fwd(x4, gamma[0].astype(np.float64), beta[0].astype(np.float64), np.zeros(c), np.ones(c))
+        ref = np.maximum(pre, 0.2 * pre)
+        assert_close(ctx.download(mm), mm2, 1e-5, "moving mean")
+        assert_close(ctx.download(mv), mv2, 1e-5, "moving var")
+    assert_close(ctx.download(y).reshape(x4.shape), ref, TOL[mode], "bn fwd")
+    dy = _prep(rs.randn(*shape), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    yq = bf16_round(ref) if mode == "bf16" else ref      # the kernel takes the activation mask from the stored y
+    dpre = dy.astype(np.float64).reshape(x4.shape) * (np.where(yq > 0, 1.0, 0.0) if cond else np.where(yq > 0, 1.0, 0.2))
+    if cond:
+        dx, dg, db = nn.cond_batchnorm_bwd(dpre, x4, labels, gamma.astype(np.float64), st)
+    else:
+        dx, dg, db = nn.batch_norm_train_bwd(dpre, x4, gamma[0].astype(np.float64), st)
+        dg, db = dg[None], db[None]
+    assert_close(ctx.download(xd.grad).reshape(x4.shape), dx, TOL[mode] * 2, "bn dx")
+    assert_close(gp.grad(ctx), dg, 2e-4, "bn dgamma")
+    assert_close(bp.grad(ctx), db, 2e-4, "bn dbeta")
+
+
+def test_batch_norm_infer(dev):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(3)
+    x = _prep(rs.randn(5, 7, 7, 128), mode)
+    g, b, mm, mv = (rs.rand(128).astype(np.float32) + 0.5 for _ in range(4))
+    ctx.new_step()
+    up = lambda a: ctx.upload(a, L.F32)
+    y = O.batch_norm_infer(ctx, ctx.upload(x), up(g), up(b), up(mm), up(mv), act=L.ACT_RELU)
+    ref = np.maximum(nn.batch_norm_infer(x.astype(np.float64), g, b, mm, mv), 0)
+    assert_close(ctx.download(y), ref, TOL[mode], "bn infer")
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3, 128), (3, 3, 128, 128), (1, 1, 128, 128), (128, 1), (300, 128), (3072, 10), (5, 5, 64, 64)])
+def test_spectral_norm(dev, shape):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "bf16":
+        pytest.skip("spectral norm is fp32 regardless of the activation dtype")
+    rs = np.random.RandomState(shape[0] * 13 + shape[-1])
+    w = (rs.randn(*shape) * 0.1).astype(np.float32)
+    u = rs.randn(1, shape[-1]).astype(np.float32)
+    ctx.new_step()
+    wp = FakeParam(ctx, w)
+    ud = ctx.persistent((shape[-1],), L.F32)
+    ctx.view(ud).copy_(torch.from_numpy(u.reshape(-1)))
+    torch.cuda.synchronize()
+    (W,) = O.spectral_norm_batch(ctx, [(wp.t, ud, True)])
+    wbar, sigma, u2, cache = nn.spectral_norm_fwd(w.astype(np.float64), u.astype(np.float64))
+    assert_close(ctx.download(W.sigma), np.array([sigma]), 1e-5, "sigma")
+    assert_close(ctx.download(ud), u2.reshape(-1), 1e-5, "u'")
+    g = rs.randn(*shape).astype(np.float32)
+    dwb = W.grad_target()
+    ctx.upload(g, L.F32, out=dwb)
+    ctx.backward()
+    ref = nn.spectral_norm_bwd(g.astype(np.float64), w.astype(np.float64), u.astype(np.float64), cache)
+    assert_close(wp.grad(ctx), ref, 5e-5, "sn backward")
+    # NO_OPS: u untouched
+    ctx.new_step()
+    before = ctx.download(ud).copy()
+    O.spectral_norm_batch(ctx, [(wp.t, ud, False)])
+    assert np.array_equal(ctx.download(ud), before)
+
+
+def test_elementwise_and_resampling(dev):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(9)
+    x = _prep(rs.randn(3, 8, 6, 10), mode)
+    dy_full = _prep(rs.randn(3, 8, 6, 10), mode)
+    for kind, f, df in ((L.ACT_RELU, lambda v: np.maximum(v, 0), lambda v, y: (v > 0) * 1.0),
+                        (L.ACT_LRELU, lambda v: np.maximum(v, 0.2 * v), lambda v, y: np.where(v > 0, 1.0, 0.2)),
+                        (L.ACT_TANH, np.tanh, lambda v, y: 1 - y * y),
+                        (L.ACT_SIGMOID, lambda v: 1 / (1 + np.exp(-v)), lambda v, y: y * (1 - y))):
+        ctx.new_step()
+        xd = ctx.upload(x)
+        xd.req = True
+        y = O.act(ctx, xd, kind)
+        ref = f(x.astype(np.float64))
+        assert_close(ctx.download(y), ref, TOL[mode], "act %d" % kind)
+        y.grad = ctx.upload(dy_full)
+        ctx.backward()
+        yq = bf16_round(ref) if mode == "bf16" else ref
+        assert_close(ctx.download(xd.grad), dy_full * df(x.astype(np.float64), yq), TOL[mode], "act bwd %d" % kind)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    y = O.meanpool2(ctx, xd)
+    assert_close(ctx.download(y), nn.meanpool2(x.astype(np.float64)), TOL[mode], "meanpool")
+    dy = _prep(rs.randn(3, 4, 3, 10), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert_close(ctx.download(xd.grad), nn.meanpool2_bwd(dy.astype(np.float64)), TOL[mode], "meanpool bwd")
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    y = O.upsample2(ctx, xd)
+    assert np.array_equal(ctx.download(y), nn.upsample2(x))
+    dy = _prep(rs.randn(3, 16, 12, 10), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert_close(ctx.download(xd.grad), nn.upsample2_bwd(dy.astype(np.float64)), TOL[mode], "upsample bwd")
+    ctx.new_step()
+    a, b = ctx.upload(x), ctx.upload(dy_full)
+    a.req = b.req = True
+    y = O.add(ctx, a, b)
+    assert_close(ctx.download(y), x.astype(np.float64) + dy_full, TOL[mode], "add")
+    y.grad = ctx.upload(x)
+    ctx.backward()
+    assert np.array_equal(ctx.download(a.grad), x) and np.array_equal(ctx.download(b.grad), x)
+    # conv_cond_concat
+    ctx.new_step()
+    yb = np.eye(10, dtype=np.float32)[rs.randint(10, size=3)]
+    xd = ctx.upload(x)
+    xd.req = True
+    y = O.concat_channels(ctx, xd, ctx.upload(yb, L.F32))
+    ref = np.concatenate([x, np.broadcast_to(yb[:, None, None, :], (3, 8, 6, 10))], axis=3)
+    assert np.array_equal(ctx.download(y), ref)
+    dy = _prep(rs.randn(3, 8, 6, 20), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert np.array_equal(ctx.download(xd.grad), dy[..., :10])
+
+
+def test_preprocess_cifar(dev):
+    from oracle import cifar as oc
+    ctx, mode = dev
+    rs = np.random.RandomState(1)
+    img = rs.randint(0, 256, size=(4, 3072))
+    noise = rs.uniform(0, 1 / 128., size=(4, 3072)).astype(np.float32)
+    ctx.new_step()
+    out = ctx.empty((4, 3072))
+    ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, 4, ctx.upload(img).ptr, ctx.upload(noise, 0).ptr, out.dtype, out.ptr))
+    assert_close(ctx.download(out), oc.preprocess_real(img, noise), 4e-3 if mode == "bf16" else 1e-6, "preprocess")
+
+
+def test_head_and_losses(dev):
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(17)
+    n, d, v = 6, 128, 10
+    x = _prep(rs.randn(n, 8, 8, d), mode)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    feat = O.act_meanhw(ctx, xd, L.ACT_RELU)
+    fref = np.maximum(x.astype(np.float64), 0).mean(axis=(1, 2))
+    assert_close(ctx.download(feat), fref, 1e-5, "act_meanhw")
+    table = FakeParam(ctx, rs.randn(v, 300) * 0.08)
+    labels = rs.randint(v, size=n).astype(np.int32)
+    lab = ctx.upload(labels)
+    e = O.gather_rows(ctx, table.t, lab, n)
+    assert np.array_equal(ctx.download(e), ctx.download(table.t)[labels])
+    wemb = FakeParam(ctx, rs.randn(300, d) * 0.05)
+    bemb = FakeParam(ctx, rs.randn(d) * 0.05)
+    emb = O.linear(ctx, e, O.Weight(ctx, wemb.t), bemb.t)
+    wpsi = FakeParam(ctx, rs.randn(d, 1) * 0.1)
+    bpsi = FakeParam(ctx, rs.randn(1))
+    psi = O.reshape(ctx, O.linear(ctx, feat, O.Weight(ctx, wpsi.t), bpsi.t), (-1,))
+    logit = O.proj_logit(ctx, feat, psi, emb)
+    T = ctx.download(table.t).astype(np.float64)
+    We, be, Wp, bpv = (ctx.download(p.t).astype(np.float64) for p in (wemb, bemb, wpsi, bpsi))
+    emb_ref = T[labels] @ We + be
+    psi_ref = (fref @ Wp + bpv).reshape(-1)
+    lref = psi_ref + (fref * emb_ref).sum(1)
+    assert_close(ctx.download(logit), lref, 2e-5, "proj logit")
+    loss = ctx.persistent((1,), L.F32, fill=0.0)
+    real, fake = O.rows(ctx, logit, 0, 3), O.rows(ctx, logit, 3, 6)
+    O.loss_term(ctx, L.LOSS_HINGE_REAL, real, 1.0, loss)
+    O.loss_term(ctx, L.LOSS_HINGE_FAKE, fake, 0.5, loss)
+    lossref = np.maximum(1 - lref[:3], 0).mean() + 0.5 * np.maximum(1 + lref[3:], 0).mean()
+    assert_close(ctx.download(loss), np.array([lossref]), 1e-5, "hinge loss")
+    ctx.backward()
+    dl = np.concatenate([-(1 - lref[:3] > 0) / 3.0, 0.5 * (1 + lref[3:] > 0) / 3.0])
+    dfeat = dl[:, None] * emb_ref + dl[:, None] * Wp.reshape(1, -1)
+    dx = np.broadcast_to(dfeat[:, None, None, :] / 64.0, x.shape) * (x > 0)
+    assert_close(ctx.download(xd.grad), dx, TOL[mode], "head dx")
+    demb = dl[:, None] * fref
+    assert_close(wemb.grad(ctx), T[labels].T @ demb, 1e-4, "dW_emb")
+    dT = np.zeros_like(T)
+    np.add.at(dT, labels, demb @ We.T)
+    assert_close(table.grad(ctx), dT, 1e-4, "d embedding_map")
+    assert_close(wpsi.grad(ctx), fref.T @ dl[:, None], 1e-4, "dW_psi")
+
+    # rcgan-u pieces: all-label logits, learned confusion softmax, weighted loss, perm BCE
+    ctx.new_step()
+    feat = FakeParam(ctx, rs.randn(n, d))
+    psi = FakeParam(ctx, rs.randn(n))
+    E = FakeParam(ctx, rs.randn(v, d) * 0.1)
+    cl = FakeParam(ctx, rs.randn(v, v))
+    E.t.grad = None          # in the model E is an activation (output of the projection Linear)
+    lg = O.proj_logit_all(ctx, feat.t, psi.t, E.t)
+    F_, P_, E_, CL = (ctx.download(p.t).astype(np.float64) for p in (feat, psi, E, cl))
+    lgref = P_[:, None] + F_ @ E_.T
+    assert_close(ctx.download(lg), lgref, 2e-5, "all-label logits")
+    C = O.softmax_rows(ctx, cl.t)
+    Cref = nn.softmax_rows(CL)
+    yc = O.gather_rows(ctx, C, lab, n)
+    loss = ctx.persistent((1,), L.F32, fill=0.0)
+    O.loss_term(ctx, L.LOSS_HINGE_FAKE, lg, 1.0, loss, wts=yc)
+    ycref = Cref[labels]
+    term = np.maximum(1 + lgref, 0)
+    assert_close(ctx.download(loss), np.array([(term * ycref).sum(1).mean()]), 1e-5, "weighted hinge")
+    ctx.backward()
+    dlg = (1 + lgref > 0) * ycref / n
+    assert_close(feat.grad(ctx), dlg @ E_, 1e-4, "dfeat all")
+    assert_close(E.grad(ctx), dlg.T @ F_, 1e-4, "dE")
+    assert_close(psi.grad(ctx), dlg.sum(1), 1e-4, "dpsi all")
+    dC = np.zeros_like(Cref)
+    np.add.at(dC, labels, term / n)
+    assert_close(cl.grad(ctx), nn.softmax_rows_bwd(dC, Cref), 1e-4, "d confusion_logits")
+    ctx.new_step()
+    xl = FakeParam(ctx, rs.randn(n, v) * 3)
+    loss = ctx.persistent((1,), L.F32, fill=0.0)
+    O.bce_onehot_term(ctx, xl.t, lab, 2.0, loss)
+    X = ctx.download(xl.t).astype(np.float64)
+    Z = np.eye(v)[labels]
+    assert_close(ctx.download(loss), np.array([2.0 * nn.sigmoid_ce_logits(X, Z).mean()]), 1e-5, "bce")
+    assert_close(ctx.download(xl.t.grad), 2.0 * nn.sigmoid_ce_logits_bwd(X, Z) / X.size, 1e-5, "bce grad")
+    for kind, z in ((L.LOSS_CE_ONES, 1.0), (L.LOSS_CE_ZEROS, 0.0), (L.LOSS_NEG_MEAN, None)):
+        ctx.new_step()
+        xl = FakeParam(ctx, rs.randn(n) * 3)
+        xl.t.grad = None
+        loss = ctx.persistent((1,), L.F32, fill=0.0)
+        O.loss_term(ctx, kind, xl.t, 1.0, loss)
+        X = ctx.download(xl.t).astype(np.float64)
+        if z is None:
+            lr_, gr_ = -X.mean(), -np.ones_like(X) / n
+        else:
+            lr_, gr_ = nn.sigmoid_ce_logits(X, z).mean(), nn.sigmoid_ce_logits_bwd(X, z) / n
+        assert_close(ctx.download(loss), np.array([lr_]), 1e-5, "loss kind %d" % kind)
+        assert_close(ctx.download(xl.t.grad), gr_, 1e-5, "loss grad kind %d" % kind)
+
+
+def test_adam_tf(dev):
+    from rcgan_amd import _lib as L
+    from rcgan_amd.runtime import ParamGroup
+    ctx, mode = dev
+    if mode == "bf16":
+        pytest.skip("optimiser state is fp32 regardless of the activation dtype")
+    rs = np.random.RandomState(2)
+    w0 = rs.randn(1000).astype(np.float32)
+    pg = ParamGroup(ctx, [("w", (1000,), w0)])
+    w, m, v = w0.copy(), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    for t in range(1, 4):
+        g = rs.randn(1000).astype(np.float32)
+        pg.set("w", g, "grad")
+        pg.set_hyper(2e-4, t)
+        pg.adam(0.5, 0.999, clip=1.0, grad_scale=0.5)
+        w, m, v = nn.adam_tf(w, g * np.float32(0.5), m, v, t, 2e-4, 0.5, 0.999, clip=1.0)
+    ctx.sync()
+    assert_close(pg.get("w"), w, 1e-6, "adam w")
+    assert_close(pg.get("w", "m"), m, 1e-6, "adam m")
+    assert_close(pg.get("w", "v"), v, 1e-6, "adam v")
+
+
+def test_rng_and_graph_replay(dev):
+    import ctypes as C
+    from rcgan_amd import _lib as L
+    ctx, mode = dev
+    if mode == "bf16":
+        pytest.skip("one dtype is enough")
+    n = 1 << 16
+    buf = ctx.persistent((n,), L.F32)
+    state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+    torch.cuda.synchronize()
+    draw = lambda kind, lo, hi: ctx.check(ctx.lib.rcgan_rng_fill(ctx.h, n, L.F32, kind, lo, hi, 1234, C.c_void_p(state.data_ptr()), C.c_void_p(buf.ptr)))
+    draw(0, 0.0, 1.0 / 128)
+    u = ctx.download(buf).copy()
+    assert 0 <= u.min() and u.max() < 1.0 / 128 and abs(u.mean() * 256 - 1) < 0.02
+    draw(1, 0.0, 1.0)
+    z = ctx.download(buf).copy()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    ctx.sync()
+    ctx.graph_begin()
+    draw(1, 0.0, 1.0)
+    gid = ctx.graph_end()
+    ctx.graph_launch(gid)
+    a = ctx.download(buf).copy()
+    ctx.graph_launch(gid)
+    b = ctx.download(buf).copy()
+    assert not np.array_equal(a, b) and not np.array_equal(a, z)
