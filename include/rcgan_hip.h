@@ -139,11 +139,11 @@ int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int dt
                        const int32_t* labels, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, int act, void* y);
 /* Backward of stats+apply (gradient flows through the batch statistics).  dgamma/dbeta: [n_labels][c]
- * (= or += by accumulate).  y is the forward output (gives the activation mask). */
+ * (= or += by accumulate); dx = or += by accumulate_dx.  y is the forward output (activation mask). */
 int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype,
                  const void* x, const void* y, const void* dy, const int32_t* labels,
                  const float* gamma, const float* mean, const float* rstd, int act,
-                 void* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
+                 void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
 /* Inference-mode batch norm with moving statistics (gen_sampler, mnist/model.py:745-754). */
 int rcgan_bn_infer(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, const float* gamma,
                    const float* beta, const float* moving_mean, const float* moving_var, float eps,

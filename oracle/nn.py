@@ -256,10 +256,16 @@ def adam_tf(w, g, m, v, t, lr, beta1, beta2, eps=1e-8, clip=None):
     bias correction).  ``clip``: variable constraint applied right after the update
     (mnist/ops.py:102-111, tf.clip_by_value(x,-1,1))."""
     dt = w.dtype.type
-    lr_t = dt(lr) * np.sqrt(dt(1.0) - dt(beta2) ** dt(t)) / (dt(1.0) - dt(beta1) ** dt(t))
-    m = dt(beta1) * m + dt(1.0 - beta1) * g
-    v = dt(beta2) * v + dt(1.0 - beta2) * g * g
-    w = w - lr_t * m / (np.sqrt(v) + dt(eps))
+    # arithmetic form of TF's ApplyAdam kernel (tensorflow/core/kernels/training_ops.cc):
+    #   alpha = lr*sqrt(1-beta2_power)/(1-beta1_power); m += (g-m)*(1-b1); v += (g^2-v)*(1-b2);
+    #   var -= (m*alpha)/(sqrt(v)+eps); beta powers are variables multiplied by beta once per step.
+    b1p, b2p = dt(1.0), dt(1.0)
+    for _ in range(int(t)):
+        b1p, b2p = dt(b1p * dt(beta1)), dt(b2p * dt(beta2))
+    alpha = dt(lr) * np.sqrt(dt(1.0) - b2p) / (dt(1.0) - b1p)
+    m = m + (g - m) * (dt(1.0) - dt(beta1))
+    v = v + (g * g - v) * (dt(1.0) - dt(beta2))
+    w = w - (m * alpha) / (np.sqrt(v) + dt(eps))
     if clip is not None:
         w = np.clip(w, -clip, clip)
     return w, m, v

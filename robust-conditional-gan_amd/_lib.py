@@ -74,7 +74,7 @@ SIGNATURES = {
     "rcgan_bn_workspace_bytes": (SZ, [I, I]),
     "rcgan_bn_stats": (I, [P, I, I, I, P, F, P, P, P, P, F, P, SZ]),
     "rcgan_bn_apply_fwd": (I, [P, I, I, I, I, P, P, P, P, P, P, I, P]),
-    "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, I, P, SZ]),
+    "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, SZ]),
     "rcgan_bn_infer": (I, [P, I, I, I, P, P, P, P, P, F, I, P]),
     "rcgan_sn_save_floats": (SZ, [I, I]),
     "rcgan_sn_power_iter": (I, [P, C.POINTER(SnItem), I]),
@@ -122,6 +122,9 @@ def load():
         raise RuntimeError(
             "librcgan_hip.so is missing (%s): build it with robust-conditional-gan_amd/csrc/build.sh "
             "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    # torch first: it bundles its own libamdhip64.so.7 and librcgan_hip.so must bind to the SAME HIP
+    # runtime (one SONAME, first loader wins); two runtimes in a process cannot share streams or pointers
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol

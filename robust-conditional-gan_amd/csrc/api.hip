@@ -21,13 +21,16 @@ __global__ void slab_reduce2_kernel(const float* slab, float* out, long count, i
 
 __global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
                                float beta2, float eps, float clip, float grad_scale) {
+  // the arithmetic form of TF's ApplyAdam kernel: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
+  // m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); w -= (m*alpha)/(sqrt(v)+eps), all in fp32
   const float lr = hyper[0], t = hyper[1];
-  const float lr_t = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
+  const float alpha = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i] * grad_scale;
-    float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    float wi = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+    float mi = m[i] + (gi - m[i]) * omb1;
+    float vi = v[i] + (gi * gi - v[i]) * omb2;
+    float wi = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
     if (clip > 0.f) wi = fminf(fmaxf(wi, -clip), clip);
     m[i] = mi; v[i] = vi; w[i] = wi;
   }

@@ -113,7 +113,7 @@ __global__ void bn_bwd_combine_kernel(int c, int ngroups, int n_labels, const in
 template <typename T>
 __global__ void bn_bwd_apply_kernel(long total, long rows, int rows_per_sample, int c, const T* x, const T* y, const T* dy,
                                     const int32_t* labels, const float* gamma, const float* mean, const float* rstd,
-                                    const float* s12, int act, T* dx) {
+                                    const float* s12, int act, T* dx, int accumulate_dx) {
   const float invM = 1.f / (float)rows;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int ch = (int)(i % c);
@@ -125,6 +125,7 @@ __global__ void bn_bwd_apply_kernel(long total, long rows, int rows_per_sample, 
     float xh = (Elem<T>::ld(x + i) - mean[ch]) * rs;
     float dxh = g * gamma[(long)l * c + ch];
     float v = rs * (dxh - s12[ch] * invM - xh * s12[c + ch] * invM);
+    if (accumulate_dx) v += Elem<T>::ld(dx + i);
     Elem<T>::st(dx + i, v);
   }
 }
@@ -190,7 +191,7 @@ int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int dt
 
 int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x, const void* y,
                  const void* dy, const int32_t* labels, const float* gamma, const float* mean, const float* rstd, int act,
-                 void* dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+                 void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
   RC_REQUIRE(ctx, n_labels >= 1 && n_labels <= MAX_LABELS, "n_labels %d", n_labels);
   RC_REQUIRE(ctx, labels != nullptr || n_labels == 1, "labels required for n_labels > 1");
   long rows = (long)n * rows_per_sample;
@@ -212,7 +213,7 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
   long total = rows * c;
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total, rows,
                                                    rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, mean,
-                                                   rstd, (const float*)s12, act, (T*)dx));
+                                                   rstd, (const float*)s12, act, (T*)dx, accumulate_dx));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

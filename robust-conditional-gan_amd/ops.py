@@ -241,8 +241,7 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
             dy = y.grad
             if dy is None:
                 return
-            assert x.grad is None, "batch-norm input gradient is written once"
-            dx, _ = grad_of(ctx, x)
+            dx, acc_dx = grad_of(ctx, x)
             # parameter gradients always accumulate into the (zeroed) slab; frozen params get a scratch
             if gamma.req:
                 dg, db = gamma.grad, beta.grad
@@ -250,7 +249,7 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
                 dg = zeros_like_grad(ctx, gamma)
                 db = zeros_like_grad(ctx, beta)
             ctx.check(ctx.lib.rcgan_bn_bwd(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(y), _p(dy), _p(labels), _p(gamma),
-                                           _p(mean), _p(rstd), act, _p(dx), _p(dg), _p(db), 1,
+                                           _p(mean), _p(rstd), act, _p(dx), acc_dx, _p(dg), _p(db), 1,
                                            C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         ctx.record(bw)
     return y
@@ -377,9 +376,13 @@ def cast(ctx, x, dtype):
         def bw():
             if y.grad is None:
                 return
-            assert x.grad is None
-            dx, _ = grad_of(ctx, x)
-            ctx.check(ctx.lib.rcgan_cast(ctx.h, x.size, dtype, _p(y.grad), x.dtype, _p(dx)))
+            dx, acc = grad_of(ctx, x)
+            if not acc:
+                ctx.check(ctx.lib.rcgan_cast(ctx.h, x.size, dtype, _p(y.grad), x.dtype, _p(dx)))
+            else:
+                tmp = ctx.empty(x.shape, x.dtype)
+                ctx.check(ctx.lib.rcgan_cast(ctx.h, x.size, dtype, _p(y.grad), x.dtype, _p(tmp)))
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, x.size, x.dtype, 1.0, _p(tmp), 1.0, _p(dx)))
         ctx.record(bw)
     return y
 

@@ -368,7 +368,7 @@ def test_head_and_losses(dev):
     lossref = np.maximum(1 - lref[:3], 0).mean() + 0.5 * np.maximum(1 + lref[3:], 0).mean()
     assert_close(ctx.download(loss), np.array([lossref]), 1e-5, "hinge loss")
     ctx.backward()
-    dl = np.concatenate([-(1 - lref[:3] > 0) / 3.0, 0.5 * (1 + lref[3:] > 0) / 3.0])
+    dl = np.concatenate([-1.0 * (1 - lref[:3] > 0) / 3.0, 0.5 * (1 + lref[3:] > 0) / 3.0])
     dfeat = dl[:, None] * emb_ref + dl[:, None] * Wp.reshape(1, -1)
     dx = np.broadcast_to(dfeat[:, None, None, :] / 64.0, x.shape) * (x > 0)
     assert_close(ctx.download(xd.grad), dx, TOL[mode], "head dx")
@@ -446,9 +446,9 @@ def test_adam_tf(dev):
         pg.adam(0.5, 0.999, clip=1.0, grad_scale=0.5)
         w, m, v = nn.adam_tf(w, g * np.float32(0.5), m, v, t, 2e-4, 0.5, 0.999, clip=1.0)
     ctx.sync()
-    assert_close(pg.get("w"), w, 1e-6, "adam w")
-    assert_close(pg.get("w", "m"), m, 1e-6, "adam m")
-    assert_close(pg.get("w", "v"), v, 1e-6, "adam v")
+    assert_close(pg.get("w"), w, 2e-6, "adam w")
+    assert_close(pg.get("w", "m"), m, 2e-6, "adam m")
+    assert_close(pg.get("w", "v"), v, 2e-6, "adam v")
 
 
 def test_rng_and_graph_replay(dev):
