@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the RCGAN G+D training iteration on MI355X (BASELINE.json metric).
+
+Workload (config.workload): CIFAR-10 32x32 SNGAN-projection ResNet RCGAN, per-GPU critic batch 64,
+bf16 activations with fp32 master weights / accumulation (BASELINE.json configs[2]).  One "step" is one
+reference iteration (cifar10/gan_resnet.py:928-947): 1 generator update on 2*B fakes + N_CRITIC=5
+discriminator updates on B real + B fake each; images/sec = 5*B*n_gpus / t_iteration (real images
+consumed).  Weak scaling: per-GPU batch fixed, one process per GPU, RCCL all-reduce of the flat gradient
+slabs.  Inputs are synthetic and resident in HBM before the timed region; z and the
+dequantisation noise are drawn on the device inside the captured step graphs.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (conv_mfma_kernel<128,128>, fwd + dgrad of the 3x3 convs): algorithmic flops
+               of its launches in one iteration / their summed duration measured with HIP events on the
+               launch stream, against the dense bf16 MFMA peak.
+  cpu_baseline the numpy oracle (kind "port": TensorFlow 1.5 is not installable) timed on the host cores for
+               a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_CRITIC = 5
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+POOL = 8                      # synthetic batches resident on the device
+
+
+def build_pool(m, rank, alpha):
+    """Synthetic label / image streams uploaded once; returns device tensors to cycle through."""
+    from rcgan_amd import data as D
+    B = m.B
+    rs = np.random.RandomState(1234 + rank)
+    n = POOL * B
+    images = rs.randint(0, 256, size=(n, 3072))
+    clean = rs.randint(10, size=n)
+    Cm = D.C_ALPHA(alpha)
+    lab, rnd, bia, inv = D.corrupt_labels(clean, Cm, rs)
+    dev = m.ctx.device
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    second = rnd[:n] if m.alg in ("biased", "unbiased") else bia[:n]
+    pool = dict(images=to(images, torch.int32).reshape(POOL, B, 3072), labels=to(lab, torch.int32).reshape(POOL, B),
+                labels_random=to(rnd[:n], torch.int32).reshape(POOL, B), labels_biased=to(bia[:n], torch.int32).reshape(POOL, B),
+                inv_weights=to(inv[:n], torch.float32).reshape(POOL, B, 10), second=to(second, torch.int32).reshape(POOL, B))
+    rs2 = np.random.RandomState(99 + rank)
+    pool["labels_random_G"] = to(rs2.randint(10, size=(POOL, 2 * B)), torch.int32)
+    pool["labels_biased_G"] = to(rs2.randint(10, size=(POOL, 2 * B)), torch.int32)
+    torch.cuda.synchronize()
+    return pool
+
+
+def feed_d(m, pool, i):
+    ctx, v = m.ctx, m.ctx.view
+    k = i % POOL
+    B = m.B
+    with torch.cuda.stream(ctx.stream):
+        v(m.inp["images"]).copy_(pool["images"][k], non_blocking=True)
+        v(m.inp["labels"]).copy_(pool["labels"][k], non_blocking=True)
+        v(m.inp["labels_random"]).copy_(pool["labels_random"][k], non_blocking=True)
+        v(m.inp["labels_biased"]).copy_(pool["labels_biased"][k], non_blocking=True)
+        v(m.inp["inv_weights"]).copy_(pool["inv_weights"][k], non_blocking=True)
+        la = v(m.inp["labels_all"])
+        la[:B].copy_(pool["labels"][k], non_blocking=True)
+        la[B:].copy_(pool["second"][k], non_blocking=True)
+
+
+def feed_g(m, pool, i):
+    ctx, v = m.ctx, m.ctx.view
+    k = i % POOL
+    with torch.cuda.stream(ctx.stream):
+        v(m.inp["labels_random_G"]).copy_(pool["labels_random_G"][k], non_blocking=True)
+        v(m.inp["labels_biased_G"]).copy_(pool["labels_biased_G"][k], non_blocking=True)
+
+
+def iteration(m, pool, it, dcount):
+    """gan_resnet.py:928-947: [G step if it>0] then N_CRITIC D steps (logging-only forward passes excluded)."""
+    if it > 0:
+        feed_g(m, pool, it)
+        m.g_step(iteration=it)
+    for _ in range(N_CRITIC):
+        feed_d(m, pool, dcount[0])
+        dcount[0] += 1
+        m.d_step(iteration=it)
+
+
+def kernel_roofline(m, pool):
+    """One eager (un-captured) iteration with every conv_mfma_kernel<128,128> launch bracketed by HIP events."""
+    from rcgan_amd import _lib as L
+    ctx = m.ctx
+    saved = m.use_graphs
+    m.use_graphs = False
+    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 1))
+    iteration(m, pool, 1, [0])
+    n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
+    ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(fl)))
+    m.use_graphs = saved
+    if n.value == 0 or ms.value <= 0:
+        return None
+    achieved = fl.value / (ms.value * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_mfma_kernel<128,128>", "launches_per_iteration": n.value,
+            "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+            "flops_per_launch_avg": fl.value / n.value}
+
+
+def cpu_baseline(alpha):
+    """numpy oracle on the host cores, bounded sample: one D step + one G step at B=16 (the iteration is
+    5 D steps + 1 G step, so img/s = 5*16 / (5*t_D + t_G))."""
+    from oracle import cifar as oc
+    B = 16
+    rs = np.random.RandomState(0)
+    P, U = oc.init_params(0, "rcgan")
+    Cm = oc.c_alpha(alpha)
+    lab = rs.randint(10, size=B)
+    db = dict(real=oc.preprocess_real(rs.randint(0, 256, size=(B, 3072)), rs.uniform(0, 1 / 128., size=(B, 3072))),
+              labels=lab, labels_random=rs.randint(10, size=B), labels_biased=rs.randint(10, size=B),
+              inv_weights=np.linalg.inv(Cm)[lab], z=rs.randn(B, 128))
+    gb = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B), z=rs.randn(2 * B, 128))
+    tr = oc.Trainer(P, U, dict(algorithm="rcgan", C=Cm), lr=2e-4)
+    t0 = time.time()
+    tr.d_step(0, db)
+    t1 = time.time()
+    tr.g_step(1, gb)
+    t2 = time.time()
+    td, tg = t1 - t0, t2 - t1
+    return {"value": round(5 * B / (5 * td + tg), 3), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "numpy oracle, CIFAR RCGAN B=16 fp32: 1 D step (%.2fs) + 1 G step (%.2fs) timed; iteration = 5 D + 1 G" % (td, tg)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU critic batch")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--algorithm", default="rcgan")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+
+    alpha = 0.6
+    m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0,
+                   device=local, use_graphs=not args.no_graphs, device_rng=True, world_size=world, rank=rank)
+    pool = build_pool(m, rank, alpha)
+    dcount = [0]
+    warm = max(args.warmup, 2)      # iteration 0 has no G step; graphs are captured on first use
+    for it in range(warm):
+        iteration(m, pool, it, dcount)
+    m.ctx.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        iteration(m, pool, warm + k, dcount)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=m.ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    d_loss, g_loss = m.losses()
+    ok = np.isfinite(d_loss) and np.isfinite(g_loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = N_CRITIC * args.batch * world / (dt / args.steps)
+        # algorithmic flops of one iteration: 60.858*B GFLOP per GPU
+        out = {"metric": "images/sec G+D train step (CIFAR-10 RCGAN bs=64)", "value": round(value, 2), "unit": "images/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "CIFAR-10 32x32 SNGAN-projection ResNet %s, per-GPU batch %d, iteration = 1 G step (2B fakes) + 5 D steps (B real + B fake)"
+                                      % (args.algorithm.upper(), args.batch),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
+                          "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
+                          "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
+                          "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}
+        out["roofline"] = kernel_roofline(m, pool) if args.dtype == "bf16" else None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(alpha)
+        print(json.dumps(out), flush=True)
+    else:
+        if args.dtype == "bf16":
+            kernel_roofline(m, pool)      # keep ranks in lock-step through the extra (all-reducing) iteration
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    m.ctx.close()
+
+
+if __name__ == "__main__":
+    main()

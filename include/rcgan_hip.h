@@ -59,6 +59,14 @@ int rcgan_stream_sync(rcgan_ctx* ctx);
 /* HIP-event timing on the ctx stream (bench.py roofline leg): slot in [0,64). */
 int rcgan_event_record(rcgan_ctx* ctx, int slot);
 int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* ms);
+/* Per-kernel profiling: while armed, every launch of the chosen kernel is bracketed by HIP events on the ctx
+ * stream (eager launches only, not graph replays).  rcgan_prof_end returns the number of launches, their
+ * summed duration and their summed ALGORITHMIC flops (2*M*K*Cout per launch). */
+#define RCGAN_PROF_CONV_MFMA_128 1   /* conv_mfma_kernel<128,128> (fwd + dgrad) */
+#define RCGAN_PROF_CONV_MFMA_64 2    /* conv_mfma_kernel<64,64> */
+#define RCGAN_PROF_WGRAD_MFMA 3      /* conv_mfma_wgrad_kernel */
+int rcgan_prof_begin(rcgan_ctx* ctx, int which);
+int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);
 /* hipGraph capture of everything launched on the ctx stream between begin/end; replay with launch.
  * Replaces the per-step sess.run dispatch (gan_resnet.py:931,938; mnist/model.py:347-372). */
 int rcgan_graph_begin(rcgan_ctx* ctx);

@@ -54,6 +54,8 @@ SIGNATURES = {
     "rcgan_stream_sync": (I, [P]),
     "rcgan_event_record": (I, [P, I]),
     "rcgan_event_elapsed_ms": (I, [P, I, I, C.POINTER(F)]),
+    "rcgan_prof_begin": (I, [P, I]),
+    "rcgan_prof_end": (I, [P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rcgan_graph_begin": (I, [P]),
     "rcgan_graph_end": (I, [P, C.POINTER(I)]),
     "rcgan_graph_launch": (I, [P, I]),

@@ -9,6 +9,13 @@ template <typename T> int direct_dgrad(rcgan_ctx*, const rcgan_conv_desc*, const
 template <typename T> int direct_wgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, float*, float*, int, void*, size_t);
 template <typename T> int colsum_launch(rcgan_ctx*, const T*, long, int, float*, int, float*);
 template <typename T> int sumpool2_masked_launch(rcgan_ctx*, int, int, int, int, const T*, const T*, T*, int);
+int small_fwd_kind(const rcgan_conv_desc* d);
+int small_dgrad_kind(const rcgan_conv_desc* d);
+int small_wgrad_kind(const rcgan_conv_desc* d);
+size_t small_wgrad_ws_bytes(const rcgan_conv_desc* d);
+template <typename T> int small_fwd(rcgan_ctx*, const rcgan_conv_desc*, int, const T*, const float*, const float*, T*);
+template <typename T> int small_dgrad(rcgan_ctx*, const rcgan_conv_desc*, int, const T*, const float*, T*, int);
+template <typename T> int small_wgrad(rcgan_ctx*, const rcgan_conv_desc*, int, const T*, const T*, float*, float*, int, void*, size_t);
 
 __global__ void slab_reduce2_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,6 +75,8 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->capturing = false;
   c->devtmp = nullptr;
   c->devtmp_bytes = 0;
+  c->prof_which = 0;
+  c->prof_flops = 0.0;
   for (int i = 0; i < 64; ++i) c->event_made[i] = false;
   *out = c;
   return RCGAN_OK;
@@ -144,6 +153,32 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int id) {
   return RCGAN_OK;
 }
 
+int rcgan_prof_begin(rcgan_ctx* ctx, int which) {
+  for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
+  ctx->prof_ev.clear();
+  ctx->prof_flops = 0.0;
+  ctx->prof_which = which;
+  return RCGAN_OK;
+}
+
+int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops) {
+  ctx->prof_which = 0;
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double ms = 0.0;
+  size_t n = ctx->prof_ev.size() / 2;
+  for (size_t i = 0; i < n; ++i) {
+    float t = 0.f;
+    RC_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    ms += t;
+  }
+  for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
+  ctx->prof_ev.clear();
+  if (launches) *launches = (int)n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = ctx->prof_flops;
+  return RCGAN_OK;
+}
+
 int rcgan_selftest(rcgan_ctx* ctx) {
   g_use_tr = -1;
   return ensure_selftest(ctx);
@@ -191,8 +226,12 @@ size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {
   same_pad(d->w, d->kw, d->stride, &ow, &p);
   long M = (long)d->n * oh * ow;
   size_t ws = direct_wgrad_ws_bytes(d);
+  if (small_wgrad_kind(d)) {
+    size_t s = small_wgrad_ws_bytes(d);
+    if (s > ws) ws = s;
+  }
   if (mfma_wgrad_eligible(d)) {
-    size_t s = (size_t)mfma_wgrad_splits(d, M) * d->kh * d->kw * d->cin * d->cout * sizeof(float) + (size_t)cdiv(M, 2048) * d->cout * sizeof(float) + 256;
+    size_t s = (size_t)mfma_wgrad_splits(d, M) * d->kh * d->kw * d->cin * d->cout * sizeof(float) + (size_t)(cdiv(M, 2048) + 1024) * d->cout * sizeof(float) + 256;
     if (s > ws) ws = s;
   }
   // upsample-folded data gradient: full-resolution dx scratch
@@ -223,6 +262,9 @@ int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, co
     a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
     a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
     return mfma_conv_launch(ctx, a);
+  }
+  if (int kind = small_fwd_kind(d)) {
+    RC_DISPATCH_DTYPE(ctx, d->dtype, return small_fwd<T>(ctx, d, kind, (const T*)x, (const float*)prepared, bias, (T*)y));
   }
   RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_fwd<T>(ctx, d, (const T*)x, (const float*)prepared, nullptr, bias, (T*)y));
   return RCGAN_OK;
@@ -255,6 +297,9 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
     a.up = 0; a.relu_in = 0; a.accumulate = acc_now;
     rc = mfma_conv_launch(ctx, a);
     if (rc) return rc;
+  } else if (int kind = (mask == nullptr && !up) ? small_dgrad_kind(d) : 0) {
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = small_dgrad<T>(ctx, d, kind, (const T*)dy, (const float*)prepared, (T*)target, acc_now));
+    if (rc) return rc;
   } else {
     RC_DISPATCH_DTYPE(ctx, d->dtype, rc = direct_dgrad<T>(ctx, d, (const T*)dy, (const float*)prepared, nullptr, nullptr, (const T*)mask, (T*)target, acc_now));
     if (rc) return rc;
@@ -285,7 +330,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     a.M = (long)d->n * d->h * d->w;
     int nz = mfma_wgrad_splits(d, a.M);
     long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-    size_t need = (size_t)nz * cnt * sizeof(float) + (size_t)cdiv(a.M, 2048) * d->cout * sizeof(float);
+    size_t need = (size_t)nz * cnt * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     int nzz = mfma_wgrad_launch(ctx, a, nz);
     if (nzz < 0) return nzz;
@@ -297,6 +342,9 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
       if (rc) return rc;
     }
     return RCGAN_OK;
+  }
+  if (int kind = small_wgrad_kind(d)) {
+    RC_DISPATCH_DTYPE(ctx, d->dtype, return small_wgrad<T>(ctx, d, kind, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
   }
   RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_wgrad<T>(ctx, d, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
   return RCGAN_OK;

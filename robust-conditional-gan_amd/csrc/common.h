@@ -19,6 +19,30 @@ struct rcgan_ctx {
   bool capturing;
   void* devtmp;        // small persistent device scratch (descriptor tables for batched launches)
   size_t devtmp_bytes;
+  // per-kernel HIP-event profiling (bench.py roofline leg): every launch of kernel `prof_which` is bracketed
+  int prof_which;
+  std::vector<hipEvent_t> prof_ev;
+  double prof_flops;
+};
+
+// brackets one launch with events when profiling is armed for kernel id `which`
+struct ProfScope {
+  rcgan_ctx* c; bool on;
+  ProfScope(rcgan_ctx* ctx, int which, double flops) : c(ctx), on(ctx->prof_which == which) {
+    if (!on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e, c->stream);
+    c->prof_ev.push_back(e);
+    c->prof_flops += flops;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, c->stream);
+    c->prof_ev.push_back(e);
+  }
 };
 
 #define RC_FAIL(ctx, code, ...)                         \

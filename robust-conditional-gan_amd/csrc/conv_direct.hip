@@ -219,6 +219,45 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, long ro
     partial[(long)blockIdx.y * c + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// vectorised partial column sums: each thread owns 8 consecutive columns (one 16-B bf16 / two 16-B fp32
+// loads per row), row lanes reduced through LDS.  Requires c % 8 == 0 and (c/8) | 256.
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  uint4 a = *(const uint4*)p;
+  uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_to_f32((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] = bf16_to_f32((bf16_t)(w[j] >> 16)); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_partial_kernel(const T* x, long rows, int c, long rows_per_blk, float* partial) {
+  __shared__ float red[2048];
+  const int chunks = c / 8, nrl = 256 / chunks;
+  const int ch = threadIdx.x % chunks, rl = threadIdx.x / chunks;
+  const long rb = (long)blockIdx.x * rows_per_blk;
+  long re = rb + rows_per_blk;
+  if (re > rows) re = rows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (long r = rb + rl; r < re; r += nrl) {
+    float v[8];
+    load8(x + r * c + ch * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl * c + ch * 8 + j] = acc[j];
+  __syncthreads();
+  for (int col = threadIdx.x; col < c; col += 256) {
+    float s = 0.f;
+    for (int q = 0; q < nrl; ++q) s += red[q * c + col];
+    partial[(long)blockIdx.x * c + col] = s;
+  }
+}
+
 template <class Op>
 static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz) {
   dim3 grid(cdiv(op.N, 64), cdiv(op.M, 64), nz);
@@ -243,12 +282,22 @@ size_t direct_wgrad_ws_bytes(const rcgan_conv_desc* d) {
   ConvGeom g = make_geom(d);
   long K = (long)g.KH * g.KW * g.Cin, M = (long)g.N * g.OH * g.OW;
   int nz = wgrad_splits(K, g.Cout, M);
-  size_t bias_part = (size_t)cdiv(M, 2048) * g.Cout * sizeof(float);
+  size_t bias_part = (size_t)(cdiv(M, 2048) + 1024) * g.Cout * sizeof(float);
   return (size_t)nz * K * g.Cout * sizeof(float) + bias_part + 256;
 }
 
 template <typename T>
 int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int accumulate, float* partial_ws) {
+  if (partial_ws != nullptr && rows >= 2048 && c % 8 == 0 && c <= 256 && 256 % (c / 8) == 0) {
+    long rpb = 256;
+    while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
+    int nb = cdiv(rows, rpb);          // <= 1024 <= the cdiv(rows, 2048)*... slots? see colsum_ws_rows()
+    hipLaunchKernelGGL(colsum_vec_partial_kernel<T>, dim3(nb), dim3(256), 0, ctx->stream, x, rows, c, rpb, partial_ws);
+    RC_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, (const float*)partial_ws, (long)nb, c, out, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   if (rows <= 4096 || partial_ws == nullptr) {
     hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, x, rows, c, out, accumulate);
     RC_LAUNCH_CHECK(ctx);

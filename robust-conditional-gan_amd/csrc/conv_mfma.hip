@@ -339,7 +339,11 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), a.Cout / BN);
-  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+  {
+    ProfScope ps(ctx, BM == 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
+                 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+  }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
@@ -371,7 +375,10 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
   a.m_chunk = ((a.M + nz - 1) / nz + 63) / 64 * 64;
   int nzz = cdiv(a.M, a.m_chunk);
   dim3 grid(a.KH * a.KW * (a.Cin / 128) * (a.Cout / 128), nzz);
-  hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
+  }
   RC_LAUNCH_CHECK(ctx);
   return nzz;
 }

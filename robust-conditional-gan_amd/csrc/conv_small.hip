@@ -1,0 +1,388 @@
+// Convolutions with a 3-channel (<= 4) side: the image ends of both CIFAR nets (D.Block.1.Conv1 /
+// Shortcut: 3 -> 128; G.Output: 256 -> 3) and their gradients.  None of them is GEMM-shaped enough for
+// MFMA (K = 27 or N = 3): all are HBM-bound on the big-channel tensor, so each kernel streams that tensor
+// exactly once with coalesced accesses and keeps the small side in registers / LDS.
+//   family K  "small reduction":  out[m][n]   = sum_{t, c<Cs} in[pix(m,t)][c] * w(t,c,n)      (N = 128/256)
+//   family S  "small output":     out[m][n<4] = sum_{t, c<C}  in[pix(m,t)][c] * w(t,c,n)      (C = 128/256)
+//   family W  "small-side wgrad": dW[t][cs][n] = sum_m S[pix(m,+-t)][cs] * Bg[m][n]
+// Reference call sites: cifar10/gan_resnet.py:337-352 (D.Block.1), :368 (G.Output) via conv2d.py:181-187.
+#include "common.h"
+
+// packed 8-wide store / CPL-wide load helpers (bf16: one 16-B / 8-B / 4-B access instead of scalar shorts)
+__device__ __forceinline__ void store8(float* o, const float* v, int accumulate) {
+  float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
+  if (accumulate) {
+    float4 x = *(const float4*)o, y = *(const float4*)(o + 4);
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+  }
+  *(float4*)o = a;
+  *(float4*)(o + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* o, const float* v, int accumulate) {
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = v[j];
+  if (accumulate) {
+    uint4 x = *(const uint4*)o;
+    uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[2 * j] += bf16_to_f32((bf16_t)(w[j] & 0xffff)); t[2 * j + 1] += bf16_to_f32((bf16_t)(w[j] >> 16)); }
+  }
+  uint4 pk;
+  pk.x = (uint32_t)f32_to_bf16(t[0]) | ((uint32_t)f32_to_bf16(t[1]) << 16);
+  pk.y = (uint32_t)f32_to_bf16(t[2]) | ((uint32_t)f32_to_bf16(t[3]) << 16);
+  pk.z = (uint32_t)f32_to_bf16(t[4]) | ((uint32_t)f32_to_bf16(t[5]) << 16);
+  pk.w = (uint32_t)f32_to_bf16(t[6]) | ((uint32_t)f32_to_bf16(t[7]) << 16);
+  *(uint4*)o = pk;
+}
+template <int CPL> __device__ __forceinline__ void loadv(const float* p, float* a) {
+  if (CPL == 4) { float4 v = *(const float4*)p; a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+  else { float2 v = *(const float2*)p; a[0] = v.x; a[1] = v.y; }
+}
+template <int CPL> __device__ __forceinline__ void loadv(const bf16_t* p, float* a) {
+  if (CPL == 4) {
+    uint2 v = *(const uint2*)p;
+    a[0] = bf16_to_f32((bf16_t)(v.x & 0xffff)); a[1] = bf16_to_f32((bf16_t)(v.x >> 16));
+    a[2] = bf16_to_f32((bf16_t)(v.y & 0xffff)); a[3] = bf16_to_f32((bf16_t)(v.y >> 16));
+  } else {
+    uint32_t v = *(const uint32_t*)p;
+    a[0] = bf16_to_f32((bf16_t)(v & 0xffff)); a[1] = bf16_to_f32((bf16_t)(v >> 16));
+  }
+}
+
+struct SmallGeom {
+  int N, H, W;          // batch, spatial size of the OUTPUT pixel grid (stride-s conv: output grid)
+  int IH, IW;           // spatial size of the gathered tensor
+  int KH, KW, S, PT, PL;
+  int Cs, Cb;           // small / big channel counts
+  long M;               // N*H*W
+};
+
+// ------------------------------------------------------------------------------------------------
+// family K: each thread produces 8 consecutive big channels of one pixel
+// WMODE 0: w(t,c,n) = W[(t*Cs+c)*Cb + n]            (forward, HWIO with Cin = Cs, Cout = Cb)
+// WMODE 1: w(t,c,n) = W[((T-1-t)*Cb + n)*Cs + c]    (data gradient of a conv with Cin = Cb, Cout = Cs)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WMODE>
+__global__ __launch_bounds__(256) void conv_smallk_kernel(SmallGeom g, const T* in, const float* w, const float* bias,
+                                                           T* out, int accumulate) {
+  extern __shared__ float Ws[];            // [K][Cb]
+  const int Tt = g.KH * g.KW, K = Tt * g.Cs;
+  for (int i = threadIdx.x; i < K * g.Cb; i += 256) {
+    int n = i % g.Cb, k = i / g.Cb;
+    int c = k % g.Cs, t = k / g.Cs;
+    Ws[i] = WMODE == 0 ? w[(long)k * g.Cb + n] : w[((long)(Tt - 1 - t) * g.Cb + n) * g.Cs + c];
+  }
+  __syncthreads();
+  const int tpp = g.Cb / 8;                // threads per pixel
+  const int ppb = 256 / tpp;               // pixels per block pass
+  const int n0 = (threadIdx.x % tpp) * 8;
+  const int pl = threadIdx.x / tpp;
+  for (long m = (long)blockIdx.x * ppb + pl; m < g.M; m += (long)gridDim.x * ppb) {
+    int ow = (int)(m % g.W);
+    long q = m / g.W;
+    int oh = (int)(q % g.H);
+    int b = (int)(q / g.H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[n0 + j] : 0.f;
+    for (int t = 0; t < Tt; ++t) {
+      int kh = t / g.KW, kw = t - kh * g.KW;
+      int ih = oh * g.S + kh - g.PT, iw = ow * g.S + kw - g.PL;
+      if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
+      const T* p = in + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
+      for (int c = 0; c < g.Cs; ++c) {
+        float a = Elem<T>::ld(p + c);
+        const float* wr = Ws + (t * g.Cs + c) * g.Cb + n0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, wr[j], acc[j]);
+      }
+    }
+    store8(out + m * g.Cb + n0, acc, accumulate);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// family S: one wavefront per pixel, lanes over the big channels, <= 4 outputs reduced across the wave
+// WMODE 0: w(t,c,n) = W[(t*Cb+c)*Cs + n]            (forward, Cin = Cb, Cout = Cs)
+// WMODE 1: w(t,c,n) = W[((T-1-t)*Cs + n)*Cb + c]    (data gradient of a conv with Cin = Cs, Cout = Cb)
+// CPL = big channels per lane (Cb = 64*CPL)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WMODE, int CPL>
+__global__ __launch_bounds__(256) void conv_smalln_kernel(SmallGeom g, const T* in, const float* w, const float* bias,
+                                                           T* out, int accumulate, int relu_in) {
+  const int Tt = g.KH * g.KW;
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * CPL;
+  // this lane's weights: [t][j<CPL][n<4] kept in registers for 3x3 / 1x1 filters (Tt <= 9)
+  float wr[9][CPL][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float v = 0.f;
+        if (t < Tt && n < g.Cs)
+          v = WMODE == 0 ? w[((long)t * g.Cb + c0 + j) * g.Cs + n] : w[((long)(Tt - 1 - t) * g.Cs + n) * g.Cb + c0 + j];
+        wr[t][j][n] = v;
+      }
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwave = (long)gridDim.x * 4;
+  for (long m = wave; m < g.M; m += nwave) {
+    int ow = (int)(m % g.W);
+    long q = m / g.W;
+    int oh = (int)(q % g.H);
+    int b = (int)(q / g.H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t >= Tt) break;
+      int kh = t / g.KW, kw = t - kh * g.KW;
+      int ih = oh + kh - g.PT, iw = ow + kw - g.PL;
+      if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
+      const T* p = in + (((long)b * g.IH + ih) * g.IW + iw) * g.Cb + c0;
+      float av[CPL];
+      loadv<CPL>(p, av);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        float a = av[j];
+        if (relu_in) a = a > 0.f ? a : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = fmaf(a, wr[t][j][n], acc[n]);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = wave_sum(acc[n]);
+    if (lane < g.Cs) {
+      float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      if (bias) v += bias[lane];
+      T* o = out + m * g.Cs + lane;
+      if (accumulate) v += Elem<T>::ld(o);
+      Elem<T>::st(o, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// family W: partial[blk][k<K][n<Cb] = sum over the block's pixels of S[pix(m,sign*t)][cs] * Bg[m][n]
+// SIGN +1: S gathered at (oh + kh - PT)   (filter gradient with the small tensor as conv INPUT)
+// SIGN -1: S gathered at (oh - kh + PT)   (filter gradient with the small tensor as conv OUTPUT gradient)
+// also partial[blk][K][n] = sum Bg[m][n] and partial[blk][K+1][c<Cs] = sum S[m][c]  (bias gradients)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int SIGN>
+__global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* S, const T* Bg, float* partial,
+                                                           long pix_per_block, int relu_big) {
+  __shared__ float red[256];
+  const int Tt = g.KH * g.KW, K = Tt * g.Cs;
+  const int npl = 256 / g.Cb > 0 ? 256 / g.Cb : 1;     // pixel lanes (Cb = 128 -> 2, 256 -> 1)
+  const int n = threadIdx.x % g.Cb;
+  const int pl = threadIdx.x / g.Cb;
+  const bool active = pl < npl;
+  float acc[37];
+#pragma unroll
+  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
+  float ssum = 0.f;
+  const long mb = (long)blockIdx.x * pix_per_block;
+  long me = mb + pix_per_block;
+  if (me > g.M) me = g.M;
+  if (active) {
+    for (long m = mb + pl; m < me; m += npl) {
+      int ow = (int)(m % g.W);
+      long q = m / g.W;
+      int oh = (int)(q % g.H);
+      int b = (int)(q / g.H);
+      float bg = Elem<T>::ld(Bg + m * g.Cb + n);
+      if (relu_big) bg = bg > 0.f ? bg : 0.f;
+      acc[36] += bg;
+      if (n < g.Cs) ssum += Elem<T>::ld(S + m * g.Cs + n);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t >= Tt) break;
+        int kh = t / g.KW, kw = t - kh * g.KW;
+        int ih = SIGN > 0 ? oh + kh - g.PT : oh - kh + g.PT;
+        int iw = SIGN > 0 ? ow + kw - g.PL : ow - kw + g.PL;
+        if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
+        const T* p = S + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c >= g.Cs) break;
+          acc[t * 4 + c] = fmaf(Elem<T>::ld(p + c), bg, acc[t * 4 + c]);
+        }
+      }
+    }
+  }
+  // reduce the pixel lanes through LDS and write the block's partial slab
+  float* slab = partial + (long)blockIdx.x * (K + 2) * g.Cb;
+  for (int k = 0; k <= K + 1; ++k) {
+    int src = k >= K ? 36 : (k / g.Cs) * 4 + (k % g.Cs);
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 37; ++s)
+      if (s == src) v = acc[s];
+    if (k == K + 1) v = ssum;
+    red[threadIdx.x] = active ? v : 0.f;
+    __syncthreads();
+    if (pl == 0) {
+      float tot = 0.f;
+      for (int q = 0; q < npl; ++q) tot += red[q * g.Cb + n];
+      slab[(long)k * g.Cb + n] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// out (= or +=) sum_blk partial[blk][k][n], written as dW in HWIO order.
+// ORIENT 0: dW[(t*Cs+c)*Cb + n], dbias[n<Cb] from slot K   ORIENT 1: dW[(t*Cb+n)*Cs + c], dbias[c<Cs] from slot K+1.
+__global__ void conv_smallw_reduce_kernel(const float* partial, int nblk, int K, int Cs, int Cb, int orient, float* dw,
+                                          float* dbias, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = (K + 2) * Cb;
+  if (i >= total) return;
+  int k = i / Cb, n = i % Cb;
+  if (k >= K) {
+    bool mine = (orient == 0 && k == K) || (orient == 1 && k == K + 1 && n < Cs);
+    if (!mine || !dbias) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * total + i];
+    if (accumulate) s += dbias[n];
+    dbias[n] = s;
+    return;
+  }
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long)b * total + i];
+  int t = k / Cs, c = k % Cs;
+  long o = orient == 0 ? (long)k * Cb + n : ((long)t * Cb + n) * Cs + c;
+  if (accumulate) s += dw[o];
+  dw[o] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static SmallGeom small_geom(const rcgan_conv_desc* d) {
+  SmallGeom g;
+  int oh, ow, pt, pl;
+  same_pad(d->h, d->kh, d->stride, &oh, &pt);
+  same_pad(d->w, d->kw, d->stride, &ow, &pl);
+  g.N = d->n; g.H = oh; g.W = ow; g.IH = d->h; g.IW = d->w;
+  g.KH = d->kh; g.KW = d->kw; g.S = d->stride; g.PT = pt; g.PL = pl;
+  g.M = (long)d->n * oh * ow;
+  g.Cs = 0; g.Cb = 0;
+  return g;
+}
+
+static bool plain(const rcgan_conv_desc* d) {
+  return !(d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_FORCE_DIRECT)) && d->kh * d->kw <= 9 && d->kh == d->kw;
+}
+
+// forward eligibility
+int small_fwd_kind(const rcgan_conv_desc* d) {
+  if (!plain(d)) return 0;
+  if (d->cin <= 4 && (d->cout == 128 || d->cout == 256) && !(d->flags & RCGAN_CONV_IN_RELU)) return 1;               // family K
+  if (d->cout <= 4 && (d->cin == 128 || d->cin == 256) && d->stride == 1) return 2;                                  // family S
+  return 0;
+}
+int small_dgrad_kind(const rcgan_conv_desc* d) {
+  if (!plain(d) || d->stride != 1 || (d->flags & RCGAN_CONV_IN_RELU)) return 0;
+  if (d->cout <= 4 && (d->cin == 128 || d->cin == 256)) return 1;    // dX[m][big] from dY[m][small]: family K, WMODE 1
+  if (d->cin <= 4 && (d->cout == 128 || d->cout == 256)) return 2;   // dX[m][small] from dY[m][big]: family S, WMODE 1
+  return 0;
+}
+int small_wgrad_kind(const rcgan_conv_desc* d) {
+  if (!plain(d) || d->stride != 1) return 0;
+  if (d->cin <= 4 && (d->cout == 128 || d->cout == 256) && !(d->flags & RCGAN_CONV_IN_RELU)) return 1;   // S = x, Bg = dy
+  if (d->cout <= 4 && (d->cin == 128 || d->cin == 256)) return 2;                                         // S = dy, Bg = x
+  return 0;
+}
+
+size_t small_wgrad_ws_bytes(const rcgan_conv_desc* d) {
+  long M = (long)d->n * d->h * d->w;
+  int cs = d->cin <= 4 ? d->cin : d->cout, cb = d->cin <= 4 ? d->cout : d->cin;
+  long nblk = (M + 255) / 256;
+  if (nblk > 1024) nblk = 1024;
+  return (size_t)nblk * (d->kh * d->kw * cs + 2) * cb * sizeof(float) + 256;
+}
+
+template <typename T>
+int small_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, const float* w, const float* bias, T* y) {
+  SmallGeom g = small_geom(d);
+  const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  if (kind == 1) {
+    g.Cs = d->cin; g.Cb = d->cout;
+    size_t lds = (size_t)d->kh * d->kw * g.Cs * g.Cb * sizeof(float);
+    int ppb = 256 / (g.Cb / 8);
+    long blocks = (g.M + ppb - 1) / ppb;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((conv_smallk_kernel<T, 0>), dim3((int)blocks), dim3(256), lds, ctx->stream, g, x, w, bias, y, acc);
+  } else {
+    g.Cs = d->cout; g.Cb = d->cin;
+    long blocks = (g.M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const int relu = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 4>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+    else hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 2>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+template int small_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, int, const float*, const float*, const float*, float*);
+template int small_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, int, const bf16_t*, const float*, const float*, bf16_t*);
+
+template <typename T>
+int small_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* dy, const float* w, T* dx, int accumulate) {
+  SmallGeom g = small_geom(d);     // stride 1: output grid == input grid
+  g.PT = d->kh - 1 - g.PT; g.PL = d->kw - 1 - g.PL;     // gather offsets of the flipped filter
+  if (kind == 1) {
+    g.Cs = d->cout; g.Cb = d->cin;
+    size_t lds = (size_t)d->kh * d->kw * g.Cs * g.Cb * sizeof(float);
+    int ppb = 256 / (g.Cb / 8);
+    long blocks = (g.M + ppb - 1) / ppb;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((conv_smallk_kernel<T, 1>), dim3((int)blocks), dim3(256), lds, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate);
+  } else {
+    g.Cs = d->cin; g.Cb = d->cout;
+    long blocks = (g.M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 4>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate, 0);
+    else hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 2>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate, 0);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+template int small_dgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, int, const float*, const float*, float*, int);
+template int small_dgrad<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, int, const bf16_t*, const float*, bf16_t*, int);
+
+template <typename T>
+int small_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, const T* dy, float* dw, float* dbias,
+                int accumulate, void* ws, size_t ws_bytes) {
+  SmallGeom g = small_geom(d);
+  size_t need = small_wgrad_ws_bytes(d);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  long nblk = (g.M + 255) / 256;
+  if (nblk > 1024) nblk = 1024;
+  long ppb = (g.M + nblk - 1) / nblk;
+  nblk = (g.M + ppb - 1) / ppb;
+  float* partial = (float*)ws;
+  if (kind == 1) {
+    g.Cs = d->cin; g.Cb = d->cout;
+    hipLaunchKernelGGL((conv_smallw_kernel<T, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, x, dy, partial, ppb, 0);
+    RC_LAUNCH_CHECK(ctx);
+    int K = d->kh * d->kw * g.Cs;
+    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,
+                       (int)nblk, K, g.Cs, g.Cb, 0, dw, dbias, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+  } else {
+    g.Cs = d->cout; g.Cb = d->cin;
+    const int relu = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    hipLaunchKernelGGL((conv_smallw_kernel<T, -1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, dy, x, partial, ppb, relu);
+    RC_LAUNCH_CHECK(ctx);
+    int K = d->kh * d->kw * g.Cs;
+    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,
+                       (int)nblk, K, g.Cs, g.Cb, 1, dw, dbias, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  return RCGAN_OK;
+}
+template int small_wgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, int, const float*, const float*, float*, float*, int, void*, size_t);
+template int small_wgrad<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, int, const bf16_t*, const bf16_t*, float*, float*, int, void*, size_t);

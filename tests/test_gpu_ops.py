@@ -47,6 +47,11 @@ CONV_CASES = [
     (2, 8, 8, 256, 128, 1, 1, False, False),    # MFMA 1x1
     (5, 32, 32, 128, 128, 3, 1, False, True),   # MFMA 128x128 tile (M = 5120 -> 40 blocks < 384 -> 64 tile) ...
     (48, 32, 32, 128, 128, 3, 1, False, False), # ... and M = 49152 -> 384 blocks of 128x128
+    (4, 32, 32, 3, 128, 3, 1, False, False),    # image-end kernels: D.Block.1.Conv1 (small reduction / small-side wgrad)
+    (4, 32, 32, 3, 128, 1, 1, False, False),    # D.Block.1.Shortcut
+    (3, 16, 16, 256, 3, 3, 1, False, False),    # G.Output (small output)
+    (3, 10, 6, 128, 3, 3, 1, False, True),      # small output with folded input ReLU (generic dgrad because of the mask)
+    (2, 8, 8, 3, 256, 3, 1, False, False),
 ]
 
 
