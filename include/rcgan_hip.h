@@ -143,9 +143,9 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
  * of a [1][c] table = plain batch norm).  Replaces tf.nn.batch_normalization + embedding_lookup
  * (cifar10/common/ops/normalization.py:47-57) and tf.contrib.layers.batch_norm (mnist/ops.py:38-44)
  * fused with the following relu / lrelu (gan_resnet.py:305,317,366; mnist/model.py:661-719). */
-int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int dtype, const void* x,
+int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
                        const int32_t* labels, const float* gamma, const float* beta,
-                       const float* mean, const float* rstd, int act, void* y);
+                       const float* mean, const float* rstd, int act, void* y, void* ws, size_t ws_bytes);
 /* Backward of stats+apply (gradient flows through the batch statistics).  dgamma/dbeta: [n_labels][c]
  * (= or += by accumulate); dx = or += by accumulate_dx.  y is the forward output (activation mask). */
 int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype,

@@ -140,6 +140,164 @@ __global__ void bn_infer_kernel(long total, int c, const T* x, const float* gamm
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 8-wide vectorised variants (c % 8 == 0): one 16-B (bf16) / two 16-B (fp32) accesses per thread per row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ld8(const float* p, float* v) {
+  float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float* v) {
+  uint4 a = *(const uint4*)p;
+  uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_to_f32((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] = bf16_to_f32((bf16_t)(w[j] >> 16)); }
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+  uint4 pk;
+  pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *(uint4*)p = pk;
+}
+
+// block = 32 channel-chunks (256 channels) x 8 row lanes; grid = (ceil(chunks/32), groups)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(long rows, int c, long rows_per_group, const T* x, const T* y,
+                                                             const T* dy, const float* mean, const float* rstd, int act,
+                                                             float* partial) {
+  __shared__ float red[2][8][256];
+  const int chunk = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  const bool on = chunk * 8 < c;
+  const long rb = (long)blockIdx.y * rows_per_group;
+  long re = rb + rows_per_group;
+  if (re > rows) re = rows;
+  float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  if (on) {
+    if (MODE == 1) { ld8(mean + chunk * 8, mu); ld8(rstd + chunk * 8, rs); }
+#pragma unroll 2
+    for (long r = rb + rl; r < re; r += 8) {
+      const long off = r * c + chunk * 8;
+      float xv[8];
+      ld8(x + off, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += xv[j]; s2[j] += xv[j] * xv[j]; }
+      } else {
+        float gv[8], yv[8];
+        ld8(dy + off, gv);
+        if (act != RCGAN_ACT_NONE) {
+          ld8(y + off, yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gv[j] *= act_grad(act, yv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += gv[j]; s2[j] += gv[j] * (xv[j] - mu[j]) * rs[j]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][rl][(threadIdx.x & 31) * 8 + j] = s1[j];
+    red[1][rl][(threadIdx.x & 31) * 8 + j] = s2[j];
+  }
+  __syncthreads();
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < c) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+    partial[((long)blockIdx.y * 2 + 0) * c + col] = a;
+    partial[((long)blockIdx.y * 2 + 1) * c + col] = b;
+  }
+}
+
+// per-(label, channel) affine of the forward: A = rstd*gamma, B = beta - mean*A   (tf.nn.batch_normalization)
+__global__ void bn_table_fwd_kernel(int n_labels, int c, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, float* A, float* B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_labels * c) return;
+  int ch = i % c;
+  float a = rstd[ch] * gamma[i];
+  A[i] = a;
+  B[i] = beta[i] - mean[ch] * a;
+}
+
+// backward constants: A = rstd*gamma [labels][c];  dx = A*g + P*x + Q with P = -rstd^2*s2/M, Q = -P*mean - rstd*s1/M
+__global__ void bn_table_bwd_kernel(int n_labels, int c, long rows, const float* gamma, const float* mean, const float* rstd,
+                                    const float* s12, float* A, float* PQ) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_labels * c) A[i] = rstd[i % c] * gamma[i];
+  if (i < c) {
+    const float invM = 1.f / (float)rows;
+    float rs = rstd[i];
+    float p = -rs * rs * s12[c + i] * invM;
+    PQ[i] = p;
+    PQ[c + i] = -p * mean[i] - rs * s12[i] * invM;
+  }
+}
+
+template <typename T>
+__global__ void bn_apply_vec_kernel(long nchunks, int rows_per_sample, int c, const T* x, const int32_t* labels,
+                                    const float* A, const float* B, int act, T* y) {
+  const int cpr = c / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr) * 8;
+    const long row = i / cpr;
+    const int l = labels ? labels[row / rows_per_sample] : 0;
+    float xv[8], a[8], b[8];
+    ld8(x + row * c + ch, xv);
+    ld8(A + (long)l * c + ch, a);
+    ld8(B + (long)l * c + ch, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = act_apply(act, xv[j] * a[j] + b[j]);
+    st8(y + row * c + ch, xv);
+  }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_vec_kernel(long nchunks, int rows_per_sample, int c, const T* x, const T* y, const T* dy,
+                                        const int32_t* labels, const float* A, const float* PQ, int act, T* dx, int accumulate_dx) {
+  const int cpr = c / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr) * 8;
+    const long row = i / cpr;
+    const int l = labels ? labels[row / rows_per_sample] : 0;
+    const long off = row * c + ch;
+    float xv[8], gv[8], a[8], p[8], q[8];
+    ld8(x + off, xv);
+    ld8(dy + off, gv);
+    if (act != RCGAN_ACT_NONE) {
+      float yv[8];
+      ld8(y + off, yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] *= act_grad(act, yv[j]);
+    }
+    ld8(A + (long)l * c + ch, a);
+    ld8(PQ + ch, p);
+    ld8(PQ + c + ch, q);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = a[j] * gv[j] + p[j] * xv[j] + q[j];
+    if (accumulate_dx) {
+      float d[8];
+      ld8(dx + off, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += d[j];
+    }
+    st8(dx + off, o);
+  }
+}
+
 static inline long stats_group_rows(long rows) {
   long g = 512;
   while (rows / g > 2048) g *= 2;
@@ -159,7 +317,7 @@ size_t rcgan_bn_workspace_bytes(int rows, int c) {
   // stats: ngroups*2*c ; bwd: ngroups*2*c + 2*c, with ngroups <= max(rows/512, n) <= rows
   long ng = (rows + 511) / 512 + 1;
   if (ng < 4096) ng = 4096;   // per-sample grouping (n <= 4096 samples)
-  return (size_t)(ng * 2 * (long)c + 2 * (long)c) * sizeof(float) + 256;
+  return (size_t)(ng * 2 * (long)c + 4 * (long)c + 2 * MAX_LABELS * (long)c) * sizeof(float) + 256;
 }
 
 int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, float eps, float* mean, float* rstd,
@@ -169,10 +327,17 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
   size_t need = (size_t)ng * 2 * c * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   float* partial = (float*)ws;
-  dim3 grid(cdiv(c, 64), ng);
-  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_kernel<T, 0>), grid, dim3(256), 0, ctx->stream, (long)rows, c, rpg,
-                                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                   (const float*)nullptr, 0, partial));
+  if (c % 8 == 0) {
+    dim3 grid(cdiv(c / 8, 32), ng);
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_vec_kernel<T, 0>), grid, dim3(256), 0, ctx->stream, (long)rows, c, rpg,
+                                                     (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                     (const float*)nullptr, 0, partial));
+  } else {
+    dim3 grid(cdiv(c, 64), ng);
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_kernel<T, 0>), grid, dim3(256), 0, ctx->stream, (long)rows, c, rpg,
+                                                     (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                     (const float*)nullptr, 0, partial));
+  }
   RC_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, ctx->stream, c, ng, (long)rows,
                      (const float*)partial, eps, mean, rstd, mm, mv, decay);
@@ -180,9 +345,21 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
   return RCGAN_OK;
 }
 
-int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int dtype, const void* x, const int32_t* labels,
-                       const float* gamma, const float* beta, const float* mean, const float* rstd, int act, void* y) {
+int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
+                       const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                       int act, void* y, void* ws, size_t ws_bytes) {
   long total = (long)n * rows_per_sample * c;
+  if (c % 8 == 0 && ws_bytes >= (size_t)2 * n_labels * c * sizeof(float)) {
+    float* A = (float*)ws;
+    float* B = A + (size_t)n_labels * c;
+    hipLaunchKernelGGL(bn_table_fwd_kernel, dim3(cdiv((long)n_labels * c, 256)), dim3(256), 0, ctx->stream, n_labels, c, gamma, beta, mean, rstd, A, B);
+    RC_LAUNCH_CHECK(ctx);
+    long nchunks = total / 8;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_vec_kernel<T>, dim3(ew_grid2(nchunks)), dim3(256), 0, ctx->stream, nchunks,
+                                                     rows_per_sample, c, (const T*)x, labels, (const float*)A, (const float*)B, act, (T*)y));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fwd_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total,
                                                    rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y));
   RC_LAUNCH_CHECK(ctx);
@@ -203,14 +380,34 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   float* partial = (float*)ws;
   float* s12 = partial + (size_t)ng * 2 * c;
-  dim3 grid(cdiv(c, 64), ng);
-  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), grid, dim3(256), 0, ctx->stream, rows, c, rpg,
-                                                   (const T*)x, (const T*)y, (const T*)dy, mean, rstd, act, partial));
+  const bool vec = c % 8 == 0 && ws_bytes >= need + ((size_t)n_labels * c + 2 * (size_t)c) * sizeof(float);
+  if (vec) {
+    dim3 grid(cdiv(c / 8, 32), ng);
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_vec_kernel<T, 1>), grid, dim3(256), 0, ctx->stream, rows, c, rpg,
+                                                     (const T*)x, (const T*)y, (const T*)dy, mean, rstd, act, partial));
+  } else {
+    dim3 grid(cdiv(c, 64), ng);
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), grid, dim3(256), 0, ctx->stream, rows, c, rpg,
+                                                     (const T*)x, (const T*)y, (const T*)dy, mean, rstd, act, partial));
+  }
   RC_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3(cdiv(c, 128)), dim3(128), 0, ctx->stream, c, ng, n_labels, labels, gamma,
                      (const float*)partial, dgamma, dbeta, s12, accumulate);
   RC_LAUNCH_CHECK(ctx);
   long total = rows * c;
+  if (vec) {
+    float* A = s12 + 2 * (size_t)c;
+    float* PQ = A + (size_t)n_labels * c;
+    hipLaunchKernelGGL(bn_table_bwd_kernel, dim3(cdiv((long)n_labels * c, 256)), dim3(256), 0, ctx->stream, n_labels, c, rows, gamma, mean, rstd,
+                       (const float*)s12, A, PQ);
+    RC_LAUNCH_CHECK(ctx);
+    long nchunks = total / 8;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<T>, dim3(ew_grid2(nchunks)), dim3(256), 0, ctx->stream, nchunks,
+                                                     rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, (const float*)A,
+                                                     (const float*)PQ, act, (T*)dx, accumulate_dx));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total, rows,
                                                    rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, mean,
                                                    rstd, (const float*)s12, act, (T*)dx, accumulate_dx));

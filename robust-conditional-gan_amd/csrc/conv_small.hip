@@ -108,22 +108,22 @@ __global__ __launch_bounds__(256) void conv_smallk_kernel(SmallGeom g, const T* 
 // WMODE 1: w(t,c,n) = W[((T-1-t)*Cs + n)*Cb + c]    (data gradient of a conv with Cin = Cs, Cout = Cb)
 // CPL = big channels per lane (Cb = 64*CPL)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WMODE, int CPL>
+template <typename T, int WMODE, int CPL, int TT>
 __global__ __launch_bounds__(256) void conv_smalln_kernel(SmallGeom g, const T* in, const float* w, const float* bias,
                                                            T* out, int accumulate, int relu_in) {
-  const int Tt = g.KH * g.KW;
+  constexpr int Tt = TT;
   const int lane = threadIdx.x & 63;
   const int c0 = lane * CPL;
   // this lane's weights: [t][j<CPL][n<4] kept in registers for 3x3 / 1x1 filters (Tt <= 9)
-  float wr[9][CPL][4];
+  float wr[TT][CPL][4];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         float v = 0.f;
-        if (t < Tt && n < g.Cs)
+        if (n < g.Cs)
           v = WMODE == 0 ? w[((long)t * g.Cb + c0 + j) * g.Cs + n] : w[((long)(Tt - 1 - t) * g.Cs + n) * g.Cb + c0 + j];
         wr[t][j][n] = v;
       }
@@ -136,17 +136,17 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(SmallGeom g, const T* 
     int b = (int)(q / g.H);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (t >= Tt) break;
-      int kh = t / g.KW, kw = t - kh * g.KW;
+    for (int t = 0; t < TT; ++t) {
+      const int kh = TT == 9 ? t / 3 : 0, kw = TT == 9 ? t % 3 : 0;
       int ih = oh + kh - g.PT, iw = ow + kw - g.PL;
-      if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
+      const bool ok = ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
+      if (!ok) { ih = 0; iw = 0; }
       const T* p = in + (((long)b * g.IH + ih) * g.IW + iw) * g.Cb + c0;
       float av[CPL];
       loadv<CPL>(p, av);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        float a = av[j];
+        float a = ok ? av[j] : 0.f;
         if (relu_in) a = a > 0.f ? a : 0.f;
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = fmaf(a, wr[t][j][n], acc[n]);
@@ -170,19 +170,20 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(SmallGeom g, const T* 
 // SIGN -1: S gathered at (oh - kh + PT)   (filter gradient with the small tensor as conv OUTPUT gradient)
 // also partial[blk][K][n] = sum Bg[m][n] and partial[blk][K+1][c<Cs] = sum S[m][c]  (bias gradients)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int SIGN>
+template <typename T, int SIGN, int TT>
 __global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* S, const T* Bg, float* partial,
                                                            long pix_per_block, int relu_big) {
   __shared__ float red[256];
-  const int Tt = g.KH * g.KW, K = Tt * g.Cs;
+  constexpr int K4 = TT * 4;
+  const int K = TT * g.Cs;
   const int npl = 256 / g.Cb > 0 ? 256 / g.Cb : 1;     // pixel lanes (Cb = 128 -> 2, 256 -> 1)
   const int n = threadIdx.x % g.Cb;
   const int pl = threadIdx.x / g.Cb;
   const bool active = pl < npl;
-  float acc[37];
+  float acc[K4];
 #pragma unroll
-  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
-  float ssum = 0.f;
+  for (int k = 0; k < K4; ++k) acc[k] = 0.f;
+  float bsum = 0.f, ssum = 0.f;
   const long mb = (long)blockIdx.x * pix_per_block;
   long me = mb + pix_per_block;
   if (me > g.M) me = g.M;
@@ -194,33 +195,32 @@ __global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* 
       int b = (int)(q / g.H);
       float bg = Elem<T>::ld(Bg + m * g.Cb + n);
       if (relu_big) bg = bg > 0.f ? bg : 0.f;
-      acc[36] += bg;
+      bsum += bg;
       if (n < g.Cs) ssum += Elem<T>::ld(S + m * g.Cs + n);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t >= Tt) break;
-        int kh = t / g.KW, kw = t - kh * g.KW;
+      for (int t = 0; t < TT; ++t) {
+        const int kh = TT == 9 ? t / 3 : 0, kw = TT == 9 ? t % 3 : 0;
         int ih = SIGN > 0 ? oh + kh - g.PT : oh - kh + g.PT;
         int iw = SIGN > 0 ? ow + kw - g.PL : ow - kw + g.PL;
-        if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
+        const bool ok = ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
+        if (!ok) { ih = 0; iw = 0; }
         const T* p = S + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if (c >= g.Cs) break;
-          acc[t * 4 + c] = fmaf(Elem<T>::ld(p + c), bg, acc[t * 4 + c]);
+          float sv = (ok && c < g.Cs) ? Elem<T>::ld(p + (c < g.Cs ? c : 0)) : 0.f;
+          acc[t * 4 + c] = fmaf(sv, bg, acc[t * 4 + c]);
         }
       }
     }
   }
   // reduce the pixel lanes through LDS and write the block's partial slab
   float* slab = partial + (long)blockIdx.x * (K + 2) * g.Cb;
-  for (int k = 0; k <= K + 1; ++k) {
-    int src = k >= K ? 36 : (k / g.Cs) * 4 + (k % g.Cs);
-    float v = 0.f;
 #pragma unroll
-    for (int s = 0; s < 37; ++s)
-      if (s == src) v = acc[s];
-    if (k == K + 1) v = ssum;
+  for (int k4 = 0; k4 < K4 + 2; ++k4) {
+    const int t = k4 / 4, c = k4 % 4;
+    if (k4 < K4 && c >= g.Cs) continue;              // uniform across the block
+    float v = k4 < K4 ? acc[k4 < K4 ? k4 : 0] : (k4 == K4 ? bsum : ssum);
+    const int k = k4 < K4 ? t * g.Cs + c : (k4 == K4 ? K : K + 1);
     red[threadIdx.x] = active ? v : 0.f;
     __syncthreads();
     if (pl == 0) {
@@ -273,7 +273,7 @@ static SmallGeom small_geom(const rcgan_conv_desc* d) {
 }
 
 static bool plain(const rcgan_conv_desc* d) {
-  return !(d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_FORCE_DIRECT)) && d->kh * d->kw <= 9 && d->kh == d->kw;
+  return !(d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_FORCE_DIRECT)) && d->kh == d->kw && (d->kh == 3 || d->kh == 1);
 }
 
 // forward eligibility
@@ -300,7 +300,7 @@ size_t small_wgrad_ws_bytes(const rcgan_conv_desc* d) {
   long M = (long)d->n * d->h * d->w;
   int cs = d->cin <= 4 ? d->cin : d->cout, cb = d->cin <= 4 ? d->cout : d->cin;
   long nblk = (M + 255) / 256;
-  if (nblk > 1024) nblk = 1024;
+  if (nblk > 512) nblk = 512;
   return (size_t)nblk * (d->kh * d->kw * cs + 2) * cb * sizeof(float) + 256;
 }
 
@@ -320,8 +320,11 @@ int small_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, co
     long blocks = (g.M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const int relu = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
-    if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 4>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
-    else hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 2>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+    const bool k3 = d->kh == 3;
+    if (g.Cb == 256 && k3) hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 4, 9>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+    else if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 4, 1>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+    else if (k3) hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 2, 9>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
+    else hipLaunchKernelGGL((conv_smalln_kernel<T, 0, 2, 1>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, x, w, bias, y, acc, relu);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -344,8 +347,12 @@ int small_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* dy,
     g.Cs = d->cin; g.Cb = d->cout;
     long blocks = (g.M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 4>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate, 0);
-    else hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 2>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate, 0);
+    const bool k3 = d->kh == 3;
+    const float* nb = nullptr;
+    if (g.Cb == 256 && k3) hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 4, 9>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, nb, dx, accumulate, 0);
+    else if (g.Cb == 256) hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 4, 1>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, nb, dx, accumulate, 0);
+    else if (k3) hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 2, 9>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, nb, dx, accumulate, 0);
+    else hipLaunchKernelGGL((conv_smalln_kernel<T, 1, 2, 1>), dim3((int)blocks), dim3(256), 0, ctx->stream, g, dy, w, nb, dx, accumulate, 0);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -360,13 +367,14 @@ int small_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, 
   size_t need = small_wgrad_ws_bytes(d);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   long nblk = (g.M + 255) / 256;
-  if (nblk > 1024) nblk = 1024;
+  if (nblk > 512) nblk = 512;
   long ppb = (g.M + nblk - 1) / nblk;
   nblk = (g.M + ppb - 1) / ppb;
   float* partial = (float*)ws;
   if (kind == 1) {
     g.Cs = d->cin; g.Cb = d->cout;
-    hipLaunchKernelGGL((conv_smallw_kernel<T, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, x, dy, partial, ppb, 0);
+    if (d->kh == 3) hipLaunchKernelGGL((conv_smallw_kernel<T, 1, 9>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, x, dy, partial, ppb, 0);
+    else hipLaunchKernelGGL((conv_smallw_kernel<T, 1, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, x, dy, partial, ppb, 0);
     RC_LAUNCH_CHECK(ctx);
     int K = d->kh * d->kw * g.Cs;
     hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,
@@ -375,7 +383,8 @@ int small_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, 
   } else {
     g.Cs = d->cout; g.Cb = d->cin;
     const int relu = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
-    hipLaunchKernelGGL((conv_smallw_kernel<T, -1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, dy, x, partial, ppb, relu);
+    if (d->kh == 3) hipLaunchKernelGGL((conv_smallw_kernel<T, -1, 9>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, dy, x, partial, ppb, relu);
+    else hipLaunchKernelGGL((conv_smallw_kernel<T, -1, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, dy, x, partial, ppb, relu);
     RC_LAUNCH_CHECK(ctx);
     int K = d->kh * d->kw * g.Cs;
     hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,

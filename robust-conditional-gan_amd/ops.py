@@ -235,7 +235,8 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
     ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), _p(mm), _p(mv), decay,
                                      C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
     y = ctx.empty(x.shape, x.dtype)
-    ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, n, rps, c, x.dtype, _p(x), _p(labels), _p(gamma), _p(beta), _p(mean), _p(rstd), act, _p(y)))
+    ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma), _p(beta), _p(mean), _p(rstd),
+                                         act, _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
     if _track(ctx, y, x, gamma, beta):
         def bw():
             dy = y.grad
