@@ -77,6 +77,11 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->devtmp_bytes = 0;
   c->prof_which = 0;
   c->prof_flops = 0.0;
+  c->zero_page = nullptr;
+  if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+    delete c;
+    return RCGAN_EHIP;
+  }
   for (int i = 0; i < 64; ++i) c->event_made[i] = false;
   *out = c;
   return RCGAN_OK;
@@ -88,6 +93,7 @@ int rcgan_destroy(rcgan_ctx* ctx) {
     if (ctx->event_made[i]) (void)hipEventDestroy(ctx->events[i]);
   for (auto g : ctx->graphs)
     if (g) (void)hipGraphExecDestroy(g);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   delete ctx;
   return RCGAN_OK;
 }
@@ -257,6 +263,7 @@ int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, co
     MfmaConvArgs a;
     fill_mfma_args(d, a);
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+    a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cin; a.Cout = d->cout;
     a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
     a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
@@ -292,6 +299,7 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
     size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared + elems; a.bias = nullptr; a.mask = (const bf16_t*)mask;
     a.out = (bf16_t*)target;
+    a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cout; a.Cout = d->cin;          // reduction over cout, output channels = cin
     a.PT = d->kh - 1 - a.PT; a.PL = d->kw - 1 - a.PL;
     a.up = 0; a.relu_in = 0; a.accumulate = acc_now;
@@ -323,6 +331,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     same_pad(d->h, d->kh, 1, &oh, &pt);
     same_pad(d->w, d->kw, 1, &ow, &pl);
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
+    a.zero = (const bf16_t*)ctx->zero_page;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
     a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
     a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;

@@ -23,6 +23,7 @@ struct rcgan_ctx {
   int prof_which;
   std::vector<hipEvent_t> prof_ev;
   double prof_flops;
+  void* zero_page;     // 256 zero bytes in device memory
 };
 
 // brackets one launch with events when profiling is armed for kernel id `which`

@@ -8,6 +8,7 @@ struct MfmaConvArgs {
   const float* bias;      // [Cout] or null
   const bf16_t* mask;     // [M][Cout] or null: output zeroed where mask <= 0 (ReLU backward)
   bf16_t* out;            // [M][Cout]
+  const bf16_t* zero;     // >= 16 zero bytes (halo source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, accumulate;
   long M;
@@ -17,6 +18,7 @@ struct MfmaWgradArgs {
   const bf16_t* x;        // [N][H(/2)][W(/2)][Cin]
   const bf16_t* dy;       // [M][Cout]
   float* slab;            // [nz][T*Cin*Cout]
+  const bf16_t* zero;     // >= 16 zero bytes (halo / tail source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, use_tr;
   long M, m_chunk;

@@ -169,6 +169,153 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (global_load_lds_dwordx4): no staging registers, no ds_write pass.
+//   * LDS rows are exactly 128 B (64 bf16); one wavefront instruction deposits 8 rows (lane l -> row l/8,
+//     16-B slot l%8).  Bank conflicts are avoided by an XOR swizzle applied on the SOURCE side: slot p of
+//     row r receives K-chunk p ^ (r & 7), and the fragment reads apply the same XOR.
+//   * the SAME-padding halo is read from a 16-byte zero page (each lane supplies its own global address).
+//   * the input ReLU, when requested, is applied to the pixel fragments after the LDS read.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+  constexpr int AI = BM / 32, BI = BN / 32;          // 1-KiB deposits per wave per tile
+  constexpr int TM = BM / 2, TN = BN / 2;
+  constexpr int NI = TN / 16, NJ = TM / 16;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const long m0 = (long)blockIdx.x * BM;
+  const int co0 = blockIdx.y * BN;
+  const int K = a.KH * a.KW * a.Cin;
+  const int KT = K / 64;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int lrow = lane >> 3, pos = lane & 7;
+
+  int p_n[AI], p_oh[AI], p_ow[AI], a_coff[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wave * AI + i) * 8 + lrow;
+    const long m = m0 + row;
+    a_coff[i] = (pos ^ (row & 7)) * 8;
+    if (m < a.M) {
+      p_ow[i] = (int)(m % a.W);
+      long t = m / a.W;
+      p_oh[i] = (int)(t % a.H);
+      p_n[i] = (int)(t / a.H);
+    } else {
+      p_n[i] = 0; p_oh[i] = -100000; p_ow[i] = 0;
+    }
+  }
+  const bf16_t* wsrc[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = (wave * BI + i) * 8 + lrow;
+    wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ (row & 7)) * 8;
+  }
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * 64;
+    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    unsigned char* stage = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
+      const bf16_t* p = a.zero;
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        if (a.up) { ih >>= 1; iw >>= 1; }
+        p = a.in + (((long)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + c0 + a_coff[i];
+      }
+      glds16(p, stage + (wave * AI + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) glds16(wsrc[i] + k0, stage + ABYTES + (wave * BI + i) * 1024);
+  };
+
+  f32x4_t acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  // byte offset of this lane's fragment inside a 16-row slab, for the two 32-deep K steps of a tile
+  const int foff0 = frow * 128 + ((kc ^ (frow & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ (frow & 7)) * 16);
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+    const unsigned char* Ab = smem + buf * STAGE + (wm * TM) * 128;
+    const unsigned char* Bb = smem + buf * STAGE + ABYTES + (wn * TN) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? foff1 : foff0;
+      bf16x8_t wf[NI], xf[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * 128 + fo);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        uint4 v = *(const uint4*)(Ab + j * 16 * 128 + fo);
+        if (a.relu_in) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+        xf[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long m = m0 + wm * TM + j * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int co = co0 + wn * TN + i * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) {
+        const float4 b = *(const float4*)(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const long off = m * a.Cout + co;
+      if (a.mask) {
+        const uint2 mk = *(const uint2*)(a.mask + off);
+        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+      }
+      if (a.accumulate) {
+        const uint2 o = *(const uint2*)(a.out + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *(uint2*)(a.out + off) = pk;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // filter gradient
 // ---------------------------------------------------------------------------------------------
@@ -289,6 +436,127 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgradArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// filter gradient, direct-to-LDS variant.  Tiles are [64 pixels][128 channels] = 256-B rows, deposited
+// 4 rows per wavefront instruction.  16-B slot s of row r is stored at slot s ^ ((r & 7) << 1): the eight
+// rows a ds_read_b64_tr_b16 half-wave touches then fall into eight distinct 32-B bank segments.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t frag_tr_swz(const unsigned char* tile, int row0, int slot0, int lane, int use_tr, int relu) {
+  // lane (g = lane>>4, i = lane&15): channel = 8*slot0 + i (slot0 even), k-slots {g*4+e} U {16+g*4+e}
+  const int g = lane >> 4, i = lane & 15;
+  s16x8_t r;
+  if (use_tr) {
+    const int row = row0 + g * 4 + (i >> 2);
+    const int sw = (row & 7) << 1;
+    const unsigned char* p = tile + row * 256 + (((slot0 + ((i & 3) >> 1)) ^ sw) << 4) + (i & 1) * 8;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * 256));
+    r = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = row0 + ((e < 4) ? (g * 4 + e) : (16 + g * 4 + (e - 4)));
+      const int slot = (slot0 + (i >> 3)) ^ ((row & 7) << 1);
+      r[e] = *(const short*)(tile + row * 256 + (slot << 4) + (i & 7) * 2);
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = r[e] < 0 ? (short)0 : r[e];
+  }
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TILE = 64 * 256;                 // bytes per operand tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 1, wo = wave >> 1;
+  const int nci = a.Cin / 128, nco = a.Cout / 128;
+  int b = blockIdx.x;
+  const int cot = b % nco; b /= nco;
+  const int cit = b % nci; b /= nci;
+  const int tap = b;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int ci0 = cit * 128, co0 = cot * 128;
+  const long mb = (long)blockIdx.y * a.m_chunk;
+  long me = mb + a.m_chunk;
+  if (me > a.M) me = a.M;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int lrow = lane >> 4, pos = lane & 15;
+
+  auto issue = [&](long p0, int buf) {
+    unsigned char* xs = smem + buf * 2 * TILE;
+    unsigned char* ys = xs + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 4 + lrow;       // 0..63
+      const long m = p0 + row;
+      const int slot = pos ^ ((row & 7) << 1);
+      const bf16_t* px = a.zero;
+      const bf16_t* py = a.zero;
+      if (m < me) {
+        int ow = (int)(m % a.W);
+        long t = m / a.W;
+        int oh = (int)(t % a.H);
+        int n = (int)(t / a.H);
+        int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+          if (a.up) { ih >>= 1; iw >>= 1; }
+          px = a.x + (((long)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + slot * 8;
+        }
+        py = a.dy + m * a.Cout + co0 + slot * 8;
+      }
+      glds16(px, xs + (wave * 4 + i) * 1024);
+      glds16(py, ys + (wave * 4 + i) * 1024);
+    }
+  };
+
+  f32x4_t acc[4][4];   // [co tile][ci tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const long ntile = (me - mb + 63) / 64;
+  if (ntile > 0) issue(mb, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (long t = 0; t < ntile; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntile) issue(mb + (t + 1) * 64, buf ^ 1);
+    const unsigned char* Xb = smem + buf * 2 * TILE;
+    const unsigned char* Yb = Xb + TILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yf[i] = frag_tr_swz(Yb, ks * 32, wo * 8 + i * 2, lane, a.use_tr, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = frag_tr_swz(Xb, ks * 32, wi * 8 + j * 2, lane, a.use_tr, a.relu_in);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + wo * 64 + i * 16 + (lane >> 4) * 4;
+      const int ci = ci0 + wi * 64 + j * 16 + (lane & 15);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      *(float4*)(slab + ((long)tap * a.Cin + ci) * a.Cout + co) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // filter preparation: fp32 HWIO (optionally / sigma) -> bf16 [Cout][T*Cin] and the rotated
 // in/out-swapped [Cin][T*Cout] used by the data gradient.
@@ -330,8 +598,33 @@ bool mfma_wgrad_eligible(const rcgan_conv_desc* d) {
   return mfma_eligible(d) && d->cin % 128 == 0 && d->cout % 128 == 0;
 }
 
+static int conv_impl() {      // 1 = direct-to-LDS (default), 0 = register-staged (RCGAN_CONV_IMPL=reg)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RCGAN_CONV_IMPL"); v = (e && e[0] == 'r') ? 0 : 1; }
+  return v;
+}
+
+template <int BM, int BN>
+static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  size_t lds = (size_t)2 * (BM + BN) * 128;
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM), a.Cout / BN);
+  {
+    ProfScope ps(ctx, BM == 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
+                 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 template <int BM, int BN>
 static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  if (conv_impl() == 1 && a.zero != nullptr) return launch_conv_glds<BM, BN>(ctx, a);
   static bool attr_set = false;
   size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(bf16_t);
   if (!attr_set) {
@@ -375,7 +668,18 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
   a.m_chunk = ((a.M + nz - 1) / nz + 63) / 64 * 64;
   int nzz = cdiv(a.M, a.m_chunk);
   dim3 grid(a.KH * a.KW * (a.Cin / 128) * (a.Cout / 128), nzz);
-  {
+  static int wg_glds = -1;     // the direct-to-LDS filter gradient measured slower (180 vs 327 TFLOP/s): opt-in only
+  if (wg_glds < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); wg_glds = (e && e[0] == 'g') ? 1 : 0; }
+  if (wg_glds == 1 && a.zero != nullptr) {
+    static bool attr2 = false;
+    size_t lds2 = (size_t)4 * 64 * 256;
+    if (!attr2) {
+      RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2 = true;
+    }
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL(conv_mfma_wgrad_glds_kernel, grid, dim3(256), lds2, ctx->stream, a);
+  } else {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
   }
