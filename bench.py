@@ -10,7 +10,7 @@ slabs.  Inputs are synthetic and resident in HBM before the timed re
 dequantisation noise are drawn on the device inside the captured step graphs.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (conv_mfma_kernel<128,128>, fwd + dgrad of the 3x3 convs): algorithmic flops
+  roofline     dominant kernel (conv_mfma_glds_kernel<128,128>, fwd + dgrad of the 3x3 convs): algorithmic flops
                of its launches in one iteration / their summed duration measured with HIP events on the
                launch stream, against the dense bf16 MFMA peak.
   cpu_baseline the numpy oracle (kind "port": TensorFlow 1.5 is not installable) timed on the host cores for
@@ -93,7 +93,7 @@ def iteration(m, pool, it, dcount):
 
 
 def kernel_roofline(m, pool):
-    """One eager (un-captured) iteration with every conv_mfma_kernel<128,128> launch bracketed by HIP events."""
+    """One eager (un-captured) iteration with every conv_mfma_glds_kernel<128,128> launch bracketed by HIP events."""
     from rcgan_amd import _lib as L
     ctx = m.ctx
     saved = m.use_graphs
@@ -108,7 +108,7 @@ def kernel_roofline(m, pool):
     achieved = fl.value / (ms.value * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_mfma_kernel<128,128>", "launches_per_iteration": n.value,
+            "kernel": "conv_mfma_glds_kernel<128,128>", "launches_per_iteration": n.value,
             "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
             "flops_per_launch_avg": fl.value / n.value}
 

@@ -417,9 +417,8 @@ class CifarRCGAN:
 
     def _allreduce(self, group):
         if self.world > 1:
-            import torch.distributed as dist
-            with torch.cuda.stream(self.ctx.stream):
-                dist.all_reduce(group.grad)
+            from .dp import allreduce_sum_
+            allreduce_sum_(group.grad, self.ctx.stream)
 
     def d_step(self, iteration=None):
         """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""

@@ -1,0 +1,38 @@
+"""Data-parallel helpers: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+Semantics = the reference's in-graph towers (cifar10/gan_resnet.py:183-192, 529-552, 697, 786): the global
+batch is split contiguously, every tower computes its loss on its own shard (own batch-norm statistics),
+the cost is the MEAN of the tower costs -- so the gradient is the mean of the per-rank gradients.  One
+all-reduce(sum) per optimiser step on the flat fp32 gradient slab; the 1/world factor is applied inside
+the Adam kernel (``grad_scale``)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(a, rank, world):
+    """rank r owns rows [r*B/N, (r+1)*B/N) of every fed array (tf.split(axis=0), gan_resnet.py:529-538)."""
+    a = np.asarray(a)
+    n = a.shape[0]
+    if n % world:
+        raise ValueError("batch %d is not divisible by %d ranks" % (n, world))
+    k = n // world
+    return a[rank * k:(rank + 1) * k]
+
+
+def allreduce_sum_(flat, stream=None):
+    """In-place sum over ranks of a flat gradient slab (no-op for a single rank)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            dist.all_reduce(flat)
+    else:
+        dist.all_reduce(flat)
+    return flat
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
