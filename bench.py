@@ -152,16 +152,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("RCGAN_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import rcgan_amd  # noqa: F401
     from rcgan_amd.cifar import CifarRCGAN
 
     alpha = 0.6
     m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0,
                    device=local, use_graphs=not args.no_graphs, device_rng=True, world_size=world, rank=rank)
+    if force_dist:
+        m.world = 2          # take the all-reduce branch; grad_scale 1/2 cancels against the doubled "sum" below
+        from rcgan_amd import dp as _dp
+        _orig = _dp.allreduce_sum_
+        def _twice(flat, stream=None):
+            _orig(flat, stream)
+            with torch.cuda.stream(stream):
+                flat.mul_(2.0)
+            return flat
+        _dp.allreduce_sum_ = _twice
     pool = build_pool(m, rank, alpha)
     dcount = [0]
     warm = max(args.warmup, 2)      # iteration 0 has no G step; graphs are captured on first use
@@ -188,6 +201,7 @@ def main():
     d_loss, g_loss = m.losses()
     ok = np.isfinite(d_loss) and np.isfinite(g_loss)
 
+    out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = N_CRITIC * args.batch * world / (dt / args.steps)
@@ -204,14 +218,21 @@ def main():
         out["roofline"] = kernel_roofline(m, pool) if args.dtype == "bf16" else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alpha)
-        print(json.dumps(out), flush=True)
     else:
         if args.dtype == "bf16":
             kernel_roofline(m, pool)      # keep ranks in lock-step through the extra (all-reducing) iteration
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     m.ctx.close()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio: flush it first so the JSON line is the last line
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -465,6 +465,41 @@ class CifarRCGAN:
     def get_state(self):
         return {k: self.ctx.download(v).reshape(1, -1) for k, v in self.state.items()}
 
+    # ---------------------------------------------------------------------------------- checkpoints
+    def state_dict(self):
+        """Everything tf.train.Saver would store (gan_resnet.py:906): variables, Adam slots (TF slot names
+        "<var>/Adam", "<var>/Adam_1"), the optimisers' step counters and the SN ``u`` vectors."""
+        out = {}
+        for gname, grp in zip(("Generator", "Discriminator", "confusion"), self.groups):
+            for n in grp.names:
+                out[n] = grp.get(n)
+                out[n + "/Adam"] = grp.get(n, "m")
+                out[n + "/Adam_1"] = grp.get(n, "v")
+            out["_opt/%s/step" % gname] = np.array([grp.t], np.int64)
+        for k, v in self.get_state().items():
+            out[k] = v
+        out["_iteration"] = np.array([self.iteration], np.int64)
+        return out
+
+    def load_state_dict(self, sd):
+        for gname, grp in zip(("Generator", "Discriminator", "confusion"), self.groups):
+            for n in grp.names:
+                if n not in sd:
+                    raise KeyError("checkpoint is missing variable %s" % n)
+                grp.set(n, sd[n])
+                if n + "/Adam" in sd:
+                    grp.set(n, sd[n + "/Adam"], "m")
+                    grp.set(n, sd[n + "/Adam_1"], "v")
+            key = "_opt/%s/step" % gname
+            if key in sd:
+                grp.t = int(sd[key][0])
+        ctx = self.ctx
+        for k, t in self.state.items():
+            if k in sd:
+                with torch.cuda.stream(ctx.stream):
+                    ctx.view(t).copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sd[k], np.float32).reshape(-1))))
+        ctx.sync()
+
     def sample(self, labels, z):
         """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32."""
         ctx, g = self.ctx, self.graph

@@ -22,7 +22,7 @@ def shard_rows(a, rank, world):
 
 def allreduce_sum_(flat, stream=None):
     """In-place sum over ranks of a flat gradient slab (no-op for a single rank)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return flat
     if stream is not None:
         with torch.cuda.stream(stream):

@@ -1,0 +1,168 @@
+"""CIFAR-10 training entry point with the reference's flag surface and output layout
+(cifar10/gan_resnet.py:38-197 flags/globals, :819-1016 loop, checkpoints and samples).
+
+Launch exactly like the reference (``cifar10/run_rcgan.sh`` ...); for more than one GPU start one process
+per GPU with ``python -m torch.distributed.run --nproc-per-node N`` -- ``--ngpus`` then has to equal N and
+(with --multi_gpu_multi_batch) keeps its reference meaning: global batch = 64*N, iterations = niters/N.
+"""
+import logging
+import os
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+
+from . import data as D
+from .host import Flags, Plot, Saver, latest_checkpoint, load_checkpoint, record_setting, save_images
+
+DATA_DIR = '../data/cifar10/cifar-10-batches-py/'
+
+
+def define_flags():
+    f = Flags()
+    f.DEFINE_string("dataset", 'cifar', "Dataset")
+    f.DEFINE_string("algorithm", 'rcgan', "Algorithm [rcgan, rcgan-u, biased, unbiased]")
+    f.DEFINE_float("alpha", 0.8, "1 - noise level")
+    f.DEFINE_string("run", '0', "run name")
+    f.DEFINE_string("log_file", None, "logging file")
+    f.DEFINE_string("parent_dir", '.', "parent directory for checkpoints")
+    f.DEFINE_string("expt_dir", None, "directory for expts")
+    f.DEFINE_integer("inception_freq", 2500, "frequncy of inception score calculation")
+    f.DEFINE_integer("sample_freq", 2500, "frequncy of dev cost calc. and sample pics")
+    f.DEFINE_integer("generated_label_accuracy_freq", 2500, "frequncy of generated label accruacy")
+    f.DEFINE_integer("sample_save_freq", 0, "frequncy of saving samples")
+    f.DEFINE_integer("batch_size", 64, "batch size")
+    f.DEFINE_integer("niters", 50000, "no. of batches")
+    f.DEFINE_float("lr", 2.0e-4, "learning rate")
+    f.DEFINE_integer("ngpus", 2, "no. of gpus")
+    f.DEFINE_boolean("multi_gpu_multi_batch", True, "multiply batch_size with #gpus and divide #iterations by #gpus")
+    f.DEFINE_boolean("confuse_init", False, "whether to initialize confusion matrix with identity")
+    f.DEFINE_float("confuse_init_diag", 0.2, "intial confusion matrix with diagonal entry")
+    f.DEFINE_float("confuse_multiplier", 1.0, "learning rate multiplier for learnable confusion matrix")
+    f.DEFINE_boolean("confuse_lr_decay", False, "whether to decay confusion matrix estimation learning rate")
+    f.DEFINE_boolean("perm_classifier", False, "whether to real fake classifier or not.")
+    f.DEFINE_float("perm_multiplier", 1.0, "whether to real fake classifier or not.")
+    f.DEFINE_string("perm_type", 'linear', "type of real fake classifier to use [linear, 2layer].")
+    f.DEFINE_boolean("restore", True, "whether to restore from past checkpoint")
+    f.DEFINE_boolean("perm_gen_label_acc", False, "min. over label permutations of the generated label accuracy")
+    f.DEFINE_string("log_level", 'info', "logging level [info, debug]")
+    # this build's additions (absent flags keep the reference behaviour)
+    f.DEFINE_string("dtype", 'bf16', "activation dtype [bf16, f32]")
+    f.DEFINE_boolean("synthetic", False, "train on the SURVEY 8(d) synthetic data instead of ../data/cifar10")
+    f.DEFINE_integer("seed", 0, "variable-initialisation seed")
+    f.DEFINE_string("data_dir", DATA_DIR, "CIFAR-10 python batches")
+    f.DEFINE_integer("sample_every", 100, "sample-grid period (the reference hard-codes 100 for cifar)")
+    return f
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    FLAGS = define_flags().parse(argv)
+    if FLAGS.log_file is None:
+        raise ValueError('flag log_file is required')                         # gan_resnet.py:81-82
+    if FLAGS.dataset != "cifar":
+        raise ValueError("only --dataset cifar is wired in this entry point")
+    logging.basicConfig(filename=FLAGS.log_file, level=logging.DEBUG if FLAGS.log_level == 'debug' else logging.INFO,
+                        format='%(asctime)s %(levelname)-8s %(message)s')
+    ALGORITHM, ALPHA = FLAGS.algorithm, FLAGS.alpha
+    logging.info('alpha = {}'.format(ALPHA))
+    C_ALPHA = D.C_ALPHA(ALPHA)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    N_GPUS = FLAGS.ngpus
+    if world > 1 and N_GPUS != world:
+        raise Exception('--ngpus %d does not match the %d launched ranks' % (N_GPUS, world))
+    if world == 1 and N_GPUS != 1:
+        logging.warning("--ngpus %d requested but one rank launched: running the %d towers' batch on one GPU", N_GPUS, N_GPUS)
+    BATCH_SIZE, ITERS = FLAGS.batch_size, FLAGS.niters
+    if FLAGS.multi_gpu_multi_batch:                                           # gan_resnet.py:190-192
+        BATCH_SIZE, ITERS = BATCH_SIZE * N_GPUS, ITERS // N_GPUS
+    per_rank = BATCH_SIZE // world
+
+    DIR = os.path.join(FLAGS.parent_dir, ALGORITHM + '_alpha' + str(ALPHA) + '_run-' + FLAGS.run + '_' +
+                       datetime.now().strftime("%Y%m%d-%H%M%S"))                # gan_resnet.py:115
+    if FLAGS.expt_dir is not None:
+        DIR = '{}/{}'.format(FLAGS.parent_dir, FLAGS.expt_dir)
+    if rank == 0:
+        os.makedirs(DIR, exist_ok=True)
+        record_setting(os.path.join(DIR, 'scripts'))
+    CHECKPOINT_DIR = os.path.join(DIR, 'checkpoint')
+    SAMPLE_FREQUENCY, SAMPLE_SAVE_FREQUENCY = FLAGS.sample_every, 0            # cifar branch, gan_resnet.py:111-114
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from .cifar import N_CRITIC, Z_DIM, CifarRCGAN
+    m = CifarRCGAN(algorithm=ALGORITHM, alpha=ALPHA, batch_size=per_rank, lr=FLAGS.lr, dtype=FLAGS.dtype, seed=FLAGS.seed,
+                   perm_classifier=FLAGS.perm_classifier, perm_multiplier=FLAGS.perm_multiplier, perm_type=FLAGS.perm_type,
+                   confuse_init=FLAGS.confuse_init, confuse_init_diag=FLAGS.confuse_init_diag,
+                   confuse_multiplier=FLAGS.confuse_multiplier, confuse_lr_decay=FLAGS.confuse_lr_decay,
+                   device=local, world_size=world, rank=rank)
+
+    # data: label noise drawn from the global numpy stream exactly as the reference does (unseeded there)
+    if FLAGS.synthetic:
+        tx, ty = D.synthetic_cifar(50000, 1234)
+        vx, vy = D.synthetic_cifar(10000, 1235)
+        train_gen = D.cifar_generator(tx, ty, BATCH_SIZE, C_ALPHA)
+        dev_gen = D.cifar_generator(vx, vy, BATCH_SIZE, C_ALPHA)
+    else:
+        train_gen, dev_gen = D.load(BATCH_SIZE, FLAGS.data_dir, C_ALPHA)
+    gen = D.inf_train_gen(train_gen)
+    gen_G = D.inf_train_gen_G(train_gen, 2)
+    from .dp import shard_rows
+    sh = lambda a: shard_rows(a, rank, world)
+
+    saver = Saver(max_to_keep=5)
+    if FLAGS.restore:
+        ckpt = latest_checkpoint(CHECKPOINT_DIR)
+        if ckpt:
+            logging.info('restore model from: {}...'.format(ckpt))
+            m.load_state_dict(load_checkpoint(ckpt))
+    plot = Plot()
+    fixed_noise = np.random.normal(size=(100, Z_DIM)).astype('float32')       # gan_resnet.py:822
+    fixed_labels = np.array([k for k in range(10) for _ in range(10)], dtype='int32')
+
+    def feed_d(batch):
+        images, labels, rnd, bia, inv = batch
+        second = rnd if ALGORITHM in ("biased", "unbiased") else bia
+        m.set_inputs(images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
+                     inv_weights=sh(inv), labels_all=np.concatenate([sh(labels), sh(second)]))
+
+    _random_labels_G, _labels_biased_G = next(gen_G)
+    for iteration in range(ITERS):                                             # gan_resnet.py:919-1016
+        t0 = time.time()
+        if 0 < iteration:
+            _random_labels_G, _labels_biased_G = next(gen_G)
+            m.set_inputs(labels_random_G=sh(_random_labels_G), labels_biased_G=sh(_labels_biased_G))
+            m.g_step(iteration=iteration)
+        for _ in range(N_CRITIC):
+            feed_d(next(gen))
+            m.d_step(iteration=iteration)
+        m.iteration = iteration + 1
+        if iteration % 10 == 0 or iteration < 5:
+            d_cost, g_cost = m.losses()
+            plot.plot('d_cost', d_cost)
+            plot.plot('g_cost', g_cost)
+            plot.plot('sec_per_iter', time.time() - t0)
+        if rank == 0 and iteration % SAMPLE_FREQUENCY == SAMPLE_FREQUENCY - 1:
+            samples = m.sample(fixed_labels, fixed_noise)
+            samples = ((samples + 1.) * (255. / 2)).astype('int32')             # gan_resnet.py:831
+            save_images(samples.reshape((100, 32, 32, 3)), os.path.join(DIR, 'samples_{}.png'.format(iteration)))
+        if rank == 0 and ((iteration < 500 and iteration % 100 == 99) or (iteration % 1000 == 999)):
+            plot.dir_flush(DIR)
+            saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', iteration)
+        plot.tick()
+    if rank == 0 and ITERS:
+        plot.dir_flush(DIR)
+        saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', max(ITERS - 1, 0))
+    m.ctx.close()
+    return DIR
+
+
+if __name__ == '__main__':
+    main()
