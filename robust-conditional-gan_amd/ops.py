@@ -176,9 +176,13 @@ def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
             if dy is None:
                 return
             if x.req:
-                assert x.grad is None, "deconv input gradient is written once"
-                dx, _ = grad_of(ctx, x)
-                ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(dx)))
+                dx, acc = grad_of(ctx, x)
+                if not acc:
+                    ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(dx)))
+                else:
+                    tmp = ctx.empty(x.shape, x.dtype)
+                    ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(tmp)))
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, x.size, x.dtype, 1.0, _p(tmp), 1.0, _p(dx)))
             if w.req:
                 ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(w.grad),
                                                             _p(bias.grad) if (bias is not None and bias.req) else None, 1,
@@ -341,9 +345,13 @@ def concat_channels(ctx, x, yb):
         def bw():
             if y.grad is None:
                 return
-            assert x.grad is None
-            dx, _ = grad_of(ctx, x)
-            ctx.check(ctx.lib.rcgan_concat_channels_bwd(ctx.h, n, hw, c1, c2, x.dtype, _p(y.grad), _p(dx)))
+            dx, acc = grad_of(ctx, x)
+            if not acc:
+                ctx.check(ctx.lib.rcgan_concat_channels_bwd(ctx.h, n, hw, c1, c2, x.dtype, _p(y.grad), _p(dx)))
+            else:
+                tmp = ctx.empty(x.shape, x.dtype)
+                ctx.check(ctx.lib.rcgan_concat_channels_bwd(ctx.h, n, hw, c1, c2, x.dtype, _p(y.grad), _p(tmp)))
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, x.size, x.dtype, 1.0, _p(tmp), 1.0, _p(dx)))
         ctx.record(bw)
     return y
 
@@ -400,7 +408,7 @@ def act_meanhw(ctx, x, kind):
         def bw():
             if y.grad is None:
                 return
-            assert x.grad is None
+            assert x.grad is None, "act_meanhw input has a single consumer in both models"
             dx, _ = grad_of(ctx, x)
             ctx.check(ctx.lib.rcgan_act_meanhw_bwd(ctx.h, n, h * w, c, x.dtype, kind, _p(x), _p(y.grad), _p(dx)))
         ctx.record(bw)

@@ -72,7 +72,10 @@ def _check(m, P, Uo, alg, perm, raw, gb, C, tol_kind):
             scale = max(float(np.abs(gref).max()), floor)
             err = float(np.abs(a - gref).max()) / scale
             if not bf16:
-                assert err <= 1e-2, "%s %s: max err %.3e of scale %.3e" % (tag, k, err, scale)
+                # norm-relative 1e-2; the max-error bound is looser because one ReLU input within ~1e-7 of zero
+                # may take the other branch under a different fp32 summation order (tests/test_gpu_mnist_step.py)
+                nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
+                assert nrm <= 1e-2 and err <= 1e-1, "%s %s: norm-rel %.3e max err %.3e of scale %.3e" % (tag, k, nrm, err, scale)
             elif np.size(gref) <= 1:
                 # one-element gradients (D.Output/b) are sums of +-1/B hinge indicators: a logit crossing the
                 # hinge threshold under bf16 rounding moves them by a whole 1/B step

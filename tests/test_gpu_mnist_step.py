@@ -1,0 +1,151 @@
+"""Step-level parity of the MNIST engine (HIP, through the C ABI) against the numpy oracle evaluated in
+float64: one D run and the two G runs of a reference iteration (mnist/model.py:347-372) from identical weights
+and batch.  fp32 activations (BASELINE cfg1/cfg2); tolerance 1e-2 of each gradient's scale with the same
+near-zero floor as the CIFAR test (batch norm over <= 8 samples)."""
+import numpy as np
+import pytest
+
+from oracle import labels as LB
+from oracle import mnist as om
+from tests.gpu_util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(rs, B, alpha=0.3):
+    C = LB.one_coin(alpha)
+    eye = np.eye(10, dtype=np.float32)
+    yr = rs.randint(10, size=B)
+    return C, dict(images=rs.rand(B, 28, 28, 1).astype(np.float32), z=rs.uniform(-1, 1, size=(B, 100)).astype(np.float32),
+                   y_real=eye[yr], y_gen=eye[rs.randint(10, size=B)], y_fake=eye[rs.randint(10, size=B)],
+                   y_real_weights=np.linalg.inv(C)[yr].astype(np.float32))
+
+
+def _cmp(tag, got, grads, grads32):
+    """HIP fp32 vs the float64 oracle, per tensor: norm-relative error <= 1e-2 (or 4x the float32 oracle's own
+    distance from float64) and max error <= 1e-1 of the tensor's scale.  The max-error bound is loose on purpose:
+    a ReLU / leaky-ReLU input within ~1e-7 of zero can take the other branch under a different fp32 summation
+    order, which moves the few gradient entries fed by that one activation by ~1e-2 of the scale while leaving
+    the rest at 1e-6 (observed: scripts/debug_mnist.py)."""
+    gmax = max(float(np.abs(g).max()) for g in grads.values())
+    for k, gref in grads.items():
+        a = got[k]
+        assert np.isfinite(a).all(), k
+        scale = max(float(np.abs(gref).max()), 1e-3 * gmax)
+        err = float(np.abs(a - gref).max()) / scale
+        nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
+        own = float(np.linalg.norm(grads32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
+        assert nrm <= max(1e-2, 4 * own) and err <= 1e-1, \
+            "%s %s: norm-rel %.3e max %.3e of scale %.3e (fp32 oracle norm-rel %.3e)" % (tag, k, nrm, err, scale, own)
+
+
+CASES = [("rcgan", "projection", False, "hinge", False), ("rcgan", "projection", True, "hinge", False),
+         ("unbiased", "projection", False, "hinge", False), ("biased", "vanilla", False, "ce", False),
+         ("rcgan", "projection", False, "hinge", True)]
+
+
+@pytest.mark.parametrize("alg,disc,est,loss,concat", CASES)
+def test_mnist_iteration_parity_fp32(alg, disc, est, loss, concat):
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.mnist import MnistRCGAN, create_variables
+    rs = np.random.RandomState(41)
+    B = 8
+    layers = (1, 3) if concat else ()
+    variables = create_variables(0, disc, est, True, disc == "projection", layers)
+    gs, ds, cs, S, U = variables
+    jit = np.random.RandomState(3)
+
+    def jitter(specs):
+        out = []
+        for n, shp, v in specs:
+            if n.endswith(("/bias", "/biases", "/beta", "/gamma")):
+                v = (v + 0.1 * jit.randn(*shp)).astype(np.float32)
+            out.append((n, shp, v))
+        return out
+    variables = (jitter(gs), jitter(ds), cs, S, U)
+    C, b = _batch(rs, B)
+    m = MnistRCGAN(algorithm=alg, alpha=0.3, batch_size=B, dtype="f32", disc_type=disc, loss_fn=loss, estimate_confuse=est,
+                   perm_regularizer=True, perm_multiplier=10.0, spectral_norm=disc == "projection", max_norm=True,
+                   concat_y=concat, concat_y_layers=layers, use_graphs=False, variables=variables)
+    try:
+        # the product's variable creation equals the oracle's
+        P, S0, U0 = om.init_params(0, disc, est, True, disc == "projection", layers)
+        for n, shp, v in gs + ds + cs:
+            assert np.array_equal(v, P[n]), n
+        P = {n: v.copy() for n, _, v in variables[0] + variables[1] + variables[2]}
+        So = {k: v.copy() for k, v in S.items()}
+        Uo = {k: v.copy() for k, v in U.items()}
+        cfg = dict(algorithm=alg, disc_type=disc, estimate_confuse=est, loss_fn=loss, perm_regularizer=True, perm_multiplier=10.0,
+                   spectral_norm=disc == "projection", C=C, concat_y=concat, concat_y_layers=layers, max_norm=True,
+                   confuse_multiplier=10.0)
+        m.set_inputs(**b)
+        # ---- D run
+        L64, g64 = om.d_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+        _, g32 = om.d_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float32)
+        m.d_step()
+        got = m.losses()
+        for k in ("d_loss_real", "d_loss_fake", "class_loss_real"):
+            assert abs(got[k] - L64[k]) <= 2e-5 * max(1.0, abs(L64[k])), (k, got[k], L64[k])
+        _cmp("D grad", m.get_grads(m.PD), g64, g32)
+        tr = om.Trainer(P, So, Uo, cfg)
+        tr.d_step(b)
+        st = m.get_state()
+        for k in So:
+            if k.startswith("generator/"):
+                assert_close(st[k], So[k], 1e-4, "moving " + k)
+        for k in Uo:
+            assert_close(st[k], Uo[k], 1e-4, "u " + k)
+        newp = m.get_params()
+        if m.clip_range is not None:
+            for k in ("discriminator/d_h4_lin/Matrix", "discriminator/d_h5_y_lin/Matrix", "discriminator/d_h5_y_lin/bias"):
+                assert np.abs(newp[k]).max() <= 1.0
+        # ---- two G runs from the device's own post-D state
+        for run in range(2):
+            newp, st = m.get_params(), m.get_state()
+            for k in P:
+                P[k] = newp[k].copy()
+            for k in So:
+                So[k] = st[k].copy()
+            for k in Uo:
+                Uo[k] = st[k].copy()
+            L64, g64 = om.g_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+            _, g32 = om.g_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float32)
+            m.g_step()
+            got = m.losses()
+            for k in ("g_loss", "class_loss_fake"):
+                assert abs(got[k] - L64[k]) <= 2e-5 * max(1.0, abs(L64[k])), (k, got[k], L64[k])
+            gg = m.get_grads(m.PG)
+            if m.PC is not None:
+                gg.update(m.get_grads(m.PC))
+            _cmp("G grad run %d" % run, gg, g64, g32)
+    finally:
+        m.ctx.close()
+
+
+def test_mnist_sampler_and_graph_replay():
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.mnist import MnistRCGAN, create_variables
+    rs = np.random.RandomState(43)
+    B = 8
+    C, b = _batch(rs, B)
+    outs = []
+    for graphs in (False, True):
+        variables = create_variables(0, "projection", True, True, True, ())
+        m = MnistRCGAN(algorithm="rcgan", batch_size=B, dtype="f32", estimate_confuse=True, use_graphs=graphs, variables=variables)
+        try:
+            m.set_inputs(**b)
+            for _ in range(3):
+                m.iteration()
+            outs.append((m.get_params(), m.get_state(), m.sampler(b["z"], b["y_gen"])))
+        finally:
+            m.ctx.close()
+    (pa, sa, xa), (pb, sb, xb) = outs
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(xa, xb) and xa.shape == (B, 28, 28, 1) and (xa > 0).all() and (xa < 1).all()
+    # sampler == oracle gen_sampler on the same weights and moving statistics
+    S = {k: v for k, v in sa.items() if "moving" in k}
+    ref = om.sampler(pa, S, b["z"], b["y_gen"])
+    assert_close(xa, ref, 1e-4, "gen_sampler")

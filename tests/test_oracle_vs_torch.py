@@ -220,3 +220,72 @@ def test_towers_equal_mean_of_shards():
     assert abs(c2 - 0.5 * (parts[0][0] + parts[1][0])) < 1e-12
     for k in g2:
         np.testing.assert_allclose(g2[k], 0.5 * (parts[0][1][k] + parts[1][1][k]), atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------------
+# MNIST
+# ----------------------------------------------------------------------------------------------------
+def _mnist_batch(rs, B):
+    from oracle import labels as LB
+    C = LB.one_coin(0.3)
+    eye = np.eye(10)
+    yr = rs.randint(10, size=B)
+    return C, dict(images=rs.rand(B, 28, 28, 1), z=rs.uniform(-1, 1, size=(B, 100)), y_real=eye[yr], y_gen=eye[rs.randint(10, size=B)],
+                   y_fake=eye[rs.randint(10, size=B)], y_real_weights=np.linalg.inv(C)[yr])
+
+
+@pytest.mark.parametrize("alg,disc,est,loss", [("rcgan", "projection", False, "hinge"), ("rcgan", "projection", True, "hinge"),
+                                               ("unbiased", "projection", False, "hinge"), ("biased", "vanilla", False, "ce"),
+                                               ("rcgan", "projection+y", False, "hinge")])
+def test_mnist_step_grads(alg, disc, est, loss):
+    from oracle import mnist as om
+    rs = _rs(31)
+    B = 3
+    concat = disc.endswith("+y")
+    disc = disc.split("+")[0]
+    layers = (1, 3) if concat else ()
+    P, S, U = om.init_params(0, disc, est, True, disc == "projection", layers)
+    for k in P:
+        if k.endswith("/bias") or k.endswith("/biases") or k.endswith("/beta") or k.endswith("/gamma"):
+            P[k] = P[k] + 0.1 * rs.randn(*P[k].shape).astype("float32")
+    C, b = _mnist_batch(rs, B)
+    cfg = dict(algorithm=alg, disc_type=disc, estimate_confuse=est, loss_fn=loss, perm_regularizer=True, perm_multiplier=10.0,
+               spectral_norm=disc == "projection", C=C, concat_y=concat, concat_y_layers=layers)
+    tm = TR.MnistTorch(P, U, cfg)
+    L = tm.losses(b)
+    Ld, gd = om.d_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float64)
+    (L["d_loss_real"] + L["d_loss_fake"] + L["class_loss_real"]).backward(retain_graph=True)
+    for k in ("d_loss_real", "d_loss_fake", "g_loss", "class_loss_real", "class_loss_fake"):
+        assert abs(Ld[k] - L[k].item()) < 1e-9, k
+    for k, p in tm.P.items():
+        if om.is_d_var(k):
+            np.testing.assert_allclose(gd[k], p.grad.numpy(), atol=1e-8, rtol=1e-6, err_msg=k)
+    for p in tm.P.values():
+        p.grad = None
+    Lg, gg = om.g_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float64)
+    (L["g_loss"] + 10.0 * L["class_loss_fake"]).backward(retain_graph=True)
+    for k, p in tm.P.items():
+        if om.is_g_var(k):
+            np.testing.assert_allclose(gg[k], p.grad.numpy(), atol=1e-8, rtol=1e-6, err_msg=k)
+    if est:
+        for p in tm.P.values():
+            p.grad = None
+        L["g_loss"].backward()
+        # c_optim minimises g_loss alone; the perm term does not depend on confusion_logits
+        np.testing.assert_allclose(gg["confusion_logits"], tm.P["confusion_logits"].grad.numpy(), atol=1e-9)
+
+
+def test_mnist_param_shapes_and_moving_stats():
+    from oracle import mnist as om
+    P, S, U = om.init_params(0, "projection", True, True, True)
+    assert P["generator/g_h2/w"].shape == (5, 5, 128, 138) and P["generator/g_h3/w"].shape == (5, 5, 1, 138)
+    assert P["discriminator/d_h0_conv/w"].shape == (5, 5, 1, 64) and U["discriminator/d_h3_conv/spectral_norm/u"].shape == (1, 64)
+    assert P["classifier/d_classifier_h1/Matrix"].shape == (784, 10) and P["confusion_logits"].shape == (10, 10)
+    rs = _rs(5)
+    C, b = _mnist_batch(rs, 4)
+    cfg = dict(algorithm="rcgan", C=C)
+    S0 = {k: v.copy() for k, v in S.items()}
+    om.d_grads(P, S, dict(U), cfg, b)
+    assert not np.array_equal(S["generator/g_bn0/moving_mean"], S0["generator/g_bn0/moving_mean"])
+    out = om.sampler(P, S, b["z"], b["y_gen"])
+    assert out.shape == (4, 28, 28, 1) and (out > 0).all() and (out < 1).all()

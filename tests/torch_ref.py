@@ -202,3 +202,110 @@ def adam_tf_torch(w, g, m, v, t, lr, b1, b2, eps=1e-8):
     m = b1 * m + (1 - b1) * g
     v = b2 * v + (1 - b2) * g * g
     return w - lr_t * m / (v.sqrt() + eps), m, v
+
+
+# ----------------------------------------------------------------------------------------------------
+# MNIST (mnist/model.py) -- second implementation for the oracle cross-check
+# ----------------------------------------------------------------------------------------------------
+def bn_train(x, gamma, beta, eps=1e-5):
+    dims = tuple(range(x.dim() - 1))
+    mean = x.mean(dim=dims, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=dims, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+class MnistTorch:
+    def __init__(self, P, U, cfg, dtype=torch.float64):
+        self.P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in P.items()}
+        self.U = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in U.items()}
+        self.cfg, self.dtype = cfg, dtype
+
+    def T(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=self.dtype)
+
+    def lin(self, x, name):
+        return x @ self.P[name + "/Matrix"] + self.P[name + "/bias"]
+
+    def conv(self, x, name, sn):
+        w = self.P[name + "/w"]
+        if sn:
+            w, _ = spectral_norm(w, self.U[name + "/spectral_norm/u"])
+        return conv2d_same(x, w, 2) + self.P[name + "/biases"]
+
+    def deconv(self, x, shape, name):
+        return conv2d_transpose_same(x, self.P[name + "/w"], shape, 2) + self.P[name + "/biases"]
+
+    def bn(self, x, name):
+        return bn_train(x, self.P[name + "/gamma"], self.P[name + "/beta"])
+
+    def cat(self, x, y):
+        y = self.T(y)
+        if x.dim() == 4:
+            n, h, w, _ = x.shape
+            return torch.cat([x, y[:, None, None, :].expand(n, h, w, y.shape[1])], 3)
+        return torch.cat([x, y], 1)
+
+    def generator(self, z, y):
+        p = "generator/"
+        B = len(z)
+        h = self.cat(self.T(z), y)
+        h0 = self.cat(F.relu(self.bn(self.lin(h, p + "g_h0_lin"), p + "g_bn0")), y)
+        h1 = F.relu(self.bn(self.lin(h0, p + "g_h1_lin"), p + "g_bn1")).reshape(B, 7, 7, 128)
+        h2 = F.relu(self.bn(self.deconv(self.cat(h1, y), (B, 14, 14, 128), p + "g_h2"), p + "g_bn2"))
+        return torch.sigmoid(self.deconv(self.cat(h2, y), (B, 28, 28, 1), p + "g_h3"))
+
+    def discriminator(self, image, y):
+        p = "discriminator/"
+        B = image.shape[0]
+        lre = lambda v: torch.maximum(v, 0.2 * v)
+        if self.cfg.get("disc_type", "projection") == "projection":
+            sn = self.cfg.get("spectral_norm", True)
+            layers = self.cfg.get("concat_y_layers", ()) if self.cfg.get("concat_y") else ()
+            x = image
+            for i in range(4):
+                if (i + 1) in layers:
+                    x = self.cat(x, y)
+                x = self.conv(x, p + "d_h%d_conv" % i, sn)
+                if i > 0:
+                    x = self.bn(x, p + "d_bn%d" % i)
+                x = lre(x)
+            h3 = x.mean(dim=(1, 2))
+            return self.lin(h3, p + "d_h4_lin") + (h3 * self.lin(self.T(y), p + "d_h5_y_lin")).sum(1, keepdim=True)
+        h0 = self.cat(lre(self.conv(self.cat(image, y), p + "d_h0_conv", False)), y)
+        h1 = lre(self.bn(self.conv(h0, p + "d_h1_conv", False), p + "d_bn1")).reshape(B, -1)
+        h3 = lre(self.bn(self.lin(self.cat(h1, y), p + "d_h3_lin"), p + "d_bn2"))
+        return self.lin(self.cat(h3, y), p + "d_h4_lin")
+
+    def losses(self, b):
+        cfg = self.cfg
+        alg = cfg["algorithm"]
+        hinge = cfg.get("loss_fn", "hinge") == "hinge"
+        bce = lambda x, z: F.binary_cross_entropy_with_logits(x, torch.full_like(x, z), reduction="none")
+        lr_ = (lambda x: F.relu(1 - x)) if hinge else (lambda x: bce(x, 1.0))
+        lf_ = (lambda x: F.relu(1 + x)) if hinge else (lambda x: bce(x, 0.0))
+        lg_ = (lambda x: -x) if hinge else (lambda x: bce(x, 1.0))
+        B = len(b["z"])
+        G = self.generator(b["z"], b["y_gen"])
+        x = self.T(b["images"])
+        eye = lambda i: np.eye(10)[np.full(B, i)]
+        out = {}
+        if alg in ("biased", "rcgan", "ambient"):
+            out["d_loss_real"] = lr_(self.discriminator(x, b["y_real"])).mean()
+        else:
+            cols = torch.cat([lr_(self.discriminator(x, eye(i))) for i in range(10)], 1)
+            out["d_loss_real"] = (cols * self.T(b["y_real_weights"])).sum(1).mean()
+        if alg in ("rcgan", "ambient") and cfg.get("estimate_confuse"):
+            los = [self.discriminator(G, eye(i)) for i in range(10)]
+            C = torch.softmax(self.P["confusion_logits"], -1)
+            yc = self.T(b["y_gen"]) @ C
+            out["d_loss_fake"] = (torch.cat([lf_(l) for l in los], 1) * yc).sum(1).mean()
+            out["g_loss"] = (torch.cat([lg_(l) for l in los], 1) * yc).sum(1).mean()
+        else:
+            lo = self.discriminator(G, b["y_fake"] if alg in ("rcgan", "ambient") else b["y_gen"])
+            out["d_loss_fake"] = lf_(lo).mean()
+            out["g_loss"] = lg_(lo).mean()
+        if cfg.get("perm_regularizer", True):
+            cl = lambda v: self.lin(v.reshape(B, -1), "classifier/d_classifier_h1")
+            out["class_loss_real"] = F.binary_cross_entropy_with_logits(cl(x), self.T(b["y_real"]))
+            out["class_loss_fake"] = F.binary_cross_entropy_with_logits(cl(G), self.T(b["y_gen"]))
+        return out
