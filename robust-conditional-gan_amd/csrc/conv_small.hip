@@ -63,42 +63,83 @@ struct SmallGeom {
 // WMODE 0: w(t,c,n) = W[(t*Cs+c)*Cb + n]            (forward, HWIO with Cin = Cs, Cout = Cb)
 // WMODE 1: w(t,c,n) = W[((T-1-t)*Cb + n)*Cs + c]    (data gradient of a conv with Cin = Cb, Cout = Cs)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WMODE>
-__global__ __launch_bounds__(256) void conv_smallk_kernel(SmallGeom g, const T* in, const float* w, const float* bias,
-                                                           T* out, int accumulate) {
-  extern __shared__ float Ws[];            // [K][Cb]
-  const int Tt = g.KH * g.KW, K = Tt * g.Cs;
-  for (int i = threadIdx.x; i < K * g.Cb; i += 256) {
-    int n = i % g.Cb, k = i / g.Cb;
-    int c = k % g.Cs, t = k / g.Cs;
-    Ws[i] = WMODE == 0 ? w[(long)k * g.Cb + n] : w[((long)(Tt - 1 - t) * g.Cb + n) * g.Cs + c];
-  }
-  __syncthreads();
-  const int tpp = g.Cb / 8;                // threads per pixel
-  const int ppb = 256 / tpp;               // pixels per block pass
-  const int n0 = (threadIdx.x % tpp) * 8;
-  const int pl = threadIdx.x / tpp;
-  for (long m = (long)blockIdx.x * ppb + pl; m < g.M; m += (long)gridDim.x * ppb) {
-    int ow = (int)(m % g.W);
-    long q = m / g.W;
-    int oh = (int)(q % g.H);
-    int b = (int)(q / g.H);
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[n0 + j] : 0.f;
-    for (int t = 0; t < Tt; ++t) {
-      int kh = t / g.KW, kw = t - kh * g.KW;
-      int ih = oh * g.S + kh - g.PT, iw = ow * g.S + kw - g.PL;
-      if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) continue;
-      const T* p = in + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
-      for (int c = 0; c < g.Cs; ++c) {
-        float a = Elem<T>::ld(p + c);
-        const float* wr = Ws + (t * g.Cs + c) * g.Cb + n0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, wr[j], acc[j]);
+// The <= 4-channel operand of a 64-pixel chunk (all taps, zero-filled halo) is gathered once into LDS
+// (Ss[p][tap*4+c]); the main loop then only issues LDS broadcast reads, FMAs and one 16/32-byte store.
+#define SM_PIX 64
+template <typename T, int TT>
+__device__ __forceinline__ void stage_small(const SmallGeom& g, const T* S, long m0, long me, int sign, float* Ss) {
+  for (int idx = threadIdx.x; idx < SM_PIX * TT; idx += 256) {
+    const int p = idx / TT, t = idx - p * TT;
+    const long m = m0 + p;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < me) {
+      int ow = (int)(m % g.W);
+      long q = m / g.W;
+      int oh = (int)(q % g.H);
+      int b = (int)(q / g.H);
+      const int kh = TT == 9 ? t / 3 : 0, kw = TT == 9 ? t % 3 : 0;
+      int ih = sign > 0 ? oh * g.S + kh - g.PT : oh - kh + g.PT;
+      int iw = sign > 0 ? ow * g.S + kw - g.PL : ow - kw + g.PL;
+      if (ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW) {
+        const T* ptr = S + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
+        for (int c = 0; c < g.Cs; ++c) v[c] = Elem<T>::ld(ptr + c);
       }
     }
-    store8(out + m * g.Cb + n0, acc, accumulate);
+    *(float4*)(Ss + p * (TT * 4) + t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <typename T, int WMODE, int TT>
+__global__ __launch_bounds__(256) void conv_smallk_kernel(SmallGeom g, const T* in, const float* w, const float* bias,
+                                                           T* out, int accumulate, long pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  float* Ws = smemf;                        // [TT*4][Cb]  (rows of unused channels are zero)
+  float* Ss = smemf + TT * 4 * g.Cb;        // [SM_PIX][TT*4]
+  for (int i = threadIdx.x; i < TT * 4 * g.Cb; i += 256) {
+    int n = i % g.Cb, k4 = i / g.Cb;
+    int c = k4 & 3, t = k4 >> 2;
+    float v = 0.f;
+    if (c < g.Cs) v = WMODE == 0 ? w[((long)t * g.Cs + c) * g.Cb + n] : w[((long)(TT - 1 - t) * g.Cb + n) * g.Cs + c];
+    Ws[i] = v;
+  }
+  const int tpp = g.Cb / 8;                // threads per pixel
+  const int ppp = 256 / tpp;               // pixels per pass
+  const int n0 = (threadIdx.x % tpp) * 8;
+  const int pl = threadIdx.x / tpp;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[n0 + j] : 0.f;
+  const long mb = (long)blockIdx.x * pix_per_block;
+  long me = mb + pix_per_block;
+  if (me > g.M) me = g.M;
+  for (long m0 = mb; m0 < me; m0 += SM_PIX) {
+    __syncthreads();
+    stage_small<T, TT>(g, in, m0, me, 1, Ss);
+    __syncthreads();
+    for (int p = pl; p < SM_PIX; p += ppp) {
+      const long m = m0 + p;
+      if (m >= me) break;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+      const float* sp = Ss + p * (TT * 4);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const float4 sv = *(const float4*)(sp + t * 4);
+        const float a4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c >= 3 && g.Cs <= 3) break;
+          const float* wr = Ws + (t * 4 + c) * g.Cb + n0;
+          const float4 w0 = *(const float4*)wr, w1 = *(const float4*)(wr + 4);
+          acc[0] = fmaf(a4[c], w0.x, acc[0]); acc[1] = fmaf(a4[c], w0.y, acc[1]);
+          acc[2] = fmaf(a4[c], w0.z, acc[2]); acc[3] = fmaf(a4[c], w0.w, acc[3]);
+          acc[4] = fmaf(a4[c], w1.x, acc[4]); acc[5] = fmaf(a4[c], w1.y, acc[5]);
+          acc[6] = fmaf(a4[c], w1.z, acc[6]); acc[7] = fmaf(a4[c], w1.w, acc[7]);
+        }
+      }
+      store8(out + m * g.Cb + n0, acc, accumulate);
+    }
   }
 }
 
@@ -173,10 +214,12 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(SmallGeom g, const T* 
 template <typename T, int SIGN, int TT>
 __global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* S, const T* Bg, float* partial,
                                                            long pix_per_block, int relu_big) {
+  __shared__ __attribute__((aligned(16))) float Ss[SM_PIX * TT * 4];
   __shared__ float red[256];
   constexpr int K4 = TT * 4;
+  constexpr int CTR = TT == 9 ? 4 : 0;                  // the un-shifted tap
   const int K = TT * g.Cs;
-  const int npl = 256 / g.Cb > 0 ? 256 / g.Cb : 1;     // pixel lanes (Cb = 128 -> 2, 256 -> 1)
+  const int npl = 256 / g.Cb > 0 ? 256 / g.Cb : 1;      // pixel lanes (Cb = 128 -> 2, 256 -> 1)
   const int n = threadIdx.x % g.Cb;
   const int pl = threadIdx.x / g.Cb;
   const bool active = pl < npl;
@@ -187,28 +230,26 @@ __global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* 
   const long mb = (long)blockIdx.x * pix_per_block;
   long me = mb + pix_per_block;
   if (me > g.M) me = g.M;
-  if (active) {
-    for (long m = mb + pl; m < me; m += npl) {
-      int ow = (int)(m % g.W);
-      long q = m / g.W;
-      int oh = (int)(q % g.H);
-      int b = (int)(q / g.H);
-      float bg = Elem<T>::ld(Bg + m * g.Cb + n);
-      if (relu_big) bg = bg > 0.f ? bg : 0.f;
-      bsum += bg;
-      if (n < g.Cs) ssum += Elem<T>::ld(S + m * g.Cs + n);
+  for (long m0 = mb; m0 < me; m0 += SM_PIX) {
+    __syncthreads();
+    stage_small<T, TT>(g, S, m0, me, SIGN, Ss);
+    __syncthreads();
+    if (active) {
+      for (int p = pl; p < SM_PIX; p += npl) {
+        const long m = m0 + p;
+        if (m >= me) break;
+        float bg = Elem<T>::ld(Bg + m * g.Cb + n);
+        if (relu_big) bg = bg > 0.f ? bg : 0.f;
+        bsum += bg;
+        const float* sp = Ss + p * K4;
+        if (n < 4) ssum += sp[CTR * 4 + n];
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const int kh = TT == 9 ? t / 3 : 0, kw = TT == 9 ? t % 3 : 0;
-        int ih = SIGN > 0 ? oh + kh - g.PT : oh - kh + g.PT;
-        int iw = SIGN > 0 ? ow + kw - g.PL : ow - kw + g.PL;
-        const bool ok = ih >= 0 && ih < g.IH && iw >= 0 && iw < g.IW;
-        if (!ok) { ih = 0; iw = 0; }
-        const T* p = S + (((long)b * g.IH + ih) * g.IW + iw) * g.Cs;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float sv = (ok && c < g.Cs) ? Elem<T>::ld(p + (c < g.Cs ? c : 0)) : 0.f;
-          acc[t * 4 + c] = fmaf(sv, bg, acc[t * 4 + c]);
+        for (int t = 0; t < TT; ++t) {
+          const float4 sv = *(const float4*)(sp + t * 4);
+          acc[t * 4 + 0] = fmaf(sv.x, bg, acc[t * 4 + 0]);
+          acc[t * 4 + 1] = fmaf(sv.y, bg, acc[t * 4 + 1]);
+          acc[t * 4 + 2] = fmaf(sv.z, bg, acc[t * 4 + 2]);
+          acc[t * 4 + 3] = fmaf(sv.w, bg, acc[t * 4 + 3]);
         }
       }
     }
@@ -234,25 +275,29 @@ __global__ __launch_bounds__(256) void conv_smallw_kernel(SmallGeom g, const T* 
 
 // out (= or +=) sum_blk partial[blk][k][n], written as dW in HWIO order.
 // ORIENT 0: dW[(t*Cs+c)*Cb + n], dbias[n<Cb] from slot K   ORIENT 1: dW[(t*Cb+n)*Cs + c], dbias[c<Cs] from slot K+1.
-__global__ void conv_smallw_reduce_kernel(const float* partial, int nblk, int K, int Cs, int Cb, int orient, float* dw,
-                                          float* dbias, int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int total = (K + 2) * Cb;
-  if (i >= total) return;
-  int k = i / Cb, n = i % Cb;
+__global__ __launch_bounds__(256) void conv_smallw_reduce_kernel(const float* partial, int nblk, int K, int Cs, int Cb, int orient,
+                                                                 float* dw, float* dbias, int accumulate) {
+  __shared__ float red[4][64];
+  const int total = (K + 2) * Cb;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int bl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i < total)
+    for (int b = bl; b < nblk; b += 4) s += partial[(long)b * total + i];
+  red[bl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (bl != 0 || i >= total) return;
+  s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  const int k = i / Cb, n = i % Cb;
   if (k >= K) {
-    bool mine = (orient == 0 && k == K) || (orient == 1 && k == K + 1 && n < Cs);
+    const bool mine = (orient == 0 && k == K) || (orient == 1 && k == K + 1 && n < Cs);
     if (!mine || !dbias) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * total + i];
     if (accumulate) s += dbias[n];
     dbias[n] = s;
     return;
   }
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * total + i];
-  int t = k / Cs, c = k % Cs;
-  long o = orient == 0 ? (long)k * Cb + n : ((long)t * Cb + n) * Cs + c;
+  const int t = k / Cs, c = k % Cs;
+  const long o = orient == 0 ? (long)k * Cb + n : ((long)t * Cb + n) * Cs + c;
   if (accumulate) s += dw[o];
   dw[o] = s;
 }
@@ -310,11 +355,13 @@ int small_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, co
   const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
   if (kind == 1) {
     g.Cs = d->cin; g.Cb = d->cout;
-    size_t lds = (size_t)d->kh * d->kw * g.Cs * g.Cb * sizeof(float);
-    int ppb = 256 / (g.Cb / 8);
-    long blocks = (g.M + ppb - 1) / ppb;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((conv_smallk_kernel<T, 0>), dim3((int)blocks), dim3(256), lds, ctx->stream, g, x, w, bias, y, acc);
+    const int TT = d->kh * d->kw;
+    size_t lds = ((size_t)TT * 4 * g.Cb + (size_t)SM_PIX * TT * 4) * sizeof(float);
+    long ppb = 256;
+    while ((g.M + ppb - 1) / ppb > 2048) ppb *= 2;
+    int blocks = cdiv(g.M, ppb);
+    if (TT == 9) hipLaunchKernelGGL((conv_smallk_kernel<T, 0, 9>), dim3(blocks), dim3(256), lds, ctx->stream, g, x, w, bias, y, acc, ppb);
+    else hipLaunchKernelGGL((conv_smallk_kernel<T, 0, 1>), dim3(blocks), dim3(256), lds, ctx->stream, g, x, w, bias, y, acc, ppb);
   } else {
     g.Cs = d->cout; g.Cb = d->cin;
     long blocks = (g.M + 3) / 4;
@@ -338,11 +385,14 @@ int small_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* dy,
   g.PT = d->kh - 1 - g.PT; g.PL = d->kw - 1 - g.PL;     // gather offsets of the flipped filter
   if (kind == 1) {
     g.Cs = d->cout; g.Cb = d->cin;
-    size_t lds = (size_t)d->kh * d->kw * g.Cs * g.Cb * sizeof(float);
-    int ppb = 256 / (g.Cb / 8);
-    long blocks = (g.M + ppb - 1) / ppb;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((conv_smallk_kernel<T, 1>), dim3((int)blocks), dim3(256), lds, ctx->stream, g, dy, w, (const float*)nullptr, dx, accumulate);
+    const int TT = d->kh * d->kw;
+    size_t lds = ((size_t)TT * 4 * g.Cb + (size_t)SM_PIX * TT * 4) * sizeof(float);
+    long ppb = 256;
+    while ((g.M + ppb - 1) / ppb > 2048) ppb *= 2;
+    int blocks = cdiv(g.M, ppb);
+    const float* nb0 = nullptr;
+    if (TT == 9) hipLaunchKernelGGL((conv_smallk_kernel<T, 1, 9>), dim3(blocks), dim3(256), lds, ctx->stream, g, dy, w, nb0, dx, accumulate, ppb);
+    else hipLaunchKernelGGL((conv_smallk_kernel<T, 1, 1>), dim3(blocks), dim3(256), lds, ctx->stream, g, dy, w, nb0, dx, accumulate, ppb);
   } else {
     g.Cs = d->cin; g.Cb = d->cout;
     long blocks = (g.M + 3) / 4;
@@ -377,7 +427,7 @@ int small_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, 
     else hipLaunchKernelGGL((conv_smallw_kernel<T, 1, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, x, dy, partial, ppb, 0);
     RC_LAUNCH_CHECK(ctx);
     int K = d->kh * d->kw * g.Cs;
-    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,
+    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 64)), dim3(256), 0, ctx->stream, (const float*)partial,
                        (int)nblk, K, g.Cs, g.Cb, 0, dw, dbias, accumulate);
     RC_LAUNCH_CHECK(ctx);
   } else {
@@ -387,7 +437,7 @@ int small_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, int kind, const T* x, 
     else hipLaunchKernelGGL((conv_smallw_kernel<T, -1, 1>), dim3((int)nblk), dim3(256), 0, ctx->stream, g, dy, x, partial, ppb, relu);
     RC_LAUNCH_CHECK(ctx);
     int K = d->kh * d->kw * g.Cs;
-    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 256)), dim3(256), 0, ctx->stream, (const float*)partial,
+    hipLaunchKernelGGL(conv_smallw_reduce_kernel, dim3(cdiv((K + 2) * g.Cb, 64)), dim3(256), 0, ctx->stream, (const float*)partial,
                        (int)nblk, K, g.Cs, g.Cb, 1, dw, dbias, accumulate);
     RC_LAUNCH_CHECK(ctx);
   }
