@@ -254,12 +254,16 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
   same_pad(d->w, d->kw, 1, &ow, &pl);
   a.N = d->n; a.H = d->h; a.W = d->w; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
   a.M = (long)d->n * d->h * d->w;
+  a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
+  if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
 }
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
   int rc = check_desc(ctx, d);
   if (rc) return rc;
   if (mfma_eligible(d)) {
+    if ((long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31))
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tensor exceeds the 32-bit element offsets of the MFMA kernels");
     MfmaConvArgs a;
     fill_mfma_args(d, a);
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
@@ -337,6 +341,8 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
     a.use_tr = g_use_tr;
     a.M = (long)d->n * d->h * d->w;
+    a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
+    if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
     int nz = mfma_wgrad_splits(d, a.M);
     long cnt = (long)d->kh * d->kw * d->cin * d->cout;
     size_t need = (size_t)nz * cnt * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);

@@ -11,6 +11,7 @@ struct MfmaConvArgs {
   const bf16_t* zero;     // >= 16 zero bytes (halo source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, accumulate;
+  int lw, lh;             // log2(W), log2(H) when both are powers of two (pixel decode by shifts), else -1
   long M;
 };
 
@@ -21,8 +22,15 @@ struct MfmaWgradArgs {
   const bf16_t* zero;     // >= 16 zero bytes (halo / tail source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, use_tr;
+  int lw, lh;
   long M, m_chunk;
 };
+
+static inline int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
 
 bool mfma_eligible(const rcgan_conv_desc* d);
 bool mfma_wgrad_eligible(const rcgan_conv_desc* d);

@@ -33,6 +33,21 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 
 
+// pixel index -> (n, oh, ow); shifts when H and W are powers of two (every layer of both nets), else divisions
+__device__ __forceinline__ void decode_pix(long m, int H, int W, int lh, int lw, int& n, int& oh, int& ow) {
+  if (lw >= 0 && lh >= 0) {
+    const unsigned mm = (unsigned)m;
+    ow = (int)(mm & (unsigned)(W - 1));
+    oh = (int)((mm >> lw) & (unsigned)(H - 1));
+    n = (int)(mm >> (lw + lh));
+  } else {
+    ow = (int)(m % W);
+    long t = m / W;
+    oh = (int)(t % H);
+    n = (int)(t / H);
+  }
+}
+
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
   uint32_t neg = ((w >> 15) & 0x00010001u) * 0xFFFFu;
   return w & ~neg;
@@ -183,7 +198,27 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
+// NS LDS stages: tile t+NS-1 is requested while tile t is multiplied; a counted s_waitcnt vmcnt leaves the
+// NS-2 newest tiles in flight across the (raw) barrier, so small-grid layers are not serialised on one
+// HBM/L2 round trip per K-tile.
+// LDS-DMA issued from inline asm: hipcc then neither counts it in its own s_waitcnt bookkeeping nor drains it
+// (vmcnt(0)) in front of every LDS read that might alias the destination -- the waits are placed by hand.
+// M0 (LDS destination base) is written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void glds16_asm(const void* gptr, unsigned lds_byte_addr /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_byte_addr) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
@@ -208,10 +243,7 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
     const long m = m0 + row;
     a_coff[i] = (pos ^ (row & 7)) * 8;
     if (m < a.M) {
-      p_ow[i] = (int)(m % a.W);
-      long t = m / a.W;
-      p_oh[i] = (int)(t % a.H);
-      p_n[i] = (int)(t / a.H);
+      decode_pix(m, a.H, a.W, a.lh, a.lw, p_n[i], p_oh[i], p_ow[i]);
     } else {
       p_n[i] = 0; p_oh[i] = -100000; p_ow[i] = 0;
     }
@@ -223,23 +255,24 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
     wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ (row & 7)) * 8;
   }
 
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   auto issue = [&](int kt, int buf) {
     const int k0 = kt * 64;
     const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    unsigned char* stage = smem + buf * STAGE;
+    const unsigned stage = lds0 + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
       const bf16_t* p = a.zero;
       if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
         if (a.up) { ih >>= 1; iw >>= 1; }
-        p = a.in + (((long)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + c0 + a_coff[i];
+        p = a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + c0 + a_coff[i]);
       }
-      glds16(p, stage + (wave * AI + i) * 1024);
+      glds16_asm(p, stage + (wave * AI + i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) glds16(wsrc[i] + k0, stage + ABYTES + (wave * BI + i) * 1024);
+    for (int i = 0; i < BI; ++i) glds16_asm(wsrc[i] + k0, stage + ABYTES + (wave * BI + i) * 1024);
   };
 
   f32x4_t acc[NI][NJ];
@@ -253,12 +286,23 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   const int foff0 = frow * 128 + ((kc ^ (frow & 7)) * 16);
   const int foff1 = frow * 128 + (((4 + kc) ^ (frow & 7)) * 16);
 
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  constexpr int PER_TILE = AI + BI;                 // glds instructions per wave per tile
+  constexpr int INFLIGHT = (NS - 2) * PER_TILE;     // newest tiles allowed to stay in flight at the wait
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < KT) issue(t, t);
+  int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+    // tile kt landed (this wave's part), then rendezvous: everyone's part landed and everyone left tile kt-1
+    if (kt + NS - 2 < KT) wait_vmcnt<INFLIGHT>(); else wait_vmcnt<0>();
+    // the barrier is issued from asm with a memory clobber: the s_barrier builtin is IntrNoMem, so the compiler
+    // could otherwise hoist the LDS reads of this tile above it in iterations that issue no further DMA
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + NS - 1 < KT) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      issue(kt + NS - 1, nb);
+    }
     const unsigned char* Ab = smem + buf * STAGE + (wm * TM) * 128;
     const unsigned char* Bb = smem + buf * STAGE + ABYTES + (wn * TN) * 128;
 #pragma unroll
@@ -279,8 +323,7 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (++buf == NS) buf = 0;
   }
 
 #pragma unroll
@@ -367,17 +410,15 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgradArgs a) {
       const long m = p0 + lrow + 16 * i;
       uint4 vx = make_uint4(0, 0, 0, 0), vy = make_uint4(0, 0, 0, 0);
       if (m < me) {
-        int ow = (int)(m % a.W);
-        long t = m / a.W;
-        int oh = (int)(t % a.H);
-        int n = (int)(t / a.H);
+        int ow, oh, n;
+        decode_pix(m, a.H, a.W, a.lh, a.lw, n, oh, ow);
         int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
         if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
           if (a.up) { ih >>= 1; iw >>= 1; }
-          vx = *(const uint4*)(a.x + (((long)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + chunk * 8);
+          vx = *(const uint4*)(a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + chunk * 8));
           if (a.relu_in) { vx.x = relu_bf16x2(vx.x); vx.y = relu_bf16x2(vx.y); vx.z = relu_bf16x2(vx.z); vx.w = relu_bf16x2(vx.w); }
         }
-        vy = *(const uint4*)(a.dy + m * a.Cout + co0 + chunk * 8);
+        vy = *(const uint4*)(a.dy + (unsigned)((unsigned)m * a.Cout + co0 + chunk * 8));
       }
       rx[i] = vx; ry[i] = vy;
     }
@@ -498,16 +539,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
       const bf16_t* px = a.zero;
       const bf16_t* py = a.zero;
       if (m < me) {
-        int ow = (int)(m % a.W);
-        long t = m / a.W;
-        int oh = (int)(t % a.H);
-        int n = (int)(t / a.H);
+        int ow, oh, n;
+        decode_pix(m, a.H, a.W, a.lh, a.lw, n, oh, ow);
         int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
         if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
           if (a.up) { ih >>= 1; iw >>= 1; }
-          px = a.x + (((long)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + slot * 8;
+          px = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + slot * 8);
         }
-        py = a.dy + m * a.Cout + co0 + slot * 8;
+        py = a.dy + (unsigned)((unsigned)m * a.Cout + co0 + slot * 8);
       }
       glds16(px, xs + (wave * 4 + i) * 1024);
       glds16(py, ys + (wave * 4 + i) * 1024);
@@ -604,19 +643,24 @@ static int conv_impl() {      // 1 = direct-to-LDS (default), 0 = register-stage
   return v;
 }
 
-template <int BM, int BN>
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int BM, int BN, int NS>
 static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  size_t lds = (size_t)2 * (BM + BN) * 128;
+  size_t lds = (size_t)NS * (BM + BN) * 128;
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), a.Cout / BN);
   {
     ProfScope ps(ctx, BM == 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
                  2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN, NS>), grid, dim3(256), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -624,7 +668,15 @@ static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 
 template <int BM, int BN>
 static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
-  if (conv_impl() == 1 && a.zero != nullptr) return launch_conv_glds<BM, BN>(ctx, a);
+  if (conv_impl() == 1 && a.zero != nullptr) {
+    if (BM == 128) return launch_conv_glds<BM, BN, 2>(ctx, a);
+    // small grids are latency-bound (one HBM/L2 round trip per K-tile): deepen the pipeline; large grids
+    // prefer the smaller LDS footprint (more resident workgroups)
+    static const int ns4_max = env_int("RCGAN_NS4_MAXBLK", 0);
+    const long blocks = (long)cdiv(a.M, BM) * (a.Cout / BN);
+    if (blocks <= ns4_max) return launch_conv_glds<BM, BN, 4>(ctx, a);
+    return launch_conv_glds<BM, BN, 2>(ctx, a);
+  }
   static bool attr_set = false;
   size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(bf16_t);
   if (!attr_set) {
@@ -644,7 +696,8 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
   long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
-  if (a.Cout % 128 == 0 && blocks128 >= 384) return launch_conv_mfma<128, 128>(ctx, a);
+  static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
+  if (a.Cout % 128 == 0 && blocks128 >= t128_min) return launch_conv_mfma<128, 128>(ctx, a);
   return launch_conv_mfma<64, 64>(ctx, a);
 }
 
