@@ -94,6 +94,15 @@ size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d);
 int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w_hwio,
                        const float* sigma /* device scalar or NULL */, void* prepared);
 
+/* The same for many filters in ONE launch (every conv of a network at the start of a step).  items: HOST array. */
+typedef struct rcgan_prepare_item {
+  rcgan_conv_desc desc;      /* only kh, kw, cin, cout, stride, dtype, flags matter */
+  const float* w;
+  const float* sigma;        /* device scalar or NULL */
+  void* prepared;            /* rcgan_conv_prepared_bytes(&desc) */
+} rcgan_prepare_item;
+int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items);
+
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
 /* y = conv2d_SAME(x, w) (+bias).  Replaces tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
  * cifar10/common/ops/conv2d.py:181-216.  x: [n, h(/2), w(/2), cin]; y: [n, oh, ow, cout]. */

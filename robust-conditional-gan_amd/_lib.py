@@ -31,6 +31,10 @@ class ConvDesc(C.Structure):
                 ("dtype", C.c_int), ("flags", C.c_int)]
 
 
+class PrepareItem(C.Structure):
+    _fields_ = [("desc", ConvDesc), ("w", C.c_void_p), ("sigma", C.c_void_p), ("prepared", C.c_void_p)]
+
+
 class SnItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("sigma", C.c_void_p), ("save", C.c_void_p),
                 ("k", C.c_int), ("c", C.c_int), ("update", C.c_int)]
@@ -62,6 +66,7 @@ SIGNATURES = {
     "rcgan_graph_destroy": (I, [P, I]),
     "rcgan_conv_prepared_bytes": (SZ, [DP]),
     "rcgan_conv_prepare": (I, [P, DP, P, P, P]),
+    "rcgan_conv_prepare_batch": (I, [P, C.POINTER(PrepareItem), I]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),

@@ -308,6 +308,15 @@ class CifarRCGAN:
                 ents.append((name, base + "/spectral_norm/u", upd))
         return ents
 
+    def _prepare_all(self, which):
+        """One launch prepares every conv filter the step will use (W/sigma -> kernel layouts)."""
+        names = []
+        for grp in which:
+            for n in grp.names:
+                if n.endswith("/Filters"):
+                    names.append((n, grp.shapes[n][0], 1))
+        self.graph.prepare_convs(names, self.ctx.act_dtype)
+
     def confusion_matrix(self):
         ctx = self.ctx
         if self.PC is not None:
@@ -326,6 +335,7 @@ class CifarRCGAN:
             self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
             self._rng(inp["z"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(True, True))
+        self._prepare_all((self.PG, self.PD))
         fake_dst = None
         if self.alg == "rcgan-u":
             real = ctx.empty((B, OUTPUT_DIM))
@@ -380,6 +390,7 @@ class CifarRCGAN:
         if self.device_rng:
             self._rng(inp["z_G"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(False, True))        # D convs + D.Output: NO_OPS; projection / perm: update
+        self._prepare_all((self.PG, self.PD))
         fake = Generator(n, inp["labels_random_G"], inp["z_G"])                                      # :719
         lab = inp["labels_random_G"] if self.alg in ("biased", "unbiased") else inp["labels_biased_G"]
         feat, wgan = Discriminator(fake, lab, update_collection=NO_OPS)                              # :721-730

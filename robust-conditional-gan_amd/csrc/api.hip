@@ -226,6 +226,15 @@ int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w,
   return direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
 }
 
+int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items) {
+  RC_REQUIRE(ctx, items != nullptr && n_items >= 0, "bad items");
+  for (int i = 0; i < n_items; ++i) {
+    int rc = check_desc(ctx, &items[i].desc);
+    if (rc) return rc;
+  }
+  return conv_prepare_batch_launch(ctx, items, n_items);
+}
+
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {
   int oh, ow, p;
   same_pad(d->h, d->kh, d->stride, &oh, &p);

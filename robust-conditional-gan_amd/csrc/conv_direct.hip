@@ -53,10 +53,7 @@ template <typename T> struct FwdOp {
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
   long M, N, R, r_chunk;
   __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, i, r); }
-  __device__ __forceinline__ float b(long r, long j) const {
-    float v = w[r * g.Cout + j];
-    return wscale ? v / *wscale : v;
-  }
+  __device__ __forceinline__ float b(long r, long j) const { return w[r * g.Cout + j]; }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     T* p = y + i * g.Cout + j;
@@ -87,8 +84,7 @@ template <typename T> struct DgradOp {
   }
   __device__ __forceinline__ float b(long r, long j) const {
     long co = r % g.Cout, kk = r / g.Cout;
-    float v = w[(kk * g.Cin + j) * g.Cout + co];
-    return wscale ? v / *wscale : v;
+    return w[(kk * g.Cin + j) * g.Cout + co];
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];          // used by the transposed-conv forward
@@ -103,6 +99,7 @@ template <typename T> struct DgradOp {
 // ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs ----
 template <typename T> struct WgradOp {
   ConvGeom g; const T* x; const T* dy; float* slab;
+  const float* wscale;   // always null (the filter gradient has no filter operand)
   long M, N, R, r_chunk;
   __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, r, i); }
   __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * g.Cout + j); }
@@ -127,6 +124,8 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = 0.f;
 
+  // spectral-norm division W / sigma: sigma is loaded once per thread, not once per operand element
+  const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
   const long ai = i0 + (tid >> 2);
   const int ar = (tid & 3) * 4;
   const int br = tid >> 4;
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
     for (int q = 0; q < 4; ++q) {
       long r = r0 + br, j = bj + q;
       float v = 0.f;
-      if (r < r_end && j < op.N) v = op.b(r, j);
+      if (r < r_end && j < op.N) v = op.b(r, j) * bscale;
       Bs[br][(tid & 15) * 4 + q] = v;
     }
     __syncthreads();
@@ -340,7 +339,7 @@ template <typename T>
 int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* dy, float* dw, float* dbias,
                  int accumulate, void* ws, size_t ws_bytes) {
   WgradOp<T> op;
-  op.g = make_geom(d); op.x = x; op.dy = dy;
+  op.g = make_geom(d); op.x = x; op.dy = dy; op.wscale = nullptr;
   long K = (long)op.g.KH * op.g.KW * op.g.Cin, M = (long)op.g.N * op.g.OH * op.g.OW;
   int nz = wgrad_splits(K, op.g.Cout, M);
   size_t need = direct_wgrad_ws_bytes(d);

@@ -614,6 +614,54 @@ __global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf1
   wd[(long)ci * T * Cout + (long)(T - 1 - t) * Cout + co] = v;
 }
 
+// batched preparation: every filter of a network in ONE launch (blockIdx.y = filter)
+struct PrepItem { const float* w; const float* sigma; void* out; int T, Cin, Cout, mfma; };
+struct PrepBatch { PrepItem it[48]; };
+
+__global__ void conv_prepare_batch_kernel(PrepBatch b) {
+  const PrepItem it = b.it[blockIdx.y];
+  const long total = (long)it.T * it.Cin * it.Cout;
+  const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const float v = it.w[idx] * inv;
+    if (it.mfma) {
+      int co = (int)(idx % it.Cout);
+      long r = idx / it.Cout;
+      int ci = (int)(r % it.Cin);
+      int t = (int)(r / it.Cin);
+      bf16_t h = f32_to_bf16(v);
+      bf16_t* wt = (bf16_t*)it.out;
+      bf16_t* wd = wt + total;
+      wt[(long)co * it.T * it.Cin + (long)t * it.Cin + ci] = h;
+      wd[(long)ci * it.T * it.Cout + (long)(it.T - 1 - t) * it.Cout + co] = h;
+    } else {
+      ((float*)it.out)[idx] = v;
+    }
+  }
+}
+
+int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n) {
+  for (int base = 0; base < n; base += 48) {
+    PrepBatch b;
+    int m = n - base < 48 ? n - base : 48;
+    long maxel = 0;
+    for (int i = 0; i < m; ++i) {
+      const rcgan_prepare_item& s = items[base + i];
+      rcgan_conv_desc d = s.desc;
+      b.it[i].w = s.w; b.it[i].sigma = s.sigma; b.it[i].out = s.prepared;
+      b.it[i].T = d.kh * d.kw; b.it[i].Cin = d.cin; b.it[i].Cout = d.cout; b.it[i].mfma = mfma_eligible(&d) ? 1 : 0;
+      long el = (long)d.kh * d.kw * d.cin * d.cout;
+      if (el > maxel) maxel = el;
+    }
+    int bx = cdiv(maxel, 256 * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(bx, m), dim3(256), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  return RCGAN_OK;
+}
+
 __global__ void conv_prepare_direct_kernel(const float* w, const float* sigma, float* out, long total) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;

@@ -55,12 +55,15 @@ class Weight:
     def req(self):
         return self.param.req
 
-    def prepared(self, desc):
-        key = (desc.kh, desc.kw, desc.cin, desc.cout, desc.dtype, desc.stride, desc.flags & L.CONV_FORCE_DIRECT)
+    @staticmethod
+    def _key(desc, nbytes):
         # the prepared layout depends only on whether the MFMA path takes this shape
+        return (desc.kh, desc.kw, desc.cin, desc.cout, desc.dtype, desc.stride, desc.flags & L.CONV_FORCE_DIRECT, nbytes)
+
+    def prepared(self, desc):
         ctx = self.ctx
         nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
-        key = key + (nbytes,)
+        key = self._key(desc, nbytes)
         if key not in self._prepared:
             buf = DT(ctx.arena.alloc(nbytes), (nbytes,), "u8", ctx.arena.buf)
             ctx.check(ctx.lib.rcgan_conv_prepare(ctx.h, C.byref(desc), _p(self.param), _p(self.sigma), _p(buf)))
@@ -75,6 +78,24 @@ class Weight:
             self.dwbar = DT(self.ctx.arena.alloc(self.param.nbytes), self.param.shape, L.F32, self.ctx.arena.buf)
             self.ctx.check(self.ctx.lib.rcgan_fill_f32(self.ctx.h, self.param.size, self.dwbar.ptr, 0.0))
         return self.dwbar
+
+
+def prepare_batch(ctx, weights_and_shapes, dtype):
+    """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride)."""
+    todo = []
+    for w, k, stride in weights_and_shapes:
+        kk, _, cin, cout = w.param.shape
+        desc = L.ConvDesc(1, 8, 8, cin, cout, k, k, stride, dtype, 0)
+        nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
+        key = Weight._key(desc, nbytes)
+        if key in w._prepared:
+            continue
+        buf = DT(ctx.arena.alloc(nbytes), (nbytes,), "u8", ctx.arena.buf)
+        w._prepared[key] = buf
+        todo.append(L.PrepareItem(desc, w.param.ptr, w.sigma.ptr if w.sigma is not None else None, buf.ptr))
+    if todo:
+        arr = (L.PrepareItem * len(todo))(*todo)
+        ctx.check(ctx.lib.rcgan_conv_prepare_batch(ctx.h, arr, len(todo)))
 
 
 def spectral_norm_batch(ctx, entries):
@@ -97,6 +118,17 @@ def spectral_norm_batch(ctx, entries):
         weights.append(Weight(ctx, param, sigma))
         saves.append((save, k, c))
     ctx.check(ctx.lib.rcgan_sn_power_iter(ctx.h, items, n))
+    # gradient scratch d/dW_bar of every trainable weight: one contiguous block, zeroed by ONE fill
+    if ctx.recording:
+        req = [w for w in weights if w.param.req]
+        total = sum((w.param.size + 63) // 64 * 64 for w in req)
+        if total:
+            base = ctx.arena.alloc(total * 4)
+            ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, total, base, 0.0))
+            off = 0
+            for w in req:
+                w.dwbar = DT(base + off * 4, w.param.shape, L.F32, ctx.arena.buf)
+                off += (w.param.size + 63) // 64 * 64
 
     def bw():
         todo = [(w, s) for w, s in zip(weights, saves) if w.dwbar is not None and w.param.req]

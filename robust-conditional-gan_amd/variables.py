@@ -78,6 +78,14 @@ class Graph:
             raise ValueError("spectral norm of %s was prefetched with update=%s but used with update=%s" % (pname, upd, update))
         return w
 
+    def prepare_convs(self, names, dtype):
+        """Batch-prepare the conv filters named in ``names`` ([(param name, k, stride)]): one launch."""
+        ws = []
+        for pn, k, stride in names:
+            w = self.sn[pn][0] if pn in self.sn else self.weight(pn)
+            ws.append((w, k, stride))
+        O.prepare_batch(self.ctx, ws, dtype)
+
     def weight(self, pname):
         if pname not in self.plain:
             self.plain[pname] = O.Weight(self.ctx, self.param(pname), None)
