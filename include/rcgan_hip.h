@@ -178,7 +178,7 @@ size_t rcgan_sn_save_floats(int k, int c);
 /* One power iteration for every item in one launch (items: HOST array, copied into the launch). */
 int rcgan_sn_power_iter(rcgan_ctx* ctx, const rcgan_sn_item* items, int n_items);
 typedef struct rcgan_sn_bwd_item {
-  const float* w; const float* dwbar; float* dw; const float* save; int k, c, accumulate;
+  const float* w; const float* dwbar; float* dw; float* save /* also scratch */; int k, c, accumulate;
 } rcgan_sn_bwd_item;
 /* dW from dW_bar, differentiating THROUGH the power iteration (no stop_gradient in the reference). */
 int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items);

@@ -3,16 +3,40 @@
 //     v = l2n(u W^T); u' = l2n(v W); sigma = v W u'^T; W_bar = W / sigma; u <- u' (unless NO_OPS)
 //   the reference puts no stop_gradient on v / u', so the backward differentiates the iteration.
 // In the reference each weight costs ~20 tiny dependent TF ops per D instantiation (pure latency);
-// here every SN weight of the discriminator is one workgroup of ONE launch: the 4 mat-vecs run as
-// wavefront reductions out of LDS/L2.
+// here every SN weight of the discriminator is handled by the same 2 (forward) / 3 (backward) launches.
 #include "common.h"
 
 #define SN_MAX_K 4096
 #define SN_MAX_C 1024
 #define SN_BATCH 24
 #define SN_EPS 1e-12f
-#define SN_NT 1024          // threads per workgroup (16 wavefronts): one workgroup per weight, latency-bound
+#define SN_RB 32            // rows of W per workgroup
+#define SN_NT 256           // threads per workgroup (4 wavefronts)
 #define SN_NW (SN_NT / 64)
+#define SN_MAX_CHUNKS (SN_MAX_K / SN_RB)
+
+// Each weight is cut into chunks of SN_RB rows; a launch is grid (chunks, weights), so that the
+// biggest filters ([1152,128] = 590 KB) are read by 36 workgroups instead of one.  The scalar
+// couplings between the phases of the iteration (|a|, |b|, sigma, <G,W>, <dv,a>) are resolved
+// between launches through a few partial sums kept in the save buffer:
+//   save layout: a[k'] v[k'] dv[k'] | b[c'] u2[c'] uin[c'] db[c'] (k', c' = k, c rounded up to 4) | {na, nb, sigma, 0} | pb[chunks][c] | pgw[chunks] pdva[chunks]
+struct SnLayout {
+  float *a, *v, *dv, *b, *u2, *uin, *db, *s, *pb, *pgw, *pdva;
+  int chunks;
+};
+__host__ __device__ inline int sn_chunks(int k) { return (k + SN_RB - 1) / SN_RB; }
+__device__ __forceinline__ SnLayout sn_layout(float* save, int k, int c) {
+  SnLayout L;
+  L.chunks = sn_chunks(k);
+  const int kp = (k + 3) & ~3, cp = (c + 3) & ~3;      // 16-byte aligned segments (float4 access)
+  L.a = save; L.v = L.a + kp; L.dv = L.v + kp;
+  L.b = L.dv + kp; L.u2 = L.b + cp; L.uin = L.u2 + cp; L.db = L.uin + cp;
+  L.s = L.db + cp;
+  L.pb = L.s + 4;
+  L.pgw = L.pb + (long)L.chunks * c;
+  L.pdva = L.pgw + L.chunks;
+  return L;
+}
 
 __device__ __forceinline__ float block_sum_nt(float v, float* red /* >= SN_NW floats */) {
   v = wave_sum(v);
@@ -28,108 +52,89 @@ __device__ __forceinline__ float block_sum_nt(float v, float* red /* >= SN_NW fl
 struct SnBatch { rcgan_sn_item it[SN_BATCH]; };
 struct SnBwdBatch { rcgan_sn_bwd_item it[SN_BATCH]; };
 
-// save layout: a[k] v[k] b[c] u2[c] uin[c] {na, nb, sigma, 0}
-__global__ __launch_bounds__(SN_NT) void sn_fwd_kernel(SnBatch batch) {
-  __shared__ float a_s[SN_MAX_K];
-  __shared__ float red[SN_NW];
-  __shared__ float part[SN_NT];
-  const rcgan_sn_item it = batch.it[blockIdx.x];
+// forward 1/2: a = W u for the chunk's rows, and the chunk's share of a W (= |a| * b)
+__global__ __launch_bounds__(SN_NT) void sn_fwd_rows_kernel(SnBatch batch) {
+  __shared__ float a_s[SN_RB];
+  const rcgan_sn_item it = batch.it[blockIdx.y];
   const int k = it.k, c = it.c;
-  const float* w = it.w;
+  const int r0 = blockIdx.x * SN_RB;
+  if (r0 >= k) return;
+  const int rows = min(SN_RB, k - r0);
+  const SnLayout L = sn_layout(it.save, k, c);
+  const float* w = it.w + (long)r0 * c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sv_a = it.save;
-  float* sv_v = sv_a + k;
-  float* sv_b = sv_v + k;
-  float* sv_u2 = sv_b + c;
-  float* sv_uin = sv_u2 + c;
-  float* sv_s = sv_uin + c;
-
-  // a = W u  (one wavefront per row)
-  float na2 = 0.f;
-  for (int r = wave; r < k; r += SN_NW) {
+  for (int r = wave; r < rows; r += SN_NW) {
     float s = 0.f;
     for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * it.u[j];
     s = wave_sum(s);
-    if (lane == 0) { a_s[r] = s; na2 += s * s; }
-  }
-  na2 = block_sum_nt(lane == 0 ? na2 : 0.f, red);
-  const float na = sqrtf(na2);
-  const float inv_na = 1.f / (na + SN_EPS);
-  for (int r = tid; r < k; r += SN_NT) {
-    float av = a_s[r];
-    sv_a[r] = av;
-    float v = av * inv_na;
-    sv_v[r] = v;
-    a_s[r] = v;            // a_s now holds v
+    if (lane == 0) { a_s[r] = s; L.a[r0 + r] = s; }
   }
   __syncthreads();
-  // b = v W : thread -> (column, k-lane)
-  int cpad = 1;
-  while (cpad < c && cpad < SN_NT) cpad <<= 1;
-  const int klanes = SN_NT / cpad;
-  const int kl = tid / cpad;
-  float nb2 = 0.f;
-  for (int cb = 0; cb < c; cb += cpad) {
-    const int col = cb + (tid % cpad);
+  for (int j = tid; j < c; j += SN_NT) {
     float s = 0.f;
-    if (col < c) {
-#pragma unroll 4
-      for (int r = kl; r < k; r += klanes) s += a_s[r] * w[(long)r * c + col];
-    }
-    part[tid] = s;
-    __syncthreads();
-    if (tid < cpad && col < c) {
-      float t = 0.f;
-      for (int q = 0; q < klanes; ++q) t += part[q * cpad + tid];
-      sv_b[col] = t;
-      nb2 += t * t;
-    }
-    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < rows; ++r) s += a_s[r] * w[(long)r * c + j];
+    L.pb[(long)blockIdx.x * c + j] = s;
+  }
+}
+
+// forward 2/2 (one workgroup per weight): norms, v, b, u', sigma, u update
+__global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
+  __shared__ float red[SN_NW];
+  const rcgan_sn_item it = batch.it[blockIdx.x];
+  const int k = it.k, c = it.c;
+  const SnLayout L = sn_layout(it.save, k, c);
+  const int tid = threadIdx.x;
+  float na2 = 0.f;
+  for (int r = tid; r < k; r += SN_NT) { float a = L.a[r]; na2 += a * a; }
+  na2 = block_sum_nt(na2, red);
+  const float na = sqrtf(na2);
+  const float inv_na = 1.f / (na + SN_EPS);
+  for (int r = tid; r < k; r += SN_NT) L.v[r] = L.a[r] * inv_na;
+  float nb2 = 0.f;
+  for (int j = tid; j < c; j += SN_NT) {
+    float s = 0.f;
+    for (int q = 0; q < L.chunks; ++q) s += L.pb[(long)q * c + j];
+    s *= inv_na;
+    L.b[j] = s;
+    nb2 += s * s;
   }
   nb2 = block_sum_nt(nb2, red);
   const float nb = sqrtf(nb2);
   const float inv_nb = 1.f / (nb + SN_EPS);
-  // u' = b/(|b|+eps); sigma = b . u'
   float sg = 0.f;
   for (int j = tid; j < c; j += SN_NT) {
-    float b = sv_b[j];
+    float b = L.b[j];
     float u2 = b * inv_nb;
-    sv_u2[j] = u2;
-    sv_uin[j] = it.u[j];
+    L.u2[j] = u2;
+    L.uin[j] = it.u[j];
+    if (it.update) it.u[j] = u2;
     sg += b * u2;
   }
   sg = block_sum_nt(sg, red);
-  if (it.update)
-    for (int j = tid; j < c; j += SN_NT) it.u[j] = sv_b[j] * inv_nb;
   if (tid == 0) {
-    sv_s[0] = na; sv_s[1] = nb; sv_s[2] = sg; sv_s[3] = 0.f;
+    L.s[0] = na; L.s[1] = nb; L.s[2] = sg; L.s[3] = 0.f;
     *it.sigma = sg;
   }
 }
 
-__global__ __launch_bounds__(SN_NT) void sn_bwd_kernel(SnBwdBatch batch) {
-  __shared__ float dv_s[SN_MAX_K];
-  __shared__ float db_s[SN_MAX_C];
+// backward 1/3: the chunk's share of <dW_bar, W>
+__global__ __launch_bounds__(SN_NT) void sn_bwd_gw_kernel(SnBwdBatch batch) {
   __shared__ float red[SN_NW];
-  const rcgan_sn_bwd_item it = batch.it[blockIdx.x];
+  const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
   const int k = it.k, c = it.c;
-  const float* w = it.w;
-  const float* g = it.dwbar;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* sv_a = it.save;
-  const float* sv_v = sv_a + k;
-  const float* sv_b = sv_v + k;
-  const float* sv_u2 = sv_b + c;
-  const float* sv_uin = sv_u2 + c;
-  const float* sv_s = sv_uin + c;
-  const float na = sv_s[0], nb = sv_s[1], sigma = sv_s[2];
-  const long total = (long)k * c;
-
+  const int r0 = blockIdx.x * SN_RB;
+  if (r0 >= k) return;
+  const int rows = min(SN_RB, k - r0);
+  const SnLayout L = sn_layout(it.save, k, c);
+  const float* w = it.w + (long)r0 * c;
+  const float* g = it.dwbar + (long)r0 * c;
+  const long total = (long)rows * c;
+  const int tid = threadIdx.x;
   float gw = 0.f;
-  if ((total & 3) == 0) {
+  if ((c & 3) == 0) {
     const float4* g4 = (const float4*)g;
     const float4* w4 = (const float4*)w;
-#pragma unroll 4
     for (long i = tid; i < total / 4; i += SN_NT) {
       float4 a = g4[i], b = w4[i];
       gw += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -138,67 +143,126 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_kernel(SnBwdBatch batch) {
     for (long i = tid; i < total; i += SN_NT) gw += g[i] * w[i];
   }
   gw = block_sum_nt(gw, red);
+  if (tid == 0) L.pgw[blockIdx.x] = gw;
+}
+
+// backward 2/3: dsigma -> db (every workgroup recomputes the c-vector), dv = W db for the chunk's rows
+__global__ __launch_bounds__(SN_NT) void sn_bwd_dv_kernel(SnBwdBatch batch) {
+  __shared__ float db_s[SN_MAX_C];
+  __shared__ float red[SN_NW];
+  const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
+  const int k = it.k, c = it.c;
+  const int r0 = blockIdx.x * SN_RB;
+  if (r0 >= k) return;
+  const int rows = min(SN_RB, k - r0);
+  const SnLayout L = sn_layout(it.save, k, c);
+  const float* w = it.w + (long)r0 * c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float na = L.s[0], nb = L.s[1], sigma = L.s[2];
+  (void)na;
+  float gw = 0.f;
+  for (int q = tid; q < L.chunks; q += SN_NT) gw += L.pgw[q];
+  gw = block_sum_nt(gw, red);
   const float dsigma = -gw / (sigma * sigma);
   // sigma = b.u2, u2 = b/(nb+eps)
   float dot = 0.f;
-  for (int j = tid; j < c; j += SN_NT) { float b = sv_b[j]; dot += dsigma * b * b; }
+  for (int j = tid; j < c; j += SN_NT) { float b = L.b[j]; dot += dsigma * b * b; }
   dot = block_sum_nt(dot, red);
   const float inv_nb = 1.f / (nb + SN_EPS);
   const float coef_b = dot / (nb * (nb + SN_EPS) * (nb + SN_EPS));
   for (int j = tid; j < c; j += SN_NT) {
-    float b = sv_b[j];
-    db_s[j] = dsigma * sv_u2[j] + dsigma * b * inv_nb - b * coef_b;
+    float b = L.b[j];
+    float d = dsigma * L.u2[j] + dsigma * b * inv_nb - b * coef_b;
+    db_s[j] = d;
+    if (blockIdx.x == 0) L.db[j] = d;
   }
   __syncthreads();
-  // dv = W db  (wavefront per row); dva = dv . a
   float dva = 0.f;
-  for (int r = wave; r < k; r += SN_NW) {
+  for (int r = wave; r < rows; r += SN_NW) {
     float s = 0.f;
     for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * db_s[j];
     s = wave_sum(s);
-    if (lane == 0) { dv_s[r] = s; dva += s * sv_a[r]; }
+    if (lane == 0) { L.dv[r0 + r] = s; dva += s * L.a[r0 + r]; }
   }
   dva = block_sum_nt(lane == 0 ? dva : 0.f, red);
+  if (tid == 0) L.pdva[blockIdx.x] = dva;
+}
+
+// backward 3/3: da for the chunk's rows, dW = dW_bar/sigma + v (x) db + da (x) u_in
+__global__ __launch_bounds__(SN_NT) void sn_bwd_dw_kernel(SnBwdBatch batch) {
+  __shared__ float da_s[SN_RB];
+  __shared__ float v_s[SN_RB];
+  __shared__ float red[SN_NW];
+  const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
+  const int k = it.k, c = it.c;
+  const int r0 = blockIdx.x * SN_RB;
+  if (r0 >= k) return;
+  const int rows = min(SN_RB, k - r0);
+  const SnLayout L = sn_layout(it.save, k, c);
+  const float* g = it.dwbar + (long)r0 * c;
+  float* dw = it.dw + (long)r0 * c;
+  const int tid = threadIdx.x;
+  const float na = L.s[0], sigma = L.s[2];
+  float dva = 0.f;
+  for (int q = tid; q < L.chunks; q += SN_NT) dva += L.pdva[q];
+  dva = block_sum_nt(dva, red);
   const float inv_na = 1.f / (na + SN_EPS);
   const float coef_a = dva / (na * (na + SN_EPS) * (na + SN_EPS));
-  for (int r = tid; r < k; r += SN_NT) dv_s[r] = dv_s[r] * inv_na - sv_a[r] * coef_a;   // da
+  if (tid < rows) {
+    da_s[tid] = L.dv[r0 + tid] * inv_na - L.a[r0 + tid] * coef_a;
+    v_s[tid] = L.v[r0 + tid];
+  }
   __syncthreads();
   const float inv_sigma = 1.f / sigma;
-  if (SN_NT % c == 0) {
-    // thread -> fixed column, rows strided: no per-element division
-    const int j = tid % c, rstep = SN_NT / c;
-    const float dbj = db_s[j], uj = sv_uin[j];
-#pragma unroll 4
-    for (int r = tid / c; r < k; r += rstep) {
-      const long i = (long)r * c + j;
-      float v = g[i] * inv_sigma + sv_v[r] * dbj + dv_s[r] * uj;
-      if (it.accumulate) v += it.dw[i];
-      it.dw[i] = v;
+  if ((c & 3) == 0) {
+    const int c4 = c >> 2;
+    const float4* g4 = (const float4*)g;
+    float4* dw4 = (float4*)dw;
+    const float4* db4 = (const float4*)L.db;
+    const float4* u4 = (const float4*)L.uin;
+    for (int i = tid; i < rows * c4; i += SN_NT) {
+      const int r = i / c4, j = i - r * c4;
+      const float4 gv = g4[i], d = db4[j], u = u4[j];
+      const float vr = v_s[r], ar = da_s[r];
+      float4 o;
+      o.x = gv.x * inv_sigma + vr * d.x + ar * u.x;
+      o.y = gv.y * inv_sigma + vr * d.y + ar * u.y;
+      o.z = gv.z * inv_sigma + vr * d.z + ar * u.z;
+      o.w = gv.w * inv_sigma + vr * d.w + ar * u.w;
+      if (it.accumulate) { float4 p = dw4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      dw4[i] = o;
     }
   } else {
-    for (long i = tid; i < total; i += SN_NT) {
-      int r = (int)(i / c), j = (int)(i % c);
-      float v = g[i] * inv_sigma + sv_v[r] * db_s[j] + dv_s[r] * sv_uin[j];
-      if (it.accumulate) v += it.dw[i];
-      it.dw[i] = v;
+    for (int i = tid; i < rows * c; i += SN_NT) {
+      const int r = i / c, j = i - r * c;
+      float o = g[i] * inv_sigma + v_s[r] * L.db[j] + da_s[r] * L.uin[j];
+      if (it.accumulate) o += dw[i];
+      dw[i] = o;
     }
   }
 }
 
 extern "C" {
 
-size_t rcgan_sn_save_floats(int k, int c) { return (size_t)2 * k + 3 * (size_t)c + 4; }
+size_t rcgan_sn_save_floats(int k, int c) {
+  const size_t kp = ((size_t)k + 3) & ~(size_t)3, cp = ((size_t)c + 3) & ~(size_t)3;
+  return 3 * kp + 4 * cp + 4 + (size_t)sn_chunks(k) * ((size_t)c + 2);
+}
 
 int rcgan_sn_power_iter(rcgan_ctx* ctx, const rcgan_sn_item* items, int n_items) {
   for (int base = 0; base < n_items; base += SN_BATCH) {
     SnBatch b;
     int n = n_items - base < SN_BATCH ? n_items - base : SN_BATCH;
+    int maxk = 1;
     for (int i = 0; i < n; ++i) {
       b.it[i] = items[base + i];
       if (b.it[i].k > SN_MAX_K || b.it[i].c > SN_MAX_C || b.it[i].k < 1 || b.it[i].c < 1)
         RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sn weight [%d,%d]", b.it[i].k, b.it[i].c);
+      if (b.it[i].k > maxk) maxk = b.it[i].k;
     }
-    hipLaunchKernelGGL(sn_fwd_kernel, dim3(n), dim3(SN_NT), 0, ctx->stream, b);
+    hipLaunchKernelGGL(sn_fwd_rows_kernel, dim3(sn_chunks(maxk), n), dim3(SN_NT), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sn_fwd_finish_kernel, dim3(n), dim3(SN_NT), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
   }
   return RCGAN_OK;
@@ -208,12 +272,19 @@ int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items) {
   for (int base = 0; base < n_items; base += SN_BATCH) {
     SnBwdBatch b;
     int n = n_items - base < SN_BATCH ? n_items - base : SN_BATCH;
+    int maxk = 1;
     for (int i = 0; i < n; ++i) {
       b.it[i] = items[base + i];
       if (b.it[i].k > SN_MAX_K || b.it[i].c > SN_MAX_C || b.it[i].k < 1 || b.it[i].c < 1)
         RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sn weight [%d,%d]", b.it[i].k, b.it[i].c);
+      if (b.it[i].k > maxk) maxk = b.it[i].k;
     }
-    hipLaunchKernelGGL(sn_bwd_kernel, dim3(n), dim3(SN_NT), 0, ctx->stream, b);
+    const dim3 grid(sn_chunks(maxk), n);
+    hipLaunchKernelGGL(sn_bwd_gw_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sn_bwd_dv_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sn_bwd_dw_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
   }
   return RCGAN_OK;

@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol():
     # size helpers are pure host functions: callable without a GPU
     d = _lib.ConvDesc(128, 32, 32, 256, 256, 3, 3, 1, _lib.BF16, 0)
     assert lib.rcgan_conv_prepared_bytes(d) >= 2 * 2 * 9 * 256 * 256
-    assert lib.rcgan_sn_save_floats(1152, 128) == 2 * 1152 + 3 * 128 + 4
+    assert lib.rcgan_sn_save_floats(1152, 128) == 3 * 1152 + 4 * 128 + 4 + 36 * (128 + 2)
 
 
 def test_no_gpu_fails_loudly():
