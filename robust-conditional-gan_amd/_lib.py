@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librcgan_hip.so")
+LIB_PATH = os.environ.get("RCGAN_LIB_PATH") or os.path.join(_HERE, "librcgan_hip.so")   # override: kernel probes only
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

@@ -28,6 +28,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
+#ifndef RCGAN_PROBE
+#define RCGAN_PROBE 0      // kernel-bottleneck probes (scripts/probes/build_probes.sh); 0 in the product build
+#endif
 #define LDS_PITCH 72          // elements per LDS row in the fwd kernel (64 + 8 pad)
 #define WG_PITCH 144          // elements per LDS row in the wgrad kernel (128 + 16 pad = 288 B)
 
@@ -48,10 +51,13 @@ __device__ __forceinline__ void decode_pix(long m, int H, int W, int lh, int lw,
   }
 }
 
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
-  uint32_t neg = ((w >> 15) & 0x00010001u) * 0xFFFFu;
-  return w & ~neg;
+// packed signed-16 max on bf16 bit patterns (v_pk_max_i16): with bound 0 this is ReLU (every negative bf16,
+// -0 included, has the int16 sign bit set); with bound 0x8000 per half it is the identity.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t w, uint32_t bound) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w), __builtin_bit_cast(s16x2_t, bound)));
 }
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) { return pk_max_i16(w, 0u); }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
@@ -256,23 +262,36 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kt * 64;
-    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const unsigned stage = lds0 + buf * STAGE;
+  // K-tiles are requested in order, so the (tap, channel) position of the next request is carried
+  // incrementally: the per-row halo test and address are recomputed once per tap, not once per K-tile
+  // (small grids run 1-2 wavefronts per SIMD and are bound by the instruction count of this loop).
+  const bf16_t* rp[AI];
+  int rstep[AI];                       // 1 if the row's source pixel exists for the current tap, else 0 (zero page)
+  int i_c0 = 0, i_kh = 0, i_kw = 0, i_k0 = 0;
+  auto set_tap = [&](int kh, int kw) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
-      const bf16_t* p = a.zero;
-      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-        if (a.up) { ih >>= 1; iw >>= 1; }
-        p = a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + c0 + a_coff[i]);
-      }
-      glds16_asm(p, stage + (wave * AI + i) * 1024);
+      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      if (a.up) { ih >>= 1; iw >>= 1; }
+      rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
+      rstep[i] = ok ? 1 : 0;
     }
+  };
+  set_tap(0, 0);
+  auto issue = [&](int buf) {
+    const unsigned stage = lds0 + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) glds16_asm(wsrc[i] + k0, stage + ABYTES + (wave * BI + i) * 1024);
+    for (int i = 0; i < AI; ++i) glds16_asm(rp[i] + i_c0 * rstep[i], stage + (wave * AI + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) glds16_asm(wsrc[i] + i_k0, stage + ABYTES + (wave * BI + i) * 1024);
+    i_k0 += 64;
+    i_c0 += 64;
+    if (i_c0 == a.Cin) {
+      i_c0 = 0;
+      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+      set_tap(i_kh, i_kw);
+    }
   };
 
   f32x4_t acc[NI][NJ];
@@ -286,11 +305,12 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   const int foff0 = frow * 128 + ((kc ^ (frow & 7)) * 16);
   const int foff1 = frow * 128 + (((4 + kc) ^ (frow & 7)) * 16);
 
+  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;      // branch-free optional input ReLU
   constexpr int PER_TILE = AI + BI;                 // glds instructions per wave per tile
   constexpr int INFLIGHT = (NS - 2) * PER_TILE;     // newest tiles allowed to stay in flight at the wait
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
-    if (t < KT) issue(t, t);
+    if (t < KT) issue(t);
   int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
     // tile kt landed (this wave's part), then rendezvous: everyone's part landed and everyone left tile kt-1
@@ -298,30 +318,50 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
     // the barrier is issued from asm with a memory clobber: the s_barrier builtin is IntrNoMem, so the compiler
     // could otherwise hoist the LDS reads of this tile above it in iterations that issue no further DMA
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if RCGAN_PROBE != 3      /* probe 3: no global loads after the prologue */
     if (kt + NS - 1 < KT) {
       int nb = buf + NS - 1;
       if (nb >= NS) nb -= NS;
-      issue(kt + NS - 1, nb);
+      issue(nb);
     }
+#endif
     const unsigned char* Ab = smem + buf * STAGE + (wm * TM) * 128;
     const unsigned char* Bb = smem + buf * STAGE + ABYTES + (wn * TN) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int fo = ks ? foff1 : foff0;
       bf16x8_t wf[NI], xf[NJ];
+#if RCGAN_PROBE == 2      /* probe: no LDS reads */
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(fo + i, kt, lane, 3));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(fo, kt + j, lane, 5));
+      (void)Ab; (void)Bb;
+#else
 #pragma unroll
       for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * 128 + fo);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         uint4 v = *(const uint4*)(Ab + j * 16 * 128 + fo);
-        if (a.relu_in) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+        v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
         xf[j] = __builtin_bit_cast(bf16x8_t, v);
       }
+#endif
+#if RCGAN_PROBE == 1      /* probe: no MFMA */
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          uint4 p = __builtin_bit_cast(uint4, wf[i]), q = __builtin_bit_cast(uint4, xf[j]);
+          acc[i][j][0] += __builtin_bit_cast(float, p.x ^ q.x ^ p.y ^ q.y ^ p.z ^ q.z ^ p.w ^ q.w);
+        }
+#else
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#endif
     }
     if (++buf == NS) buf = 0;
   }
@@ -503,15 +543,18 @@ __device__ __forceinline__ bf16x8_t frag_tr_swz(const unsigned char* tile, int r
     }
   }
   if (relu) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = r[e] < 0 ? (short)0 : r[e];
+    uint4 v = __builtin_bit_cast(uint4, r);
+    v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
+    r = __builtin_bit_cast(s16x8_t, v);
   }
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+template <int NS>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TILE = 64 * 256;                 // bytes per operand tile
+  constexpr int TILE = 32 * 256;                 // bytes per operand per stage: 32 pixels x 128 channels
+  constexpr int STAGE = 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wo = wave >> 1;
@@ -527,30 +570,40 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
   if (me > a.M) me = a.M;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int lrow = lane >> 4, pos = lane & 15;
+  const int dh = kh - a.PT, dw = kw - a.PL;
 
-  auto issue = [&](long p0, int buf) {
-    unsigned char* xs = smem + buf * 2 * TILE;
-    unsigned char* ys = xs + TILE;
+  // this lane deposits 16-B slot `pos` of rows r_i = (wave*2+i)*4 + lrow, i = 0,1, of both operand tiles
+  int r_off[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 4 + lrow;       // 0..63
-      const long m = p0 + row;
-      const int slot = pos ^ ((row & 7) << 1);
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 4 + lrow;
+    r_off[i] = (pos ^ ((row & 7) << 1)) * 8;     // source-side swizzle (channel offset)
+  }
+  const bf16_t* xbase = a.x + ci0;
+  const bf16_t* ybase = a.dy + co0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  long i_p0 = mb;
+  auto issue = [&](int buf) {
+    const unsigned stage = lds0 + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = i_p0 + (wave * 2 + i) * 4 + lrow;
       const bf16_t* px = a.zero;
       const bf16_t* py = a.zero;
       if (m < me) {
         int ow, oh, n;
         decode_pix(m, a.H, a.W, a.lh, a.lw, n, oh, ow);
-        int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
+        int ih = oh + dh, iw = ow + dw;
         if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
           if (a.up) { ih >>= 1; iw >>= 1; }
-          px = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + ci0 + slot * 8);
+          px = xbase + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + r_off[i]);
         }
-        py = a.dy + (unsigned)((unsigned)m * a.Cout + co0 + slot * 8);
+        py = ybase + (unsigned)((unsigned)m * a.Cout + r_off[i]);
       }
-      glds16(px, xs + (wave * 4 + i) * 1024);
-      glds16(py, ys + (wave * 4 + i) * 1024);
+      glds16_asm(px, stage + (wave * 2 + i) * 1024);
+      glds16_asm(py, stage + TILE + (wave * 2 + i) * 1024);
     }
+    i_p0 += 32;
   };
 
   f32x4_t acc[4][4];   // [co tile][ci tile]
@@ -559,30 +612,33 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const long ntile = (me - mb + 63) / 64;
-  if (ntile > 0) issue(mb, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (long t = 0; t < ntile; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < ntile) issue(mb + (t + 1) * 64, buf ^ 1);
-    const unsigned char* Xb = smem + buf * 2 * TILE;
-    const unsigned char* Yb = Xb + TILE;
+  const int KT = (int)((me - mb + 31) / 32);
+  constexpr int INFLIGHT = (NS - 2) * 4;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t yf[4], xf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) yf[i] = frag_tr_swz(Yb, ks * 32, wo * 8 + i * 2, lane, a.use_tr, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = frag_tr_swz(Xb, ks * 32, wi * 8 + j * 2, lane, a.use_tr, a.relu_in);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < KT) issue(t);
+  int buf = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + NS - 2 < KT) wait_vmcnt<INFLIGHT>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + NS - 1 < KT) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      issue(nb);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const unsigned char* Xb = smem + buf * STAGE;
+    const unsigned char* Yb = Xb + TILE;
+    bf16x8_t yf[4], xf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yf[i] = frag_tr_swz(Yb, 0, wo * 8 + i * 2, lane, a.use_tr, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = frag_tr_swz(Xb, 0, wi * 8 + j * 2, lane, a.use_tr, a.relu_in);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    if (++buf == NS) buf = 0;
   }
   float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
 #pragma unroll
@@ -594,6 +650,188 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
       float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       *(float4*)(slab + ((long)tap * a.Cin + ci) * a.Cout + co) = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter gradient, three horizontal taps per workgroup (3x3 filters, W in {4,8,16,32}).
+// The per-tap kernels above re-read every input and gradient pixel once per tap and channel tile
+// (64 FLOP per byte fetched from L2) and sit on the L2->LDS bandwidth.  Here one workgroup owns
+// (kh, 64 input channels, 128 output channels) and accumulates kw = 0,1,2 from the SAME staged rows:
+// the tap shift is a +-1 row offset of the transposing LDS read, the left/right SAME-padding columns
+// are removed by a loop-invariant AND mask on the input fragments (a stage is 32 consecutive pixels
+// and W divides 32, so the column of fragment slot k is k mod W in every stage).  128 FLOP per byte.
+//   stage: X rows = pixels p0-4 .. p0+35 (40 x 128 B, 8 rows per deposit), Y rows = p0 .. p0+31 (32 x 256 B)
+//   waves 2 (ci) x 2 (co): wave tile 32 ci x 64 co x 3 taps = 24 MFMA accumulators (96 registers)
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt_any() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+
+__device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p, int hi_off) {
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + hi_off));
+  s16x8_t r = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int NS, bool RELU>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int XT = 40 * 128, YT = 32 * 256, STAGE = XT + YT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 1, wo = wave >> 1;
+  const int nci = a.Cin / 64, nco = a.Cout / 128;
+  int b = blockIdx.x;
+  const int cot = b % nco; b /= nco;
+  const int cit = b % nci; b /= nci;
+  const int kh = b;
+  const int ci0 = cit * 64, co0 = cot * 128;
+  const long mb = (long)blockIdx.y * a.m_chunk;
+  long me = mb + a.m_chunk;
+  if (me > a.M) me = a.M;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int dh = kh - a.PT;
+  const int g = lane >> 4, li = lane & 15;
+
+  // ---- DMA roles -------------------------------------------------------------------------------
+  // Y: deposits q = 2*wave + {0,1}; lane -> row q*4 + lane/16, 16-B slot lane%16
+  const int y_row0 = (wave * 2) * 4 + (lane >> 4), y_row1 = y_row0 + 4;
+  const int y_c0 = co0 + ((lane & 15) ^ ((y_row0 & 7) << 1)) * 8;
+  const int y_c1 = co0 + ((lane & 15) ^ ((y_row1 & 7) << 1)) * 8;
+  // X: deposit q = wave (and q = 4 from wave 0); lane -> row q*8 + lane/8, 16-B slot lane%8
+  const int x_rowa = wave * 8 + (lane >> 3), x_rowb = 32 + (lane >> 3);
+  const int x_ca = ci0 + ((lane & 7) ^ (((x_rowa >> 1) & 3) << 1)) * 8;
+  const int x_cb = ci0 + ((lane & 7) ^ (((x_rowb >> 1) & 3) << 1)) * 8;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  auto x_src = [&](long m, int coff) -> const bf16_t* {
+    const bf16_t* p = a.zero;
+    if (m >= 0 && m < a.M) {
+      const unsigned mm = (unsigned)m;
+      const int ow = (int)(mm & (unsigned)(a.W - 1));
+      const int oh = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
+      const int n = (int)(mm >> (a.lw + a.lh));
+      int ih = oh + dh, iw = ow;
+      if (ih >= 0 && ih < a.H) {
+        if (a.up) { ih >>= 1; iw >>= 1; }
+        p = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + coff);
+      }
+    }
+    return p;
+  };
+  long i_p0 = mb;
+  auto issue = [&](int buf) {
+    const unsigned stage = lds0 + buf * STAGE;
+    const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
+    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)((unsigned)m0 * a.Cout + y_c0) : a.zero;
+    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)((unsigned)m1 * a.Cout + y_c1) : a.zero;
+    glds16_asm(py0, stage + XT + (wave * 2) * 1024);
+    glds16_asm(py1, stage + XT + (wave * 2 + 1) * 1024);
+    glds16_asm(x_src(i_p0 - 4 + x_rowa, x_ca), stage + wave * 1024);
+    if (wave == 0) glds16_asm(x_src(i_p0 - 4 + x_rowb, x_cb), stage + 4 * 1024);
+    i_p0 += 32;
+  };
+
+  // ---- fragment addresses (per lane, stage-relative) and the left/right column masks -----------------
+  // lane (g, li): channel = subtile*16 + li... transposing read: row = k-group g*4 + li/4, columns 4*(li%4)..+3
+  int offx[3][2], offy[4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 4 + (t - 1) + g * 4 + (li >> 2);
+      const int slot0 = wi * 4 + j * 2;
+      offx[t][j] = row * 128 + (((slot0 + ((li & 3) >> 1)) ^ (((row >> 1) & 3) << 1)) << 4) + (li & 1) * 8;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = g * 4 + (li >> 2);
+    const int slot0 = wo * 8 + i * 2;
+    offy[i] = XT + row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
+  }
+  uint32_t maskl[4], maskr[4];     // fragment element e <-> pixel k = (e<4 ? g*4+e : 16+g*4+e-4)
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t ml = 0, mr = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = 2 * d + h;
+      const int k = (e < 4) ? (g * 4 + e) : (16 + g * 4 + (e - 4));
+      const int ow = k & (a.W - 1);
+      if (ow != 0) ml |= 0xFFFFu << (16 * h);
+      if (ow != a.W - 1) mr |= 0xFFFFu << (16 * h);
+    }
+    maskl[d] = ml; maskr[d] = mr;
+  }
+
+  f32x4_t acc[3][4][2];   // [kw][co subtile][ci subtile]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = (int)((me - mb + 31) / 32);
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < KT) issue(t);
+  for (int kt0 = 0; kt0 < KT; kt0 += NS) {
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const int kt = kt0 + sidx;
+      if (kt < KT) {
+        // this wave's share of stage kt has landed once at most (NS-2) newer stages are still in flight
+        if (kt + NS - 2 < KT) {
+          if (wave == 0) wait_vmcnt_any<(NS - 2) * 4>(); else wait_vmcnt_any<(NS - 2) * 3>();
+        } else {
+          wait_vmcnt_any<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NS - 1 < KT) issue((sidx + NS - 1) % NS);
+        const unsigned char* sb = smem + sidx * STAGE;
+        bf16x8_t yf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          bf16x8_t xf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            uint4 v = __builtin_bit_cast(uint4, tr_pair(sb + offx[t][j], 16 * 128));
+            if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+            if (t == 0) { v.x &= maskl[0]; v.y &= maskl[1]; v.z &= maskl[2]; v.w &= maskl[3]; }
+            if (t == 2) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
+            xf[j] = __builtin_bit_cast(bf16x8_t, v);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[t][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
+  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wo * 64 + i * 16 + (lane >> 4) * 4;
+        const int ci = ci0 + wi * 32 + j * 16 + (lane & 15);
+        float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
+        *(float4*)(slab + ((long)(kh * 3 + t) * a.Cin + ci) * a.Cout + co) = v;
+      }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,17 +987,64 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return launch_conv_mfma<64, 64>(ctx, a);
 }
 
-int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
-  long tiles = (long)d->kh * d->kw * (d->cin / 128) * (d->cout / 128);
-  long want = (768 + tiles - 1) / tiles;
+static bool wgrad3_shape(int kh, int kw, int h, int w) {
+  // three-taps-per-workgroup kernel: 3x3 filters, W a power of two dividing the 32-pixel stage, H a power of two
+  return kh == 3 && kw == 3 && ilog2_exact(w) >= 0 && ilog2_exact(h) >= 0 && w >= 4 && w <= 32;
+}
+
+static int wgrad3_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); v = (e && (e[0] == 'r' || e[0] == 'g')) ? 0 : 1; }
+  return v;
+}
+
+static long wgrad_clamp_splits(long want, long M) {
   long maxs = (M + 511) / 512;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 128) want = 128;
+  return want;
+}
+
+int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
+  long tiles = (long)d->kh * d->kw * (d->cin / 128) * (d->cout / 128);
+  long want = wgrad_clamp_splits((768 + tiles - 1) / tiles, M);
+  if (wgrad3_shape(d->kh, d->kw, d->h, d->w)) {      // workspace must cover whichever kernel the launch picks
+    long tiles3 = (long)d->kh * (d->cin / 64) * (d->cout / 128);
+    long want3 = wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, M);
+    if (want3 > want) want = want3;
+  }
   return (int)want;
 }
 
+template <bool RELU>
+static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
+  constexpr int NS = 4;
+  static bool attr = false;
+  size_t lds = (size_t)NS * (40 * 128 + 32 * 256);
+  if (!attr) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad3_kernel<NS, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  {
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_wgrad3_kernel<NS, RELU>), grid, dim3(256), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
+  if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1) {
+    long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
+    int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
+    if (want > nz) want = nz;
+    a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
+    int nzz = cdiv(a.M, a.m_chunk);
+    dim3 grid((unsigned)tiles3, nzz);
+    int rc = a.relu_in ? launch_wgrad3<true>(ctx, a, grid) : launch_wgrad3<false>(ctx, a, grid);
+    return rc ? -1 : nzz;
+  }
   static bool attr_set = false;
   size_t lds = (size_t)4 * 64 * WG_PITCH * sizeof(bf16_t);
   if (!attr_set) {
@@ -769,17 +1054,18 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
   a.m_chunk = ((a.M + nz - 1) / nz + 63) / 64 * 64;
   int nzz = cdiv(a.M, a.m_chunk);
   dim3 grid(a.KH * a.KW * (a.Cin / 128) * (a.Cout / 128), nzz);
-  static int wg_glds = -1;     // the direct-to-LDS filter gradient measured slower (180 vs 327 TFLOP/s): opt-in only
-  if (wg_glds < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); wg_glds = (e && e[0] == 'g') ? 1 : 0; }
+  static int wg_glds = -1;     // per-tap kernels: direct-to-LDS (default) or register-staged (RCGAN_WGRAD_IMPL=reg)
+  if (wg_glds < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); wg_glds = (e && e[0] == 'r') ? 0 : 1; }
   if (wg_glds == 1 && a.zero != nullptr) {
+    constexpr int NS = 4;
     static bool attr2 = false;
-    size_t lds2 = (size_t)4 * 64 * 256;
+    size_t lds2 = (size_t)NS * 2 * 32 * 256;
     if (!attr2) {
-      RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad_glds_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       attr2 = true;
     }
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
-    hipLaunchKernelGGL(conv_mfma_wgrad_glds_kernel, grid, dim3(256), lds2, ctx->stream, a);
+    hipLaunchKernelGGL(conv_mfma_wgrad_glds_kernel<NS>, grid, dim3(256), lds2, ctx->stream, a);
   } else {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
