@@ -8,6 +8,10 @@ template <typename T> int direct_fwd(rcgan_ctx*, const rcgan_conv_desc*, const T
 template <typename T> int direct_dgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, const T*, T*, int);
 template <typename T> int direct_wgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, float*, float*, int, void*, size_t);
 template <typename T> int colsum_launch(rcgan_ctx*, const T*, long, int, float*, int, float*);
+template <typename T> int linear_fwd(rcgan_ctx*, long, long, long, const T*, const float*, const float*, const float*, T*);
+template <typename T> int linear_dgrad(rcgan_ctx*, long, long, long, const T*, const float*, const float*, T*, int);
+template <typename T> int linear_wgrad(rcgan_ctx*, long, long, long, const T*, const T*, float*, float*, int, void*, size_t);
+size_t linear_wgrad_ws_bytes(long m, long k, long n);
 template <typename T> int sumpool2_masked_launch(rcgan_ctx*, int, int, int, int, const T*, const T*, T*, int);
 int small_fwd_kind(const rcgan_conv_desc* d);
 int small_dgrad_kind(const rcgan_conv_desc* d);
@@ -78,7 +82,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->prof_which = 0;
   c->prof_flops = 0.0;
   c->zero_page = nullptr;
-  if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
     delete c;
     return RCGAN_EHIP;
   }
@@ -409,37 +413,37 @@ int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense layers as 1x1 convolutions on an [m,1,1,k] tensor
+// dense layers: plain row-major GEMMs on the shared fp32 GEMM core (conv_direct.hip)
 // ------------------------------------------------------------------------------------------------
-static rcgan_conv_desc lin_desc(int m, int k, int n, int dtype) {
-  rcgan_conv_desc d;
-  d.n = m; d.h = 1; d.w = 1; d.cin = k; d.cout = n; d.kh = 1; d.kw = 1; d.stride = 1; d.dtype = dtype; d.flags = RCGAN_CONV_FORCE_DIRECT;
-  return d;
+static int check_lin(rcgan_ctx* ctx, int m, int k, int n, int dtype) {
+  RC_REQUIRE(ctx, m > 0 && k > 0 && n > 0, "bad linear shape [%d,%d]x[%d,%d]", m, k, k, n);
+  RC_REQUIRE(ctx, dtype == RCGAN_F32 || dtype == RCGAN_BF16, "bad dtype %d", dtype);
+  return RCGAN_OK;
 }
 
-size_t rcgan_linear_workspace_bytes(int m, int k, int n) {
-  rcgan_conv_desc d = lin_desc(m, k, n, RCGAN_F32);
-  return direct_wgrad_ws_bytes(&d);
-}
+size_t rcgan_linear_workspace_bytes(int m, int k, int n) { return linear_wgrad_ws_bytes(m, k, n); }
 
 int rcgan_linear_fwd(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const float* w, const float* sigma,
                      const float* bias, void* y) {
-  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
-  RC_DISPATCH_DTYPE(ctx, dtype, return direct_fwd<T>(ctx, &d, (const T*)x, w, sigma, bias, (T*)y));
+  int rc = check_lin(ctx, m, k, n, dtype);
+  if (rc) return rc;
+  RC_DISPATCH_DTYPE(ctx, dtype, return linear_fwd<T>(ctx, m, k, n, (const T*)x, w, sigma, bias, (T*)y));
   return RCGAN_OK;
 }
 
 int rcgan_linear_bwd_data(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* dy, const float* w, const float* sigma,
                           void* dx, int accumulate) {
-  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
-  RC_DISPATCH_DTYPE(ctx, dtype, return direct_dgrad<T>(ctx, &d, (const T*)dy, w, sigma, nullptr, (const T*)nullptr, (T*)dx, accumulate));
+  int rc = check_lin(ctx, m, k, n, dtype);
+  if (rc) return rc;
+  RC_DISPATCH_DTYPE(ctx, dtype, return linear_dgrad<T>(ctx, m, k, n, (const T*)dy, w, sigma, (T*)dx, accumulate));
   return RCGAN_OK;
 }
 
 int rcgan_linear_bwd_weight(rcgan_ctx* ctx, int m, int k, int n, int dtype, const void* x, const void* dy, float* dw, float* dbias,
                             int accumulate, void* ws, size_t ws_bytes) {
-  rcgan_conv_desc d = lin_desc(m, k, n, dtype);
-  RC_DISPATCH_DTYPE(ctx, dtype, return direct_wgrad<T>(ctx, &d, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
+  int rc = check_lin(ctx, m, k, n, dtype);
+  if (rc) return rc;
+  RC_DISPATCH_DTYPE(ctx, dtype, return linear_wgrad<T>(ctx, m, k, n, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
   return RCGAN_OK;
 }
 

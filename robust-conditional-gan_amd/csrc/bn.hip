@@ -298,6 +298,248 @@ __global__ void bn_bwd_apply_vec_kernel(long nchunks, int rows_per_sample, int c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused variants (c % 64 == 0): statistics and their combination in ONE launch, affine tables folded into
+// the apply kernels -> 2 launches per batch norm (was 4) in each direction.
+//   * grid (c/64, groups); block = 8 channel chunks (64 channels) x 32 row lanes
+//   * every workgroup writes its group's partial sums, then bumps an arrival counter of its column block
+//     (agent-scope acq_rel); the LAST arrival of a column block combines all groups of these 64 channels in a
+//     fixed order (deterministic, fp64) and resets the counter for the next launch / graph replay.
+// ------------------------------------------------------------------------------------------------
+struct BnFusedArgs {
+  long rows; int c; long rows_per_group; int ngroups;
+  const void *x, *y, *dy;
+  const float *mean_in, *rstd_in;       // backward only
+  int act;
+  float* partial;                       // [ngroups][2][c]
+  unsigned* counter;                    // [c/64]
+  // forward finish
+  float eps; float *mean, *rstd, *mm, *mv; float decay;
+  // backward finish
+  int n_labels; int groups_per_sample; const int32_t* labels; int n_samples;
+  const float* gamma; float *dgamma, *dbeta; int accumulate; float* PQ;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
+  __shared__ float red[2][32][64];
+  __shared__ double fin[2][4][64];
+  __shared__ float lab_s[2][MAX_LABELS][64];
+  __shared__ int is_last;
+  const int t = threadIdx.x;
+  const int c = a.c;
+  const int c0 = blockIdx.x * 64;
+  const int chunk = t & 7, rl = t >> 3;
+  const long rb = (long)blockIdx.y * a.rows_per_group;
+  long re = rb + a.rows_per_group;
+  if (re > a.rows) re = a.rows;
+  const T* x = (const T*)a.x; const T* y = (const T*)a.y; const T* dy = (const T*)a.dy;
+  float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  if (MODE == 1) { ld8(a.mean_in + c0 + chunk * 8, mu); ld8(a.rstd_in + c0 + chunk * 8, rs); }
+#pragma unroll 2
+  for (long r = rb + rl; r < re; r += 32) {
+    const long off = r * c + c0 + chunk * 8;
+    float xv[8];
+    ld8(x + off, xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += xv[j]; s2[j] += xv[j] * xv[j]; }
+    } else {
+      float gv[8];
+      ld8(dy + off, gv);
+      if (a.act != RCGAN_ACT_NONE) {
+        float yv[8];
+        ld8(y + off, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] *= act_grad(a.act, yv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += gv[j]; s2[j] += gv[j] * (xv[j] - mu[j]) * rs[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][rl][chunk * 8 + j] = s1[j]; red[1][rl][chunk * 8 + j] = s2[j]; }
+  __syncthreads();
+  if (t < 128) {
+    const int which = t >> 6, col = t & 63;
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) s += red[which][q][col];
+    a.partial[((long)blockIdx.y * 2 + which) * c + c0 + col] = s;
+  }
+  // ---- arrival: the last workgroup of this column block finishes ------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    unsigned prev = __hip_atomic_fetch_add(a.counter + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (prev == (unsigned)a.ngroups - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);      // all threads: see the other workgroups' partials
+  const int col = t & 63, lane4 = t >> 6;
+  const float* part = a.partial + c0 + col;
+  const long gstride = 2L * c;
+
+  if (MODE == 0 || a.labels == nullptr) {
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll 8
+    for (int g = lane4; g < a.ngroups; g += 4) {
+      d1 += (double)__builtin_nontemporal_load(part + g * gstride);
+      d2 += (double)__builtin_nontemporal_load(part + g * gstride + c);
+    }
+    fin[0][lane4][col] = d1; fin[1][lane4][col] = d2;
+    __syncthreads();
+    if (t < 64) {
+      d1 = fin[0][0][t] + fin[0][1][t] + fin[0][2][t] + fin[0][3][t];
+      d2 = fin[1][0][t] + fin[1][1][t] + fin[1][2][t] + fin[1][3][t];
+      const int ch = c0 + t;
+      if (MODE == 0) {
+        double mean = d1 / (double)a.rows;
+        double var = d2 / (double)a.rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.mean[ch] = (float)mean;
+        a.rstd[ch] = (float)(1.0 / sqrt(var + (double)a.eps));
+        if (a.mm) {
+          // TF fused batch norm: moving -= (moving - batch) * (1 - decay), variance with Bessel's correction
+          double uvar = a.rows > 1 ? var * ((double)a.rows / (double)(a.rows - 1)) : var;
+          float om = 1.f - a.decay;
+          a.mm[ch] = a.mm[ch] - (a.mm[ch] - (float)mean) * om;
+          a.mv[ch] = a.mv[ch] - (a.mv[ch] - (float)uvar) * om;
+        }
+      } else {
+        float og = (float)d2, ob = (float)d1;
+        if (a.accumulate) { og += a.dgamma[ch]; ob += a.dbeta[ch]; }
+        a.dgamma[ch] = og; a.dbeta[ch] = ob;
+        lab_s[0][0][t] = (float)d1; lab_s[1][0][t] = (float)d2;
+      }
+    }
+  } else {
+    // conditional: groups of one sample are contiguous; sum per label (each sample is visited by exactly one (lane, l))
+    for (int l = lane4; l < a.n_labels; l += 4) {
+      double d1 = 0.0, d2 = 0.0;
+      for (int sidx = 0; sidx < a.n_samples; ++sidx) {
+        if (a.labels[sidx] != l) continue;
+        for (int q = 0; q < a.groups_per_sample; ++q) {
+          const long g = (long)sidx * a.groups_per_sample + q;
+          d1 += (double)__builtin_nontemporal_load(part + g * gstride);
+          d2 += (double)__builtin_nontemporal_load(part + g * gstride + c);
+        }
+      }
+      const long o = (long)l * c + c0 + col;
+      float og = (float)d2, ob = (float)d1;
+      if (a.accumulate) { og += a.dgamma[o]; ob += a.dbeta[o]; }
+      a.dgamma[o] = og; a.dbeta[o] = ob;
+      lab_s[0][l][col] = (float)d1; lab_s[1][l][col] = (float)d2;
+    }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    if (t < 64) {
+      // dx = A*g + P*x + Q with A = rstd*gamma[label], P = -rstd^2*s2/M, Q = -P*mean - rstd*s1/M,
+      // s1 = sum_l gamma_l*dbeta_l, s2 = sum_l gamma_l*dgamma_l
+      const int ch = c0 + t;
+      double q1 = 0.0, q2 = 0.0;
+      for (int l = 0; l < a.n_labels; ++l) {
+        double gm = (double)a.gamma[(long)l * c + ch];
+        q1 += gm * (double)lab_s[0][l][t];
+        q2 += gm * (double)lab_s[1][l][t];
+      }
+      const float invM = 1.f / (float)a.rows;
+      const float r = a.rstd_in[ch];
+      const float p = -r * r * (float)q2 * invM;
+      a.PQ[ch] = p;
+      a.PQ[c + ch] = -p * a.mean_in[ch] - r * (float)q1 * invM;
+    }
+  }
+  if (t == 0) __hip_atomic_store(a.counter + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// y = act(x*A + B), A = rstd*gamma[label], B = beta[label] - mean*A, computed in-line: the thread's 8 channels are fixed
+// (grid stride is a multiple of the chunks per row), so mean/rstd live in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fused_kernel(long nchunks, int rows_per_sample, int c, const T* x, const int32_t* labels,
+                                                             const float* gamma, const float* beta, const float* mean,
+                                                             const float* rstd, int act, T* y) {
+  const unsigned cpr = (unsigned)c / 8u;              // a power of two on this path
+  const int lcpr = __ffs((int)cpr) - 1;
+  const int lrps = (rows_per_sample & (rows_per_sample - 1)) == 0 ? __ffs(rows_per_sample) - 1 : -1;
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned stride = gridDim.x * 256u;
+  const int ch = (int)(i0 & (cpr - 1u)) * 8;
+  float mu[8], rs[8];
+  ld8(mean + ch, mu); ld8(rstd + ch, rs);
+  for (unsigned i = i0; i < (unsigned)nchunks; i += stride) {
+    const unsigned row = i >> lcpr;
+    const int l = labels ? labels[lrps >= 0 ? (row >> lrps) : (row / (unsigned)rows_per_sample)] : 0;
+    float xv[8], g[8], b[8];
+    ld8(x + (long)row * c + ch, xv);
+    ld8(gamma + (long)l * c + ch, g);
+    ld8(beta + (long)l * c + ch, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float inv = rs[j] * g[j];
+      xv[j] = act_apply(act, xv[j] * inv + (b[j] - mu[j] * inv));
+    }
+    st8(y + (long)row * c + ch, xv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long nchunks, int rows_per_sample, int c, const T* x, const T* y, const T* dy,
+                                                                 const int32_t* labels, const float* gamma, const float* rstd,
+                                                                 const float* PQ, int act, T* dx, int accumulate_dx) {
+  const unsigned cpr = (unsigned)c / 8u;              // a power of two on this path
+  const int lcpr = __ffs((int)cpr) - 1;
+  const int lrps = (rows_per_sample & (rows_per_sample - 1)) == 0 ? __ffs(rows_per_sample) - 1 : -1;
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned stride = gridDim.x * 256u;
+  const int ch = (int)(i0 & (cpr - 1u)) * 8;
+  float rs[8], p[8], q[8];
+  ld8(rstd + ch, rs); ld8(PQ + ch, p); ld8(PQ + c + ch, q);
+  for (unsigned i = i0; i < (unsigned)nchunks; i += stride) {
+    const unsigned row = i >> lcpr;
+    const int l = labels ? labels[lrps >= 0 ? (row >> lrps) : (row / (unsigned)rows_per_sample)] : 0;
+    const long off = (long)row * c + ch;
+    float xv[8], gv[8], gm[8];
+    ld8(x + off, xv);
+    ld8(dy + off, gv);
+    if (act != RCGAN_ACT_NONE) {
+      float yv[8];
+      ld8(y + off, yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] *= act_grad(act, yv[j]);
+    }
+    ld8(gamma + (long)l * c + ch, gm);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rs[j] * gm[j] * gv[j] + p[j] * xv[j] + q[j];
+    if (accumulate_dx) {
+      float d[8];
+      ld8(dx + off, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += d[j];
+    }
+    st8(dx + off, o);
+  }
+}
+
+// fused path: 64-channel column blocks, thread-fixed channel chunks in the apply kernels
+static inline bool bn_fused_ok(int c) {
+  return c >= 64 && c <= 2048 && (c & (c - 1)) == 0;      // power of two: chunks per row divide (or are) the block size
+}
+
+static inline int apply_grid_fused(long nchunks, int c) {
+  const int cpr = c / 8;
+  long b = (nchunks + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (cpr > 256) { long m = cpr / 256; b = (b + m - 1) / m * m; }   // stride (b*256) must be a multiple of cpr
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 static inline long stats_group_rows(long rows) {
   long g = 512;
   while (rows / g > 2048) g *= 2;
@@ -327,6 +569,15 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
   size_t need = (size_t)ng * 2 * c * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   float* partial = (float*)ws;
+  if (bn_fused_ok(c)) {
+    BnFusedArgs a = {};
+    a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.partial = partial;
+    a.counter = ctx->counters() + RC_COUNTER_BN;
+    a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = mm; a.mv = mv; a.decay = decay;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng), dim3(256), 0, ctx->stream, a));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   if (c % 8 == 0) {
     dim3 grid(cdiv(c / 8, 32), ng);
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_partial_vec_kernel<T, 0>), grid, dim3(256), 0, ctx->stream, (long)rows, c, rpg,
@@ -349,6 +600,13 @@ int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_
                        const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
                        int act, void* y, void* ws, size_t ws_bytes) {
   long total = (long)n * rows_per_sample * c;
+  if (bn_fused_ok(c)) {
+    long nchunks = total / 8;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
+                                                     nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   if (c % 8 == 0 && ws_bytes >= (size_t)2 * n_labels * c * sizeof(float)) {
     float* A = (float*)ws;
     float* B = A + (size_t)n_labels * c;
@@ -374,6 +632,33 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
   long rows = (long)n * rows_per_sample;
   long rpg;
   int ng;
+  if (bn_fused_ok(c)) {
+    int gps = 1;
+    if (labels) {
+      // groups never straddle samples; split each sample until the grid has a few hundred workgroups
+      rpg = rows_per_sample;
+      while ((long)n * gps * (c / 64) < 512 && rpg % 2 == 0 && rpg / 2 >= 32 && (long)n * gps * 2 <= 1024) { gps *= 2; rpg /= 2; }
+      ng = n * gps;
+    } else {
+      rpg = stats_group_rows(rows); ng = cdiv(rows, rpg);
+    }
+    size_t need = ((size_t)ng * 2 * c + 2 * (size_t)c) * sizeof(float);
+    if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+    BnFusedArgs a = {};
+    a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.y = y; a.dy = dy;
+    a.mean_in = mean; a.rstd_in = rstd; a.act = act; a.partial = (float*)ws; a.counter = ctx->counters() + RC_COUNTER_BN;
+    a.n_labels = n_labels; a.groups_per_sample = gps; a.labels = labels; a.n_samples = n;
+    a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    a.PQ = a.partial + (size_t)ng * 2 * c;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 1>), dim3(c / 64, ng), dim3(256), 0, ctx->stream, a));
+    RC_LAUNCH_CHECK(ctx);
+    long nchunks = rows * c / 8;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
+                                                     nchunks, rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, rstd,
+                                                     (const float*)a.PQ, act, (T*)dx, accumulate_dx));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   if (labels) { rpg = rows_per_sample; ng = n; }          // one group per sample: group label = sample label
   else { rpg = stats_group_rows(rows); ng = cdiv(rows, rpg); }
   size_t need = ((size_t)ng * 2 * c + 2 * (size_t)c) * sizeof(float);

@@ -24,8 +24,12 @@ struct rcgan_ctx {
   int prof_which;
   std::vector<hipEvent_t> prof_ev;
   double prof_flops;
-  void* zero_page;     // 256 zero bytes in device memory
+  void* zero_page;     // 4 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
+                       // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels
+  unsigned* counters() const { return (unsigned*)((char*)zero_page + 1024); }
 };
+#define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
+#define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish
 
 // brackets one launch with events when profiling is armed for kernel id `which`
 struct ProfScope {

@@ -108,6 +108,45 @@ template <typename T> struct WgradOp {
   }
 };
 
+// ---- fully connected layers: the same GEMM core with plain row-major operands (no pixel decode, no
+//      integer division per element): y[m][n] = x[m][:] . w[:][n];  dx[m][k] = dy[m][:] . w[k][:];
+//      dw[k][n] = x[:][k] . dy[:][n]
+template <typename T> struct LinFwdOp {
+  const T* x; const float* w; const float* bias; T* y; const float* wscale;
+  long M, N, R, r_chunk;
+  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(x + i * R + r); }
+  __device__ __forceinline__ float b(long r, long j) const { return w[r * N + j]; }
+  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+    if (bias) v += bias[j];
+    Elem<T>::st(y + i * N + j, v);
+  }
+};
+template <typename T> struct LinDgradOp {
+  const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
+  long M, N, R, r_chunk;          // N = in features, R = out features
+  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(dy + i * R + r); }
+  __device__ __forceinline__ float b(long r, long j) const { return w[j * R + r]; }
+  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+    T* p = dx + i * N + j;
+    if (accumulate) v += Elem<T>::ld(p);
+    Elem<T>::st(p, v);
+  }
+};
+template <typename T> struct LinWgradOp {
+  const T* x; const T* dy; float* out; int accumulate; int direct; const float* wscale;
+  long M, N, R, r_chunk;          // M = in features, N = out features, R = batch rows
+  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(x + r * M + i); }
+  __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * N + j); }
+  __device__ __forceinline__ void store(long i, long j, float v, int z) const {
+    if (direct) {                  // single r-chunk: straight into the gradient
+      float* p = out + i * N + j;
+      *p = accumulate ? *p + v : v;
+    } else {
+      out[(long)z * M * N + i * N + j] = v;
+    }
+  }
+};
+
 template <class Op>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   __shared__ float As[16][68];
@@ -311,6 +350,63 @@ int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int 
 }
 template int colsum_launch<float>(rcgan_ctx*, const float*, long, int, float*, int, float*);
 template int colsum_launch<bf16_t>(rcgan_ctx*, const bf16_t*, long, int, float*, int, float*);
+
+template <typename T>
+int linear_fwd(rcgan_ctx* ctx, long m, long k, long n, const T* x, const float* w, const float* wscale, const float* bias, T* y) {
+  LinFwdOp<T> op;
+  op.x = x; op.w = w; op.bias = bias; op.y = y; op.wscale = wscale;
+  op.M = m; op.N = n; op.R = k; op.r_chunk = k;
+  return launch_gemm(ctx, op, 1);
+}
+template int linear_fwd<float>(rcgan_ctx*, long, long, long, const float*, const float*, const float*, const float*, float*);
+template int linear_fwd<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, const float*, const float*, const float*, bf16_t*);
+
+template <typename T>
+int linear_dgrad(rcgan_ctx* ctx, long m, long k, long n, const T* dy, const float* w, const float* wscale, T* dx, int accumulate) {
+  LinDgradOp<T> op;
+  op.dy = dy; op.w = w; op.dx = dx; op.accumulate = accumulate; op.wscale = wscale;
+  op.M = m; op.N = k; op.R = n; op.r_chunk = n;
+  return launch_gemm(ctx, op, 1);
+}
+template int linear_dgrad<float>(rcgan_ctx*, long, long, long, const float*, const float*, const float*, float*, int);
+template int linear_dgrad<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, const float*, const float*, bf16_t*, int);
+
+size_t linear_wgrad_ws_bytes(long m, long k, long n) {
+  int nz = m <= 1024 ? 1 : wgrad_splits(k, n, m);
+  return (size_t)(nz > 1 ? nz : 0) * k * n * sizeof(float) + (size_t)(cdiv(m, 2048) + 1024) * n * sizeof(float) + 256;
+}
+
+template <typename T>
+int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy, float* dw, float* dbias, int accumulate,
+                 void* ws, size_t ws_bytes) {
+  LinWgradOp<T> op;
+  op.x = x; op.dy = dy; op.wscale = nullptr; op.accumulate = accumulate;
+  op.M = k; op.N = n; op.R = m;
+  int nz = m <= 1024 ? 1 : wgrad_splits(k, n, m);
+  size_t slab_bytes = (size_t)(nz > 1 ? nz : 0) * k * n * sizeof(float);
+  if (ws_bytes < linear_wgrad_ws_bytes(m, k, n)) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", linear_wgrad_ws_bytes(m, k, n), ws_bytes);
+  if (nz == 1) {
+    op.direct = 1; op.out = dw; op.r_chunk = m;
+    int rc = launch_gemm(ctx, op, 1);
+    if (rc) return rc;
+  } else {
+    op.direct = 0; op.out = (float*)ws;
+    op.r_chunk = ((m + nz - 1) / nz + 15) / 16 * 16;
+    nz = cdiv(m, op.r_chunk);
+    int rc = launch_gemm(ctx, op, nz);
+    if (rc) return rc;
+    long cnt = k * n;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)op.out, dw, cnt, nz, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  if (dbias) {
+    float* part = (float*)((char*)ws + slab_bytes);
+    return colsum_launch<T>(ctx, dy, m, (int)n, dbias, accumulate, part);
+  }
+  return RCGAN_OK;
+}
+template int linear_wgrad<float>(rcgan_ctx*, long, long, long, const float*, const float*, float*, float*, int, void*, size_t);
+template int linear_wgrad<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, const bf16_t*, float*, float*, int, void*, size_t);
 
 template <typename T>
 int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float* w, const float* wscale, const float* bias, T* y) {

@@ -169,7 +169,8 @@ def test_linear(dev, m, k, n):
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(0), 2e-4, "linear db")
 
 
-@pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False)])
+@pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False),
+                                        ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True)])
 def test_batch_norm(dev, shape, cond):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
