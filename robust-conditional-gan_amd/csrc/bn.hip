@@ -302,9 +302,10 @@ __global__ void bn_bwd_apply_vec_kernel(long nchunks, int rows_per_sample, int c
 // Fused variants (c % 64 == 0): statistics and their combination in ONE launch, affine tables folded into
 // the apply kernels -> 2 launches per batch norm (was 4) in each direction.
 //   * grid (c/64, groups); block = 8 channel chunks (64 channels) x 32 row lanes
-//   * every workgroup writes its group's partial sums, then bumps an arrival counter of its column block
-//     (agent-scope acq_rel); the LAST arrival of a column block combines all groups of these 64 channels in a
-//     fixed order (deterministic, fp64) and resets the counter for the next launch / graph replay.
+//   * every workgroup writes its group's partial sums with agent-scope stores, then bumps an arrival counter of
+//     its column block; the LAST arrival of a column block combines all groups of these 64 channels in a fixed
+//     order (deterministic, fp64) and resets the counter for the next launch / graph replay.  Agent-scope
+//     accesses go to the memory side, so no workgroup pays an L2 write-back/invalidate (8 XCDs = 8 L2s).
 // ------------------------------------------------------------------------------------------------
 struct BnFusedArgs {
   long rows; int c; long rows_per_group; int ngroups;
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
   __shared__ double fin[2][4][64];
   __shared__ float lab_s[2][MAX_LABELS][64];
   __shared__ int is_last;
+  __shared__ int lab_ids[32];
+  __shared__ float lacc[MODE == 1 ? 2 : 1][MODE == 1 ? MAX_LABELS : 1][4][64];   // backward: per-label sums, private per (lane4, column)
   const int t = threadIdx.x;
   const int c = a.c;
   const int c0 = blockIdx.x * 64;
@@ -362,23 +365,25 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[0][rl][chunk * 8 + j] = s1[j]; red[1][rl][chunk * 8 + j] = s2[j]; }
   __syncthreads();
-  if (t < 128) {
-    const int which = t >> 6, col = t & 63;
-    float s = 0.f;
+  // wavefront 0 writes both partial rows and then signals: the agent-scope release of thread 0 orders the
+  // stores of its OWN wavefront, so no other wavefront has to fence
+  if (t < 64) {
+    float sa = 0.f, sb = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) s += red[which][q][col];
-    a.partial[((long)blockIdx.y * 2 + which) * c + c0 + col] = s;
+    for (int q = 0; q < 32; ++q) { sa += red[0][q][t]; sb += red[1][q][t]; }
+    // agent-scope stores (write through to the memory side: visible to every XCD without an L2 write-back)
+    __hip_atomic_store(a.partial + ((long)blockIdx.y * 2 + 0) * c + c0 + t, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.partial + ((long)blockIdx.y * 2 + 1) * c + c0 + t, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores are performed before it signals
   }
   // ---- arrival: the last workgroup of this column block finishes ------------------------------------------
-  __threadfence();
-  __syncthreads();
   if (t == 0) {
-    unsigned prev = __hip_atomic_fetch_add(a.counter + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned prev = __hip_atomic_fetch_add(a.counter + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (prev == (unsigned)a.ngroups - 1u) ? 1 : 0;
   }
   __syncthreads();
   if (!is_last) return;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);      // all threads: see the other workgroups' partials
+  // the partials are read back with agent-scope loads (served from the memory side, never from a stale cache line)
   const int col = t & 63, lane4 = t >> 6;
   const float* part = a.partial + c0 + col;
   const long gstride = 2L * c;
@@ -387,8 +392,8 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
     double d1 = 0.0, d2 = 0.0;
 #pragma unroll 8
     for (int g = lane4; g < a.ngroups; g += 4) {
-      d1 += (double)__builtin_nontemporal_load(part + g * gstride);
-      d2 += (double)__builtin_nontemporal_load(part + g * gstride + c);
+      d1 += (double)__hip_atomic_load(part + g * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d2 += (double)__hip_atomic_load(part + g * gstride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     fin[0][lane4][col] = d1; fin[1][lane4][col] = d2;
     __syncthreads();
@@ -417,23 +422,64 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
       }
     }
   } else {
-    // conditional: groups of one sample are contiguous; sum per label (each sample is visited by exactly one (lane, l))
-    for (int l = lane4; l < a.n_labels; l += 4) {
-      double d1 = 0.0, d2 = 0.0;
-      for (int sidx = 0; sidx < a.n_samples; ++sidx) {
-        if (a.labels[sidx] != l) continue;
-        for (int q = 0; q < a.groups_per_sample; ++q) {
-          const long g = (long)sidx * a.groups_per_sample + q;
-          d1 += (double)__builtin_nontemporal_load(part + g * gstride);
-          d2 += (double)__builtin_nontemporal_load(part + g * gstride + c);
+    // conditional: the groups of one sample are contiguous.  Thread (column, lane4) owns samples lane4*8..+7 of
+    // every batch of 32: it sums their groups (independent loads) and adds the result to its PRIVATE per-label
+    // slot in LDS; afterwards the four lanes of a (label, column) are summed in a fixed order.
+    const int gps = a.groups_per_sample;
+#pragma unroll
+    for (int l = 0; l < MAX_LABELS; ++l) { lacc[0][l][lane4][col] = 0.f; lacc[1][l][lane4][col] = 0.f; }
+    for (int s0 = 0; s0 < a.n_samples; s0 += 32) {
+      __syncthreads();
+      if (t < 32) lab_ids[t] = (s0 + t < a.n_samples) ? a.labels[s0 + t] : -1;
+      float d1[8], d2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { d1[k] = 0.f; d2[k] = 0.f; }
+      for (int q = 0; q < gps; ++q) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {           // 16 independent loads per round
+          const int sidx = s0 + lane4 * 8 + k;
+          if (sidx < a.n_samples) {
+            const float* pp = part + ((long)sidx * gps + q) * gstride;
+            d1[k] += __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d2[k] += __hip_atomic_load(pp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
-      const long o = (long)l * c + c0 + col;
-      float og = (float)d2, ob = (float)d1;
-      if (a.accumulate) { og += a.dgamma[o]; ob += a.dbeta[o]; }
-      a.dgamma[o] = og; a.dbeta[o] = ob;
-      lab_s[0][l][col] = (float)d1; lab_s[1][l][col] = (float)d2;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = lab_ids[lane4 * 8 + k];
+        if (l >= 0 && l < MAX_LABELS) { lacc[0][l][lane4][col] += d1[k]; lacc[1][l][lane4][col] += d2[k]; }
+      }
     }
+    __syncthreads();
+    float acc1[MAX_LABELS / 4], acc2[MAX_LABELS / 4];
+#pragma unroll
+    for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
+      const int l = lane4 + 4 * slot;
+      acc1[slot] = (lacc[0][l][0][col] + lacc[0][l][1][col]) + (lacc[0][l][2][col] + lacc[0][l][3][col]);
+      acc2[slot] = (lacc[1][l][0][col] + lacc[1][l][1][col]) + (lacc[1][l][2][col] + lacc[1][l][3][col]);
+    }
+    float gm[MAX_LABELS / 4];
+#pragma unroll
+    for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
+      const int l = lane4 + 4 * slot;
+      gm[slot] = l < a.n_labels ? a.gamma[(long)l * c + c0 + col] : 0.f;
+    }
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
+      const int l = lane4 + 4 * slot;
+      if (l < a.n_labels) {
+        const long o = (long)l * c + c0 + col;
+        float og = acc2[slot], ob = acc1[slot];
+        if (a.accumulate) { og += a.dgamma[o]; ob += a.dbeta[o]; }
+        a.dgamma[o] = og; a.dbeta[o] = ob;
+        q1 += (double)gm[slot] * (double)acc1[slot];
+        q2 += (double)gm[slot] * (double)acc2[slot];
+      }
+    }
+    fin[0][lane4][col] = q1; fin[1][lane4][col] = q2;
   }
   if (MODE == 1) {
     __syncthreads();
@@ -441,11 +487,13 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
       // dx = A*g + P*x + Q with A = rstd*gamma[label], P = -rstd^2*s2/M, Q = -P*mean - rstd*s1/M,
       // s1 = sum_l gamma_l*dbeta_l, s2 = sum_l gamma_l*dgamma_l
       const int ch = c0 + t;
-      double q1 = 0.0, q2 = 0.0;
-      for (int l = 0; l < a.n_labels; ++l) {
-        double gm = (double)a.gamma[(long)l * c + ch];
-        q1 += gm * (double)lab_s[0][l][t];
-        q2 += gm * (double)lab_s[1][l][t];
+      double q1, q2;
+      if (a.labels == nullptr) {
+        const double gmm = (double)a.gamma[ch];
+        q1 = gmm * (double)lab_s[0][0][t]; q2 = gmm * (double)lab_s[1][0][t];
+      } else {
+        q1 = fin[0][0][t] + fin[0][1][t] + fin[0][2][t] + fin[0][3][t];
+        q2 = fin[1][0][t] + fin[1][1][t] + fin[1][2][t] + fin[1][3][t];
       }
       const float invM = 1.f / (float)a.rows;
       const float r = a.rstd_in[ch];
