@@ -21,13 +21,17 @@ template <typename T> int small_fwd(rcgan_ctx*, const rcgan_conv_desc*, int, con
 template <typename T> int small_dgrad(rcgan_ctx*, const rcgan_conv_desc*, int, const T*, const float*, T*, int);
 template <typename T> int small_wgrad(rcgan_ctx*, const rcgan_conv_desc*, int, const T*, const T*, float*, float*, int, void*, size_t);
 
-__global__ void slab_reduce2_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
+// out[i] (= or +=) sum_z slab[z][i]; the slabs may carry a bias-gradient tail of `nbias` floats after `count`
+__global__ void slab_reduce2_kernel(const float* slab, long stride, float* out, long count, float* bias_out, int nbias, int nz,
+                                    int accumulate) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+  if (i >= count + nbias) return;
   float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += slab[(long)z * count + i];
-  if (accumulate) s += out[i];
-  out[i] = s;
+#pragma unroll 4
+  for (int z = 0; z < nz; ++z) s += slab[(long)z * stride + i];
+  float* o = i < count ? out + i : bias_out + (i - count);
+  if (accumulate) s += *o;
+  *o = s;
 }
 
 __global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
@@ -250,7 +254,7 @@ size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {
     if (s > ws) ws = s;
   }
   if (mfma_wgrad_eligible(d)) {
-    size_t s = (size_t)mfma_wgrad_splits(d, M) * d->kh * d->kw * d->cin * d->cout * sizeof(float) + (size_t)(cdiv(M, 2048) + 1024) * d->cout * sizeof(float) + 256;
+    size_t s = (size_t)mfma_wgrad_splits(d, M) * ((size_t)d->kh * d->kw * d->cin + 1) * d->cout * sizeof(float) + (size_t)(cdiv(M, 2048) + 1024) * d->cout * sizeof(float) + 256;
     if (s > ws) ws = s;
   }
   // upsample-folded data gradient: full-resolution dx scratch
@@ -358,14 +362,19 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
     int nz = mfma_wgrad_splits(d, a.M);
     long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-    size_t need = (size_t)nz * cnt * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);
+    a.slab_stride = cnt + d->cout;
+    a.want_bias = dbias ? 1 : 0;
+    size_t need = (size_t)nz * a.slab_stride * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
-    int nzz = mfma_wgrad_launch(ctx, a, nz);
+    bool bias_done = false;
+    int nzz = mfma_wgrad_launch(ctx, a, nz, &bias_done);
     if (nzz < 0) return nzz;
-    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)a.slab, dw, cnt, nzz, accumulate);
+    const int nb = bias_done ? d->cout : 0;
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(cnt + nb, 256)), dim3(256), 0, ctx->stream, (const float*)a.slab, a.slab_stride, dw, cnt,
+                       dbias, nb, nzz, accumulate);
     RC_LAUNCH_CHECK(ctx);
-    if (dbias) {
-      float* part = (float*)((char*)ws + (size_t)nz * cnt * sizeof(float));
+    if (dbias && !bias_done) {
+      float* part = (float*)((char*)ws + (size_t)nz * a.slab_stride * sizeof(float));
       rc = colsum_launch<bf16_t>(ctx, (const bf16_t*)dy, a.M, d->cout, dbias, accumulate, part);
       if (rc) return rc;
     }

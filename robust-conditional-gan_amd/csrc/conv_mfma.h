@@ -18,7 +18,9 @@ struct MfmaConvArgs {
 struct MfmaWgradArgs {
   const bf16_t* x;        // [N][H(/2)][W(/2)][Cin]
   const bf16_t* dy;       // [M][Cout]
-  float* slab;            // [nz][T*Cin*Cout]
+  float* slab;            // [nz][slab_stride]: T*Cin*Cout filter-gradient partials (+ Cout bias-gradient partials)
+  long slab_stride;       // floats between the slabs of two pixel chunks
+  int want_bias;          // also emit column sums of dy (bias gradient) at slab[T*Cin*Cout ..]
   const bf16_t* zero;     // >= 16 zero bytes (halo / tail source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, use_tr;
@@ -36,7 +38,7 @@ bool mfma_eligible(const rcgan_conv_desc* d);
 bool mfma_wgrad_eligible(const rcgan_conv_desc* d);
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
-int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz);
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);
 int mfma_selftest(rcgan_ctx* ctx, int* host_result);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgradArgs a) {
     __syncthreads();
   }
   // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
-  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+  float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -612,6 +612,11 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  const bool do_bias = a.want_bias && tap == 0 && cit == 0 && wi == 0;     // see conv_mfma_wgrad3_kernel
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  f32x4_t accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int KT = (int)((me - mb + 31) / 32);
   constexpr int INFLIGHT = (NS - 2) * 4;
 #pragma unroll
@@ -633,6 +638,10 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
     for (int i = 0; i < 4; ++i) yf[i] = frag_tr_swz(Yb, 0, wo * 8 + i * 2, lane, a.use_tr, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) xf[j] = frag_tr_swz(Xb, 0, wi * 8 + j * 2, lane, a.use_tr, a.relu_in);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
     if (++buf == NS) buf = 0;
   }
-  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+  float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -650,6 +659,12 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
       float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       *(float4*)(slab + ((long)tap * a.Cin + ci) * a.Cout + co) = v;
     }
+  if (do_bias && (lane & 15) == 0) {
+    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(float4*)(bs + co0 + wo * 64 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,6 +785,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
     maskl[d] = ml; maskr[d] = mr;
   }
 
+  // bias gradient = column sums of dy: one extra MFMA per dy fragment against an all-ones operand, only in the
+  // workgroups of (kh = 0, first input-channel tile) and only in their wi = 0 wavefronts
+  const bool do_bias = a.want_bias && kh == 0 && cit == 0 && wi == 0;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  f32x4_t accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   f32x4_t acc[3][4][2];   // [kw][co subtile][ci subtile]
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -799,6 +821,10 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
         bf16x8_t yf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
+        if (do_bias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           bf16x8_t xf[2];
@@ -820,7 +846,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
     }
   }
   // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
-  float* slab = a.slab + (long)blockIdx.y * ((long)a.KH * a.KW * a.Cin * a.Cout);
+  float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -832,6 +858,12 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
         float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
         *(float4*)(slab + ((long)(kh * 3 + t) * a.Cin + ci) * a.Cout + co) = v;
       }
+  if (do_bias && (lane & 15) == 0) {
+    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(float4*)(bs + co0 + wo * 64 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1034,7 +1066,8 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
   return RCGAN_OK;
 }
 
-int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done) {
+  *bias_done = false;
   if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1) {
     long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
     int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
@@ -1043,6 +1076,7 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
     int nzz = cdiv(a.M, a.m_chunk);
     dim3 grid((unsigned)tiles3, nzz);
     int rc = a.relu_in ? launch_wgrad3<true>(ctx, a, grid) : launch_wgrad3<false>(ctx, a, grid);
+    *bias_done = a.want_bias != 0;
     return rc ? -1 : nzz;
   }
   static bool attr_set = false;
@@ -1066,6 +1100,7 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz) {
     }
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_wgrad_glds_kernel<NS>, grid, dim3(256), lds2, ctx->stream, a);
+    *bias_done = a.want_bias != 0;
   } else {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
