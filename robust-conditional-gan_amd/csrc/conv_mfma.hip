@@ -694,6 +694,66 @@ __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p, int hi_off) 
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// bias gradient = column sums of dy.  Extra workgroups (blockIdx.x >= number of filter tiles) stream ONLY the dy
+// rows of their pixel chunk and multiply each transposed fragment with an all-ones operand on the matrix core.
+// Kept as a separate code path so that its accumulators share registers with the filter path (occupancy).
+template <int NS>
+__device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigned char* smem, int cot, long mb, long me, float* slab) {
+  constexpr int YT = 32 * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int co0 = cot * 128;
+  const int y_row0 = (wave * 2) * 4 + (lane >> 4), y_row1 = y_row0 + 4;
+  const int y_c0 = co0 + ((lane & 15) ^ ((y_row0 & 7) << 1)) * 8;
+  const int y_c1 = co0 + ((lane & 15) ^ ((y_row1 & 7) << 1)) * 8;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  long i_p0 = mb;
+  auto issue = [&](int buf) {
+    const unsigned stage = lds0 + buf * YT;
+    const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
+    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)((unsigned)m0 * a.Cout + y_c0) : a.zero;
+    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)((unsigned)m1 * a.Cout + y_c1) : a.zero;
+    glds16_asm(py0, stage + (wave * 2) * 1024);
+    glds16_asm(py1, stage + (wave * 2 + 1) * 1024);
+    i_p0 += 32;
+  };
+  int offy[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = g * 4 + (li >> 2);
+    const int slot0 = wave * 4 + i * 2;
+    offy[i] = row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
+  }
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  f32x4_t accb[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+  const int KT = (int)((me - mb + 31) / 32);
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < KT) issue(t);
+  for (int kt0 = 0; kt0 < KT; kt0 += NS) {
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const int kt = kt0 + sidx;
+      if (kt < KT) {
+        if (kt + NS - 2 < KT) wait_vmcnt_any<(NS - 2) * 2>(); else wait_vmcnt_any<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NS - 1 < KT) issue((sidx + NS - 1) % NS);
+        const unsigned char* sb = smem + sidx * YT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(sb + offy[i], 16 * 256), ones, accb[i], 0, 0, 0);
+      }
+    }
+  }
+  if ((lane & 15) == 0) {
+    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *(float4*)(bs + co0 + wave * 32 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+  }
+}
+
 template <int NS, bool RELU>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -702,14 +762,18 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wo = wave >> 1;
   const int nci = a.Cin / 64, nco = a.Cout / 128;
+  const long mb = (long)blockIdx.y * a.m_chunk;
+  long me = mb + a.m_chunk;
+  if (me > a.M) me = a.M;
+  if ((int)blockIdx.x >= a.KH * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
+    wgrad_bias_block<NS>(a, smem, (int)blockIdx.x - a.KH * nci * nco, mb, me, a.slab + (long)blockIdx.y * a.slab_stride);
+    return;
+  }
   int b = blockIdx.x;
   const int cot = b % nco; b /= nco;
   const int cit = b % nci; b /= nci;
   const int kh = b;
   const int ci0 = cit * 64, co0 = cot * 128;
-  const long mb = (long)blockIdx.y * a.m_chunk;
-  long me = mb + a.m_chunk;
-  if (me > a.M) me = a.M;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int dh = kh - a.PT;
   const int g = lane >> 4, li = lane & 15;
@@ -785,13 +849,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
     maskl[d] = ml; maskr[d] = mr;
   }
 
-  // bias gradient = column sums of dy: one extra MFMA per dy fragment against an all-ones operand, only in the
-  // workgroups of (kh = 0, first input-channel tile) and only in their wi = 0 wavefronts
-  const bool do_bias = a.want_bias && kh == 0 && cit == 0 && wi == 0;
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
-  f32x4_t accb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   f32x4_t acc[3][4][2];   // [kw][co subtile][ci subtile]
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -821,10 +878,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
         bf16x8_t yf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
-        if (do_bias) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
-        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           bf16x8_t xf[2];
@@ -858,12 +911,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
         float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
         *(float4*)(slab + ((long)(kh * 3 + t) * a.Cin + ci) * a.Cout + co) = v;
       }
-  if (do_bias && (lane & 15) == 0) {
-    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *(float4*)(bs + co0 + wo * 64 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1074,7 +1121,7 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
     if (want > nz) want = nz;
     a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
     int nzz = cdiv(a.M, a.m_chunk);
-    dim3 grid((unsigned)tiles3, nzz);
+    dim3 grid((unsigned)(tiles3 + (a.want_bias ? a.Cout / 128 : 0)), nzz);
     int rc = a.relu_in ? launch_wgrad3<true>(ctx, a, grid) : launch_wgrad3<false>(ctx, a, grid);
     *bias_done = a.want_bias != 0;
     return rc ? -1 : nzz;
