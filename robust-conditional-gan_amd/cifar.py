@@ -314,7 +314,9 @@ class CifarRCGAN:
         for grp in which:
             for n in grp.names:
                 if n.endswith("/Filters"):
-                    names.append((n, grp.shapes[n][0], 1))
+                    shp = grp.shapes[n]
+                    # the 3-channel image-end convs (D.Block.1.*, G.Output) run at the image resolution
+                    names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8))
         self.graph.prepare_convs(names, self.ctx.act_dtype)
 
     def confusion_matrix(self):

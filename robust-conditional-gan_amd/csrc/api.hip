@@ -219,6 +219,7 @@ static int check_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d) {
 size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d) {
   size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
   if (mfma_eligible(d)) return 2 * elems * sizeof(bf16_t) + 256;
+  if (img_side(d)) return img_extra_offset(d) + img_extra_bytes(d);
   return elems * sizeof(float) + 256;
 }
 
@@ -231,7 +232,9 @@ int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w,
     bf16_t* wt = (bf16_t*)prepared;
     return mfma_prepare_launch(ctx, w, sigma, wt, wt + elems, T, d->cin, d->cout);
   }
-  return direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
+  rc = direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
+  if (rc) return rc;
+  return img_prepare_launch(ctx, d, w, sigma, prepared);
 }
 
 int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items) {
@@ -251,6 +254,10 @@ size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {
   size_t ws = direct_wgrad_ws_bytes(d);
   if (small_wgrad_kind(d)) {
     size_t s = small_wgrad_ws_bytes(d);
+    if (s > ws) ws = s;
+  }
+  if (img_side(d)) {
+    size_t s = img_wgrad_ws_bytes(d);
     if (s > ws) ws = s;
   }
   if (mfma_wgrad_eligible(d)) {
@@ -291,6 +298,7 @@ int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, co
     a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
     return mfma_conv_launch(ctx, a);
   }
+  if (img_side(d)) return img_fwd(ctx, d, x, prepared, bias, y);
   if (int kind = small_fwd_kind(d)) {
     RC_DISPATCH_DTYPE(ctx, d->dtype, return small_fwd<T>(ctx, d, kind, (const T*)x, (const float*)prepared, bias, (T*)y));
   }
@@ -325,6 +333,9 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
     a.PT = d->kh - 1 - a.PT; a.PL = d->kw - 1 - a.PL;
     a.up = 0; a.relu_in = 0; a.accumulate = acc_now;
     rc = mfma_conv_launch(ctx, a);
+    if (rc) return rc;
+  } else if (mask == nullptr && !up && img_side(d)) {
+    rc = img_dgrad(ctx, d, dy, prepared, target, acc_now);
     if (rc) return rc;
   } else if (int kind = (mask == nullptr && !up) ? small_dgrad_kind(d) : 0) {
     RC_DISPATCH_DTYPE(ctx, d->dtype, rc = small_dgrad<T>(ctx, d, kind, (const T*)dy, (const float*)prepared, (T*)target, acc_now));
@@ -380,6 +391,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     }
     return RCGAN_OK;
   }
+  if (img_side(d)) return img_wgrad(ctx, d, x, dy, dw, dbias, accumulate, ws, ws_bytes);
   if (int kind = small_wgrad_kind(d)) {
     RC_DISPATCH_DTYPE(ctx, d->dtype, return small_wgrad<T>(ctx, d, kind, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
   }

@@ -3,13 +3,13 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../librcgan_hip.so
-SRCS="api.hip conv_direct.hip conv_small.hip conv_mfma.hip elementwise.hip bn.hip sn.hip loss.hip"
+SRCS="api.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 mkdir -p _obj
 pids=()
 for s in $SRCS; do
   o=_obj/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_mfma.h -nt "$o" ] || [ ../../include/rcgan_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_mfma.h -nt "$o" ] || [ mfma_util.h -nt "$o" ] || [ ../../include/rcgan_hip.h -nt "$o" ]; then
     $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
     pids+=($!)
   fi

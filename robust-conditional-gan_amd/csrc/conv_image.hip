@@ -1,0 +1,536 @@
+// Image-end convolutions on the matrix cores (bf16): the layers with a 3-channel side -- D.Block.1.Conv1 /
+// Shortcut (3 -> 128) and G.Output (256 -> 3) of the CIFAR nets (cifar10/gan_resnet.py:337-352, :368) -- and
+// their gradients.  None of them has enough arithmetic to matter (K = 27 or N = 3); all are bound by streaming
+// the big-channel tensor once, so every kernel here reads/writes that tensor exactly once, coalesced, and pads
+// the small side to one MFMA tile (K = 32 or N = 16):
+//   small-reduction  out[m][n<Cb]  = sum_{k<32} col[m][k] * wK[n][k]          (forward of 3->Cb, dX of Cb->3)
+//   small-output     out[m][n<Cs]  = sum_{t,c<Cb} in[pix(m,t)][c] * wS[t][n][c] (forward of Cb->3, dX of 3->Cb)
+//   small-side wgrad dW[k<32][n<Cb] = sum_m col[m][k] * big[m][n]             (+ bias gradients)
+// col[m][k = t*Cs + c] is the im2col row of the <=3-channel tensor (zero outside the image), gathered with
+// scalar loads -- that tensor is ~1 MB and lives in L2.
+// The fp32 path and the shapes these kernels do not take (non power-of-two images, Cs = 4) stay on conv_small.hip.
+#include "conv_mfma.h"
+#include "mfma_util.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// eligibility + prepared-filter layouts
+// ---------------------------------------------------------------------------------------------------------
+int img_side(const rcgan_conv_desc* d) {
+  if (d->dtype != RCGAN_BF16 || d->stride != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3)) return 0;
+  if (d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_FORCE_DIRECT)) return 0;
+  const int lw = ilog2_exact(d->w), lh = ilog2_exact(d->h);
+  if (lw < 3 || lw > 5 || lh < 0 || d->h * d->w < 256) return 0;      // W in {8,16,32}; whole 256-pixel bands
+  const int T = d->kh * d->kw;
+  if (d->cin <= 3 && T * d->cin <= 31 && (d->cout == 128 || d->cout == 256) && !(d->flags & RCGAN_CONV_IN_RELU)) return 1;
+  if (d->cout <= 3 && T * d->cout <= 31 && (d->cin == 128 || d->cin == 256)) return 2;
+  return 0;
+}
+
+size_t img_extra_offset(const rcgan_conv_desc* d) {
+  size_t b = (size_t)d->kh * d->kw * d->cin * d->cout * sizeof(float);
+  return (b + 255) / 256 * 256;
+}
+
+size_t img_extra_bytes(const rcgan_conv_desc* d) {
+  const int cb = d->cin <= 3 ? d->cout : d->cin;
+  return ((size_t)cb * 32 + (size_t)d->kh * d->kw * 16 * cb) * sizeof(bf16_t) + 256;
+}
+
+__global__ void img_prepare_kernel(int side, int T, int Cin, int Cout, const float* w, const float* sigma, bf16_t* extra) {
+  const int Cb = side == 1 ? Cout : Cin;
+  const long total = (long)Cb * 32 + (long)T * 16 * Cb;
+  const float inv = sigma ? 1.f / *sigma : 1.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    extra[e] = img_prepare_elem(e, side, T, Cin, Cout, w, inv);
+}
+
+int img_prepare_launch(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w, const float* sigma, void* prepared) {
+  const int side = img_side(d);
+  if (!side) return RCGAN_OK;
+  const int T = d->kh * d->kw, cb = side == 1 ? d->cout : d->cin;
+  const long total = (long)cb * 32 + (long)T * 16 * cb;
+  hipLaunchKernelGGL(img_prepare_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, side, T, d->cin, d->cout, w, sigma,
+                     (bf16_t*)((char*)prepared + img_extra_offset(d)));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// im2col geometry of the small tensor
+// ---------------------------------------------------------------------------------------------------------
+struct ColGeom {
+  const bf16_t* s;       // [N][H][W][Cs]
+  int H, W, lw, lh, Cs, TT, PT, PL, sign;   // sign +1: (oh + kh - PT, ow + kw - PL);  -1: (oh - kh + PT, ow - kw + PL)
+  long M;
+};
+
+// (row offset, column offset, channel) of im2col column k; dh = 1 << 20 marks a padding column (k >= TT*Cs)
+__device__ __forceinline__ void col_tap(const ColGeom& g, int k, int& dh, int& dw, int& c) {
+  if (k >= g.TT * g.Cs) { dh = 1 << 20; dw = 0; c = 0; return; }
+  const int t = k / g.Cs;
+  c = k - t * g.Cs;
+  const int kh = g.TT == 9 ? t / 3 : 0, kw = g.TT == 9 ? t - 3 * (t / 3) : 0;
+  dh = g.sign > 0 ? kh - g.PT : g.PT - kh;
+  dw = g.sign > 0 ? kw - g.PL : g.PL - kw;
+}
+
+__device__ __forceinline__ uint32_t col_load(const ColGeom& g, long m, int dh, int dw, int c) {
+  if (m >= g.M) return 0u;
+  const unsigned mm = (unsigned)m;
+  const int ow = (int)(mm & (unsigned)(g.W - 1)) + dw;
+  const int oh = (int)((mm >> g.lw) & (unsigned)(g.H - 1)) + dh;
+  if (oh < 0 || oh >= g.H || ow < 0 || ow >= g.W) return 0u;
+  const unsigned n = mm >> (g.lw + g.lh);
+  return (uint32_t)g.s[(((n << g.lh) + oh) << g.lw | (unsigned)ow) * (unsigned)g.Cs + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small reduction: out[m][n] = sum_k col[m][k] * wK[n][k].  One wavefront per 16-pixel tile; the filter
+// fragments (Cb/16 x 4 registers) stay in registers.  Filter rows are permuted so that a lane ends up with
+// 8 consecutive channels of its pixel in two accumulators: one 16-byte store.
+// ---------------------------------------------------------------------------------------------------------
+struct ImgKArgs {
+  ColGeom g;
+  const bf16_t* wK;      // [Cb][32]
+  const float* bias;     // [Cb] or null
+  bf16_t* out;           // [M][Cb]
+  int Cb, accumulate;
+};
+
+template <int NF>      // Cb / 16
+__global__ __launch_bounds__(256) void conv_img_small_red_kernel(ImgKArgs a) {
+  const int lane = threadIdx.x & 63, g4 = lane >> 4, px = lane & 15;
+  // A operand (filter): fragment i, MFMA row j = lane&15, k = 8*g4..+7.  Row j of fragment pair (2q, 2q+1) maps to
+  // channel q*32 + (j>>2)*8 + (i&1)*4 + (j&3): D rows 4*g4..+3 of the pair are channels q*32 + g4*8 + 0..7.
+  bf16x8_t wf[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int ch = (i >> 1) * 32 + (px >> 2) * 8 + (i & 1) * 4 + (px & 3);
+    wf[i] = *(const bf16x8_t*)(a.wK + ch * 32 + g4 * 8);
+  }
+  int dh[8], dw[8], cc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) col_tap(a.g, g4 * 8 + e, dh[e], dw[e], cc[e]);
+  float bv[NF / 2][8];
+#pragma unroll
+  for (int q = 0; q < NF / 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[q][j] = a.bias ? a.bias[q * 32 + g4 * 8 + j] : 0.f;
+
+  const long ntile = (a.g.M + 15) >> 4;
+  const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long)gridDim.x * 4;
+  for (long tile = wave0; tile < ntile; tile += nwave) {
+    const long m = tile * 16 + px;
+    uint32_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col_load(a.g, m, dh[e], dw[e], cc[e]);
+    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)));
+    {   // M is a multiple of 256 on this path (whole 16-pixel tiles): the MFMAs always run with every lane active
+      bf16_t* orow = a.out + m * a.Cb + g4 * 8;
+#pragma unroll
+      for (int q = 0; q < NF / 2; ++q) {
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * q], xf, z, 0, 0, 0);
+        const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * q + 1], xf, z, 0, 0, 0);
+        float o[8] = {lo[0] + bv[q][0], lo[1] + bv[q][1], lo[2] + bv[q][2], lo[3] + bv[q][3],
+                      hi[0] + bv[q][4], hi[1] + bv[q][5], hi[2] + bv[q][6], hi[3] + bv[q][7]};
+        uint4* dst = (uint4*)(orow + q * 32);
+        if (a.accumulate) {
+          const uint4 p = *dst;
+          const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[2 * j] += bf16_to_f32((bf16_t)(w[j] & 0xffff)); o[2 * j + 1] += bf16_to_f32((bf16_t)(w[j] >> 16)); }
+        }
+        uint4 pk;
+        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        pk.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
+        pk.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+        *dst = pk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small output: out[m][n<Cs] = sum_{t, c<Cb} in[pix(m,t)][c] * wS[t][n][c].
+// One workgroup = a band of 256 pixels (256/W image rows) of one image.  Per 64-channel chunk the band WITH its
+// halo (zero page outside the image) and the chunk's filter rows are deposited in LDS by LDS-DMA (double
+// buffered); the 9 taps are row offsets of the fragment reads, so the big tensor is fetched once instead of once
+// per tap.  16-B slot s of LDS row r holds channel chunk s ^ (r & 7) (source-side swizzle).
+// ---------------------------------------------------------------------------------------------------------
+struct ImgSArgs {
+  const bf16_t* in;      // [N][H][W][Cb]
+  const bf16_t* wS;      // [TT][16][Cb]
+  const float* bias;     // [Cs] or null
+  bf16_t* out;           // [N][H][W][Cs]
+  const bf16_t* zero;
+  int N, H, W, lw, lh, Cb, Cs, relu_in, accumulate;
+};
+
+template <int TT>
+__global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HALO = TT == 9 ? 1 : 0;
+  constexpr int XROWS = TT == 9 ? 352 : 256;      // LDS pixel rows per stage (>= (R+2)*(W+2)), 128 B each
+  constexpr int NXI = XROWS / 32;                 // pixel deposits per wavefront (8 rows each)
+  constexpr int NWI = TT == 9 ? 5 : 1;            // filter deposits per wavefront
+  constexpr int STAGE = (XROWS + NWI * 32) * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R = 256 >> a.lw, bands = a.H / R;
+  const int b = blockIdx.x / bands, r0 = (blockIdx.x - b * bands) * R;
+  const int cols = a.W + 2 * HALO, npt = (R + 2 * HALO) * cols;
+
+  int xoff[NXI], woff[NWI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int tr = (i * 4 + wave) * 8 + (lane >> 3);
+    xoff[i] = -1;
+    if (tr < npt) {
+      const int ty = tr / cols, tx = tr - ty * cols;
+      const int ih = r0 + ty - HALO, iw = tx - HALO;
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        xoff[i] = ((b * a.H + ih) * a.W + iw) * a.Cb + (((lane & 7) ^ (tr & 7)) << 3);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int wr = (i * 4 + wave) * 8 + (lane >> 3);
+    woff[i] = wr < TT * 16 ? wr * a.Cb + (((lane & 7) ^ (wr & 7)) << 3) : -1;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto issue = [&](int c0, int buf) {
+    const unsigned stage = lds0 + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) glds16_asm(xoff[i] >= 0 ? a.in + xoff[i] + c0 : a.zero, stage + (i * 4 + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) glds16_asm(woff[i] >= 0 ? a.wS + woff[i] + c0 : a.zero, stage + XROWS * 128 + (i * 4 + wave) * 1024);
+  };
+
+  // fragment geometry: pixel fragment f of this wavefront = band pixels wave*64 + f*16 + (lane&15)
+  const int px = lane & 15, g4 = lane >> 4;
+  int tr0[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int p = wave * 64 + f * 16 + px;
+    tr0[f] = ((p >> a.lw) + HALO) * cols + (p & (a.W - 1)) + HALO;
+  }
+  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = a.Cb / 64;
+  issue(0, 0);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ch + 1 < nch) issue((ch + 1) * 64, buf ^ 1);
+    const unsigned char* xs = smem + buf * STAGE;
+    const unsigned char* ws = xs + XROWS * 128;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const int dtr = TT == 9 ? (t / 3 - 1) * cols + (t % 3 - 1) : 0;
+      const int wr = t * 16 + px;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = ks * 4 + g4;
+        const bf16x8_t wf = *(const bf16x8_t*)(ws + wr * 128 + ((kc ^ (wr & 7)) << 4));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int tr = tr0[f] + dtr;
+          uint4 v = *(const uint4*)(xs + tr * 128 + ((kc ^ (tr & 7)) << 4));
+          v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, v), acc[f], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[row = n][col = pixel]: lanes 0..15 hold n = 0..3 of their pixel
+  if (g4 == 0) {
+    const long mbase = ((long)b * a.H + r0) * a.W + wave * 64;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bf16_t* o = a.out + (mbase + f * 16 + px) * a.Cs;
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        if (n < a.Cs) {
+          float v = acc[f][n] + (a.bias ? a.bias[n] : 0.f);
+          if (a.accumulate) v += bf16_to_f32(o[n]);
+          o[n] = f32_to_bf16(v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small-side filter gradient: slab[blk][k<32][n<Cb] = sum over the block's pixels of col[m][k] * big[m][n].
+// A workgroup takes PB = 32768/Cb pixels: the big rows arrive by LDS-DMA ([pixel][128 channels] per half, read back
+// transposed), the im2col columns are gathered to LDS as [k][pixel].  Column 31 can be forced to ones: row 31 of
+// the result is then the column sum of the big tensor (bias gradient when the big tensor is dy); an extra MFMA
+// against an all-ones A operand gives the column sums of col (bias gradient when the small tensor is dy).
+// ---------------------------------------------------------------------------------------------------------
+struct ImgWArgs {
+  ColGeom g;
+  const bf16_t* big;     // [M][Cb]
+  const bf16_t* zero;
+  float* slab;           // [nblk][32*Cb + 32]
+  int ones_col, relu_big;
+};
+
+template <int CB>
+__global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PB = 32768 / CB;                  // pixels per workgroup: 256 (Cb = 128) or 128 (Cb = 256)
+  constexpr int NH = CB / 128;                    // 128-channel halves
+  constexpr int CPITCH = PB * 2 + 16;             // bytes per im2col row (+16: the 16 rows of a fragment read hit 16 bank groups)
+  constexpr int NFW = CB / 64;                    // 16-channel fragments per wavefront
+  unsigned char* bigs = smem;                     // [NH][PB][256 B]
+  unsigned char* cols = smem + NH * PB * 256;     // [32][CPITCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long m0 = (long)blockIdx.x * PB;
+
+  // big rows: deposits of 4 rows x 256 B; NH*PB/4 deposits, split over the 4 wavefronts
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  constexpr int NDEP = NH * PB / 16;              // per wavefront
+#pragma unroll 4
+  for (int i = 0; i < NDEP; ++i) {
+    const int dep = i * 4 + wave;                 // 0 .. NH*PB/4
+    const int half = dep / (PB / 4), row = (dep - half * (PB / 4)) * 4 + (lane >> 4);
+    const long m = m0 + row;
+    const int slot = (lane & 15) ^ ((row & 7) << 1);
+    const bf16_t* p = m < a.g.M ? a.big + (unsigned)((unsigned)m * CB + half * 128 + slot * 8) : a.zero;
+    glds16_asm(p, lds0 + dep * 1024);
+  }
+  // im2col columns: thread -> column k = tid/8, pixels (tid%8)*(PB/8) .. +PB/8
+  {
+    const int k = tid >> 3, pg = tid & 7;
+    int dh, dw, c;
+    col_tap(a.g, k, dh, dw, c);
+    const bool ones = a.ones_col && k == 31;
+#pragma unroll
+    for (int j = 0; j < PB / 64; ++j) {
+      uint32_t v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const long m = m0 + pg * (PB / 8) + j * 8 + e;
+        v[e] = ones ? (m < a.g.M ? 0x3F80u : 0u) : col_load(a.g, m, dh, dw, c);
+      }
+      *(uint4*)(cols + k * CPITCH + (pg * (PB / 8) + j * 8) * 2) =
+          make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // wavefront w: channels w*(CB/4) .. +CB/4 (inside one half); both 16-column groups of the 32 im2col columns
+  const int g4 = lane >> 4, li = lane & 15;
+  const int chw = wave * (CB / 4);
+  const unsigned char* bh = bigs + (chw / 128) * PB * 256;
+  const int slotw = (chw % 128) / 8;
+  const uint32_t relu_lb = a.relu_big ? 0u : 0x80008000u;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  f32x4_t acc[NFW][2], accs[2];
+#pragma unroll
+  for (int i = 0; i < NFW; ++i) { acc[i][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+  accs[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; accs[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < PB / 32; ++ks) {
+    bf16x8_t cf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // the transposing read hands lane group g4 the pixels {4*g4..+3} U {16+4*g4..+3} of the 32-pixel step: same order here
+      const unsigned char* cp = cols + (j * 16 + li) * CPITCH + (ks * 32 + g4 * 4) * 2;
+      const uint2 lo = *(const uint2*)cp, hi = *(const uint2*)(cp + 32);
+      cf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
+    if (wave == 0) {
+      accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, cf[0], accs[0], 0, 0, 0);
+      accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, cf[1], accs[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+      const int row = ks * 32 + g4 * 4 + (li >> 2);
+      const int slot0 = slotw + i * 2;
+      const unsigned char* p = bh + row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
+      uint4 v = __builtin_bit_cast(uint4, tr_pair(p, 16 * 256));
+      v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, v);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, cf[0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, cf[1], acc[i][1], 0, 0, 0);
+    }
+  }
+  // D[row = channel (4*g4 + r)][col = im2col column li (+16 j)]
+  float* slab = a.slab + (long)blockIdx.x * (32 * CB + 32);
+#pragma unroll
+  for (int i = 0; i < NFW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *(float4*)(slab + (j * 16 + li) * CB + chw + i * 16 + g4 * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  if (wave == 0 && g4 == 0) { slab[32 * CB + li] = accs[0][0]; slab[32 * CB + 16 + li] = accs[1][0]; }
+}
+
+// dW (HWIO) and the bias gradient from the workgroup slabs.  thread block = 16 outputs x 16 slab lanes.
+//   orient 0 (small = conv input):   dW[k*Cb + n],  k = t*Cs + c;  dbias[n<Cb] = row 31 (ones column)
+//   orient 1 (small = dy):           dW[(t*Cb + n)*Cs + c];        dbias[c<Cs] = column sums of the centre tap
+__global__ __launch_bounds__(256) void conv_img_wgrad_reduce_kernel(const float* slab, int nblk, int Cb, int Cs, int TT, int orient,
+                                                                    float* dw, float* dbias, int accumulate) {
+  __shared__ float red[16][17];
+  const int per = 32 * Cb + 32;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), bl = threadIdx.x >> 4;
+  float s = 0.f;
+  if (i < per)
+    for (int b = bl; b < nblk; b += 16) s += slab[(long)b * per + i];
+  red[bl][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (bl != 0 || i >= per) return;
+  s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+  const int K = TT * Cs;
+  float* o = nullptr;
+  if (i < 32 * Cb) {
+    const int k = i / Cb, n = i - k * Cb;
+    if (k < K) {
+      const int t = k / Cs, c = k - t * Cs;
+      o = orient == 0 ? dw + (long)k * Cb + n : dw + ((long)t * Cb + n) * Cs + c;
+    } else if (orient == 0 && k == 31 && dbias) {
+      o = dbias + n;
+    }
+  } else if (orient == 1 && dbias) {
+    const int k = i - 32 * Cb, ctr = TT == 9 ? 4 : 0;
+    if (k >= ctr * Cs && k < ctr * Cs + Cs) o = dbias + (k - ctr * Cs);
+  }
+  if (!o) return;
+  if (accumulate) s += *o;
+  *o = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static ColGeom col_geom(const rcgan_conv_desc* d, const bf16_t* s, int Cs, int sign, int pt, int pl) {
+  ColGeom g;
+  g.s = s; g.H = d->h; g.W = d->w; g.lw = ilog2_exact(d->w); g.lh = ilog2_exact(d->h); g.Cs = Cs; g.TT = d->kh * d->kw;
+  g.PT = pt; g.PL = pl; g.sign = sign; g.M = (long)d->n * d->h * d->w;
+  return g;
+}
+
+static const bf16_t* img_wk(const rcgan_conv_desc* d, const void* prepared) { return (const bf16_t*)((const char*)prepared + img_extra_offset(d)); }
+static const bf16_t* img_ws(const rcgan_conv_desc* d, const void* prepared) {
+  return img_wk(d, prepared) + (size_t)(d->cin <= 3 ? d->cout : d->cin) * 32;
+}
+
+static int launch_small_red(rcgan_ctx* ctx, ImgKArgs& a) {
+  long tiles = (a.g.M + 15) / 16;
+  long blocks = (tiles + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  if (a.Cb == 128) hipLaunchKernelGGL(conv_img_small_red_kernel<8>, dim3((int)blocks), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(conv_img_small_red_kernel<16>, dim3((int)blocks), dim3(256), 0, ctx->stream, a);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+static int launch_small_out(rcgan_ctx* ctx, const rcgan_conv_desc* d, ImgSArgs& a) {
+  a.N = d->n; a.H = d->h; a.W = d->w; a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
+  a.zero = (const bf16_t*)ctx->zero_page;
+  const int R = 256 / d->w;
+  dim3 grid(d->n * (d->h / R));
+  if (d->kh == 3) {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * (352 + 160) * 128;
+    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(conv_img_small_out_kernel<9>, grid, dim3(256), lds, ctx->stream, a);
+  } else {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * (256 + 32) * 128;
+    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(conv_img_small_out_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
+  int pt, pl, oh, ow;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  if (img_side(d) == 1) {
+    ImgKArgs a;
+    a.g = col_geom(d, (const bf16_t*)x, d->cin, +1, pt, pl);
+    a.wK = img_wk(d, prepared); a.bias = bias; a.out = (bf16_t*)y; a.Cb = d->cout; a.accumulate = acc;
+    return launch_small_red(ctx, a);
+  }
+  ImgSArgs a;
+  a.in = (const bf16_t*)x; a.wS = img_ws(d, prepared); a.bias = bias; a.out = (bf16_t*)y;
+  a.Cb = d->cin; a.Cs = d->cout; a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0; a.accumulate = acc;
+  return launch_small_out(ctx, d, a);
+}
+
+// dX = conv of dY with the rotated filter (gather offsets PT' = k-1-PT); no input-ReLU mask here (the caller keeps
+// masked data gradients on the generic path)
+int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, void* dx, int accumulate) {
+  int pt, pl, oh, ow;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  pt = d->kh - 1 - pt; pl = d->kw - 1 - pl;
+  if (img_side(d) == 2) {            // dX[m][Cin big] from dY[m][Cout small]
+    ImgKArgs a;
+    a.g = col_geom(d, (const bf16_t*)dy, d->cout, +1, pt, pl);
+    a.wK = img_wk(d, prepared); a.bias = nullptr; a.out = (bf16_t*)dx; a.Cb = d->cin; a.accumulate = accumulate;
+    return launch_small_red(ctx, a);
+  }
+  if (pt != (d->kh == 3 ? 1 : 0) || pl != pt) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "asymmetric padding");
+  ImgSArgs a;                        // dX[m][Cin small] from dY[m][Cout big]
+  a.in = (const bf16_t*)dy; a.wS = img_ws(d, prepared); a.bias = nullptr; a.out = (bf16_t*)dx;
+  a.Cb = d->cout; a.Cs = d->cin; a.relu_in = 0; a.accumulate = accumulate;
+  return launch_small_out(ctx, d, a);
+}
+
+size_t img_wgrad_ws_bytes(const rcgan_conv_desc* d) {
+  const int cb = d->cin <= 3 ? d->cout : d->cin;
+  const long M = (long)d->n * d->h * d->w, pb = 32768 / cb;
+  return (size_t)((M + pb - 1) / pb) * (32 * (size_t)cb + 32) * sizeof(float) + 256;
+}
+
+int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+              void* ws, size_t ws_bytes) {
+  int pt, pl, oh, ow;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  const size_t need = img_wgrad_ws_bytes(d);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  const int side = img_side(d);
+  const int cb = side == 1 ? d->cout : d->cin, cs = side == 1 ? d->cin : d->cout;
+  ImgWArgs a;
+  // side 1: col = im2col(x) (+), big = dy;  side 2: col = dy gathered at (oh - kh + PT), big = x
+  a.g = side == 1 ? col_geom(d, (const bf16_t*)x, cs, +1, pt, pl) : col_geom(d, (const bf16_t*)dy, cs, -1, pt, pl);
+  a.big = side == 1 ? (const bf16_t*)dy : (const bf16_t*)x;
+  a.zero = (const bf16_t*)ctx->zero_page;
+  a.slab = (float*)ws;
+  a.ones_col = side == 1 ? 1 : 0;
+  a.relu_big = (side == 2 && (d->flags & RCGAN_CONV_IN_RELU)) ? 1 : 0;
+  const long pb = 32768 / cb;
+  const int nblk = (int)((a.g.M + pb - 1) / pb);
+  const size_t lds = (size_t)65536 + 32 * (pb * 2 + 16);
+  if (cb == 128) {
+    static bool attr = false;
+    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(conv_img_wgrad_kernel<128>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+  } else {
+    static bool attr = false;
+    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_wgrad_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(conv_img_wgrad_kernel<256>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  const int per = 32 * cb + 32;
+  hipLaunchKernelGGL(conv_img_wgrad_reduce_kernel, dim3(cdiv(per, 16)), dim3(256), 0, ctx->stream, (const float*)a.slab, nblk, cb, cs,
+                     d->kh * d->kw, side == 1 ? 0 : 1, dw, dbias, accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}

@@ -42,4 +42,14 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);
 int mfma_selftest(rcgan_ctx* ctx, int* host_result);
+// image-end kernels (conv_image.hip): bf16 convs with a <= 3-channel side
+int img_side(const rcgan_conv_desc* d);          // 0: not taken; 1: cin small; 2: cout small
+size_t img_extra_offset(const rcgan_conv_desc* d);
+size_t img_extra_bytes(const rcgan_conv_desc* d);
+size_t img_wgrad_ws_bytes(const rcgan_conv_desc* d);
+int img_prepare_launch(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w, const float* sigma, void* prepared);
+int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y);
+int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, void* dx, int accumulate);
+int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+              void* ws, size_t ws_bytes);
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n);

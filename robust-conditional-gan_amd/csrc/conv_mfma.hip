@@ -22,11 +22,7 @@
 //   read with ds_read_b64_tr_b16 (the gfx950 LDS transpose read).  Pixel ranges are split across
 //   blocks into fp32 slabs that a second kernel reduces (deterministic, no atomics).
 #include "conv_mfma.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#include "mfma_util.h"
 
 #ifndef RCGAN_PROBE
 #define RCGAN_PROBE 0      // kernel-bottleneck probes (scripts/probes/build_probes.sh); 0 in the product build
@@ -50,14 +46,6 @@ __device__ __forceinline__ void decode_pix(long m, int H, int W, int lh, int lw,
     n = (int)(t / H);
   }
 }
-
-// packed signed-16 max on bf16 bit patterns (v_pk_max_i16): with bound 0 this is ReLU (every negative bf16,
-// -0 included, has the int16 sign bit set); with bound 0x8000 per half it is the identity.
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t w, uint32_t bound) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w), __builtin_bit_cast(s16x2_t, bound)));
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) { return pk_max_i16(w, 0u); }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
@@ -202,26 +190,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// NS LDS stages: tile t+NS-1 is requested while tile t is multiplied; a counted s_waitcnt vmcnt leaves the
-// NS-2 newest tiles in flight across the (raw) barrier, so small-grid layers are not serialised on one
-// HBM/L2 round trip per K-tile.
-// LDS-DMA issued from inline asm: hipcc then neither counts it in its own s_waitcnt bookkeeping nor drains it
-// (vmcnt(0)) in front of every LDS read that might alias the destination -- the waits are placed by hand.
-// M0 (LDS destination base) is written in the same statement that uses it and restored afterwards.
-__device__ __forceinline__ void glds16_asm(const void* gptr, unsigned lds_byte_addr /* wave-uniform */) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gptr), "s"(lds_byte_addr) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0, "unsupported vmcnt immediate");
 }
 
 template <int BM, int BN, int NS>
@@ -678,22 +646,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
 //   stage: X rows = pixels p0-4 .. p0+35 (40 x 128 B, 8 rows per deposit), Y rows = p0 .. p0+31 (32 x 256 B)
 //   waves 2 (ci) x 2 (co): wave tile 32 ci x 64 co x 3 taps = 24 MFMA accumulators (96 registers)
 // ---------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void wait_vmcnt_any() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else static_assert(N == 0, "unsupported vmcnt immediate");
-}
-
-__device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p, int hi_off) {
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + hi_off));
-  s16x8_t r = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, r);
-}
-
 // bias gradient = column sums of dy.  Extra workgroups (blockIdx.x >= number of filter tiles) stream ONLY the dy
 // rows of their pixel chunk and multiply each transposed fragment with an all-ones operand on the matrix core.
 // Kept as a separate code path so that its accumulators share registers with the filter path (occupancy).
@@ -932,7 +884,7 @@ __global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf1
 }
 
 // batched preparation: every filter of a network in ONE launch (blockIdx.y = filter)
-struct PrepItem { const float* w; const float* sigma; void* out; int T, Cin, Cout, mfma; };
+struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
 struct PrepBatch { PrepItem it[48]; };
 
 __global__ void conv_prepare_batch_kernel(PrepBatch b) {
@@ -955,6 +907,12 @@ __global__ void conv_prepare_batch_kernel(PrepBatch b) {
       ((float*)it.out)[idx] = v;
     }
   }
+  if (it.img) {      // bf16 layouts of the image-end kernels (conv_image.hip)
+    const int cb = it.img == 1 ? it.Cout : it.Cin;
+    const long extra = (long)cb * 32 + (long)it.T * 16 * cb;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < extra; e += (long)gridDim.x * blockDim.x)
+      ((bf16_t*)it.extra)[e] = img_prepare_elem(e, it.img, it.T, it.Cin, it.Cout, it.w, inv);
+  }
 }
 
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n) {
@@ -967,6 +925,8 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
       rcgan_conv_desc d = s.desc;
       b.it[i].w = s.w; b.it[i].sigma = s.sigma; b.it[i].out = s.prepared;
       b.it[i].T = d.kh * d.kw; b.it[i].Cin = d.cin; b.it[i].Cout = d.cout; b.it[i].mfma = mfma_eligible(&d) ? 1 : 0;
+      b.it[i].img = b.it[i].mfma ? 0 : img_side(&d);
+      b.it[i].extra = b.it[i].img ? (char*)s.prepared + img_extra_offset(&d) : nullptr;
       long el = (long)d.kh * d.kw * d.cin * d.cout;
       if (el > maxel) maxel = el;
     }

@@ -81,11 +81,12 @@ class Weight:
 
 
 def prepare_batch(ctx, weights_and_shapes, dtype):
-    """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride)."""
+    """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride, hw):
+    hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant."""
     todo = []
-    for w, k, stride in weights_and_shapes:
+    for w, k, stride, hw in weights_and_shapes:
         kk, _, cin, cout = w.param.shape
-        desc = L.ConvDesc(1, 8, 8, cin, cout, k, k, stride, dtype, 0)
+        desc = L.ConvDesc(1, hw, hw, cin, cout, k, k, stride, dtype, 0)
         nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
         key = Weight._key(desc, nbytes)
         if key in w._prepared:

@@ -79,11 +79,11 @@ class Graph:
         return w
 
     def prepare_convs(self, names, dtype):
-        """Batch-prepare the conv filters named in ``names`` ([(param name, k, stride)]): one launch."""
+        """Batch-prepare the conv filters named in ``names`` ([(param name, k, stride, input hw)]): one launch."""
         ws = []
-        for pn, k, stride in names:
+        for pn, k, stride, hw in names:
             w = self.sn[pn][0] if pn in self.sn else self.weight(pn)
-            ws.append((w, k, stride))
+            ws.append((w, k, stride, hw))
         O.prepare_batch(self.ctx, ws, dtype)
 
     def weight(self, pname):

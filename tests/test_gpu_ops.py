@@ -52,6 +52,10 @@ CONV_CASES = [
     (3, 16, 16, 256, 3, 3, 1, False, False),    # G.Output (small output)
     (3, 10, 6, 128, 3, 3, 1, False, True),      # small output with folded input ReLU (generic dgrad because of the mask)
     (2, 8, 8, 3, 256, 3, 1, False, False),
+    (2, 32, 32, 256, 3, 3, 1, False, False),    # G.Output at the image resolution (MFMA small-output kernel, 4 channel chunks)
+    (3, 16, 16, 128, 3, 1, 1, False, False),    # 1x1 small output
+    (2, 32, 8, 3, 256, 3, 1, False, False),     # W = 8 bands, 256-channel small reduction
+    (5, 16, 32, 128, 2, 3, 1, False, True),     # 2 output channels, folded input ReLU
 ]
 
 
