@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
 // Direct-to-LDS variant (global_load_lds_dwordx4): no staging registers, no ds_write pass.
 //   * LDS rows are exactly 128 B (64 bf16); one wavefront instruction deposits 8 rows (lane l -> row l/8,
 //     16-B slot l%8).  Bank conflicts are avoided by an XOR swizzle applied on the SOURCE side: slot p of
-//     row r receives K-chunk p ^ (r & 7), and the fragment reads apply the same XOR.
+//     row r receives K-chunk p ^ ((r >> 1) & 7), and the fragment reads apply the same XOR.  (A ds_read_b128
+//     serves 16 lanes = 16 consecutive rows per pass; two 128-B rows share one 256-B bank row, so the row
+//     PAIR index must pick the slot: rows r and r+8 would collide with p ^ (r & 7).)
 //   * the SAME-padding halo is read from a 16-byte zero page (each lane supplies its own global address).
 //   * the input ReLU, when requested, is applied to the pixel fragments after the LDS read.
 // ---------------------------------------------------------------------------------------------
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   for (int i = 0; i < AI; ++i) {
     const int row = (wave * AI + i) * 8 + lrow;
     const long m = m0 + row;
-    a_coff[i] = (pos ^ (row & 7)) * 8;
+    a_coff[i] = (pos ^ ((row >> 1) & 7)) * 8;
     if (m < a.M) {
       decode_pix(m, a.H, a.W, a.lh, a.lw, p_n[i], p_oh[i], p_ow[i]);
     } else {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int row = (wave * BI + i) * 8 + lrow;
-    wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ (row & 7)) * 8;
+    wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ ((row >> 1) & 7)) * 8;
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
 
   const int frow = lane & 15, kc = lane >> 4;
   // byte offset of this lane's fragment inside a 16-row slab, for the two 32-deep K steps of a tile
-  const int foff0 = frow * 128 + ((kc ^ (frow & 7)) * 16);
-  const int foff1 = frow * 128 + (((4 + kc) ^ (frow & 7)) * 16);
+  const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
 
   const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;      // branch-free optional input ReLU
   constexpr int PER_TILE = AI + BI;                 // glds instructions per wave per tile
@@ -983,7 +985,7 @@ static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   }
   dim3 grid(cdiv(a.M, BM), a.Cout / BN);
   {
-    ProfScope ps(ctx, BM == 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
+    ProfScope ps(ctx, BM >= 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
                  2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN, NS>), grid, dim3(256), lds, ctx->stream, a);
   }
@@ -1022,6 +1024,9 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
   long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
   static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
+  static const int t256_min = env_int("RCGAN_T256_MINBLK", 1 << 30);     // experiment: 256-pixel tiles (1 wave/SIMD)
+  if (a.Cout % 256 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 256) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 256, 2>(ctx, a);
+  if (a.Cout % 128 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 128) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 128, 2>(ctx, a);
   if (a.Cout % 128 == 0 && blocks128 >= t128_min) return launch_conv_mfma<128, 128>(ctx, a);
   return launch_conv_mfma<64, 64>(ctx, a);
 }
