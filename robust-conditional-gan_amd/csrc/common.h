@@ -93,15 +93,15 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
 }
 
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
-  uint32_t u;
 #if defined(__HIP_DEVICE_COMPILE__)
-  u = __float_as_uint(f);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);      // v_cvt_pk_bf16_f32: round-to-nearest-even, quiet NaN
 #else
+  uint32_t u;
   memcpy(&u, &f, 4);
-#endif
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
+#endif
 }
 
 template <typename T> struct Elem;

@@ -351,8 +351,45 @@ int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int 
 template int colsum_launch<float>(rcgan_ctx*, const float*, long, int, float*, int, float*);
 template int colsum_launch<bf16_t>(rcgan_ctx*, const bf16_t*, long, int, float*, int, float*);
 
+// y[row][n <= 16]: the GEMM tiling would put the whole reduction in one workgroup (one 64-column tile); here one
+// workgroup per row splits K over its 256 threads (the RCGAN permutation classifier: [B,3072] x [3072,10]).
+template <typename T>
+__global__ __launch_bounds__(256) void linear_skinny_fwd_kernel(int k, int n, const T* x, const float* w, const float* wscale,
+                                                                const float* bias, T* y) {
+  __shared__ float red[4][16];
+  const int row = blockIdx.x, t = threadIdx.x;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const T* xr = x + (long)row * k;
+  for (int kk = t; kk < k; kk += 256) {
+    const float xv = Elem<T>::ld(xr + kk);
+    const float* wr = w + (long)kk * n;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < n) acc[j] = fmaf(xv, wr[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float v = wave_sum(acc[j]);
+    if ((t & 63) == 0) red[t >> 6][j] = v;
+  }
+  __syncthreads();
+  if (t < n) {
+    float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (wscale) v /= *wscale;
+    if (bias) v += bias[t];
+    Elem<T>::st(y + (long)row * n + t, v);
+  }
+}
+
 template <typename T>
 int linear_fwd(rcgan_ctx* ctx, long m, long k, long n, const T* x, const float* w, const float* wscale, const float* bias, T* y) {
+  if (n <= 16 && k >= 512 && m <= 65535) {
+    hipLaunchKernelGGL(linear_skinny_fwd_kernel<T>, dim3((int)m), dim3(256), 0, ctx->stream, (int)k, (int)n, x, w, wscale, bias, y);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   LinFwdOp<T> op;
   op.x = x; op.w = w; op.bias = bias; op.y = y; op.wscale = wscale;
   op.M = m; op.N = n; op.R = k; op.r_chunk = k;

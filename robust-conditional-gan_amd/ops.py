@@ -325,10 +325,18 @@ def add(ctx, a, b):
         def bw():
             if y.grad is None:
                 return
-            for t in (a, b):
-                if t.req:
-                    dx, acc = grad_of(ctx, t)
-                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, t.size, t.dtype, 1.0, _p(y.grad), float(acc), _p(dx)))
+            # y.grad is dead after this closure, so ONE input without a gradient yet may simply adopt the buffer
+            # (later contributions accumulate into it in place); every other input gets a copy / an accumulate
+            adopted = False
+            for t in (b, a):
+                if not t.req:
+                    continue
+                if t.grad is None and not adopted and t.shape == y.grad.shape:
+                    t.grad = y.grad
+                    adopted = True
+                    continue
+                dx, acc = grad_of(ctx, t)
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, t.size, t.dtype, 1.0, _p(y.grad), float(acc), _p(dx)))
         ctx.record(bw)
     return y
 
