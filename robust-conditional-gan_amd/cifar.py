@@ -280,6 +280,7 @@ class CifarRCGAN:
         self.seed = seed
         self._graphs = {}
         self.iteration = 0
+        self._pg_prepared_version = -1
         torch.cuda.synchronize()
 
     # ---------------------------------------------------------------------------------- helpers
@@ -308,16 +309,30 @@ class CifarRCGAN:
                 ents.append((name, base + "/spectral_norm/u", upd))
         return ents
 
+    @staticmethod
+    def _filter_names(grp):
+        names = []
+        for n in grp.names:
+            if n.endswith("/Filters"):
+                shp = grp.shapes[n]
+                # the 3-channel image-end convs (D.Block.1.*, G.Output) run at the image resolution
+                names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8))
+        return names
+
     def _prepare_all(self, which):
-        """One launch prepares every conv filter the step will use (W/sigma -> kernel layouts)."""
+        """One launch prepares every spectrally normalised conv filter the step will use (W/sigma changes with
+        every power iteration).  The generator's filters are NOT normalised: their kernel layouts are refreshed
+        only when the parameters change (_refresh_generator_filters)."""
         names = []
         for grp in which:
-            for n in grp.names:
-                if n.endswith("/Filters"):
-                    shp = grp.shapes[n]
-                    # the 3-channel image-end convs (D.Block.1.*, G.Output) run at the image resolution
-                    names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8))
+            if grp is not self.PG:
+                names += self._filter_names(grp)
         self.graph.prepare_convs(names, self.ctx.act_dtype)
+
+    def _refresh_generator_filters(self):
+        if self._pg_prepared_version != self.PG.version:
+            self.graph.refresh_persistent(self._filter_names(self.PG), self.ctx.act_dtype)
+            self._pg_prepared_version = self.PG.version
 
     def confusion_matrix(self):
         ctx = self.ctx
@@ -329,6 +344,7 @@ class CifarRCGAN:
     def _d_body(self):
         """Forward + backward of disc_cost (gan_resnet.py:557-697) on this rank's shard."""
         ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
+        self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
         g.begin_step({1})
         self.PD.zero_grad()
@@ -383,6 +399,7 @@ class CifarRCGAN:
         """Forward + backward of gen_cost (gan_resnet.py:715-786) on this rank's shard."""
         ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
         n = GEN_BS_MULTIPLE * B
+        self._refresh_generator_filters()
         ctx.new_step()
         g.begin_step({0, 2} if self.PC is not None else {0})
         self.PG.zero_grad()
@@ -436,6 +453,7 @@ class CifarRCGAN:
     def d_step(self, iteration=None):
         """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""
         it = self.iteration if iteration is None else iteration
+        self._refresh_generator_filters()
         self._run("d", self._d_body)
         self._allreduce(self.PD)
         self.PD.t += 1
@@ -446,11 +464,13 @@ class CifarRCGAN:
         """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op
         (gan_resnet.py:806-817)."""
         it = self.iteration if iteration is None else iteration
+        self._refresh_generator_filters()
         self._run("g", self._g_body)
         self._allreduce(self.PG)
         self.PG.t += 1
         self.PG.set_hyper(self.lr * lr_decay(it), self.PG.t)
         self.PG.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+        self._refresh_generator_filters()
         if self.PC is not None:
             self._allreduce(self.PC)
             self.PC.t += 1
@@ -516,6 +536,7 @@ class CifarRCGAN:
     def sample(self, labels, z):
         """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32."""
         ctx, g = self.ctx, self.graph
+        self._refresh_generator_filters()
         ctx.new_step()
         g.begin_step(set())
         rec, ctx.recording = ctx.recording, False

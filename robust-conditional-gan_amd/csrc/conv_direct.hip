@@ -147,10 +147,13 @@ template <typename T> struct LinWgradOp {
   }
 };
 
+// 64 x 64 output tile, K-step 32, fp32 FMA.  The operand elements of step s+1 are fetched into registers before
+// the FMAs of step s and written to the other LDS buffer after them: one barrier per step, and the (gather)
+// load latency -- what bounds the few-workgroup dense layers of the nets -- overlaps the arithmetic.
 template <class Op>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
-  __shared__ float As[16][68];
-  __shared__ float Bs[16][68];
+  __shared__ float As[2][32][68];
+  __shared__ float Bs[2][32][68];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
@@ -166,38 +169,49 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   // spectral-norm division W / sigma: sigma is loaded once per thread, not once per operand element
   const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
   const long ai = i0 + (tid >> 2);
-  const int ar = (tid & 3) * 4;
+  const int ar = (tid & 3) * 8;
   const int br = tid >> 4;
   const long bj = j0 + (tid & 15) * 4;
-  for (long r0 = r_begin; r0 < r_end; r0 += 16) {
+  float ra[8], rb[8];
+  auto fetch = [&](long r0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      long r = r0 + ar + q;
-      float v = 0.f;
-      if (ai < op.M && r < r_end) v = op.a(ai, r);
-      As[ar + q][tid >> 2] = v;
+    for (int q = 0; q < 8; ++q) {
+      const long r = r0 + ar + q;
+      ra[q] = (ai < op.M && r < r_end) ? op.a(ai, r) : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      long r = r0 + br, j = bj + q;
-      float v = 0.f;
-      if (r < r_end && j < op.N) v = op.b(r, j) * bscale;
-      Bs[br][(tid & 15) * 4 + q] = v;
+    for (int q = 0; q < 8; ++q) {
+      const long r = r0 + br + 16 * (q >> 2), j = bj + (q & 3);
+      rb[q] = (r < r_end && j < op.N) ? op.b(r, j) * bscale : 0.f;
     }
-    __syncthreads();
+  };
+  auto stash = [&](int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+    for (int q = 0; q < 8; ++q) As[buf][ar + q][tid >> 2] = ra[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Bs[buf][br + 16 * (q >> 2)][(tid & 15) * 4 + (q & 3)] = rb[q];
+  };
+  if (r_begin < r_end) { fetch(r_begin); stash(0); }
+  __syncthreads();
+  int buf = 0;
+  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+    const bool more = r0 + 32 < r_end;
+    if (more) fetch(r0 + 32);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
       float a4[4], b4[4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) a4[p] = As[kk][ty * 4 + p];
+      for (int p = 0; p < 4; ++p) a4[p] = As[buf][kk][ty * 4 + p];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b4[q] = Bs[kk][tx * 4 + q];
+      for (int q = 0; q < 4; ++q) b4[q] = Bs[buf][kk][tx * 4 + q];
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[p][q] = fmaf(a4[p], b4[q], acc[p][q]);
     }
+    if (more) stash(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {

@@ -889,26 +889,41 @@ __global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf1
 struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
 struct PrepBatch { PrepItem it[48]; };
 
-__global__ void conv_prepare_batch_kernel(PrepBatch b) {
+__global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
+  __shared__ bf16_t tile[64][66];
   const PrepItem it = b.it[blockIdx.y];
   const long total = (long)it.T * it.Cin * it.Cout;
   const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const float v = it.w[idx] * inv;
-    if (it.mfma) {
-      int co = (int)(idx % it.Cout);
-      long r = idx / it.Cout;
-      int ci = (int)(r % it.Cin);
-      int t = (int)(r / it.Cin);
-      bf16_t h = f32_to_bf16(v);
-      bf16_t* wt = (bf16_t*)it.out;
-      bf16_t* wd = wt + total;
-      wt[(long)co * it.T * it.Cin + (long)t * it.Cin + ci] = h;
-      wd[(long)ci * it.T * it.Cout + (long)(it.T - 1 - t) * it.Cout + co] = h;
-    } else {
-      ((float*)it.out)[idx] = v;
+  if (it.mfma) {
+    // 64(ci) x 64(co) tiles of one tap: read along co, write the straight (rotated-tap) copy along co and the
+    // transposed copy along ci through LDS -- all three streams coalesced
+    bf16_t* wt = (bf16_t*)it.out;
+    bf16_t* wd = wt + total;
+    const int nci = it.Cin / 64, nco = it.Cout / 64;
+    const int ntiles = it.T * nci * nco;
+    const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+      const int cot = tl % nco, cit = (tl / nco) % nci, t = tl / (nco * nci);
+      const int ci0 = cit * 64, co0 = cot * 64;
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int ci = i * 4 + grp;
+        const bf16_t h = f32_to_bf16(it.w[((long)t * it.Cin + ci0 + ci) * it.Cout + co0 + lane64] * inv);
+        wd[(long)(ci0 + ci) * it.T * it.Cout + (long)(it.T - 1 - t) * it.Cout + co0 + lane64] = h;
+        tile[ci][lane64] = h;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int co = i * 4 + grp;
+        wt[(long)(co0 + co) * it.T * it.Cin + (long)t * it.Cin + ci0 + lane64] = tile[lane64][co];
+      }
     }
+    return;
   }
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    ((float*)it.out)[idx] = it.w[idx] * inv;
   if (it.img) {      // bf16 layouts of the image-end kernels (conv_image.hip)
     const int cb = it.img == 1 ? it.Cout : it.Cin;
     const long extra = (long)cb * 32 + (long)it.T * 16 * cb;
@@ -932,9 +947,9 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
       long el = (long)d.kh * d.kw * d.cin * d.cout;
       if (el > maxel) maxel = el;
     }
-    int bx = cdiv(maxel, 256 * 8);
+    int bx = cdiv(maxel, 4096 * 2);      // two 64x64 tiles per workgroup for the largest filter
     if (bx < 1) bx = 1;
-    if (bx > 512) bx = 512;
+    if (bx > 288) bx = 288;
     hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(bx, m), dim3(256), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
   }

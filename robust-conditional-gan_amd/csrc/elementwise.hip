@@ -43,6 +43,98 @@ __global__ void fill_kernel(size_t count, float* p, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+
+// ---- 8-channel vectorised resampling kernels (c % 8 == 0, < 2^32 chunks): one 16-B (bf16) access per window pixel,
+//      32-bit index arithmetic ----------------------------------------------------------------------------------
+__device__ __forceinline__ void rs_ld8(const float* p, float* v) {
+  float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void rs_ld8(const bf16_t* p, float* v) {
+  uint4 a = *(const uint4*)p;
+  uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_to_f32((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] = bf16_to_f32((bf16_t)(w[j] >> 16)); }
+}
+__device__ __forceinline__ void rs_st8(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void rs_st8(bf16_t* p, const float* v) {
+  uint4 pk;
+  pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *(uint4*)p = pk;
+}
+
+// thread = 8 channels of one LOW-resolution pixel.  MODE 0: low = scale * sum(2x2 window of hi) [, masked by xmask > 0]
+//                                                  MODE 1: the 2x2 window of hi (=|+=) scale * low
+template <typename T, int MODE>
+__global__ void resample2_vec_kernel(unsigned nchunks, int oh, int ow, int c, float scale, const T* src, const T* xmask, T* dst,
+                                     int accumulate) {
+  const unsigned cpr = (unsigned)c >> 3;
+  const size_t rowpitch = (size_t)2 * ow * c;          // one hi-res image row
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) {
+    const unsigned ch = (i % cpr) << 3;
+    unsigned p = i / cpr;
+    const unsigned x2 = p % (unsigned)ow;
+    p /= (unsigned)ow;
+    const unsigned y2 = p % (unsigned)oh, b = p / (unsigned)oh;
+    const size_t lo = (size_t)i << 3;
+    const size_t hi = (((size_t)b * 2 * oh + 2 * y2) * 2 * ow + 2 * x2) * c + ch;
+    if (MODE == 0) {
+      float a0[8], a1[8], a2[8], a3[8], o[8];
+      rs_ld8(src + hi, a0); rs_ld8(src + hi + rowpitch, a1); rs_ld8(src + hi + c, a2); rs_ld8(src + hi + rowpitch + c, a3);
+      // add_n order of gan_resnet.py:239-240: [::2,::2] + [1::2,::2] + [::2,1::2] + [1::2,1::2]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (((a0[j] + a1[j]) + a2[j]) + a3[j]) * scale;
+      if (xmask) {
+        float m[8];
+        rs_ld8(xmask + lo, m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!(m[j] > 0.f)) o[j] = 0.f;
+      }
+      if (accumulate) {
+        float d[8];
+        rs_ld8(dst + lo, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += d[j];
+      }
+      rs_st8(dst + lo, o);
+    } else {
+      float v[8];
+      rs_ld8(src + lo, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= scale;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = hi + (q & 1) * (size_t)c + (q >> 1) * rowpitch;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[j];
+        if (accumulate) {
+          float d[8];
+          rs_ld8(dst + off, d);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += d[j];
+        }
+        rs_st8(dst + off, o);
+      }
+    }
+  }
+}
+
+static inline bool resample_vec_ok(int n, int oh, int ow, int c) {
+  return c % 8 == 0 && (size_t)n * oh * ow * (c / 8) < ((size_t)1 << 31);
+}
+static inline int resample_grid(size_t nchunks) {
+  size_t b = (nchunks + 255) / 256;
+  if (b > 16384) b = 16384;
+  return b < 1 ? 1 : (int)b;
+}
+
 // y[n][h/2][w/2][c] = mean of the 2x2 window
 template <typename T>
 __global__ void meanpool2_fwd_kernel(int n, int h, int w, int c, const T* x, T* y) {
@@ -249,6 +341,12 @@ int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float v) {
 int rcgan_meanpool2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y) {
   RC_REQUIRE(ctx, (h % 2 == 0) && (w % 2 == 0), "odd spatial size %dx%d", h, w);
   size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  if (resample_vec_ok(n, h / 2, w / 2, c)) {
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((resample2_vec_kernel<T, 0>), dim3(resample_grid(cnt / 8)), dim3(256), 0, ctx->stream,
+                                                     (unsigned)(cnt / 8), h / 2, w / 2, c, 0.25f, (const T*)x, (const T*)nullptr, (T*)y, 0));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(meanpool2_fwd_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, (const T*)x, (T*)y));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -256,6 +354,12 @@ int rcgan_meanpool2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, c
 
 int rcgan_meanpool2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate) {
   size_t cnt = (size_t)n * h * w * c;
+  if (h % 2 == 0 && w % 2 == 0 && resample_vec_ok(n, h / 2, w / 2, c)) {
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((resample2_vec_kernel<T, 1>), dim3(resample_grid(cnt / 32)), dim3(256), 0, ctx->stream,
+                                                     (unsigned)(cnt / 32), h / 2, w / 2, c, 0.25f, (const T*)dy, (const T*)nullptr, (T*)dx, accumulate));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(expand2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, 0.25f, (const T*)dy, (T*)dx, accumulate));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -264,6 +368,12 @@ int rcgan_meanpool2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, c
 // h, w: OUTPUT (upsampled) size
 int rcgan_upsample2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* x, void* y) {
   size_t cnt = (size_t)n * h * w * c;
+  if (h % 2 == 0 && w % 2 == 0 && resample_vec_ok(n, h / 2, w / 2, c)) {
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((resample2_vec_kernel<T, 1>), dim3(resample_grid(cnt / 32)), dim3(256), 0, ctx->stream,
+                                                     (unsigned)(cnt / 32), h / 2, w / 2, c, 1.f, (const T*)x, (const T*)nullptr, (T*)y, 0));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(expand2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, 1.f, (const T*)x, (T*)y, 0));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -271,6 +381,12 @@ int rcgan_upsample2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, c
 
 int rcgan_upsample2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate) {
   size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  if (resample_vec_ok(n, h / 2, w / 2, c)) {
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((resample2_vec_kernel<T, 0>), dim3(resample_grid(cnt / 8)), dim3(256), 0, ctx->stream,
+                                                     (unsigned)(cnt / 8), h / 2, w / 2, c, 1.f, (const T*)dy, (const T*)nullptr, (T*)dx, accumulate));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, (const T*)dy, (const T*)nullptr, (T*)dx, accumulate));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -303,6 +419,12 @@ int rcgan_preprocess_cifar(rcgan_ctx* ctx, int n, const int32_t* img, const floa
 template <typename T>
 int sumpool2_masked_launch(rcgan_ctx* ctx, int n, int h, int w, int c, const T* dy, const T* xmask, T* dx, int accumulate) {
   size_t cnt = (size_t)n * (h / 2) * (w / 2) * c;
+  if (resample_vec_ok(n, h / 2, w / 2, c)) {
+    hipLaunchKernelGGL((resample2_vec_kernel<T, 0>), dim3(resample_grid(cnt / 8)), dim3(256), 0, ctx->stream, (unsigned)(cnt / 8), h / 2, w / 2, c,
+                       1.f, dy, xmask, dx, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, dy, xmask, dx, accumulate);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;

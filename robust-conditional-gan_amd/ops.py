@@ -5,6 +5,8 @@ at mnist/model.py:250-262).  No arithmetic happens in Python or in PyTorch.
 """
 import ctypes as C
 
+import torch
+
 from . import _lib as L
 from .runtime import DT
 
@@ -80,18 +82,28 @@ class Weight:
         return self.dwbar
 
 
-def prepare_batch(ctx, weights_and_shapes, dtype):
+def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None):
     """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride, hw):
-    hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant."""
+    hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant.
+    persistent: None -> per-step arena buffers, skipped when already prepared this step;
+                dict {param name: {key: DT}} -> (re)fill buffers that survive the step (filters that only change
+                with their optimiser step)."""
     todo = []
     for w, k, stride, hw in weights_and_shapes:
         kk, _, cin, cout = w.param.shape
         desc = L.ConvDesc(1, hw, hw, cin, cout, k, k, stride, dtype, 0)
         nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
         key = Weight._key(desc, nbytes)
-        if key in w._prepared:
-            continue
-        buf = DT(ctx.arena.alloc(nbytes), (nbytes,), "u8", ctx.arena.buf)
+        if persistent is None:
+            if key in w._prepared:
+                continue
+            buf = DT(ctx.arena.alloc(nbytes), (nbytes,), "u8", ctx.arena.buf)
+        else:
+            slot = persistent.setdefault(w.param.name, {})
+            if key not in slot:
+                t = torch.empty(int(nbytes), dtype=torch.uint8, device=ctx.device)
+                slot[key] = DT(t.data_ptr(), (nbytes,), "u8", t)
+            buf = slot[key]
         w._prepared[key] = buf
         todo.append(L.PrepareItem(desc, w.param.ptr, w.sigma.ptr if w.sigma is not None else None, buf.ptr))
     if todo:

@@ -256,6 +256,7 @@ class ParamGroup:
         self.hyper_host = torch.zeros(256, 2, dtype=torch.float32).pin_memory()   # ring: async H2D sources
         self._hslot = 0
         self.t = 0
+        self.version = 0        # bumped by every write to the values (set / adam): keys caches of derived layouts
         host = np.zeros(self.count, np.float32)
         for name, shape, init in specs:
             o = self.offsets[name]
@@ -286,6 +287,8 @@ class ParamGroup:
         a = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, np.float32).reshape(-1)))
         with self._on_stream():
             getattr(self, which)[o:o + a.numel()].copy_(a)
+        if which == "value":
+            self.version += 1
 
     def zero_grad(self):
         c = self.ctx
@@ -306,3 +309,4 @@ class ParamGroup:
         c.check(c.lib.rcgan_adam_tf(c.h, hi - lo, self.value.data_ptr() + o, self.grad.data_ptr() + o,
                                     self.m.data_ptr() + o, self.v.data_ptr() + o, self.hyper.data_ptr(),
                                     beta1, beta2, eps, clip, grad_scale))
+        self.version += 1

@@ -38,6 +38,7 @@ class Graph:
         self._params = {}
         self.sn = {}                    # param name -> (Weight, update flag) prefetched this step
         self.plain = {}                 # param name -> Weight (no SN), per step
+        self.persist = {}               # param name -> {layout key: DT}: prepared filters that outlive the step
         self.index = {}
         for gi, g in enumerate(groups):
             for n in g.names:
@@ -86,7 +87,15 @@ class Graph:
             ws.append((w, k, stride, hw))
         O.prepare_batch(self.ctx, ws, dtype)
 
+    def refresh_persistent(self, names, dtype):
+        """(Re)prepare the un-normalised filters in ``names`` into buffers that survive the step: called after their
+        optimiser step (or any other write to the parameters), NOT once per step."""
+        ws = [(O.Weight(self.ctx, self.groups[self.index[pn]].param(pn), None), k, stride, hw) for pn, k, stride, hw in names]
+        O.prepare_batch(self.ctx, ws, dtype, persistent=self.persist)
+
     def weight(self, pname):
         if pname not in self.plain:
-            self.plain[pname] = O.Weight(self.ctx, self.param(pname), None)
+            w = O.Weight(self.ctx, self.param(pname), None)
+            w._prepared.update(self.persist.get(pname, {}))
+            self.plain[pname] = w
         return self.plain[pname]
