@@ -1,0 +1,22 @@
+#!/bin/bash
+# rcgany on MNIST: the reference preset (mnist/run_rcgany.sh), one MI355X.
+# Multi-GPU: NGPUS=8 ./run_rcgany.sh starts one rank per GPU (RCCL gradient all-reduce); extra flags pass through.
+script_file='run_rcgany.sh'
+checkpoint_dir='rcgany'
+trial=0
+alpha=0.125
+epoch=100
+ngpus=${NGPUS:-1}
+mkdir -p "$checkpoint_dir"
+launch="python -u"
+if [ "$ngpus" -gt 1 ]; then
+  launch="python -m torch.distributed.run --nnodes=1 --nproc-per-node $ngpus --master-addr 127.0.0.1"
+fi
+$launch main.py \
+    --algorithm "rcgan" --alpha $alpha --disc_type "projection" \
+    --noestimate_confuse --noaux_classifier \
+    --add_noise --noise_alpha 0.3 --noise_start 30 --noise_end 80 \
+    --concat_y --concat_y_layers 1 \
+    --spectral_norm --max_norm \
+    --checkpoint_dir $checkpoint_dir --script_file ${script_file} \
+    --epoch $epoch "$@" 2>&1 | tee -a ${checkpoint_dir}/rcgany_alpha${alpha}_epoch${epoch}_${trial}.txt

@@ -357,6 +357,75 @@ class MnistRCGAN:
             out["class_loss_fake"] /= self.perm_mult      # the accumulator holds the weighted term of the G objective
         return out
 
+    def evaluate(self):
+        """Forward pass only, on the current static inputs: the console metrics of the reference's loop
+        (errD_real / errD_fake / errG / prob_real / prob_fake, model.py:374-399).  Like every ``sess.run`` of the
+        reference it runs D and G in training mode (batch statistics, power-iteration update).  The losses are
+        formed on the host from the downloaded logits -- logging only, nothing here feeds the optimisers."""
+        ctx, g, inp = self.ctx, self.graph, self.inp
+        ctx.new_step()
+        g.begin_step(set())
+        rec, ctx.recording = ctx.recording, False
+        try:
+            self._sn_prefetch()
+            G = self.generator(inp["z"], inp["y_gen"])
+            if self.alg in ("biased", "rcgan", "ambient"):
+                lr_, wr = ctx.download(self.discriminator(inp["images"], inp["y_real"])).astype(np.float64), None
+            else:
+                lr_ = ctx.download(self.discriminator_all_labels(inp["images"])).astype(np.float64)
+                wr = ctx.download(inp["y_real_weights"]).astype(np.float64)
+            if self.alg in ("rcgan", "ambient") and self.est:
+                lf = ctx.download(self.discriminator_all_labels(G)).astype(np.float64)
+                C = ctx.download(self.confusion()).astype(np.float64).reshape(Y_DIM, Y_DIM)
+                wf = ctx.download(inp["y_gen"]).astype(np.float64) @ C
+            else:
+                y = inp["y_fake"] if self.alg in ("rcgan", "ambient") else inp["y_gen"]
+                lf, wf = ctx.download(self.discriminator(G, y)).astype(np.float64), None
+        finally:
+            ctx.recording = rec
+        softplus = lambda x: np.logaddexp(0.0, x)
+        if self.loss_fn == "hinge":
+            f_real, f_fake, f_g = (lambda x: np.maximum(1 - x, 0)), (lambda x: np.maximum(1 + x, 0)), (lambda x: -x)
+        else:
+            f_real, f_fake, f_g = (lambda x: softplus(-x)), softplus, (lambda x: softplus(-x))
+        sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+        red = lambda a, w: a.reshape(len(a), -1).mean(1) if w is None else (a * w).sum(1)
+        return dict(d_loss_real=float(red(f_real(lr_), wr).mean()), d_loss_fake=float(red(f_fake(lf), wf).mean()),
+                    g_loss=float(red(f_g(lf), wf).mean()), prob_real=red(sig(lr_), wr), prob_fake=red(sig(lf), wf))
+
+    # ------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """TF variable names -> arrays: parameters, Adam slots ("<var>/Adam", "<var>/Adam_1"), optimiser steps,
+        BN moving statistics and power-iteration vectors (what tf.train.Saver stores for DCGAN, model.py:845-854)."""
+        sd = {}
+        for gname, grp in zip(("generator", "discriminator", "confusion"), self.groups):
+            for n in grp.names:
+                sd[n] = grp.get(n)
+                sd[n + "/Adam"] = grp.get(n, "m")
+                sd[n + "/Adam_1"] = grp.get(n, "v")
+            sd["_opt/%s/step" % gname] = np.array([grp.t], np.int64)
+        sd.update(self.get_state())
+        return sd
+
+    def load_state_dict(self, sd):
+        for gname, grp in zip(("generator", "discriminator", "confusion"), self.groups):
+            for n in grp.names:
+                if n not in sd:
+                    raise KeyError("checkpoint is missing variable %s" % n)
+                grp.set(n, sd[n])
+                if n + "/Adam" in sd:
+                    grp.set(n, sd[n + "/Adam"], "m")
+                    grp.set(n, sd[n + "/Adam_1"], "v")
+            key = "_opt/%s/step" % gname
+            if key in sd:
+                grp.t = int(sd[key][0])
+        ctx = self.ctx
+        with torch.cuda.stream(ctx.stream):
+            for k, t in self.state.items():
+                if k in sd:
+                    ctx.view(t).copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sd[k], np.float32).reshape(-1))))
+        ctx.sync()
+
     def get_params(self):
         out = {}
         for grp in self.groups:

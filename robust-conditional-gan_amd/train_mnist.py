@@ -1,0 +1,217 @@
+"""MNIST training entry point with the reference's flag surface, console output and output tree
+(mnist/main.py flags + directory naming; DCGAN.train, mnist/model.py:226-492; save/load :836-866).
+
+  <checkpoint_dir>/<prefix><algorithm>_<alpha>_<disc_type>_<timestamp>/      (or .../<--checkpoint>)
+      script/{*.py, <script_file>, command.txt}        utils.dump_script
+      samples/train_EE_IIII.png                        10x10 grid every 700 updates (fixed z, 10 per class)
+      samples/samples_<epoch>.npy                      100 x [100,28,28,1] every 5th epoch (previous one removed)
+      mnist_<batch>_28_28/DCGAN.model-<step>.npz       every 700 updates (+ TF-style `checkpoint` index)
+
+Per batch: one D update, two G (+ confusion-matrix) updates on the same z (model.py:347-372).  Deviations, all
+logging-only: the console metrics are evaluated only for the lines that are printed; the generated-label accuracy
+and recover_labels need the frozen MNIST classifier graph (SURVEY 8f "next" rows) and are reported as skipped.
+Multi-GPU: one rank per GPU under torch.distributed.run; every rank takes batch_size/world rows of each batch.
+"""
+import os
+import shutil
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+
+from . import data_mnist as DM
+from .host import Flags, Saver, latest_checkpoint, load_checkpoint, save_images
+
+
+def define_flags():
+    f = Flags()
+    f.DEFINE_integer("epoch", 5, "Epoch to train [25]")
+    f.DEFINE_float("learning_rate", 0.0002, "Learning rate of for adam [0.0002]")
+    f.DEFINE_float("beta1", 0.5, "Momentum term of adam [0.5]")
+    f.DEFINE_float("train_size", np.inf, "The size of train images [np.inf]")
+    f.DEFINE_integer("batch_size", 100, "The size of batch images")
+    f.DEFINE_integer("input_height", 108, "unused for mnist (forced to 28)")
+    f.DEFINE_integer("input_width", None, "unused for mnist (forced to 28)")
+    f.DEFINE_integer("output_height", 64, "unused for mnist (forced to 28)")
+    f.DEFINE_integer("output_width", None, "unused for mnist (forced to 28)")
+    f.DEFINE_string("dataset", "mnist", "The name of dataset [mnist]")
+    f.DEFINE_string("checkpoint_dir", "rcgan", "Directory name to save the checkpoints [checkpoint]")
+    f.DEFINE_string("checkpoint", None, "Directory name to save the checkpoints [checkpoint]")
+    f.DEFINE_string("sample_dir", "samples/", "Directory name to save the image samples")
+    f.DEFINE_string("data_dir", "../data/", "Root directory of dataset [data]")
+    f.DEFINE_string('dir_prefix', None, "dir name prefix")
+    f.DEFINE_string('logs_dir', './logs', "logs directory")
+    f.DEFINE_boolean('logs_at_ckpt', False, "set logs dir to chechkpoint dir")
+    f.DEFINE_string('script_file', None, "script file name for storing script along with results")
+    f.DEFINE_boolean("train", False, "True for training, False for testing [False]")
+    f.DEFINE_boolean("crop", False, "unused")
+    f.DEFINE_boolean("visualize", False, "unused")
+    f.DEFINE_integer("z_dim", 100, "Dimension of input noise Z to the generator")
+    f.DEFINE_string("algorithm", "biased", "[biased, unbiased, rcgan, ambient]")
+    f.DEFINE_boolean("estimate_confuse", True, "whether to estimate confusion matrix")
+    f.DEFINE_float("confuse_multiplier", 10.0, "learning rate multiplier for confusion matrix")
+    f.DEFINE_boolean("perm_regularizer", True, "whether to use auxillary permutation regularizer classifier")
+    f.DEFINE_float("perm_multiplier", 10.0, "learning rate multiplier for permutation regularizer")
+    f.DEFINE_float("alpha", 1.0, "noise in labels")
+    f.DEFINE_boolean("confusion_class_depend", False, "class dependent rows of the confusion matrix instead of one coin")
+    f.DEFINE_string("disc_type", "vanilla", "type of discriminator to use [vanilla, projection]")
+    f.DEFINE_string('loss_fn', 'hinge', 'GAN loss function')
+    f.DEFINE_boolean("real_match", False, 'whether to match y_gen with y_real in for each batch')
+    f.DEFINE_boolean('add_noise', False, 'whether to add noise to both real and fake labels y_real, y_fake')
+    f.DEFINE_float("noise_alpha", 0.3, "effective noise in labels")
+    f.DEFINE_integer("noise_start", 30, "noise schedule start")
+    f.DEFINE_integer("noise_end", 80, "noise schedule end")
+    f.DEFINE_boolean('concat_y', False, 'whether to concat y to projection discriminator')
+    f.DEFINE_list('concat_y_layers', ['1'], 'layers of projection discriminator where we want to concat y [1, 2, 3, 4]')
+    f.DEFINE_boolean('spectral_norm', True, 'spectral normalization on conv2d layers of the discriminator')
+    f.DEFINE_boolean('max_norm', True, 'maximum value (clip) normalization on linear layers of discriminator')
+    f.DEFINE_integer("recover_epoch", 1000, "recover_labels epochs")
+    f.DEFINE_integer("recover_batch_size", 500, "recover_labels batch")
+    f.DEFINE_float("recover_learning_rate", 5.e+2, "recover_labels learning rate")
+    # this build's additions (absent flags keep the reference behaviour)
+    f.DEFINE_string("dtype", 'f32', "activation dtype [f32, bf16]")
+    f.DEFINE_boolean("synthetic", False, "train on SURVEY 8(d) synthetic digits instead of <data_dir>/mnist")
+    f.DEFINE_integer("synthetic_size", 7000, "number of synthetic samples")
+    f.DEFINE_integer("seed", 0, "variable-initialisation seed")
+    f.DEFINE_integer("save_every", 700, "checkpoint / sample-grid period in updates (the reference hard-codes 700)")
+    f.DEFINE_integer("sample_epochs", 5, "samples_<epoch>.npy period (the reference hard-codes 5)")
+    return f
+
+
+def dump_script(dirname, script_file, src_dir, file_list):
+    """utils.dump_script (mnist/utils.py:253-270)."""
+    dest = os.path.join(dirname, 'script')
+    os.makedirs(dest, exist_ok=True)
+    print('copying files to {}'.format(dest))
+    for name in file_list:
+        p = os.path.join(src_dir, name)
+        if os.path.exists(p):
+            print('copying {}'.format(name))
+            shutil.copy2(p, dest)
+    if script_file is not None and os.path.exists(script_file):
+        print('copying {}'.format(script_file))
+        shutil.copy2(script_file, dest)
+    with open(os.path.join(dest, "command.txt"), "w") as f:
+        f.write(" ".join(sys.argv) + "\n")
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    FLAGS = define_flags().parse(argv)
+    layers = [int(x) for x in FLAGS.concat_y_layers]
+    prefix = '' if FLAGS.dir_prefix is None else FLAGS.dir_prefix + '_'
+    if FLAGS.checkpoint is None:                                               # main.py:74-80
+        ckpt_root = os.path.join(FLAGS.checkpoint_dir, prefix + FLAGS.algorithm + "_" + str(FLAGS.alpha) + "_" +
+                                 FLAGS.disc_type + "_" + datetime.now().strftime("%Y%m%d-%H%M%S"))
+    else:
+        ckpt_root = os.path.join(FLAGS.checkpoint_dir, FLAGS.checkpoint)
+    sample_dir = os.path.join(ckpt_root, 'samples/')
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    B = FLAGS.batch_size
+    if B % world:
+        raise ValueError("--batch_size %d is not divisible by the %d launched ranks" % (B, world))
+    if rank == 0:
+        os.makedirs(ckpt_root, exist_ok=True)
+        os.makedirs(sample_dir, exist_ok=True)
+        dump_script(ckpt_root, FLAGS.script_file, os.getcwd(), ['main.py', 'model.py', 'utils.py', 'ops.py', 'sn.py'])
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- data (DCGAN.__init__ -> load_mnist, model.py:83-89) ----------------------------------------------
+    if FLAGS.synthetic:
+        X, y = DM.synthetic(FLAGS.synthetic_size, 1234)
+        data = DM.corrupt(X, y, FLAGS.alpha, FLAGS.confusion_class_depend, FLAGS.real_match)
+    else:
+        data = DM.load_mnist(FLAGS.data_dir, FLAGS.alpha, FLAGS.confusion_class_depend, FLAGS.real_match)
+    np.set_printoptions(precision=4, suppress=True)
+    print('C=\n', data["C"])
+    print('C_inv=\n', np.linalg.inv(data["C"]))
+    data_X, y_real, y_gen, y_fake, y_w = data["X"], data["y_real"], data["y_gen"], data["y_fake"], data["y_real_weights"]
+
+    from .dp import shard_rows
+    from .mnist import Z_DIM, MnistRCGAN
+    if FLAGS.z_dim != Z_DIM:
+        raise ValueError("--z_dim %d: the generator is built for z_dim = %d" % (FLAGS.z_dim, Z_DIM))
+    m = MnistRCGAN(algorithm=FLAGS.algorithm, alpha=FLAGS.alpha, batch_size=B // world, learning_rate=FLAGS.learning_rate,
+                   beta1=FLAGS.beta1, dtype=FLAGS.dtype, seed=FLAGS.seed, disc_type=FLAGS.disc_type, loss_fn=FLAGS.loss_fn,
+                   estimate_confuse=FLAGS.estimate_confuse, confuse_multiplier=FLAGS.confuse_multiplier,
+                   perm_regularizer=FLAGS.perm_regularizer, perm_multiplier=FLAGS.perm_multiplier,
+                   spectral_norm=FLAGS.spectral_norm, max_norm=FLAGS.max_norm, concat_y=FLAGS.concat_y, concat_y_layers=layers,
+                   device=local, world_size=world, rank=rank, confusion_matrix=data["C"])
+    sh = lambda a: shard_rows(a, rank, world)
+    model_dir = os.path.join(ckpt_root, "{}_{}_{}_{}".format("mnist", B, 28, 28))          # model.py:836-840
+    saver = Saver(max_to_keep=5)
+
+    counter = 1
+    if not FLAGS.train:                                                        # main.py:133-138
+        print(" [*] Reading checkpoints...")
+        ck = latest_checkpoint(model_dir)
+        if ck:
+            m.load_state_dict(load_checkpoint(ck))
+            counter = int(ck.rsplit("-", 1)[1])
+            print(" [*] Success to read {}".format(os.path.basename(ck)))
+        else:
+            print(" [*] Failed to find a checkpoint")
+            print("[!] Training a model first, then run test mode")
+
+    # ---- DCGAN.train (model.py:270-492) ------------------------------------------------------------------------
+    sample_z = np.random.uniform(-1, 1, size=(B, Z_DIM))
+    picks = [i for c in range(10) for i in np.where(y_gen[:, c] == 1)[0][0:10]]
+    sample_inputs, sample_labels = data_X[picks[0:100]], y_gen[picks[0:100]]
+    start_time = time.time()
+    for epoch in range(FLAGS.epoch):
+        batch_idxs = int(min(len(data_X), FLAGS.train_size)) // B
+        cur_real, cur_fake = y_real, y_fake
+        if FLAGS.add_noise:                                                    # model.py:293-333
+            eff = DM.noise_schedule(epoch, FLAGS.alpha, FLAGS.noise_alpha, FLAGS.noise_start, FLAGS.noise_end)
+            cur_real, cur_fake = DM.add_noise(y_real, y_fake, eff)
+        for idx in range(batch_idxs):
+            lo, hi = idx * B, (idx + 1) * B
+            batch_z = np.random.uniform(-1, 1, [B, Z_DIM]).astype(np.float32)
+            m.set_inputs(images=sh(data_X[lo:hi]), z=sh(batch_z), y_real=sh(cur_real[lo:hi]), y_gen=sh(y_gen[lo:hi]),
+                         y_fake=sh(cur_fake[lo:hi]), y_real_weights=sh(y_w[lo:hi]))
+            m.iteration()                                                      # D once, G (+C) twice: model.py:347-372
+            counter += 1
+            if rank == 0 and ((epoch < 1 and idx < 20) or idx % 350 == 0):
+                ev = m.evaluate()
+                pr, pf = ev["prob_real"], ev["prob_fake"]
+                print("Epoch: [%2d] [%4d/%4d] time: %4.2f, d_loss: %.3f, g_loss: %.3f, "
+                      "d_real: %2d, %.3f, %.3f, d_fake: %2d, %.3f, %.3f"
+                      % (epoch, idx, batch_idxs, time.time() - start_time, ev["d_loss_fake"] + ev["d_loss_real"], ev["g_loss"],
+                         int((pr >= 0.5).sum()), pr.min(), pr.max(), int((pf <= 0.5).sum()), pf.min(), pf.max()))
+            if rank == 0 and np.mod(counter, FLAGS.save_every) == 1:
+                n = min(len(sample_labels), B)
+                if n == B and world == 1:
+                    m.set_inputs(images=sample_inputs[:n], z=sample_z[:n], y_real=sample_labels[:n], y_gen=sample_labels[:n],
+                                 y_fake=sample_labels[:n], y_real_weights=sample_labels[:n])
+                    ev = m.evaluate()
+                    print("[Sample] d_loss: %.8f, g_loss: %.8f" % (ev["d_loss_real"] + ev["d_loss_fake"], ev["g_loss"]))
+                samples = m.sampler(sample_z[:n], sample_labels[:n])
+                save_images((samples.reshape(n, 28, 28) * 255.).clip(0, 255).astype(np.uint8),
+                            os.path.join(sample_dir, 'train_{:02d}_{:04d}.png'.format(epoch, idx)))
+                saver.save(m.state_dict(), model_dir, "DCGAN.model", counter)
+        if rank == 0 and np.mod(epoch + 1, FLAGS.sample_epochs) == 0:          # model.py:470-489
+            n = min(len(sample_labels), 100)
+            samples = [m.sampler(np.random.uniform(-1, 1, size=(n, Z_DIM)), sample_labels[:n]).reshape(n, 28, 28, 1)
+                       for _ in range(100)]
+            np.save(os.path.join(sample_dir, "samples_" + str(epoch)), samples)
+            old = os.path.join(sample_dir, "samples_" + str(epoch - FLAGS.sample_epochs) + '.npy')
+            if epoch + 1 != FLAGS.sample_epochs and os.path.exists(old):
+                os.remove(old)
+            print('######EPOCH={}, mean generated label accuracy=skipped (needs mnist_dcnn/graph_optimized.pb)'.format(epoch))
+    if rank == 0:
+        saver.save(m.state_dict(), model_dir, "DCGAN.model", counter)
+        print("recover_labels: skipped (SURVEY 8f next row)")
+    m.ctx.close()
+    return ckpt_root
+
+
+if __name__ == '__main__':
+    main()

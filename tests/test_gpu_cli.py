@@ -34,3 +34,47 @@ def test_train_cli_layout_and_restore(tmp_path):
     assert d2 == d
     sd2 = load_checkpoint(latest_checkpoint(os.path.join(d, "checkpoint")))
     assert int(sd2["_opt/Discriminator/step"][0]) == 2 * int(sd["_opt/Discriminator/step"][0])
+
+
+def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
+    """mnist/main.py's flag surface (run_rcganu.sh preset + an ignored unknown flag), console lines, output tree
+    (script/, samples/train_EE_IIII.png, samples_<epoch>.npy, mnist_<B>_28_28/DCGAN.model-<step>), restore without
+    --train, and the vanilla-discriminator CE preset with --add_noise."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.host import latest_checkpoint, load_checkpoint
+    from rcgan_amd.train_mnist import main
+    root = str(tmp_path)
+    argv = ["--algorithm", "rcgan", "--alpha", "0.3", "--disc_type", "projection", "--estimate_confuse", "--aux_classifier",
+            "--noadd_noise", "--noconcat_y", "--spectral_norm", "--max_norm", "--checkpoint_dir", root, "--checkpoint", "e1",
+            "--epoch", "2", "--batch_size", "100", "--synthetic", "--synthetic_size", "500", "--save_every", "3",
+            "--sample_epochs", "1", "--train"]
+    d = main(argv)
+    out = capsys.readouterr().out
+    assert "Epoch: [ 0] [   0/   5]" in out and "d_real:" in out and "[Sample] d_loss:" in out
+    assert os.path.exists(os.path.join(d, "script", "command.txt"))
+    grids = sorted(glob.glob(os.path.join(d, "samples", "train_*.png")))
+    assert grids and os.path.basename(grids[0]) == "train_00_0002.png"
+    from PIL import Image
+    assert Image.open(grids[0]).size == (280, 280)
+    assert os.path.exists(os.path.join(d, "samples", "samples_1.npy")) and not os.path.exists(os.path.join(d, "samples", "samples_0.npy"))
+    assert np.load(os.path.join(d, "samples", "samples_1.npy")).shape == (100, 100, 28, 28, 1)
+    mdir = os.path.join(d, "mnist_100_28_28")
+    ck = latest_checkpoint(mdir)
+    assert ck is not None and os.path.basename(ck) == "DCGAN.model-11"
+    sd = load_checkpoint(ck)
+    assert sd["generator/g_h1_lin/Matrix"].shape == (1034, 6272) and "confusion_logits" in sd
+    assert "discriminator/d_h0_conv/w/Adam_1" in sd and np.isfinite(sd["generator/g_h3/w"]).all()
+    steps = int(sd["_opt/discriminator/step"][0])
+    assert steps == 10 and int(sd["_opt/generator/step"][0]) == 20
+    # test mode (no --train): restores, then trains on (main.py:133-138)
+    d2 = main([a for a in argv if a != "--train"])
+    assert d2 == d and " [*] Success to read DCGAN.model-11" in capsys.readouterr().out
+    sd2 = load_checkpoint(latest_checkpoint(mdir))
+    assert int(sd2["_opt/discriminator/step"][0]) == 2 * steps
+    # biased preset: vanilla D, CE loss, real_match, no SN / max-norm; plus the --add_noise schedule
+    d3 = main(["--algorithm", "biased", "--alpha", "0.6", "--disc_type", "vanilla", "--loss_fn", "ce", "--real_match",
+               "--noestimate_confuse", "--add_noise", "--noise_alpha", "0.3", "--noise_start", "1", "--noise_end", "2",
+               "--nospectral_norm", "--nomax_norm", "--checkpoint_dir", root, "--checkpoint", "e2", "--epoch", "2",
+               "--batch_size", "64", "--synthetic", "--synthetic_size", "256", "--train"])
+    sd3 = load_checkpoint(latest_checkpoint(os.path.join(d3, "mnist_64_28_28")))
+    assert sd3["discriminator/d_h3_lin/Matrix"].shape[1] == 1024 and all(np.isfinite(v).all() for v in sd3.values())

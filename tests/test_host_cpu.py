@@ -141,3 +141,42 @@ def test_dp_two_ranks_gloo_equals_tower_mean(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_MAXERR" in outs[0]
+
+
+@pytest.mark.parametrize("fn", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "labels_mnist_*.npz"))))
+def test_product_mnist_label_streams_bit_exact(fn):
+    """The product's load_mnist corruption (rcgan_amd.data_mnist) against the vectors the reference's own
+    DCGAN.load_mnist produced (scripts/make_golden_labels.py)."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import data_mnist as DM
+    g = np.load(fn)
+    synth = lambda n, seed: np.random.RandomState(seed).randint(0, 10, size=n).astype(np.int64)
+    y = np.concatenate([synth(60000, int(g["train_label_seed"])), synth(10000, int(g["test_label_seed"]))])
+    X = (np.arange(70000) % 251).astype(np.float64)
+    d = DM.corrupt(X, y, float(g["alpha"]), confusion_class_depend=bool(g["depend"]), real_match=bool(g["match"]))
+    assert np.array_equal(np.argmax(d["y_actual"], 1), g["y_actual"])
+    assert np.array_equal(np.argmax(d["y_real"], 1), g["y_real"])
+    assert np.array_equal(np.argmax(d["y_gen"], 1), g["y_gen"])
+    assert np.array_equal(np.argmax(d["y_fake"], 1), g["y_fake"])
+    assert np.array_equal(np.round(d["X"] * 255.).astype(np.uint8), g["x_first_pixel"])
+    assert np.array_equal(d["C"], g["C"])
+    assert np.array_equal(d["y_real_weights"][:8], g["w_first8"])
+
+
+def test_product_mnist_noise_schedule_matches_oracle():
+    """--add_noise annealing (mnist/model.py:293-333): product host code vs the oracle restatement, schedule values and
+    the re-corruption stream."""
+    import rcgan_amd  # noqa: F401
+    from oracle import labels as OL
+    from rcgan_amd import data_mnist as DM
+    for alpha, na, s, e in ((0.125, 0.3, 30, 80), (0.6, 0.3, 2, 9), (0.3, 0.3, 5, 6)):
+        for ep in (0, 1, s - 1, s, s + 1, (s + e) // 2, e, e + 3):
+            assert DM.noise_schedule(ep, alpha, na, s, e) == OL.mnist_noise_schedule(ep, alpha, na, s, e)
+    rs = np.random.RandomState(3)
+    yr = np.eye(10)[rs.randint(10, size=500)]
+    yf = np.eye(10)[rs.randint(10, size=500)]
+    a = DM.add_noise(yr, yf, 0.7, np.random.RandomState(11))
+    b = OL.mnist_add_noise(yr, yf, 0.7, np.random.RandomState(11))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        DM.noise_schedule(0, 0.5, 0.95, 1, 2)
