@@ -24,9 +24,6 @@
 #include "conv_mfma.h"
 #include "mfma_util.h"
 
-#ifndef RCGAN_PROBE
-#define RCGAN_PROBE 0      // kernel-bottleneck probes (scripts/probes/build_probes.sh); 0 in the product build
-#endif
 #define LDS_PITCH 72          // elements per LDS row in the fwd kernel (64 + 8 pad)
 #define WG_PITCH 144          // elements per LDS row in the wgrad kernel (128 + 16 pad = 288 B)
 
@@ -194,21 +191,31 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// KS > 1: intra-workgroup split of the reduction.  Layers whose grid is smaller than the chip (the 8x8 / 4x4 stages:
+// <= 1 workgroup per CU) are bound by the serial chain of K-tiles of one workgroup, with three quarters of each
+// SIMD's wave slots empty.  KS groups of 4 wavefronts then take K-tiles g, g+KS, g+2KS, ... of the SAME output tile,
+// each group with its own LDS pipeline (the barriers stay workgroup-wide: all groups run the same iteration count),
+// and the partial accumulators are summed through LDS in a fixed order before the epilogue.
+template <int BM, int BN, int NS, int KS>
+__global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
   constexpr int AI = BM / 32, BI = BN / 32;          // 1-KiB deposits per wave per tile
   constexpr int TM = BM / 2, TN = BN / 2;
   constexpr int NI = TN / 16, NJ = TM / 16;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KS > 1 ? wave_all >> 2 : 0;       // K-split group of this wavefront
+  const int wave = wave_all & 3;
+  unsigned char* smem = smem_all + grp * (NS * STAGE);
   const int wm = wave & 1, wn = wave >> 1;
   const long m0 = (long)blockIdx.x * BM;
   const int co0 = blockIdx.y * BN;
   const int K = a.KH * a.KW * a.Cin;
-  const int KT = K / 64;
+  const int KT_all = K / 64;
+  const int KT = KS > 1 ? (KT_all - grp + KS - 1) / KS : KT_all;      // K-tiles of this group
+  const int KT_max = (KT_all + KS - 1) / KS;                          // iterations every group runs (barrier count)
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int lrow = lane >> 3, pos = lane & 7;
 
@@ -248,20 +255,26 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
       rstep[i] = ok ? 1 : 0;
     }
   };
+  auto advance = [&](int steps) {        // move the (tap, channel) cursor `steps` K-tiles on
+    bool moved = false;
+    i_k0 += 64 * steps;
+    i_c0 += 64 * steps;
+    while (i_c0 >= a.Cin) {
+      i_c0 -= a.Cin;
+      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+      moved = true;
+    }
+    if (moved) set_tap(i_kh, i_kw);
+  };
   set_tap(0, 0);
+  if (KS > 1 && grp > 0) advance(grp);
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i) glds16_asm(rp[i] + i_c0 * rstep[i], stage + (wave * AI + i) * 1024);
 #pragma unroll
     for (int i = 0; i < BI; ++i) glds16_asm(wsrc[i] + i_k0, stage + ABYTES + (wave * BI + i) * 1024);
-    i_k0 += 64;
-    i_c0 += 64;
-    if (i_c0 == a.Cin) {
-      i_c0 = 0;
-      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
-      set_tap(i_kh, i_kw);
-    }
+    advance(KS);
   };
 
   f32x4_t acc[NI][NJ];
@@ -282,58 +295,64 @@ __global__ __launch_bounds__(256) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   for (int t = 0; t < NS - 1; ++t)
     if (t < KT) issue(t);
   int buf = 0;
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = 0; kt < KT_max; ++kt) {
     // tile kt landed (this wave's part), then rendezvous: everyone's part landed and everyone left tile kt-1
     if (kt + NS - 2 < KT) wait_vmcnt<INFLIGHT>(); else wait_vmcnt<0>();
     // the barrier is issued from asm with a memory clobber: the s_barrier builtin is IntrNoMem, so the compiler
     // could otherwise hoist the LDS reads of this tile above it in iterations that issue no further DMA
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if RCGAN_PROBE != 3      /* probe 3: no global loads after the prologue */
     if (kt + NS - 1 < KT) {
       int nb = buf + NS - 1;
       if (nb >= NS) nb -= NS;
       issue(nb);
     }
-#endif
-    const unsigned char* Ab = smem + buf * STAGE + (wm * TM) * 128;
-    const unsigned char* Bb = smem + buf * STAGE + ABYTES + (wn * TN) * 128;
+    if (KS == 1 || kt < KT) {
+      const unsigned char* Ab = smem + buf * STAGE + (wm * TM) * 128;
+      const unsigned char* Bb = smem + buf * STAGE + ABYTES + (wn * TN) * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fo = ks ? foff1 : foff0;
-      bf16x8_t wf[NI], xf[NJ];
-#if RCGAN_PROBE == 2      /* probe: no LDS reads */
+      for (int ks = 0; ks < 2; ++ks) {
+        const int fo = ks ? foff1 : foff0;
+        bf16x8_t wf[NI], xf[NJ];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(fo + i, kt, lane, 3));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) xf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(fo, kt + j, lane, 5));
-      (void)Ab; (void)Bb;
-#else
-#pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * 128 + fo);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        uint4 v = *(const uint4*)(Ab + j * 16 * 128 + fo);
-        v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
-        xf[j] = __builtin_bit_cast(bf16x8_t, v);
-      }
-#endif
-#if RCGAN_PROBE == 1      /* probe: no MFMA */
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * 128 + fo);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          uint4 p = __builtin_bit_cast(uint4, wf[i]), q = __builtin_bit_cast(uint4, xf[j]);
-          acc[i][j][0] += __builtin_bit_cast(float, p.x ^ q.x ^ p.y ^ q.y ^ p.z ^ q.z ^ p.w ^ q.w);
+          uint4 v = *(const uint4*)(Ab + j * 16 * 128 + fo);
+          v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+          xf[j] = __builtin_bit_cast(bf16x8_t, v);
         }
-#else
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (++buf == NS) buf = 0;
+  }
+
+  if (KS > 1) {
+    // sum the groups' partial tiles in group order: groups 1.. park their accumulators in LDS (the pipelines are idle)
+    __syncthreads();
+    float* part = (float*)smem_all;                 // [KS-1][256 threads][NI*NJ*4]
+    constexpr int PER = NI * NJ * 4;
+    if (grp > 0) {
+      float* dst = part + ((grp - 1) * 256 + (tid & 255)) * PER;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#endif
+        for (int j = 0; j < NJ; ++j) *(f32x4_t*)(dst + (i * NJ + j) * 4) = acc[i][j];
     }
-    if (++buf == NS) buf = 0;
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* src = part + ((g - 1) * 256 + tid) * PER;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] += *(const f32x4_t*)(src + (i * NJ + j) * 4);
+    }
   }
 
 #pragma unroll
@@ -990,19 +1009,19 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int KS = 1>
 static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  size_t lds = (size_t)NS * (BM + BN) * 128;
+  size_t lds = (size_t)KS * NS * (BM + BN) * 128;
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), a.Cout / BN);
   {
     ProfScope ps(ctx, BM >= 128 ? RCGAN_PROF_CONV_MFMA_128 : RCGAN_PROF_CONV_MFMA_64,
                  2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN, NS>), grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN, NS, KS>), grid, dim3(256 * KS), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -1015,7 +1034,13 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
     // small grids are latency-bound (one HBM/L2 round trip per K-tile): deepen the pipeline; large grids
     // prefer the smaller LDS footprint (more resident workgroups)
     static const int ns4_max = env_int("RCGAN_NS4_MAXBLK", 0);
+    static const int ks4_max = env_int("RCGAN_KS4_MAXBLK", 288), ks2_max = env_int("RCGAN_KS2_MAXBLK", 576);
     const long blocks = (long)cdiv(a.M, BM) * (a.Cout / BN);
+    const int ktiles = a.KH * a.KW * a.Cin / 64;
+    if constexpr (BM == 64) {
+      if (blocks <= ks4_max && ktiles >= 8) return launch_conv_glds<BM, BN, 2, 4>(ctx, a);
+      if (blocks <= ks2_max && ktiles >= 4) return launch_conv_glds<BM, BN, 2, 2>(ctx, a);
+    }
     if (blocks <= ns4_max) return launch_conv_glds<BM, BN, 4>(ctx, a);
     return launch_conv_glds<BM, BN, 2>(ctx, a);
   }
