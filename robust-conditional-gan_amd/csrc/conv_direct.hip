@@ -365,6 +365,70 @@ int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int 
 template int colsum_launch<float>(rcgan_ctx*, const float*, long, int, float*, int, float*);
 template int colsum_launch<bf16_t>(rcgan_ctx*, const bf16_t*, long, int, float*, int, float*);
 
+// ---- tiny dense layers (a few thousand outputs): one thread per output element.  The 64x64-tile GEMM would run
+//      them in 1-4 workgroups, i.e. on 1-4 of the 256 CUs, for the whole reduction; here the outputs spread over
+//      the chip and each thread walks the reduction with independent, cache-resident loads.
+//      MODE 0: y[m][n] = x[m][:] . w[:][n] (/sigma) + b[n]      MODE 1: dx[m][k] (+)= dy[m][:] . w[k][:] (/sigma)
+//      MODE 2: dw[k][n] (+)= x[:][k] . dy[:][n]
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void linear_tiny_kernel(int m, int k, int n, const T* a, const void* bptr, const float* wscale,
+                                                          const float* bias, void* out, int accumulate) {
+  const int rows = MODE == 2 ? k : m, cols = MODE == 1 ? k : n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx - r * cols;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (MODE == 0) {
+    const T* x = a + (long)r * k;
+    const float* w = (const float*)bptr + c;
+    int q = 0;
+    for (; q + 4 <= k; q += 4) {
+      s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
+      s1 = fmaf(Elem<T>::ld(x + q + 1), w[(long)(q + 1) * n], s1);
+      s2 = fmaf(Elem<T>::ld(x + q + 2), w[(long)(q + 2) * n], s2);
+      s3 = fmaf(Elem<T>::ld(x + q + 3), w[(long)(q + 3) * n], s3);
+    }
+    for (; q < k; ++q) s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
+  } else if (MODE == 1) {
+    const T* dy = a + (long)r * n;
+    const float* w = (const float*)bptr + (long)c * n;
+    int q = 0;
+    for (; q + 4 <= n; q += 4) {
+      s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
+      s1 = fmaf(Elem<T>::ld(dy + q + 1), w[q + 1], s1);
+      s2 = fmaf(Elem<T>::ld(dy + q + 2), w[q + 2], s2);
+      s3 = fmaf(Elem<T>::ld(dy + q + 3), w[q + 3], s3);
+    }
+    for (; q < n; ++q) s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
+  } else {
+    const T* x = a + r;
+    const T* dy = (const T*)bptr + c;
+    int q = 0;
+    for (; q + 4 <= m; q += 4) {
+      s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
+      s1 = fmaf(Elem<T>::ld(x + (long)(q + 1) * k), Elem<T>::ld(dy + (long)(q + 1) * n), s1);
+      s2 = fmaf(Elem<T>::ld(x + (long)(q + 2) * k), Elem<T>::ld(dy + (long)(q + 2) * n), s2);
+      s3 = fmaf(Elem<T>::ld(x + (long)(q + 3) * k), Elem<T>::ld(dy + (long)(q + 3) * n), s3);
+    }
+    for (; q < m; ++q) s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
+  }
+  float v = (s0 + s1) + (s2 + s3);
+  if (MODE != 2 && wscale) v /= *wscale;
+  if (MODE == 0) {
+    if (bias) v += bias[c];
+    Elem<T>::st((T*)out + idx, v);
+  } else if (MODE == 1) {
+    T* p = (T*)out + idx;
+    if (accumulate) v += Elem<T>::ld(p);
+    Elem<T>::st(p, v);
+  } else {
+    float* p = (float*)out + idx;
+    *p = accumulate ? *p + v : v;
+  }
+}
+
+static inline bool linear_tiny(long outputs, long red) { return outputs <= 65536 && red <= 4096; }
+
 // y[row][n <= 16]: the GEMM tiling would put the whole reduction in one workgroup (one 64-column tile); here one
 // workgroup per row splits K over its 256 threads (the RCGAN permutation classifier: [B,3072] x [3072,10]).
 template <typename T>
@@ -404,6 +468,12 @@ int linear_fwd(rcgan_ctx* ctx, long m, long k, long n, const T* x, const float* 
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
   }
+  if (linear_tiny(m * n, k)) {
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 0>), dim3(cdiv(m * n, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)w,
+                       wscale, bias, (void*)y, 0);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   LinFwdOp<T> op;
   op.x = x; op.w = w; op.bias = bias; op.y = y; op.wscale = wscale;
   op.M = m; op.N = n; op.R = k; op.r_chunk = k;
@@ -414,6 +484,12 @@ template int linear_fwd<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, con
 
 template <typename T>
 int linear_dgrad(rcgan_ctx* ctx, long m, long k, long n, const T* dy, const float* w, const float* wscale, T* dx, int accumulate) {
+  if (linear_tiny(m * k, n)) {
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 1>), dim3(cdiv(m * k, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, dy, (const void*)w,
+                       wscale, (const float*)nullptr, (void*)dx, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   LinDgradOp<T> op;
   op.dy = dy; op.w = w; op.dx = dx; op.accumulate = accumulate; op.wscale = wscale;
   op.M = m; op.N = k; op.R = n; op.r_chunk = n;
@@ -430,6 +506,14 @@ size_t linear_wgrad_ws_bytes(long m, long k, long n) {
 template <typename T>
 int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy, float* dw, float* dbias, int accumulate,
                  void* ws, size_t ws_bytes) {
+  if (linear_tiny(k * n, m)) {
+    if (ws_bytes < linear_wgrad_ws_bytes(m, k, n)) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", linear_wgrad_ws_bytes(m, k, n), ws_bytes);
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 2>), dim3(cdiv(k * n, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)dy,
+                       (const float*)nullptr, (const float*)nullptr, (void*)dw, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    if (dbias) return colsum_launch<T>(ctx, dy, m, (int)n, dbias, accumulate, (float*)ws);
+    return RCGAN_OK;
+  }
   LinWgradOp<T> op;
   op.x = x; op.dy = dy; op.wscale = nullptr; op.accumulate = accumulate;
   op.M = k; op.N = n; op.R = m;
