@@ -106,8 +106,15 @@ def kernel_roofline(m, pool):
     if n.value == 0 or ms.value <= 0:
         return None
     achieved = fl.value / (ms.value * 1e-3) / 1e12
+    # HBM bytes per launch of this kernel: measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+    # WRITE_SIZE cannot share a pass; corrections as MI355X_MICROARCH.md prescribes) and committed with the profile
+    traffic = None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv128.json")
+    if os.path.exists(tf):
+        with open(tf) as f:
+            traffic = float(json.load(f)["traffic_bytes_per_launch"])
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "kernel": "conv_mfma_glds_kernel<128,128>", "launches_per_iteration": n.value,
             "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
             "flops_per_launch_avg": fl.value / n.value}
