@@ -198,6 +198,9 @@ int rcgan_upsample2_fwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, c
 int rcgan_upsample2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, const void* dy, void* dx, int accumulate);
 /* y[n,h,w,:c1] = x ; y[n,h,w,c1:] = onehot rows yb[n,:c2]  (conv_cond_concat, mnist/ops.py:46-51);
  * the adjoint copies the first c1 channels back. */
+/* Zero-pad the channel axis: y[rows][before + c + after] (tf.pad; the option-A shortcut of the generated-label-accuracy
+   classifier, cifar10/resnet-110/graph_optimized.pb used by gan_resnet.py:424-455).  Inference only. */
+int rcgan_pad_channels(rcgan_ctx* ctx, size_t rows, int c, int before, int after, int dtype, const void* x, void* y);
 int rcgan_concat_channels_fwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* x,
                               const float* yb, void* y);
 int rcgan_concat_channels_bwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* dy, void* dx);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "rcgan_meanpool2_bwd": (I, [P, I, I, I, I, I, P, P, I]),
     "rcgan_upsample2_fwd": (I, [P, I, I, I, I, I, P, P]),
     "rcgan_upsample2_bwd": (I, [P, I, I, I, I, I, P, P, I]),
+    "rcgan_pad_channels": (I, [P, SZ, I, I, I, I, P, P]),
     "rcgan_concat_channels_fwd": (I, [P, I, I, I, I, I, P, P, P]),
     "rcgan_concat_channels_bwd": (I, [P, I, I, I, I, I, P, P]),
     "rcgan_preprocess_cifar": (I, [P, I, P, P, I, P]),

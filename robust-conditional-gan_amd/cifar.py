@@ -533,6 +533,16 @@ class CifarRCGAN:
                     ctx.view(t).copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sd[k], np.float32).reshape(-1))))
         ctx.sync()
 
+    def confusion_matrix_value(self):
+        """The confusion matrix the losses use, as a host array [10,10]: softmax of the learned logits (rcgan-u) or the
+        fixed one-coin matrix (gan_resnet.py:499-524)."""
+        ctx = self.ctx
+        if self.PC is None:
+            return ctx.download(self.inp["C_const"]).reshape(VOCAB_SIZE, VOCAB_SIZE)
+        logits = self.PC.get("confusion_logits").astype(np.float64)
+        e = np.exp(logits - logits.max(axis=1, keepdims=True))
+        return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
     def sample(self, labels, z):
         """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32."""
         ctx, g = self.ctx, self.graph

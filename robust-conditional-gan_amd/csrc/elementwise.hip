@@ -283,6 +283,19 @@ __global__ void rng_fill_kernel(size_t count, int kind, float lo, float hi, uint
 
 __global__ void rng_advance_kernel(uint64_t* state, uint64_t n) { state[0] += n; }
 
+// y[row][before + c] = x[row][c], zero in the `before` leading and `after` trailing channels (tf.pad on the channel axis:
+// the option-A shortcut of the label-classifier ResNet, resnet-110/graph_optimized.pb nodes conv{2,3}_0/Pad)
+template <typename T>
+__global__ void pad_channels_kernel(size_t rows, int c, int before, int after, const T* x, T* y) {
+  const int co = before + c + after;
+  const size_t total = rows * (size_t)co;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % co) - before;
+    const size_t r = i / co;
+    Elem<T>::st(y + i, (ch >= 0 && ch < c) ? Elem<T>::ld(x + r * c + ch) : 0.f);
+  }
+}
+
 extern "C" {
 
 int rcgan_rng_fill(rcgan_ctx* ctx, size_t count, int dtype, int kind, float lo, float hi, uint64_t seed, void* state, void* y) {
@@ -388,6 +401,15 @@ int rcgan_upsample2_bwd(rcgan_ctx* ctx, int n, int h, int w, int c, int dtype, c
     return RCGAN_OK;
   }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, h, w, c, (const T*)dy, (const T*)nullptr, (T*)dx, accumulate));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_pad_channels(rcgan_ctx* ctx, size_t rows, int c, int before, int after, int dtype, const void* x, void* y) {
+  RC_REQUIRE(ctx, c > 0 && before >= 0 && after >= 0, "bad channel padding %d + %d + %d", before, c, after);
+  const size_t cnt = rows * (size_t)(before + c + after);
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(pad_channels_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, rows, c, before, after,
+                                                   (const T*)x, (T*)y));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

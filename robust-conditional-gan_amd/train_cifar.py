@@ -133,6 +133,25 @@ def main(argv=None):
         m.set_inputs(images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
                      inv_weights=sh(inv), labels_all=np.concatenate([sh(labels), sh(second)]))
 
+    # generated-label accuracy (gan_resnet.py:424-455, 847-861): 1000 samples, 100 per class, ONE classifier batch
+    label_100_list = [label for label in range(10) for _ in range(10)]
+    GEN_ACC_FREQ = FLAGS.generated_label_accuracy_freq
+    acc_state = {"clf": None, "max": 0.0}
+
+    def save_samples(n):
+        all_samples = [m.sample(label_100_list, np.random.normal(size=(100, Z_DIM)).astype('float32')) for _ in range(int(n / 100))]
+        all_samples = ((np.concatenate(all_samples, axis=0) + 1.) * (255.99 / 2)).astype('int32')     # gan_resnet.py:858
+        return all_samples.reshape((-1, 32, 32, 3)), np.concatenate([label_100_list] * int(n / 100), axis=0)
+
+    def label_accuracy(confusion_matrix=None):
+        from .eval_cifar import LabelClassifier, generated_label_accuracy
+        if acc_state["clf"] is None:
+            acc_state["clf"] = LabelClassifier(local)
+        samples, labels = save_samples(1000)
+        acc = generated_label_accuracy(samples, labels, confusion_matrix=confusion_matrix, classifier=acc_state["clf"])
+        logging.info('generated label accuracy: {}'.format(acc))
+        return acc
+
     _random_labels_G, _labels_biased_G = next(gen_G)
     for iteration in range(ITERS):                                             # gan_resnet.py:919-1016
         t0 = time.time()
@@ -153,13 +172,27 @@ def main(argv=None):
             samples = m.sample(fixed_labels, fixed_noise)
             samples = ((samples + 1.) * (255. / 2)).astype('int32')             # gan_resnet.py:831
             save_images(samples.reshape((100, 32, 32, 3)), os.path.join(DIR, 'samples_{}.png'.format(iteration)))
+        if rank == 0 and GEN_ACC_FREQ > 0 and iteration % GEN_ACC_FREQ == GEN_ACC_FREQ - 1:            # gan_resnet.py:995-1005
+            logging.info('starting calculating generated label accuracy.')
+            accuracy = label_accuracy()
+            acc_state["max"] = max(acc_state["max"], accuracy)
+            plot.plot('gen_label_acc', accuracy)
+            plot.plot('gen_label_acc_max', acc_state["max"])
+            logging.info('finished calculating generated label accuracy.')
         if rank == 0 and ((iteration < 500 and iteration % 100 == 99) or (iteration % 1000 == 999)):
             plot.dir_flush(DIR)
             saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', iteration)
         plot.tick()
+    if rank == 0 and GEN_ACC_FREQ > 0:                                          # gan_resnet.py:1021-1035
+        cm = m.confusion_matrix_value() if FLAGS.perm_gen_label_acc else None
+        logging.info('starting calculating %sgenerated label accuracy.' % ('min. permuted ' if cm is not None else ''))
+        plot.plot('gen_label_acc', label_accuracy(cm))
+        logging.info('finished calculating generated label accuracy.')
     if rank == 0 and ITERS:
         plot.dir_flush(DIR)
         saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', max(ITERS - 1, 0))
+    if acc_state["clf"] is not None:
+        acc_state["clf"].close()
     m.ctx.close()
     return DIR
 

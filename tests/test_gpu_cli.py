@@ -9,15 +9,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_train_cli_layout_and_restore(tmp_path):
+def test_train_cli_layout_and_restore(tmp_path, caplog):
     import rcgan_amd  # noqa: F401
     from rcgan_amd.host import latest_checkpoint, load_checkpoint
     from rcgan_amd.train_cifar import main
     parent = str(tmp_path)
     argv = ["--dataset", "cifar", "--algorithm", "rcgan-u", "--alpha", "0.6", "--run", "0", "--log_file", os.path.join(parent, "log.txt"),
             "--parent_dir", parent, "--expt_dir", "e1", "--ngpus", "1", "--multi_gpu_multi_batch", "--perm_classifier", "--confuse_init",
-            "--niters", "3", "--batch_size", "8", "--synthetic", "--sample_every", "2", "--noaux_classifier", "--bogus_flag", "7"]
-    d = main(argv)
+            "--niters", "3", "--batch_size", "8", "--synthetic", "--sample_every", "2", "--noaux_classifier", "--bogus_flag", "7",
+            "--generated_label_accuracy_freq", "2", "--perm_gen_label_acc"]
+    import logging
+    with caplog.at_level(logging.INFO):
+        d = main(argv)
+    log = caplog.text
+    assert log.count("generated label accuracy: ") == 2 and "min. permuted generated label accuracy" in log
+    assert glob.glob(os.path.join(d, "gen_label_acc.jpg"))
     assert os.path.isdir(os.path.join(d, "scripts")) and os.path.exists(os.path.join(d, "scripts", "command.txt"))
     assert os.path.exists(os.path.join(d, "samples_1.png"))
     from PIL import Image
