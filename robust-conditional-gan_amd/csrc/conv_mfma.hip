@@ -1083,7 +1083,8 @@ static int wgrad3_enabled() {
 }
 
 static long wgrad_clamp_splits(long want, long M) {
-  long maxs = (M + 511) / 512;
+  static const int min_px = env_int("RCGAN_WGRAD_MINPX", 256);
+  long maxs = (M + min_px - 1) / min_px;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 128) want = 128;
