@@ -108,6 +108,10 @@ size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
  * cifar10/common/ops/conv2d.py:181-216.  x: [n, h(/2), w(/2), cin]; y: [n, oh, ow, cout]. */
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
                      const float* bias /* or NULL */, void* y);
+/* y = conv2d_SAME(x, w) (+bias) + residual: the pre-activation residual sum `shortcut + output` of
+ * gan_resnet.py:328 folded into the convolution's epilogue.  residual: [n, oh, ow, cout] or NULL, must not alias y. */
+int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
+                              const float* bias /* or NULL */, const void* residual /* or NULL */, void* y);
 /* dx = d(conv)/dx.  With IN_RELU, dx is masked by x>0 (x = the pre-activation input).  With
  * IN_UPSAMPLE2X dx is the gradient w.r.t. the low-resolution input.  ACCUMULATE: dx += ...
  * Replaces tf.nn.conv2d_backprop_input (autodiff of the above).  ws: rcgan_conv_workspace_bytes. */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rcgan_conv_prepare_batch": (I, [P, C.POINTER(PrepareItem), I]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
+    "rcgan_conv2d_fwd_residual": (I, [P, DP, P, P, P, P, P]),
     "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),
     "rcgan_conv2d_bwd_weight": (I, [P, DP, P, P, P, P, I, P, SZ]),
     "rcgan_deconv2d_fwd": (I, [P, DP, P, P, P, P]),

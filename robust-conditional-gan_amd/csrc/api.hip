@@ -283,14 +283,29 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
 }
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
+  return rcgan_conv2d_fwd_residual(ctx, d, x, prepared, bias, nullptr, y);
+}
+
+int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
+                              const void* residual, void* y) {
   int rc = check_desc(ctx, d);
   if (rc) return rc;
+  if (residual != nullptr && !mfma_eligible(d)) {      // other kernels: plain forward, then y += residual
+    RC_REQUIRE(ctx, residual != y, "residual must not alias the output");
+    rc = rcgan_conv2d_fwd_residual(ctx, d, x, prepared, bias, nullptr, y);
+    if (rc) return rc;
+    int oh, ow, p;
+    same_pad(d->h, d->kh, d->stride, &oh, &p);
+    same_pad(d->w, d->kw, d->stride, &ow, &p);
+    return rcgan_axpby(ctx, (size_t)d->n * oh * ow * d->cout, d->dtype, 1.f, residual, 1.f, y);
+  }
   if (mfma_eligible(d)) {
     if ((long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31))
       RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tensor exceeds the 32-bit element offsets of the MFMA kernels");
     MfmaConvArgs a;
     fill_mfma_args(d, a);
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+    a.resid = (const bf16_t*)residual;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cin; a.Cout = d->cout;
     a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
@@ -327,6 +342,7 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
     fill_mfma_args(d, a);
     size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared + elems; a.bias = nullptr; a.mask = (const bf16_t*)mask;
+    a.resid = nullptr;
     a.out = (bf16_t*)target;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cout; a.Cout = d->cin;          // reduction over cout, output channels = cin

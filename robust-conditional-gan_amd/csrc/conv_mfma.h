@@ -7,6 +7,7 @@ struct MfmaConvArgs {
   const bf16_t* wt;       // [Cout][T*Cin]
   const float* bias;      // [Cout] or null
   const bf16_t* mask;     // [M][Cout] or null: output zeroed where mask <= 0 (ReLU backward)
+  const bf16_t* resid;    // [M][Cout] or null: added to the output (residual connection, gan_resnet.py:328)
   bf16_t* out;            // [M][Cout]
   const bf16_t* zero;     // >= 16 zero bytes (halo source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;

@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
         v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
         v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
       }
+      if (a.resid) {
+        const uint2 o = *(const uint2*)(a.resid + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
       uint2 pk;
       pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
       pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
@@ -377,6 +382,11 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
       }
       if (a.accumulate) {
         const uint2 o = *(const uint2*)(a.out + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      if (a.resid) {
+        const uint2 o = *(const uint2*)(a.resid + off);
         v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
         v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
       }

@@ -159,11 +159,13 @@ def spectral_norm_batch(ctx, entries):
 # ----------------------------------------------------------------------------------------------------
 # convolution / dense
 # ----------------------------------------------------------------------------------------------------
-def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumulate_into=None, force_direct=False):
+def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumulate_into=None, force_direct=False,
+           residual=None):
     """SAME conv on NHWC x with HWIO weight [k,k,cin,cout] (tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
     cifar10/common/ops/conv2d.py:181-216).  in_up / in_relu fold the preceding nearest-2x upsample
     (gan_resnet.py:263-264) and ReLU into the operand load; accumulate_into adds the result into an
-    existing tensor (the residual sum of gan_resnet.py:328)."""
+    existing tensor (the residual sum of gan_resnet.py:328); residual adds another tensor in the epilogue
+    (y = conv + residual: the identity-shortcut blocks, where the shortcut is the block input itself)."""
     n, hs, ws_, cin = x.shape
     h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
     cout = weight.param.shape[-1]
@@ -180,9 +182,13 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     else:
         y = ctx.empty((n, oh, ow, cout), x.dtype)
         fdesc = desc
-    ctx.check(ctx.lib.rcgan_conv2d_fwd(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(y)))
+    if residual is not None:
+        assert residual.shape == (n, oh, ow, cout) and accumulate_into is None, (residual.shape, (n, oh, ow, cout))
+        ctx.check(ctx.lib.rcgan_conv2d_fwd_residual(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(residual), _p(y)))
+    else:
+        ctx.check(ctx.lib.rcgan_conv2d_fwd(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(y)))
     prev_req = y.req if accumulate_into is not None else False
-    if _track(ctx, y, x, weight.param, bias) or prev_req:
+    if _track(ctx, y, x, weight.param, bias, residual) or prev_req:
         y.req = True
         xr, wr, br = x.req, weight.req, (bias is not None and bias.req)
 
@@ -203,6 +209,13 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
                                                               C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
                 else:
                     raise NotImplementedError("bias-only gradient")
+            if residual is not None and residual.req:
+                # d(residual) = dy.  dy is dead after this closure: a residual without a gradient yet adopts the
+                # buffer (later contributions accumulate into it in place), otherwise one accumulate
+                if residual.grad is None:
+                    residual.grad = dy
+                else:
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, residual.size, residual.dtype, 1.0, _p(dy), 1.0, _p(residual.grad)))
         ctx.record(bw)
     return y
 

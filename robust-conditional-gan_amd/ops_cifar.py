@@ -40,9 +40,9 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
            conv_type='conv2d', channel_multiplier=0, padding='SAME',
            spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
            mask_type=None, weightnorm=None, biases=True, gain=1.,
-           _in_upsample=False, _in_relu=False, _accumulate_into=None):
+           _in_upsample=False, _in_relu=False, _accumulate_into=None, _residual=None):
     """cifar10/common/ops/conv2d.py:31-218 (conv2d path).  The underscore arguments are this build's
-    fusion hooks (nearest-2x upsample / ReLU folded into the operand load, residual accumulate)."""
+    fusion hooks (nearest-2x upsample / ReLU folded into the operand load, residual accumulate / residual add)."""
     if conv_type != 'conv2d':
         raise NotImplementedError('{0} is not supported!'.format(conv_type))
     if mask_type is not None or weightnorm or inputs_norm or padding != 'SAME' or gain != 1.:
@@ -59,7 +59,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
     if inputs.shape[-1] != input_dim:
         raise ValueError("input_dim %d does not match inputs %s" % (input_dim, inputs.shape))
     return O.conv2d(g.ctx, inputs, w, b, filter_size, stride, in_up=_in_upsample, in_relu=_in_relu,
-                    accumulate_into=_accumulate_into)
+                    accumulate_into=_accumulate_into, residual=_residual)
 
 
 def Linear(inputs, input_dim, output_dim, name,

@@ -102,6 +102,39 @@ def test_conv2d_fwd_bwd(dev, case):
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "conv dbias %s" % (case,))
 
 
+@pytest.mark.parametrize("cin", [64, 6])
+def test_conv_residual_block(dev, cin):
+    """Identity-shortcut block x + conv2(relu(conv1(relu(x)))) with the sum folded into conv2's epilogue
+    (gan_resnet.py:295-328): values and the gradient reaching x (shortcut + masked conv path, same buffer)."""
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(40 + cin)
+    x = _prep(rs.randn(3, 8, 8, cin), mode)
+    w1 = (rs.randn(3, 3, cin, cin) / np.sqrt(9 * cin)).astype(np.float32)
+    w2 = (rs.randn(3, 3, cin, cin) / np.sqrt(9 * cin)).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    p1, p2 = FakeParam(ctx, w1), FakeParam(ctx, w2)
+    h = O.conv2d(ctx, xd, O.Weight(ctx, p1.t), None, 3, in_relu=True)
+    y = O.conv2d(ctx, h, O.Weight(ctx, p2.t), None, 3, in_relu=True, residual=xd)
+    mf = mode == "bf16" and cin % 64 == 0
+    q = (lambda a: bf16_round(a)) if mf else (lambda a: a)
+    x64 = x.astype(np.float64)
+    h_ref = nn.conv2d_fwd(np.maximum(x64, 0), q(w1).astype(np.float64))
+    hq = bf16_round(h_ref).astype(np.float64) if mode == "bf16" else h_ref
+    ref = x64 + nn.conv2d_fwd(np.maximum(hq, 0), q(w2).astype(np.float64))
+    assert_close(ctx.download(y), ref, TOL[mode] * 2, "residual conv fwd")
+    dy = _prep(rs.randn(*ref.shape), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    dy64 = dy.astype(np.float64)
+    dh = nn.conv2d_bwd_input(dy64, q(w2).astype(np.float64), hq.shape) * (hq > 0)
+    dhq = bf16_round(dh).astype(np.float64) if mode == "bf16" else dh
+    dx = dy64 + nn.conv2d_bwd_input(dhq, q(w1).astype(np.float64), x.shape) * (x64 > 0)
+    assert_close(ctx.download(xd.grad), dx, TOL[mode] * 3, "residual conv dx")
+
+
 def test_conv_accumulate_and_force_direct(dev):
     from rcgan_amd import ops as O
     ctx, mode = dev
