@@ -55,6 +55,13 @@ int rcgan_destroy(rcgan_ctx* ctx);
 const char* rcgan_last_error(rcgan_ctx* ctx);
 const char* rcgan_version(void);
 int rcgan_set_stream(rcgan_ctx* ctx, void* stream);
+/* Fork/join onto the context's second stream: launches between side_begin and side_end run on it, ordered after
+ * everything issued before the fork; side_join makes the main stream wait for them.  Used to run a layer's filter
+ * gradient next to its data gradient (two sess.run-internal independent TF ops: conv2d_backprop_filter /
+ * conv2d_backprop_input).  Works under rcgan_graph_begin/end (becomes a fork/join in the captured graph). */
+int rcgan_side_begin(rcgan_ctx* ctx);
+int rcgan_side_end(rcgan_ctx* ctx);
+int rcgan_side_join(rcgan_ctx* ctx);
 int rcgan_stream_sync(rcgan_ctx* ctx);
 /* HIP-event timing on the ctx stream (bench.py roofline leg): slot in [0,64). */
 int rcgan_event_record(rcgan_ctx* ctx, int slot);

@@ -55,6 +55,9 @@ SIGNATURES = {
     "rcgan_last_error": (C.c_char_p, [P]),
     "rcgan_version": (C.c_char_p, []),
     "rcgan_set_stream": (I, [P, P]),
+    "rcgan_side_begin": (I, [P]),
+    "rcgan_side_end": (I, [P]),
+    "rcgan_side_join": (I, [P]),
     "rcgan_stream_sync": (I, [P]),
     "rcgan_event_record": (I, [P, I]),
     "rcgan_event_elapsed_ms": (I, [P, I, I, C.POINTER(F)]),

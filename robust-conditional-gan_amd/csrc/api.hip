@@ -85,6 +85,13 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->devtmp_bytes = 0;
   c->prof_which = 0;
   c->prof_flops = 0.0;
+  c->main_stream = c->stream; c->side_stream = nullptr; c->fork_ev = nullptr; c->join_ev = nullptr; c->on_side = false;
+  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return RCGAN_EHIP;
+  }
   c->zero_page = nullptr;
   if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
     delete c;
@@ -102,13 +109,45 @@ int rcgan_destroy(rcgan_ctx* ctx) {
   for (auto g : ctx->graphs)
     if (g) (void)hipGraphExecDestroy(g);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+  if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
   return RCGAN_OK;
 }
 
 const char* rcgan_last_error(rcgan_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
-int rcgan_set_stream(rcgan_ctx* ctx, void* stream) { ctx->stream = (hipStream_t)stream; return RCGAN_OK; }
+int rcgan_set_stream(rcgan_ctx* ctx, void* stream) {
+  RC_REQUIRE(ctx, !ctx->on_side, "set_stream inside a side section");
+  ctx->stream = ctx->main_stream = (hipStream_t)stream;
+  return RCGAN_OK;
+}
+
+// Fork: launches issued until rcgan_side_end go to the side stream, ordered after everything issued so far on the main
+// stream.  Join: the main stream waits for the side section.  Between end and join the two streams run concurrently.
+int rcgan_side_begin(rcgan_ctx* ctx) {
+  RC_REQUIRE(ctx, !ctx->on_side, "side sections do not nest");
+  RC_HIP(ctx, hipEventRecord(ctx->fork_ev, ctx->main_stream));
+  RC_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->fork_ev, 0));
+  ctx->stream = ctx->side_stream;
+  ctx->on_side = true;
+  return RCGAN_OK;
+}
+
+int rcgan_side_end(rcgan_ctx* ctx) {
+  RC_REQUIRE(ctx, ctx->on_side, "no side section open");
+  RC_HIP(ctx, hipEventRecord(ctx->join_ev, ctx->side_stream));
+  ctx->stream = ctx->main_stream;
+  ctx->on_side = false;
+  return RCGAN_OK;
+}
+
+int rcgan_side_join(rcgan_ctx* ctx) {
+  RC_REQUIRE(ctx, !ctx->on_side, "close the side section first");
+  RC_HIP(ctx, hipStreamWaitEvent(ctx->main_stream, ctx->join_ev, 0));
+  return RCGAN_OK;
+}
 
 int rcgan_stream_sync(rcgan_ctx* ctx) {
   RC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -24,6 +24,11 @@ struct rcgan_ctx {
   int prof_which;
   std::vector<hipEvent_t> prof_ev;
   double prof_flops;
+  // fork/join onto a second stream (rcgan_side_begin/end/join): lets an independent kernel pair -- a layer's filter
+  // gradient and its data gradient -- share the chip when neither fills it.  Capturable (event fork/join).
+  hipStream_t main_stream, side_stream;
+  hipEvent_t fork_ev, join_ev;
+  bool on_side;
   void* zero_page;     // 4 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
                        // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels
   unsigned* counters() const { return (unsigned*)((char*)zero_page + 1024); }

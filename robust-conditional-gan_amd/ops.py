@@ -196,19 +196,27 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
             dy = y.grad
             if dy is None:
                 return
+            if br and not wr:
+                raise NotImplementedError("bias-only gradient")
+            # filter gradient and data gradient only share their inputs: run them side by side on two streams (most
+            # layers of these nets leave the chip half empty); the filter gradient gets its own workspace
+            fork = bool(xr and wr and ctx.overlap)
+            if wr:
+                dw = weight.grad_target()
+                if fork:
+                    ctx.check(ctx.lib.rcgan_side_begin(ctx.h))
+                ctx.check(ctx.lib.rcgan_conv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(dw),
+                                                          _p(bias.grad) if br else None, 1,
+                                                          C.c_void_p(ctx.ws2_ptr if fork else ctx.ws_ptr), ctx.ws_bytes))
+                if fork:
+                    ctx.check(ctx.lib.rcgan_side_end(ctx.h))
             if xr:
                 dx, acc = grad_of(ctx, x)
                 d2 = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_ACCUMULATE if acc else 0))
                 ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
                                                         _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
-            if wr or br:
-                dw = weight.grad_target() if wr else None
-                if wr:
-                    ctx.check(ctx.lib.rcgan_conv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(dw),
-                                                              _p(bias.grad) if br else None, 1,
-                                                              C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
-                else:
-                    raise NotImplementedError("bias-only gradient")
+            if fork:
+                ctx.check(ctx.lib.rcgan_side_join(ctx.h))
             if residual is not None and residual.req:
                 # d(residual) = dy.  dy is dead after this closure: a residual without a gradient yet adopts the
                 # buffer (later contributions accumulate into it in place), otherwise one accumulate

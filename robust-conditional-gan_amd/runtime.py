@@ -15,6 +15,8 @@ kernels.  Layout in HBM (one process per GPU, sized for 288 GB):
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -117,6 +119,12 @@ class Context:
         self.arena = Arena(arena_bytes, self.device)
         self.ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device)
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), int(ws_bytes)
+        # opt-in (RCGAN_OVERLAP=1): filter gradients launched on a side stream next to their data gradient, with their own
+        # workspace.  Measured on MI355X: 12.1 ms/iteration with the fork/join in the captured graph vs 11.4 without --
+        # the graph's cross-stream dependencies cost more than the idle CUs they fill -- so it stays off.
+        self.overlap = os.environ.get("RCGAN_OVERLAP", "0") == "1"
+        self.ws2 = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device) if self.overlap else None
+        self.ws2_ptr = self.ws2.data_ptr() if self.overlap else 0
         self.tape = []
         self.recording = True
         self._keep = []
