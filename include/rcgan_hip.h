@@ -176,6 +176,10 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
 int rcgan_bn_infer(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, const float* gamma,
                    const float* beta, const float* moving_mean, const float* moving_var, float eps,
                    int act, void* y);
+/* Its adjoint w.r.t. x: dx (= or +=) dy * act'(y) * gamma / sqrt(moving_var + eps).  Used by recover_labels
+ * (mnist/model.py:494-640), which differentiates the frozen sampler w.r.t. its latent input. */
+int rcgan_bn_infer_bwd(rcgan_ctx* ctx, int rows, int c, int dtype, const void* y, const void* dy, const float* gamma,
+                       const float* moving_var, float eps, int act, void* dx, int accumulate);
 
 /* ---- spectral normalisation (mnist/sn.py:31-75 == cifar10/common/ops/sn.py:31-75) --------------- */
 typedef struct rcgan_sn_item {
@@ -266,6 +270,12 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
  * (perm regulariser: gan_resnet.py:693-694,782-783; mnist/model.py:218-221). */
 int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels,
                              float weight, float* loss_acc, float* dx);
+/* recover_labels objective (mnist/model.py:533-537): gen [r*ydim, pix] = one generated image per (real sample r, label y),
+ * actual [r, pix], yrec [r, ydim] = softmax of the recovered label logits.
+ *   loss = mean_r sum_y yrec[r,y] * mean_pix (actual[r] - gen[r,y])^2
+ * Writes loss [1], dgen (same shape as gen, or NULL) and dyrec [r, ydim] (or NULL).  ws: r*ydim floats. */
+int rcgan_recover_mse_fwd_bwd(rcgan_ctx* ctx, int r, int ydim, int pix, int dtype, const void* gen, const void* actual,
+                              const float* yrec, float* loss, void* dgen, float* dyrec, void* ws, size_t ws_bytes);
 /* C = softmax(logits) row-wise and its adjoint (gan_resnet.py:522, mnist/model.py:106). */
 int rcgan_softmax_rows_fwd(rcgan_ctx* ctx, int rows, int cols, const float* logits, float* p);
 int rcgan_softmax_rows_bwd(rcgan_ctx* ctx, int rows, int cols, const float* p, const float* dp, float* dlogits,

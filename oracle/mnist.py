@@ -130,8 +130,8 @@ class Net:
             if self.cfg.get("update_moving", True):
                 self.S[name + "/moving_mean"], self.S[name + "/moving_variance"] = st["moving_mean"], st["moving_variance"]
             return y
-        return Var(nn.batch_norm_infer(x.v, g.v, b.v, self.S[name + "/moving_mean"].astype(self.dtype),
-                                       self.S[name + "/moving_variance"].astype(self.dtype)))
+        return self.t.batch_norm_infer(x, g, b, self.S[name + "/moving_mean"].astype(self.dtype),
+                                       self.S[name + "/moving_variance"].astype(self.dtype))
 
     def cond_concat(self, x, y):
         # conv_cond_concat (ops.py:46-51) / concat([h, y], 1)
@@ -146,7 +146,7 @@ class Net:
     def generator(self, z, y, train=True):
         p = "generator/"
         B = z.shape[0]
-        h = self.cond_concat(self.const(z), y)
+        h = self.cond_concat(z if isinstance(z, Var) else self.const(z), y)
         h0 = self.t.relu(self.bn(self.linear(h, p + "g_h0_lin"), p + "g_bn0", train))
         h0 = self.cond_concat(h0, y)
         h1 = self.t.relu(self.bn(self.linear(h0, p + "g_h1_lin"), p + "g_bn1", train))
@@ -337,3 +337,21 @@ def sampler(P, S, z, y, dtype=np.float32):
     """gen_sampler (model.py:733-757): inference-mode BN."""
     net = Net(P, S, {}, "none", {}, dtype)
     return net.generator(np.asarray(z, dtype), np.asarray(y, dtype), train=False).v
+
+
+def recover_step(P, S, z, logits, actual, lr, dtype=np.float64):
+    """One iteration of DCGAN.recover_labels (mnist/model.py:519-537, 606-630): z [R*10,100], logits [R,10], actual [R,784].
+    loss = mean_r sum_y softmax(logits)[r,y] * mean_pix (actual[r] - sampler(z[r,y], onehot y))^2; plain SGD on z and logits.
+    Returns (loss, new z, new logits, y_recover)."""
+    net = Net(P, S, {}, "none", {}, dtype)
+    t = net.t
+    R = logits.shape[0]
+    zv, lv = Var(np.asarray(z, dtype), req=True), Var(np.asarray(logits, dtype), req=True)
+    hard_y = np.tile(np.eye(Y_DIM, dtype=dtype), (R, 1))
+    G = net.generator(zv, hard_y, train=False)                                  # [R*10,28,28,1]
+    yrec = t.softmax_rows(lv)
+    diff = t.add(t.reshape(G, (R, Y_DIM, -1)), Var(-np.asarray(actual, dtype).reshape(R, 1, -1)))
+    sq = t.scale(t.sum_axis(t.mul(diff, diff), 2), 1.0 / diff.v.shape[2])      # [R,10]
+    loss = t.scale(t.sum_axis(t.sum_axis(t.mul(sq, yrec), 1), 0), 1.0 / R)
+    t.backward(loss)
+    return float(loss.v), zv.v - lr * zv.g, lv.v - lr * lv.g, yrec.v

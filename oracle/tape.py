@@ -238,6 +238,17 @@ class Tape:
             _acc(beta, db)
         return self.rec(out, bw, x, gamma, beta)
 
+    def batch_norm_infer(self, x, gamma, beta, mm, mv, eps=1e-5):
+        """Inference-mode batch norm (moving statistics), differentiable w.r.t. x only: the frozen sampler that
+        recover_labels (mnist/model.py:494-640) optimises through."""
+        out = Var(nn.batch_norm_infer(x.v, gamma.v, beta.v, mm, mv, eps))
+
+        def bw():
+            if out.g is None:
+                return
+            _acc(x, out.g * (gamma.v / np.sqrt(mv + eps)))
+        return self.rec(out, bw, x)
+
     def spectral_norm(self, w, u_read, u_write, key, update):
         """u_read[key] is the persistent ``u`` ([1,C]) as it stood when the step began: every SN
         evaluation of one weight inside a step sees the same u (the reference leaves the order of

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rcgan_bn_apply_fwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, I, P, P, SZ]),
     "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, SZ]),
     "rcgan_bn_infer": (I, [P, I, I, I, P, P, P, P, P, F, I, P]),
+    "rcgan_bn_infer_bwd": (I, [P, I, I, I, P, P, P, P, F, I, P, I]),
     "rcgan_sn_save_floats": (SZ, [I, I]),
     "rcgan_sn_power_iter": (I, [P, C.POINTER(SnItem), I]),
     "rcgan_sn_bwd": (I, [P, C.POINTER(SnBwdItem), I]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "rcgan_proj_logit_all_bwd": (I, [P, I, I, I, P, P, P, P, P, P, I]),
     "rcgan_loss_fwd_bwd": (I, [P, I, I, I, P, P, F, P, P, P]),
     "rcgan_bce_onehot_fwd_bwd": (I, [P, I, I, P, P, F, P, P]),
+    "rcgan_recover_mse_fwd_bwd": (I, [P, I, I, I, I, P, P, P, P, P, P, P, SZ]),
     "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),
     "rcgan_softmax_rows_bwd": (I, [P, I, I, P, P, P, I]),
     "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),

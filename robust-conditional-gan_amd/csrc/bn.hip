@@ -130,6 +130,21 @@ __global__ void bn_bwd_apply_kernel(long total, long rows, int rows_per_sample, 
   }
 }
 
+// dx (=|+=) dy * act'(y) * gamma / sqrt(moving_var + eps): the adjoint of bn_infer w.r.t. its input (statistics and
+// affine parameters are constants of the frozen sampler, mnist/model.py:494-640 recover_labels)
+template <typename T>
+__global__ void bn_infer_bwd_kernel(long total, int c, const T* y, const T* dy, const float* gamma, const float* mv, float eps, int act,
+                                    T* dx, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    float g = Elem<T>::ld(dy + i);
+    if (act != RCGAN_ACT_NONE) g *= act_grad(act, Elem<T>::ld(y + i));
+    float v = g * gamma[ch] / sqrtf(mv[ch] + eps);
+    if (accumulate) v += Elem<T>::ld(dx + i);
+    Elem<T>::st(dx + i, v);
+  }
+}
+
 template <typename T>
 __global__ void bn_infer_kernel(long total, int c, const T* x, const float* gamma, const float* beta, const float* mm,
                                 const float* mv, float eps, int act, T* y) {
@@ -753,6 +768,17 @@ int rcgan_bn_infer(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, co
   long total = (long)rows * c;
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_infer_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total, c,
                                                    (const T*)x, gamma, beta, mm, mv, eps, act, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_bn_infer_bwd(rcgan_ctx* ctx, int rows, int c, int dtype, const void* y, const void* dy, const float* gamma,
+                       const float* mv, float eps, int act, void* dx, int accumulate) {
+  RC_REQUIRE(ctx, act == RCGAN_ACT_NONE || act == RCGAN_ACT_RELU || act == RCGAN_ACT_TANH || act == RCGAN_ACT_SIGMOID,
+             "activation %d has no output-side derivative", act);
+  long total = (long)rows * c;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_infer_bwd_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total, c,
+                                                   (const T*)y, (const T*)dy, gamma, mv, eps, act, (T*)dx, accumulate));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

@@ -183,6 +183,41 @@ static inline int g1(long total) {
   return (int)b;
 }
 
+
+// recover_labels objective (mnist/model.py:533-537): gen holds, for every real sample r, one generated image per
+// label y (row r*ydim + y).  sq[r][y] = mean over pixels of (actual[r] - gen[r,y])^2;
+// loss = mean_r sum_y sq[r][y] * yrec[r][y].  One workgroup per (r, y): writes its loss term, d loss / d yrec and
+// d loss / d gen; the terms are summed in a fixed order by recover_sum_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void recover_mse_kernel(int r_count, int ydim, int pix, const T* gen, const T* actual, const float* yrec,
+                                                          float* terms, T* dgen, float* dyrec) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, r = row / ydim;
+  const T* g = gen + (long)row * pix;
+  const T* a = actual + (long)r * pix;
+  const float w = yrec[row], inv_r = 1.f / (float)r_count, inv_p = 1.f / (float)pix;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < pix; i += 256) {
+    const float d = Elem<T>::ld(g + i) - Elem<T>::ld(a + i);
+    s += d * d;
+    if (dgen) Elem<T>::st(dgen + (long)row * pix + i, 2.f * d * inv_p * w * inv_r);
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) {
+    const float sq = s * inv_p;
+    terms[row] = sq * w * inv_r;
+    if (dyrec) dyrec[row] = sq * inv_r;
+  }
+}
+
+__global__ __launch_bounds__(256) void recover_sum_kernel(int n, const float* terms, float* loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += terms[i];
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) *loss = s;
+}
+
 extern "C" {
 
 int rcgan_act_meanhw_fwd(rcgan_ctx* ctx, int n, int hw, int c, int dtype, int act, const void* x, float* feat) {
@@ -261,6 +296,20 @@ int rcgan_softmax_rows_fwd(rcgan_ctx* ctx, int rows, int cols, const float* l, f
 
 int rcgan_softmax_rows_bwd(rcgan_ctx* ctx, int rows, int cols, const float* p, const float* dp, float* dl, int accumulate) {
   hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, ctx->stream, rows, cols, p, dp, dl, accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_recover_mse_fwd_bwd(rcgan_ctx* ctx, int r_count, int ydim, int pix, int dtype, const void* gen, const void* actual,
+                              const float* yrec, float* loss, void* dgen, float* dyrec, void* ws, size_t ws_bytes) {
+  RC_REQUIRE(ctx, r_count > 0 && ydim > 0 && pix > 0, "bad recover shape [%d,%d,%d]", r_count, ydim, pix);
+  const size_t need = (size_t)r_count * ydim * sizeof(float);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  float* terms = (float*)ws;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(recover_mse_kernel<T>, dim3(r_count * ydim), dim3(256), 0, ctx->stream, r_count, ydim, pix,
+                                                   (const T*)gen, (const T*)actual, yrec, terms, (T*)dgen, dyrec));
+  RC_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(recover_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, r_count * ydim, (const float*)terms, loss);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

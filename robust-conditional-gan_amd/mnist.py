@@ -5,6 +5,8 @@ Host-side mirror of /root/reference mnist/model.py: generator :705-731, gen_samp
 (one D run, then TWO G runs on the same batch).  The reference's five logging-only ``.eval()`` passes per
 iteration (:374-398), which also mutate BN moving averages and SN ``u``, are not executed.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -392,6 +394,55 @@ class MnistRCGAN:
         red = lambda a, w: a.reshape(len(a), -1).mean(1) if w is None else (a * w).sum(1)
         return dict(d_loss_real=float(red(f_real(lr_), wr).mean()), d_loss_fake=float(red(f_fake(lf), wf).mean()),
                     g_loss=float(red(f_g(lf), wf).mean()), prob_real=red(sig(lr_), wr), prob_fake=red(sig(lf), wf))
+
+    # ------------------------------------------------------------------------------------ recover_labels
+    def recover_labels(self, images, y_actual, epochs=1000, learning_rate=5.e+2, seed=0, log_every=100, log=print):
+        """DCGAN.recover_labels (mnist/model.py:494-640): for each of the R given real images, gradient descent
+        (plain SGD, lr 500) on one latent z per (image, label) and on R x 10 label logits through the FROZEN sampler
+        (inference-mode batch norm), minimising  mean_r sum_y softmax(logits)[r,y] * mse(image_r, G(z[r,y], onehot y)).
+        Needs batch_size == R * 10 (the sampler batch, model.py:523).  Returns dict(y_recover, z_recover, mse_loss,
+        zero_one_loss, history); variables start from TF's default glorot-uniform initialiser (RandomState(seed))."""
+        ctx, g = self.ctx, self.graph
+        images = np.asarray(images, np.float32).reshape(len(images), -1)
+        y_actual = np.asarray(y_actual, np.float64)
+        R = len(images)
+        if self.B != R * Y_DIM:
+            raise ValueError("recover_labels on %d images needs an engine built with batch_size=%d (got %d)" % (R, R * Y_DIM, self.B))
+        rs = np.random.RandomState(seed)
+        glorot = lambda shape: rs.uniform(-np.sqrt(6.0 / sum(shape)), np.sqrt(6.0 / sum(shape)), size=shape).astype(np.float32)
+        P = ctx.persistent
+        z = P((R * Y_DIM, Z_DIM), L.F32)
+        logits = P((R, Y_DIM), L.F32)
+        ctx.view(logits).copy_(torch.from_numpy(glorot((R, Y_DIM))))        # creation order: y_logit_recover, then z_recover
+        ctx.view(z).copy_(torch.from_numpy(glorot((R * Y_DIM, Z_DIM))))
+        hard_y = P((R * Y_DIM, Y_DIM), L.F32)
+        ctx.view(hard_y).copy_(torch.from_numpy(np.tile(np.eye(Y_DIM, dtype=np.float32), (R, 1))))
+        actual = P((R, images.shape[1]), ctx.act_dtype)
+        ctx.view(actual).copy_(torch.from_numpy(images).to(ctx.view(actual).dtype))
+        loss = P((1,), L.F32, fill=0.0)
+        history = []
+        t0 = time.time()
+        res = {}
+        for epoch in range(epochs):
+            ctx.new_step()
+            g.begin_step(set())
+            z.grad = logits.grad = None
+            z.req = logits.req = True
+            yrec = O.softmax_rows(ctx, logits)
+            G = self.generator(O.cast(ctx, z, ctx.act_dtype), hard_y, train=False)
+            O.recover_mse(ctx, O.reshape(ctx, G, (R * Y_DIM, -1)), actual, yrec, loss)
+            ctx.backward()
+            # tf.train.GradientDescentOptimizer(lr).minimize(mse, var_list=[z_recover, y_logit_recover]); metrics of THIS run
+            if (epoch + 1) % log_every == 0 or epoch == epochs - 1:
+                yr = ctx.download(yrec).astype(np.float64)
+                onehot = np.eye(Y_DIM)[np.argmax(yr, 1)]
+                res = dict(mse_loss=float(ctx.download(loss)[0]), zero_one_loss=float(np.mean(1.0 - (y_actual * onehot).sum(1))))
+                history.append((epoch, res["mse_loss"], res["zero_one_loss"]))
+                log("Recover Epoch: [%2d] time: %4.2f, mse_loss: %.5g, zeroone_loss: %.5g" % (epoch, time.time() - t0, res["mse_loss"], res["zero_one_loss"]))
+            for var in (z, logits):
+                ctx.check(ctx.lib.rcgan_axpby(ctx.h, var.size, L.F32, -float(learning_rate), var.grad.ptr, 1.0, var.ptr))
+        res.update(y_recover=ctx.download(O.softmax_rows(ctx, logits)), z_recover=ctx.download(z), history=history)
+        return res
 
     # ------------------------------------------------------------------------------------ checkpoints
     def state_dict(self):

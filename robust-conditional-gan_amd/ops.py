@@ -327,10 +327,46 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
 
 
 def batch_norm_infer(ctx, x, gamma, beta, mm, mv, act=L.ACT_NONE, eps=1e-5):
+    """Inference-mode batch norm (moving statistics; gen_sampler, mnist/model.py:745-754).  Differentiable w.r.t. x only:
+    recover_labels (model.py:494-640) optimises the sampler's INPUT with every parameter and statistic frozen."""
     n, rps, c = _rows(x)
     y = ctx.empty(x.shape, x.dtype)
     ctx.check(ctx.lib.rcgan_bn_infer(ctx.h, n * rps, c, x.dtype, _p(x), _p(gamma), _p(beta), _p(mm), _p(mv), eps, act, _p(y)))
+    if _track(ctx, y, x):
+        if gamma.req or beta.req:
+            raise NotImplementedError("inference-mode batch norm has no parameter gradients")
+
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_bn_infer_bwd(ctx.h, n * rps, c, x.dtype, _p(y), _p(y.grad), _p(gamma), _p(mv), eps, act, _p(dx), acc))
+        ctx.record(bw)
     return y
+
+
+def recover_mse(ctx, gen, actual, yrec, loss):
+    """recover_labels objective (mnist/model.py:533-537): mean_r sum_y yrec[r,y] * mean_pix (actual[r] - gen[r*ydim+y])^2,
+    written to ``loss`` [1]; gradients flow to gen and yrec."""
+    r, ydim = yrec.shape
+    pix = gen.size // (r * ydim)
+    assert gen.shape[0] == r * ydim and actual.size == r * pix and gen.dtype == actual.dtype
+    rec = _track(ctx, loss, gen, yrec)
+    dgen = ctx.empty(gen.shape, gen.dtype) if (rec and gen.req) else None
+    dyr = ctx.empty(yrec.shape, L.F32) if (rec and yrec.req) else None
+    ctx.check(ctx.lib.rcgan_recover_mse_fwd_bwd(ctx.h, r, ydim, pix, gen.dtype, _p(gen), _p(actual), _p(yrec), _p(loss), _p(dgen), _p(dyr),
+                                                C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+    if rec:
+        def bw():
+            for t, d in ((gen, dgen), (yrec, dyr)):
+                if d is None:
+                    continue
+                if t.grad is None:
+                    t.grad = d
+                else:
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, t.size, t.dtype, 1.0, _p(d), 1.0, _p(t.grad)))
+        ctx.record(bw)
+    return loss
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -596,6 +632,7 @@ def softmax_rows(ctx, logits):
         def bw():
             if p.grad is None:
                 return
-            ctx.check(ctx.lib.rcgan_softmax_rows_bwd(ctx.h, r, c, _p(p), _p(p.grad), _p(logits.grad), 1))
+            dl, acc = grad_of(ctx, logits)
+            ctx.check(ctx.lib.rcgan_softmax_rows_bwd(ctx.h, r, c, _p(p), _p(p.grad), _p(dl), acc))
         ctx.record(bw)
     return p

@@ -9,7 +9,9 @@
 
 Per batch: one D update, two G (+ confusion-matrix) updates on the same z (model.py:347-372).  Deviations, all
 logging-only: the console metrics are evaluated only for the lines that are printed; the generated-label accuracy
-and recover_labels need the frozen MNIST classifier graph (SURVEY 8f "next" rows) and are reported as skipped.
+needs the frozen MNIST classifier graph, which the reference checkout does not contain, and is reported as skipped;
+recover_labels writes its result (recovered label distribution, loss history) as recover.npz into the reference's
+recover_bs<R>_epoch<E>_lr<lr>/<timestamp>/ directory instead of TF summaries.
 Multi-GPU: one rank per GPU under torch.distributed.run; every rank takes batch_size/world rows of each batch.
 """
 import os
@@ -206,10 +208,33 @@ def main(argv=None):
             if epoch + 1 != FLAGS.sample_epochs and os.path.exists(old):
                 os.remove(old)
             print('######EPOCH={}, mean generated label accuracy=skipped (needs mnist_dcnn/graph_optimized.pb)'.format(epoch))
+    final_state = None
     if rank == 0:
-        saver.save(m.state_dict(), model_dir, "DCGAN.model", counter)
-        print("recover_labels: skipped (SURVEY 8f next row)")
+        final_state = m.state_dict()
+        saver.save(final_state, model_dir, "DCGAN.model", counter)
     m.ctx.close()
+
+    # ---- dcgan.recover_labels(FLAGS) (main.py:140, model.py:494-640): label recovery through the frozen sampler ------------
+    if rank == 0 and FLAGS.recover_epoch > 0:
+        R = FLAGS.recover_batch_size
+        print(" [*] Load SUCCESS")
+        rec = MnistRCGAN(algorithm=FLAGS.algorithm, alpha=FLAGS.alpha, batch_size=R * 10, learning_rate=FLAGS.learning_rate,
+                         beta1=FLAGS.beta1, dtype=FLAGS.dtype, seed=FLAGS.seed, disc_type=FLAGS.disc_type, loss_fn=FLAGS.loss_fn,
+                         estimate_confuse=FLAGS.estimate_confuse, confuse_multiplier=FLAGS.confuse_multiplier,
+                         perm_regularizer=FLAGS.perm_regularizer, perm_multiplier=FLAGS.perm_multiplier,
+                         spectral_norm=FLAGS.spectral_norm, max_norm=FLAGS.max_norm, concat_y=FLAGS.concat_y, concat_y_layers=layers,
+                         device=local, use_graphs=False, confusion_matrix=data["C"])
+        rec.load_state_dict(final_state)
+        recover_path = os.path.join(ckpt_root, 'recover_bs{}_epoch{}_lr{:.5g}'.format(R, FLAGS.recover_epoch, FLAGS.recover_learning_rate),
+                                    datetime.now().strftime("%Y%m%d-%H%M%S"))
+        print('Saving to recovery plots to {}.'.format(recover_path))
+        os.makedirs(recover_path, exist_ok=True)
+        idx = np.random.randint(len(data_X), size=[R])                          # model.py:618-619
+        out = rec.recover_labels(data_X[idx], data["y_actual"][idx], epochs=FLAGS.recover_epoch,
+                                 learning_rate=FLAGS.recover_learning_rate, seed=FLAGS.seed)
+        np.savez(os.path.join(recover_path, "recover.npz"), batch_idx=idx, y_actual=data["y_actual"][idx], y_recover=out["y_recover"],
+                 history=np.array(out["history"], np.float64), mse_loss=out["mse_loss"], zero_one_loss=out["zero_one_loss"])
+        rec.ctx.close()
     return ckpt_root
 
 

@@ -53,9 +53,15 @@ def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     argv = ["--algorithm", "rcgan", "--alpha", "0.3", "--disc_type", "projection", "--estimate_confuse", "--aux_classifier",
             "--noadd_noise", "--noconcat_y", "--spectral_norm", "--max_norm", "--checkpoint_dir", root, "--checkpoint", "e1",
             "--epoch", "2", "--batch_size", "100", "--synthetic", "--synthetic_size", "500", "--save_every", "3",
-            "--sample_epochs", "1", "--train"]
+            "--sample_epochs", "1", "--train", "--recover_epoch", "200", "--recover_batch_size", "6", "--recover_learning_rate", "50"]
     d = main(argv)
     out = capsys.readouterr().out
+    assert "Recover Epoch: [99] time:" in out and "Recover Epoch: [199] time:" in out
+    rec = glob.glob(os.path.join(d, "recover_bs6_epoch200_lr50", "*", "recover.npz"))
+    assert len(rec) == 1
+    rz = np.load(rec[0])
+    assert rz["y_recover"].shape == (6, 10) and np.allclose(rz["y_recover"].sum(1), 1.0, atol=1e-5)
+    assert rz["history"][-1][1] < rz["history"][0][1]         # the mse objective went down
     assert "Epoch: [ 0] [   0/   5]" in out and "d_real:" in out and "[Sample] d_loss:" in out
     assert os.path.exists(os.path.join(d, "script", "command.txt"))
     grids = sorted(glob.glob(os.path.join(d, "samples", "train_*.png")))
@@ -81,6 +87,6 @@ def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     d3 = main(["--algorithm", "biased", "--alpha", "0.6", "--disc_type", "vanilla", "--loss_fn", "ce", "--real_match",
                "--noestimate_confuse", "--add_noise", "--noise_alpha", "0.3", "--noise_start", "1", "--noise_end", "2",
                "--nospectral_norm", "--nomax_norm", "--checkpoint_dir", root, "--checkpoint", "e2", "--epoch", "2",
-               "--batch_size", "64", "--synthetic", "--synthetic_size", "256", "--train"])
+               "--batch_size", "64", "--synthetic", "--synthetic_size", "256", "--train", "--recover_epoch", "0"])
     sd3 = load_checkpoint(latest_checkpoint(os.path.join(d3, "mnist_64_28_28")))
     assert sd3["discriminator/d_h3_lin/Matrix"].shape[1] == 1024 and all(np.isfinite(v).all() for v in sd3.values())

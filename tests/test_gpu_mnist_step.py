@@ -149,3 +149,45 @@ def test_mnist_sampler_and_graph_replay():
     S = {k: v for k, v in sa.items() if "moving" in k}
     ref = om.sampler(pa, S, b["z"], b["y_gen"])
     assert_close(xa, ref, 1e-4, "gen_sampler")
+
+
+def test_recover_labels_matches_oracle():
+    """DCGAN.recover_labels (mnist/model.py:494-640): SGD on the latent z of every (image, label) pair and
+    on the label logits through the frozen sampler (inference-mode batch norm).  Product (HIP, fp32) vs the float64
+    oracle over three updates from identical initial variables."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.mnist import MnistRCGAN, create_variables
+    R = 4
+    rs = np.random.RandomState(9)
+    gs, ds, cs, S, U = create_variables(0, "projection", False, True, True, ())
+    S = {k: (rs.uniform(0.5, 1.5, size=v.shape) if k.endswith("moving_variance") else rs.uniform(-0.2, 0.2, size=v.shape)).astype(np.float32)
+         for k, v in S.items()}
+    m = MnistRCGAN(algorithm="rcgan", alpha=0.3, batch_size=R * 10, dtype="f32", disc_type="projection", use_graphs=False,
+                   variables=(gs, ds, cs, S, U))
+    try:
+        images = rs.rand(R, 28, 28, 1).astype(np.float32)
+        y_actual = np.eye(10)[rs.randint(10, size=R)]
+        lr, seed, steps = 50.0, 4, 3
+        hist = []
+        res = m.recover_labels(images, y_actual, epochs=steps, learning_rate=lr, seed=seed, log_every=1, log=hist.append)
+        # the oracle from the same glorot-uniform start (creation order: logits, then z)
+        g = np.random.RandomState(seed)
+        glorot = lambda shape: g.uniform(-np.sqrt(6.0 / sum(shape)), np.sqrt(6.0 / sum(shape)), size=shape).astype(np.float32)
+        logits, z = glorot((R, 10)).astype(np.float64), glorot((R * 10, 100)).astype(np.float64)
+        P = {n: v.astype(np.float64) for n, _, v in gs + ds + cs}
+        S64 = {k: v.astype(np.float64) for k, v in S.items()}
+        losses = []
+        for _ in range(steps):
+            loss, z, logits, yrec = om.recover_step(P, S64, z, logits, images.reshape(R, -1), lr)
+            losses.append(loss)
+        got_losses = [h[1] for h in res["history"]]
+        assert np.allclose(got_losses, losses, rtol=2e-5), (got_losses, losses)
+        assert losses[-1] < losses[0]                      # the descent direction is a descent direction
+        assert_close(res["z_recover"], z, 2e-4, "z after %d SGD steps" % steps)
+        sm = np.exp(logits - logits.max(1, keepdims=True))
+        assert_close(res["y_recover"], sm / sm.sum(1, keepdims=True), 2e-5, "softmax of the recovered logits")
+        assert len(hist) == steps and hist[0].startswith("Recover Epoch: [ 0] time:")
+        with pytest.raises(ValueError):
+            m.recover_labels(images[:2], y_actual[:2], epochs=1)
+    finally:
+        m.ctx.close()
