@@ -58,7 +58,7 @@ def _labels_all(alg, raw):
 def _check(m, P, Uo, alg, perm, raw, gb, C, tol_kind):
     """Reference = the oracle evaluated in float64 on the same weights / batch.  (The fp32 oracle is itself
     2e-4..4e-3 away from the fp64 result on these gradients -- batch-norm over 4 samples is badly
-    conditioned -- and the HIP fp32 path lands at the same distance, see scripts/debug_gstep.py.)"""
+    conditioned -- and the HIP fp32 path lands at the same distance, see tests/tools/debug_gstep.py.)"""
     from rcgan_amd import _lib as L
     cfg = dict(algorithm=alg, C=C, perm_classifier=perm, perm_multiplier=1.0)
     bf16 = m.ctx.act_dtype == L.BF16

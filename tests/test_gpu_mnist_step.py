@@ -26,7 +26,7 @@ def _cmp(tag, got, grads, grads32):
     distance from float64) and max error <= 1e-1 of the tensor's scale.  The max-error bound is loose on purpose:
     a ReLU / leaky-ReLU input within ~1e-7 of zero can take the other branch under a different fp32 summation
     order, which moves the few gradient entries fed by that one activation by ~1e-2 of the scale while leaving
-    the rest at 1e-6 (observed: scripts/debug_mnist.py)."""
+    the rest at 1e-6 (observed: tests/tools/debug_mnist.py)."""
     gmax = max(float(np.abs(g).max()) for g in grads.values())
     for k, gref in grads.items():
         a = got[k]
