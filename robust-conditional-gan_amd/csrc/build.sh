@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../librcgan_hip.so
-SRCS="api.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
+SRCS="api.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_mfma8.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 mkdir -p _obj
 pids=()

@@ -1,0 +1,272 @@
+// 256 x 256-tile, 8-wavefront, four-phases-per-K-tile schedule of the implicit-GEMM convolution (forward and data
+// gradient of the 3x3 / 1x1 stride-1 SAME convs with Cout % 256 == 0: the 256-channel generator blocks).
+//
+// The 128 x 128 kernel (conv_mfma.hip) drains its one in-flight K-tile before every barrier; that structure tops
+// out near 900 TFLOP/s.  Here a K-tile (64 reduction elements) is cut into four 16-KiB half-tiles, each fetched by
+// one LDS-DMA burst (2 x global_load_lds_dwordx4 per wavefront), and the work on it into four phases of 16 MFMAs
+// (one quadrant of the wavefront's 128 px x 64 co tile over the whole K-tile).  Every phase issues the burst of one
+// half-tile of the NEXT K-tile, so loads, LDS fragment reads and MFMAs of different wavefronts interleave, and the
+// s_waitcnt before each barrier is COUNTED (vmcnt(4): the two newest bursts stay in flight across it).
+//
+//   workgroup tile : 256 pixels x 256 output channels, K-tile 64 = one filter tap x 64 input channels
+//   wavefronts     : 8 = 2 (pixels, 128 each) x 4 (channels, 64 each); accumulators 4 x 8 MFMA tiles = 128 AGPRs
+//   half-tiles     : P0 / P1 = the first / second 64 pixels of BOTH wavefront rows, C0 / C1 = the first / second
+//                    32 channels of ALL FOUR wavefront columns -- i.e. exactly what phase 1 (P0,C0), 2 (+C1),
+//                    3 (+P1), 4 (C0 again) read, whatever the wavefront
+//   schedule       : tile t, phase p issues half-tile p of tile t+1 in the order P0, C0, C1, P1; needed at
+//                    (t+1).1, (t+1).1, (t+1).2, (t+1).3 -> at most the two newest bursts may be outstanding at
+//                    each wait.  LDS: 2 K-tile buffers x (256 + 256) rows x 128 B = 128 KiB.
+//   hazards        : a burst is read only after (own vmcnt wait) + (workgroup barrier); a half-tile region is
+//                    re-filled at the earliest three phases after its last read, with >= 1 barrier in between.
+#include "conv_mfma.h"
+#include "mfma_util.h"
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+}  // namespace
+
+template <int VAR>
+__global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HALF = 128 * 128;                 // bytes of one half-tile (128 rows x 128 B)
+  constexpr int XOFF = 0, WOFF = 2 * HALF, BUF = 4 * HALF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;        // pixel half / channel quarter of this wavefront
+  const long m0 = (long)blockIdx.x * 256;
+  const int co0 = blockIdx.y * 256;
+  const int K = a.KH * a.KW * a.Cin;
+  const int KT = K / 64;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int lrow = lane >> 3, pos = lane & 7;
+
+  // ---- DMA roles: per half-tile this wavefront deposits rows (wave*2 + j)*8 + lrow, j = 0,1 (of 128) ----------------
+  // LDS row r of X half h  <->  tile pixel (r>>6)*128 + h*64 + (r&63);  W half h: channel (r>>5)*64 + h*32 + (r&31)
+  int p_n[4], p_oh[4], p_ow[4], a_coff[4];       // index = h*2 + j
+  const bf16_t* wsrc[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wave * 2 + j) * 8 + lrow;
+      const int swz = (pos ^ ((r >> 1) & 7)) * 8;
+      const long m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      a_coff[h * 2 + j] = swz;
+      if (m < a.M) {
+        const unsigned mm = (unsigned)m;
+        if (a.lw >= 0) {
+          p_ow[h * 2 + j] = (int)(mm & (unsigned)(a.W - 1));
+          p_oh[h * 2 + j] = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
+          p_n[h * 2 + j] = (int)(mm >> (a.lw + a.lh));
+        } else {
+          p_ow[h * 2 + j] = (int)(m % a.W);
+          p_oh[h * 2 + j] = (int)((m / a.W) % a.H);
+          p_n[h * 2 + j] = (int)(m / ((long)a.W * a.H));
+        }
+      } else {
+        p_n[h * 2 + j] = 0; p_oh[h * 2 + j] = -100000; p_ow[h * 2 + j] = 0;
+      }
+      const int co = co0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      wsrc[h * 2 + j] = a.wt + (long)co * K + swz;
+    }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const bf16_t* rp[4];
+  int rstep[4];
+  int i_c0 = 0, i_kh = 0, i_kw = 0, i_k0 = 0;
+  auto set_tap = [&](int kh, int kw) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
+      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      if (a.up) { ih >>= 1; iw >>= 1; }
+      rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
+      rstep[i] = ok ? 1 : 0;
+    }
+  };
+  set_tap(0, 0);
+  // half-tile ids: 0 = P0, 1 = C0, 2 = C1, 3 = P1 (issue order); the cursor moves on after P1
+  auto issue = [&](int which, int buf) {
+    const unsigned base = lds0 + buf * BUF;
+    if (which == 0 || which == 3) {
+      const int h = which == 0 ? 0 : 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
+      if (which == 3) {
+        i_k0 += 64;
+        i_c0 += 64;
+        if (i_c0 == a.Cin) {
+          i_c0 = 0;
+          if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+          set_tap(i_kh, i_kw);
+        }
+      }
+    } else {
+      const int h = which - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16_asm(wsrc[h * 2 + j] + i_k0, base + WOFF + h * HALF + (wave * 2 + j) * 1024);
+    }
+  };
+
+  f32x4_t acc[4][8];       // [co fragment = c-half*2 + g][px fragment = p-half*4 + f]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
+  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;
+  const int xrow0 = wm * 64 * 128;                // byte offset of this wavefront's rows inside an X half-tile
+  const int wrow0 = wn * 32 * 128;                // ... inside a W half-tile
+
+  bf16x8_t xf[2][4], wf[2][2];                    // [ks][fragment] of the current pixel half / channel half
+  auto load_x = [&](const unsigned char* bufp, int h) {
+    const unsigned char* p = bufp + XOFF + h * HALF + xrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        uint4 v = *(const uint4*)(p + f * 16 * 128 + (ks ? foff1 : foff0));
+        v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+        xf[ks][f] = __builtin_bit_cast(bf16x8_t, v);
+      }
+  };
+  auto load_w = [&](const unsigned char* bufp, int h) {
+    const unsigned char* p = bufp + WOFF + h * HALF + wrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) wf[ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
+  };
+  auto mma = [&](int ph, int ch) {
+    if (VAR & 2) { wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          acc[ch * 2 + g][ph * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f], 0, 0, 0);
+    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: the whole first K-tile
+#pragma unroll
+  for (int w = 0; w < 4; ++w) issue(w, 0);
+  wait_vm<0>();
+  wg_barrier();
+
+  for (int t = 0; t < KT; ++t) {
+    const unsigned char* bufp = smem + (t & 1) * BUF;
+    const int nb = (t + 1) & 1;
+    const bool more = t + 1 < KT;
+    // phase 1: (P0, C0)
+    load_x(bufp, 0);
+    load_w(bufp, 0);
+    if (more) issue(0, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0);
+    if (more) wait_vm<4>(); else wait_vm<2>();    // C1 of this tile has landed (newer: P1 [, P0 of the next tile])
+    wg_barrier();
+    // phase 2: (P0, C1)
+    load_w(bufp, 1);
+    if (more) issue(1, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 1);
+    if (more) wait_vm<4>(); else wait_vm<0>();    // P1 of this tile has landed
+    wg_barrier();
+    // phase 3: (P1, C1)
+    load_x(bufp, 1);
+    if (more) issue(2, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 1);
+    wg_barrier();                                  // (C0 of this tile landed long ago)
+    // phase 4: (P1, C0)
+    load_w(bufp, 0);
+    if (more) issue(3, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 0);
+    if (more) wait_vm<4>();                       // P0 and C0 of the next tile have landed (newer: its C1, P1)
+    wg_barrier();
+  }
+
+  // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long m = m0 + wm * 128 + j * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) {
+        const float4 b = *(const float4*)(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const long off = m * a.Cout + co;
+      if (a.mask) {
+        const uint2 mk = *(const uint2*)(a.mask + off);
+        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+      }
+      if (a.accumulate) {
+        const uint2 o = *(const uint2*)(a.out + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      if (a.resid) {
+        const uint2 o = *(const uint2*)(a.resid + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *(uint2*)(a.out + off) = pk;
+    }
+  }
+}
+
+template <int VAR>
+static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 4 * 128 * 128;
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, 256), a.Cout / 256);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_128, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL(conv_mfma_p8_kernel<VAR>, grid, dim3(512), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static int var = -1;
+  if (var < 0) { const char* e = getenv("RCGAN_P8_VAR"); var = e ? atoi(e) : 0; }
+  switch (var) {
+    case 1: return launch8<1>(ctx, a);
+    case 2: return launch8<2>(ctx, a);
+    case 3: return launch8<3>(ctx, a);
+    default: return launch8<0>(ctx, a);
+  }
+}

@@ -56,6 +56,8 @@ CONV_CASES = [
     (3, 16, 16, 128, 3, 1, 1, False, False),    # 1x1 small output
     (2, 32, 8, 3, 256, 3, 1, False, False),     # W = 8 bands, 256-channel small reduction
     (5, 16, 32, 128, 2, 3, 1, False, True),     # 2 output channels, folded input ReLU
+    (52, 32, 32, 64, 256, 3, 1, False, True),   # 208 workgroups of 256x256: the 8-wavefront four-phase kernel (fwd; dgrad stays 64->...)
+    (50, 32, 32, 256, 256, 1, 1, False, False), # four-phase kernel forward AND data gradient (Cin = Cout = 256), M tail (51200 = 200 tiles)
 ]
 
 
