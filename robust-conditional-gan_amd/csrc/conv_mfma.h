@@ -53,5 +53,5 @@ int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void*
 int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, void* dx, int accumulate);
 int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
               void* ws, size_t ws_bytes);
-int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);      // conv_mfma8.hip: 256 x 256 tile, 8 wavefronts
+int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n);

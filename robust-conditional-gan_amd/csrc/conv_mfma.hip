@@ -1075,7 +1075,9 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
   static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
   static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);         // 256 x 256 four-phase kernel (conv_mfma8.hip)
-  if (a.Cout % 256 == 0 && a.zero != nullptr && (long)cdiv(a.M, 256) * (a.Cout / 256) >= p8_min) return mfma_conv8_launch(ctx, a);
+  if (a.Cout % 256 == 0 && a.zero != nullptr && (long)cdiv(a.M, 256) * (a.Cout / 256) >= p8_min) return mfma_conv8_launch(ctx, a, true);
+  static const int p8n_min = env_int("RCGAN_P8N_MINBLK", 190);
+  if (a.Cout % 128 == 0 && a.zero != nullptr && (long)cdiv(a.M, 256) * (a.Cout / 128) >= p8n_min) return mfma_conv8_launch(ctx, a, false);
   static const int t256_min = env_int("RCGAN_T256_MINBLK", 1 << 30);     // experiment: 256-pixel tiles (1 wave/SIMD)
   if (a.Cout % 256 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 256) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 256, 2>(ctx, a);
   if (a.Cout % 128 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 128) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 128, 2>(ctx, a);

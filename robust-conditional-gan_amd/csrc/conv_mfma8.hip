@@ -34,7 +34,7 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
-template <int VAR>
+template <bool RELU>
 __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALF = 128 * 128;                 // bytes of one half-tile (128 rows x 128 B)
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   const int frow = lane & 15, kc = lane >> 4;
   const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
   const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
-  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;
   const int xrow0 = wm * 64 * 128;                // byte offset of this wavefront's rows inside an X half-tile
   const int wrow0 = wn * 32 * 128;                // ... inside a W half-tile
 
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         uint4 v = *(const uint4*)(p + f * 16 * 128 + (ks ? foff1 : foff0));
-        v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+        if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
         xf[ks][f] = __builtin_bit_cast(bf16x8_t, v);
       }
   };
@@ -152,8 +151,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       for (int g = 0; g < 2; ++g) wf[ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
   };
   auto mma = [&](int ph, int ch) {
-    if (VAR & 2) { wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
           acc[ch * 2 + g][ph * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f], 0, 0, 0);
-    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // prologue: the whole first K-tile
@@ -243,30 +241,232 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   }
 }
 
-template <int VAR>
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 128-tile variant (Cout % 128 == 0: D.Block.1.Conv2 and its data gradient).  8 wavefronts = 4 (pixels, 64
+// each) x 2 (channels, 64 each); two phases of 16 MFMAs per K-tile: phase A multiplies the first 32 pixels of every
+// wavefront row (half-tile P0) with the whole filter tile W, phase B the second 32 (P1) with W kept in registers.
+// Bursts: t.A issues P0 and W of tile t+1 (4 loads), t.B issues P1 (2 loads); waits vmcnt(4) / vmcnt(2).
+// LDS: 2 x (256 + 128) rows x 128 B = 96 KiB.
+// ---------------------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HALF = 128 * 128;
+  constexpr int XOFF = 0, WOFF = 2 * HALF, BUF = 3 * HALF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;        // pixel quarter / channel half of this wavefront
+  const long m0 = (long)blockIdx.x * 256;
+  const int co0 = blockIdx.y * 128;
+  const int K = a.KH * a.KW * a.Cin;
+  const int KT = K / 64;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int lrow = lane >> 3, pos = lane & 7;
+
+  // X half h, LDS row r <-> tile pixel (r>>5)*64 + h*32 + (r&31);  W row r <-> channel r
+  int p_n[4], p_oh[4], p_ow[4], a_coff[4];       // index = h*2 + j
+  const bf16_t* wsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + lrow;
+    const int swz = (pos ^ ((r >> 1) & 7)) * 8;
+    wsrc[j] = a.wt + (long)(co0 + r) * K + swz;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long m = m0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      a_coff[h * 2 + j] = swz;
+      if (m < a.M) {
+        const unsigned mm = (unsigned)m;
+        if (a.lw >= 0) {
+          p_ow[h * 2 + j] = (int)(mm & (unsigned)(a.W - 1));
+          p_oh[h * 2 + j] = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
+          p_n[h * 2 + j] = (int)(mm >> (a.lw + a.lh));
+        } else {
+          p_ow[h * 2 + j] = (int)(m % a.W);
+          p_oh[h * 2 + j] = (int)((m / a.W) % a.H);
+          p_n[h * 2 + j] = (int)(m / ((long)a.W * a.H));
+        }
+      } else {
+        p_n[h * 2 + j] = 0; p_oh[h * 2 + j] = -100000; p_ow[h * 2 + j] = 0;
+      }
+    }
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const bf16_t* rp[4];
+  int rstep[4];
+  int i_c0 = 0, i_kh = 0, i_kw = 0, i_k0 = 0;
+  auto set_tap = [&](int kh, int kw) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
+      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      if (a.up) { ih >>= 1; iw >>= 1; }
+      rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
+      rstep[i] = ok ? 1 : 0;
+    }
+  };
+  set_tap(0, 0);
+  auto issue_x = [&](int h, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], lds0 + buf * BUF + XOFF + h * HALF + (wave * 2 + j) * 1024);
+  };
+  auto issue_w = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_asm(wsrc[j] + i_k0, lds0 + buf * BUF + WOFF + (wave * 2 + j) * 1024);
+  };
+  auto advance = [&]() {
+    i_k0 += 64;
+    i_c0 += 64;
+    if (i_c0 == a.Cin) {
+      i_c0 = 0;
+      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+      set_tap(i_kh, i_kw);
+    }
+  };
+
+  f32x4_t acc[4][4];       // [co fragment][px fragment = half*2 + f]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
+  const int xrow0 = wm * 32 * 128, wrow0 = wn * 64 * 128;
+
+  bf16x8_t xf[2][2], wf[2][4];
+  auto load_x = [&](const unsigned char* bufp, int h) {
+    const unsigned char* p = bufp + XOFF + h * HALF + xrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        uint4 v = *(const uint4*)(p + f * 16 * 128 + (ks ? foff1 : foff0));
+        if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+        xf[ks][f] = __builtin_bit_cast(bf16x8_t, v);
+      }
+  };
+  auto load_w = [&](const unsigned char* bufp) {
+    const unsigned char* p = bufp + WOFF + wrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wf[ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
+  };
+  auto mma = [&](int ph) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          acc[g][ph * 2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][g], xf[ks][f], acc[g][ph * 2 + f], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  issue_x(0, 0); issue_w(0); issue_x(1, 0); advance();
+  wait_vm<0>();
+  wg_barrier();
+  for (int t = 0; t < KT; ++t) {
+    const unsigned char* bufp = smem + (t & 1) * BUF;
+    const int nb = (t + 1) & 1;
+    const bool more = t + 1 < KT;
+    // phase A: P0 x W
+    load_x(bufp, 0);
+    load_w(bufp);
+    if (more) { issue_x(0, nb); issue_w(nb); }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    if (more) wait_vm<4>(); else wait_vm<0>();    // P1 of this tile has landed (newer: P0 and W of the next)
+    wg_barrier();
+    // phase B: P1 x W (registers)
+    load_x(bufp, 1);
+    if (more) { issue_x(1, nb); advance(); }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    if (more) wait_vm<2>();                       // P0 and W of the next tile have landed (newer: its P1)
+    wg_barrier();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long m = m0 + wm * 64 + j * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) {
+        const float4 b = *(const float4*)(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const long off = m * a.Cout + co;
+      if (a.mask) {
+        const uint2 mk = *(const uint2*)(a.mask + off);
+        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+      }
+      if (a.accumulate) {
+        const uint2 o = *(const uint2*)(a.out + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      if (a.resid) {
+        const uint2 o = *(const uint2*)(a.resid + off);
+        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *(uint2*)(a.out + off) = pk;
+    }
+  }
+}
+
+template <bool RELU>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 4 * 128 * 128;
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_128, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
-    hipLaunchKernelGGL(conv_mfma_p8_kernel<VAR>, grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(conv_mfma_p8_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
 
-int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
-  static int var = -1;
-  if (var < 0) { const char* e = getenv("RCGAN_P8_VAR"); var = e ? atoi(e) : 0; }
-  switch (var) {
-    case 1: return launch8<1>(ctx, a);
-    case 2: return launch8<2>(ctx, a);
-    case 3: return launch8<3>(ctx, a);
-    default: return launch8<0>(ctx, a);
+template <bool RELU>
+static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 3 * 128 * 128;
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8n_kernel<RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
+  dim3 grid(cdiv(a.M, 256), a.Cout / 128);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_128, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL(conv_mfma_p8n_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// wide = 256 output channels per workgroup (Cout % 256 == 0), else 128
+int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
+  if (wide) return a.relu_in ? launch8<true>(ctx, a) : launch8<false>(ctx, a);
+  return a.relu_in ? launch8n<true>(ctx, a) : launch8n<false>(ctx, a);
 }
