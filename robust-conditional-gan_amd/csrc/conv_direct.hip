@@ -373,46 +373,56 @@ template int colsum_launch<bf16_t>(rcgan_ctx*, const bf16_t*, long, int, float*,
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void linear_tiny_kernel(int m, int k, int n, const T* a, const void* bptr, const float* wscale,
                                                           const float* bias, void* out, int accumulate) {
+  // workgroup = 64 outputs x 4 slices of the reduction (summed through LDS in a fixed order): four times shorter
+  // dependent-load chains than one thread per output
+  __shared__ float part[4][64];
   const int rows = MODE == 2 ? k : m, cols = MODE == 1 ? k : n;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= rows * cols) return;
-  const int r = idx / cols, c = idx - r * cols;
+  const int red = MODE == 0 ? k : (MODE == 1 ? n : m);
+  const int idx = blockIdx.x * 64 + (threadIdx.x & 63), kp = threadIdx.x >> 6;
+  const bool live = idx < rows * cols;
+  const int r = live ? idx / cols : 0, c = live ? idx - r * cols : 0;
+  const int chunk = (red + 3) / 4;
+  const int q0 = kp * chunk, q1 = min(red, q0 + chunk);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (MODE == 0) {
-    const T* x = a + (long)r * k;
-    const float* w = (const float*)bptr + c;
-    int q = 0;
-    for (; q + 4 <= k; q += 4) {
-      s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
-      s1 = fmaf(Elem<T>::ld(x + q + 1), w[(long)(q + 1) * n], s1);
-      s2 = fmaf(Elem<T>::ld(x + q + 2), w[(long)(q + 2) * n], s2);
-      s3 = fmaf(Elem<T>::ld(x + q + 3), w[(long)(q + 3) * n], s3);
+  if (live) {
+    int q = q0;
+    if (MODE == 0) {
+      const T* x = a + (long)r * k;
+      const float* w = (const float*)bptr + c;
+      for (; q + 4 <= q1; q += 4) {
+        s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
+        s1 = fmaf(Elem<T>::ld(x + q + 1), w[(long)(q + 1) * n], s1);
+        s2 = fmaf(Elem<T>::ld(x + q + 2), w[(long)(q + 2) * n], s2);
+        s3 = fmaf(Elem<T>::ld(x + q + 3), w[(long)(q + 3) * n], s3);
+      }
+      for (; q < q1; ++q) s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
+    } else if (MODE == 1) {
+      const T* dy = a + (long)r * n;
+      const float* w = (const float*)bptr + (long)c * n;
+      for (; q + 4 <= q1; q += 4) {
+        s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
+        s1 = fmaf(Elem<T>::ld(dy + q + 1), w[q + 1], s1);
+        s2 = fmaf(Elem<T>::ld(dy + q + 2), w[q + 2], s2);
+        s3 = fmaf(Elem<T>::ld(dy + q + 3), w[q + 3], s3);
+      }
+      for (; q < q1; ++q) s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
+    } else {
+      const T* x = a + r;
+      const T* dy = (const T*)bptr + c;
+      for (; q + 4 <= q1; q += 4) {
+        s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
+        s1 = fmaf(Elem<T>::ld(x + (long)(q + 1) * k), Elem<T>::ld(dy + (long)(q + 1) * n), s1);
+        s2 = fmaf(Elem<T>::ld(x + (long)(q + 2) * k), Elem<T>::ld(dy + (long)(q + 2) * n), s2);
+        s3 = fmaf(Elem<T>::ld(x + (long)(q + 3) * k), Elem<T>::ld(dy + (long)(q + 3) * n), s3);
+      }
+      for (; q < q1; ++q) s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
     }
-    for (; q < k; ++q) s0 = fmaf(Elem<T>::ld(x + q), w[(long)q * n], s0);
-  } else if (MODE == 1) {
-    const T* dy = a + (long)r * n;
-    const float* w = (const float*)bptr + (long)c * n;
-    int q = 0;
-    for (; q + 4 <= n; q += 4) {
-      s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
-      s1 = fmaf(Elem<T>::ld(dy + q + 1), w[q + 1], s1);
-      s2 = fmaf(Elem<T>::ld(dy + q + 2), w[q + 2], s2);
-      s3 = fmaf(Elem<T>::ld(dy + q + 3), w[q + 3], s3);
-    }
-    for (; q < n; ++q) s0 = fmaf(Elem<T>::ld(dy + q), w[q], s0);
-  } else {
-    const T* x = a + r;
-    const T* dy = (const T*)bptr + c;
-    int q = 0;
-    for (; q + 4 <= m; q += 4) {
-      s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
-      s1 = fmaf(Elem<T>::ld(x + (long)(q + 1) * k), Elem<T>::ld(dy + (long)(q + 1) * n), s1);
-      s2 = fmaf(Elem<T>::ld(x + (long)(q + 2) * k), Elem<T>::ld(dy + (long)(q + 2) * n), s2);
-      s3 = fmaf(Elem<T>::ld(x + (long)(q + 3) * k), Elem<T>::ld(dy + (long)(q + 3) * n), s3);
-    }
-    for (; q < m; ++q) s0 = fmaf(Elem<T>::ld(x + (long)q * k), Elem<T>::ld(dy + (long)q * n), s0);
   }
-  float v = (s0 + s1) + (s2 + s3);
+  part[kp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kp != 0 || !live) return;
+  const int t = threadIdx.x;
+  float v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
   if (MODE != 2 && wscale) v /= *wscale;
   if (MODE == 0) {
     if (bias) v += bias[c];
@@ -469,7 +479,7 @@ int linear_fwd(rcgan_ctx* ctx, long m, long k, long n, const T* x, const float* 
     return RCGAN_OK;
   }
   if (linear_tiny(m * n, k)) {
-    hipLaunchKernelGGL((linear_tiny_kernel<T, 0>), dim3(cdiv(m * n, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)w,
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 0>), dim3(cdiv(m * n, 64)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)w,
                        wscale, bias, (void*)y, 0);
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
@@ -485,7 +495,7 @@ template int linear_fwd<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, con
 template <typename T>
 int linear_dgrad(rcgan_ctx* ctx, long m, long k, long n, const T* dy, const float* w, const float* wscale, T* dx, int accumulate) {
   if (linear_tiny(m * k, n)) {
-    hipLaunchKernelGGL((linear_tiny_kernel<T, 1>), dim3(cdiv(m * k, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, dy, (const void*)w,
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 1>), dim3(cdiv(m * k, 64)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, dy, (const void*)w,
                        wscale, (const float*)nullptr, (void*)dx, accumulate);
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
@@ -508,7 +518,7 @@ int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy
                  void* ws, size_t ws_bytes) {
   if (linear_tiny(k * n, m)) {
     if (ws_bytes < linear_wgrad_ws_bytes(m, k, n)) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", linear_wgrad_ws_bytes(m, k, n), ws_bytes);
-    hipLaunchKernelGGL((linear_tiny_kernel<T, 2>), dim3(cdiv(k * n, 256)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)dy,
+    hipLaunchKernelGGL((linear_tiny_kernel<T, 2>), dim3(cdiv(k * n, 64)), dim3(256), 0, ctx->stream, (int)m, (int)k, (int)n, x, (const void*)dy,
                        (const float*)nullptr, (const float*)nullptr, (void*)dw, accumulate);
     RC_LAUNCH_CHECK(ctx);
     if (dbias) return colsum_launch<T>(ctx, dy, m, (int)n, dbias, accumulate, (float*)ws);
