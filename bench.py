@@ -10,7 +10,7 @@ slabs.  Inputs are synthetic and resident in HBM before the timed re
 dequantisation noise are drawn on the device inside the captured step graphs.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (conv_mfma_glds_kernel<128,128>, fwd + dgrad of the 3x3 convs): algorithmic flops
+  roofline     dominant kernel (conv_mfma_p8_kernel: fwd + dgrad of the 256-channel convs, 256x256 tiles): algorithmic flops
                of its launches in one iteration / their summed duration measured with HIP events on the
                launch stream, against the dense bf16 MFMA peak.
   cpu_baseline the numpy oracle (kind "port": TensorFlow 1.5 is not installable) timed on the host cores for
@@ -93,12 +93,13 @@ def iteration(m, pool, it, dcount):
 
 
 def kernel_roofline(m, pool):
-    """One eager (un-captured) iteration with every conv_mfma_glds_kernel<128,128> launch bracketed by HIP events."""
+    """One eager (un-captured) iteration with every conv_mfma_p8_kernel launch (the dominant kernel: forward and data
+    gradient of the 256-channel 3x3 / 1x1 convolutions, 256 x 256 tiles) bracketed by HIP events on the launch stream."""
     from rcgan_amd import _lib as L
     ctx = m.ctx
     saved = m.use_graphs
     m.use_graphs = False
-    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 1))
+    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 4))       # RCGAN_PROF_CONV_P8
     iteration(m, pool, 1, [0])
     n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
     ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(fl)))
@@ -109,13 +110,13 @@ def kernel_roofline(m, pool):
     # HBM bytes per launch of this kernel: measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass; corrections as MI355X_MICROARCH.md prescribes) and committed with the profile
     traffic = None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv128.json")
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv_p8.json")
     if os.path.exists(tf):
         with open(tf) as f:
             traffic = float(json.load(f)["traffic_bytes_per_launch"])
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "kernel": "conv_mfma_glds_kernel<128,128>", "launches_per_iteration": n.value,
+            "kernel": "conv_mfma_p8_kernel", "launches_per_iteration": n.value,
             "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
             "flops_per_launch_avg": fl.value / n.value}
 

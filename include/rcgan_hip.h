@@ -72,6 +72,8 @@ int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* 
 #define RCGAN_PROF_CONV_MFMA_128 1   /* conv_mfma_kernel<128,128> (fwd + dgrad) */
 #define RCGAN_PROF_CONV_MFMA_64 2    /* conv_mfma_kernel<64,64> */
 #define RCGAN_PROF_WGRAD_MFMA 3      /* conv_mfma_wgrad_kernel */
+#define RCGAN_PROF_CONV_P8 4         /* conv_mfma_p8_kernel: 256 x 256 tile, 8 wavefronts (fwd + dgrad of the 256-channel layers) */
+#define RCGAN_PROF_CONV_P8N 5        /* conv_mfma_p8n_kernel: 256 x 128 tile */
 int rcgan_prof_begin(rcgan_ctx* ctx, int which);
 int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);
 /* hipGraph capture of everything launched on the ctx stream between begin/end; replay with launch.

@@ -441,7 +441,7 @@ static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_128, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_p8_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -458,7 +458,7 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 128);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_128, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_p8n_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
