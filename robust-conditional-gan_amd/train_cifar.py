@@ -154,6 +154,9 @@ def main(argv=None):
 
     _random_labels_G, _labels_biased_G = next(gen_G)
     for iteration in range(ITERS):                                             # gan_resnet.py:919-1016
+        timed = iteration % 10 == 0 or iteration < 5
+        if timed:
+            m.ctx.sync()               # launches are asynchronous: drain the queue so sec_per_iter times THIS iteration only
         t0 = time.time()
         if 0 < iteration:
             _random_labels_G, _labels_biased_G = next(gen_G)
@@ -163,7 +166,7 @@ def main(argv=None):
             feed_d(next(gen))
             m.d_step(iteration=iteration)
         m.iteration = iteration + 1
-        if iteration % 10 == 0 or iteration < 5:
+        if timed:
             d_cost, g_cost = m.losses()
             plot.plot('d_cost', d_cost)
             plot.plot('g_cost', g_cost)
