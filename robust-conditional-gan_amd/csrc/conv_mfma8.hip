@@ -12,7 +12,7 @@
 //   wavefronts     : 8 = 2 (pixels, 128 each) x 4 (channels, 64 each); accumulators 4 x 8 MFMA tiles = 128 AGPRs
 //   half-tiles     : P0 / P1 = the first / second 64 pixels of BOTH wavefront rows, C0 / C1 = the first / second
 //                    32 channels of ALL FOUR wavefront columns -- i.e. exactly what phase 1 (P0,C0), 2 (+C1),
-//                    3 (+P1), 4 (C0 again) read, whatever the wavefront
+//                    3 (+P1) read, whatever the wavefront; phase 4 (P1,C0) runs out of registers
 //   schedule       : tile t, phase p issues half-tile p of tile t+1 in the order P0, C0, C1, P1; needed at
 //                    (t+1).1, (t+1).1, (t+1).2, (t+1).3 -> at most the two newest bursts may be outstanding at
 //                    each wait.  LDS: 2 K-tile buffers x (256 + 256) rows x 128 B = 128 KiB.
@@ -34,7 +34,7 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
-template <bool RELU>
+template <bool RELU, bool XCDSWZ>
 __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALF = 128 * 128;                 // bytes of one half-tile (128 rows x 128 B)
@@ -43,7 +43,11 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;        // pixel half / channel quarter of this wavefront
-  const long m0 = (long)blockIdx.x * 256;
+  // workgroups are dealt round-robin to the 8 XCDs (8 private L2s): give each XCD a CONTIGUOUS run of pixel tiles so the
+  // SAME-padding halo rows shared by neighbouring tiles are L2 hits (bijective when the grid is a multiple of 8)
+  unsigned mt = blockIdx.x;
+  if (XCDSWZ && (gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long m0 = (long)mt * 256;
   const int co0 = blockIdx.y * 256;
   const int K = a.KH * a.KW * a.Cin;
   const int KT = K / 64;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   const int xrow0 = wm * 64 * 128;                // byte offset of this wavefront's rows inside an X half-tile
   const int wrow0 = wn * 32 * 128;                // ... inside a W half-tile
 
-  bf16x8_t xf[2][4], wf[2][2];                    // [ks][fragment] of the current pixel half / channel half
+  bf16x8_t xf[2][4], wfc[2][2][2];                // [ks][fragment] of the current pixel half; [channel half][ks][fragment]
   auto load_x = [&](const unsigned char* bufp, int h) {
     const unsigned char* p = bufp + XOFF + h * HALF + xrow0;
 #pragma unroll
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int g = 0; g < 2; ++g) wf[ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
+      for (int g = 0; g < 2; ++g) wfc[h][ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
   };
   auto mma = [&](int ph, int ch) {
     __builtin_amdgcn_s_setprio(1);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
-          acc[ch * 2 + g][ph * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f], 0, 0, 0);
+          acc[ch * 2 + g][ph * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -193,8 +197,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     mma(1, 1);
     wg_barrier();                                  // (C0 of this tile landed long ago)
-    // phase 4: (P1, C0)
-    load_w(bufp, 0);
+    // phase 4: (P1, C0) -- both operands are still in registers
     if (more) issue(3, nb);
     __builtin_amdgcn_sched_barrier(0);
     mma(1, 0);
@@ -431,18 +434,18 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
   }
 }
 
-template <bool RELU>
+template <bool RELU, bool XCDSWZ>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 4 * 128 * 128;
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
-    hipLaunchKernelGGL(conv_mfma_p8_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -467,6 +470,11 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 
 // wide = 256 output channels per workgroup (Cout % 256 == 0), else 128
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
-  if (wide) return a.relu_in ? launch8<true>(ctx, a) : launch8<false>(ctx, a);
+  static int swz = -1;
+  if (swz < 0) { const char* e = getenv("RCGAN_P8_XCD"); swz = e ? atoi(e) : 1; }
+  if (wide) {
+    if (swz) return a.relu_in ? launch8<true, true>(ctx, a) : launch8<false, true>(ctx, a);
+    return a.relu_in ? launch8<true, false>(ctx, a) : launch8<false, false>(ctx, a);
+  }
   return a.relu_in ? launch8n<true>(ctx, a) : launch8n<false>(ctx, a);
 }
