@@ -54,31 +54,26 @@ def build_pool(m, rank, alpha):
     rs2 = np.random.RandomState(99 + rank)
     pool["labels_random_G"] = to(rs2.randint(10, size=(POOL, 2 * B)), torch.int32)
     pool["labels_biased_G"] = to(rs2.randint(10, size=(POOL, 2 * B)), torch.int32)
+    # packed per-step batches in the engine's feed layout (CifarRCGAN.feed_layout): one copy per step
+    host = lambda t: t.cpu().numpy()
+    fd, fg = [], []
+    for k in range(POOL):
+        fd.append(m.pack_feed("d", images=host(pool["images"][k]), labels=host(pool["labels"][k]), labels_random=host(pool["labels_random"][k]),
+                              labels_biased=host(pool["labels_biased"][k]), inv_weights=host(pool["inv_weights"][k]),
+                              labels_all=np.concatenate([host(pool["labels"][k]), host(pool["second"][k])])))
+        fg.append(m.pack_feed("g", labels_random_G=host(pool["labels_random_G"][k]), labels_biased_G=host(pool["labels_biased_G"][k])))
+    pool["feed_d"] = torch.from_numpy(np.stack(fd)).to(dev)
+    pool["feed_g"] = torch.from_numpy(np.stack(fg)).to(dev)
     torch.cuda.synchronize()
     return pool
 
 
 def feed_d(m, pool, i):
-    ctx, v = m.ctx, m.ctx.view
-    k = i % POOL
-    B = m.B
-    with torch.cuda.stream(ctx.stream):
-        v(m.inp["images"]).copy_(pool["images"][k], non_blocking=True)
-        v(m.inp["labels"]).copy_(pool["labels"][k], non_blocking=True)
-        v(m.inp["labels_random"]).copy_(pool["labels_random"][k], non_blocking=True)
-        v(m.inp["labels_biased"]).copy_(pool["labels_biased"][k], non_blocking=True)
-        v(m.inp["inv_weights"]).copy_(pool["inv_weights"][k], non_blocking=True)
-        la = v(m.inp["labels_all"])
-        la[:B].copy_(pool["labels"][k], non_blocking=True)
-        la[B:].copy_(pool["second"][k], non_blocking=True)
+    m.set_feed("d", pool["feed_d"][i % POOL])         # one device-to-device copy of the packed batch
 
 
 def feed_g(m, pool, i):
-    ctx, v = m.ctx, m.ctx.view
-    k = i % POOL
-    with torch.cuda.stream(ctx.stream):
-        v(m.inp["labels_random_G"]).copy_(pool["labels_random_G"][k], non_blocking=True)
-        v(m.inp["labels_biased_G"]).copy_(pool["labels_biased_G"][k], non_blocking=True)
+    m.set_feed("g", pool["feed_g"][i % POOL])
 
 
 def iteration(m, pool, it, dcount):

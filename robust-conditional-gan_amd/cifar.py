@@ -14,7 +14,7 @@ import torch
 from . import _lib as L
 from . import ops as O
 from .ops_cifar import NO_OPS, Conv2D, Linear, cond_batchnorm, embed_y
-from .runtime import Context, ParamGroup
+from .runtime import DT, Context, ParamGroup
 from .variables import Graph, variable_scope
 
 Z_DIM = 128
@@ -265,12 +265,23 @@ class CifarRCGAN:
         f32, i32, act = L.F32, "i32", ctx.act_dtype
         P = ctx.persistent
         # static step inputs (graph replays read these addresses)
-        self.inp = dict(
-            images=P((B, OUTPUT_DIM), i32), noise=P((B, OUTPUT_DIM), f32), labels=P((B,), i32),
-            labels_random=P((B,), i32), labels_biased=P((B,), i32), inv_weights=P((B, VOCAB_SIZE), f32),
-            z=P((B, Z_DIM), act), labels_all=P((2 * B,), i32),
-            labels_random_G=P((2 * B,), i32), labels_biased_G=P((2 * B,), i32), z_G=P((2 * B, Z_DIM), act),
-            arange=P((VOCAB_SIZE,), i32), C_const=P((VOCAB_SIZE, VOCAB_SIZE), f32))
+        # The per-step batch inputs live in two contiguous 4-byte-word slabs ("feeds"), so a loader hands a whole D-step /
+        # G-step batch over with ONE copy (set_feed); the named views below alias the slabs (set_inputs still works).
+        self.feed_layout = {
+            "d": [("images", (B, OUTPUT_DIM), i32), ("labels", (B,), i32), ("labels_random", (B,), i32), ("labels_biased", (B,), i32),
+                  ("inv_weights", (B, VOCAB_SIZE), f32), ("labels_all", (2 * B,), i32)],
+            "g": [("labels_random_G", (2 * B,), i32), ("labels_biased_G", (2 * B,), i32)]}
+        self.feed, self.inp = {}, {}
+        for key, fields in self.feed_layout.items():
+            words = sum(int(np.prod(shp)) for _, shp, _ in fields)
+            slab = torch.zeros(words, dtype=torch.int32, device=ctx.device)
+            self.feed[key] = slab
+            off = 0
+            for name, shp, dt in fields:
+                self.inp[name] = DT(slab.data_ptr() + 4 * off, shp, dt, slab, name)
+                off += int(np.prod(shp))
+        self.inp.update(noise=P((B, OUTPUT_DIM), f32), z=P((B, Z_DIM), act), z_G=P((2 * B, Z_DIM), act),
+                        arange=P((VOCAB_SIZE,), i32), C_const=P((VOCAB_SIZE, VOCAB_SIZE), f32))
         ctx.view(self.inp["arange"]).copy_(torch.arange(VOCAB_SIZE, dtype=torch.int32))
         ctx.view(self.inp["C_const"]).copy_(torch.from_numpy(C_ALPHA(alpha).astype(np.float32)))
         self.loss_d = P((1,), f32, fill=0.0)
@@ -291,6 +302,22 @@ class CifarRCGAN:
                 dst = ctx.view(self.inp[k])
                 src = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
                 dst.copy_(src.reshape(dst.shape).to(dst.dtype), non_blocking=False)
+
+    def pack_feed(self, key, **arrays):
+        """Host-side packing of one step's batch into the feed layout (int32 words; float fields bit-cast): what a data
+        loader prepares (pinned) so that set_feed is a single transfer."""
+        parts = []
+        for name, shp, dt in self.feed_layout[key]:
+            a = np.ascontiguousarray(np.asarray(arrays[name]).reshape(shp))
+            parts.append(a.astype(np.float32).view(np.int32).reshape(-1) if dt == L.F32 else a.astype(np.int32).reshape(-1))
+        return np.concatenate(parts)
+
+    def set_feed(self, key, blob):
+        """One copy of a packed batch (numpy int32 array or device / pinned int32 tensor) into the D-step ("d") or G-step
+        ("g") inputs."""
+        src = blob if isinstance(blob, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blob, dtype=np.int32))
+        with torch.cuda.stream(self.ctx.stream):
+            self.feed[key].copy_(src.reshape(-1), non_blocking=True)
 
     def _rng(self, t, kind, lo, hi):
         ctx = self.ctx

@@ -219,3 +219,26 @@ def test_multi_step_trajectory_fp32():
         assert far < 0.02, far
     finally:
         m.ctx.close()
+
+
+def test_packed_feed_equals_named_inputs():
+    """set_feed (one copy of a packed batch) fills exactly what set_inputs fills field by field."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+    m = CifarRCGAN(algorithm="unbiased", alpha=0.6, batch_size=4, dtype="f32", seed=0, device=0, use_graphs=False)
+    try:
+        rs = np.random.RandomState(2)
+        B = 4
+        d = dict(images=rs.randint(0, 256, size=(B, 3072)), labels=rs.randint(10, size=B), labels_random=rs.randint(10, size=B),
+                 labels_biased=rs.randint(10, size=B), inv_weights=rs.randn(B, 10).astype(np.float32), labels_all=rs.randint(10, size=2 * B))
+        g = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B))
+        m.set_feed("d", m.pack_feed("d", **d))
+        m.set_feed("g", m.pack_feed("g", **g))
+        got = {k: m.ctx.download(m.inp[k]) for k in list(d) + list(g)}
+        m.set_inputs(**{k: np.zeros_like(v) for k, v in list(d.items()) + list(g.items())})
+        m.set_inputs(**d, **g)
+        for k, v in list(d.items()) + list(g.items()):
+            assert np.array_equal(got[k], np.asarray(v).reshape(got[k].shape).astype(got[k].dtype)), k
+            assert np.array_equal(m.ctx.download(m.inp[k]), got[k]), k
+    finally:
+        m.ctx.close()
