@@ -482,7 +482,10 @@ int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
     same_pad(d->w, d->kw, d->stride, &ow, &p);
     (void)oh; (void)ow;
     long rows = (long)d->n * d->h * d->w;
-    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = colsum_launch<T>(ctx, (const T*)dy, rows, d->cin, dbias, accumulate, (float*)nullptr));
+    // partial column sums go to the tail of the workspace (the filter-gradient slabs sit at its head and are consumed)
+    size_t need = ((size_t)(cdiv(rows, 2048) + 1024) * d->cin * sizeof(float) + 255) / 256 * 256;
+    float* part = (ws != nullptr && ws_bytes >= direct_wgrad_ws_bytes(d) + need) ? (float*)((char*)ws + (ws_bytes - need) / 256 * 256) : nullptr;
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = colsum_launch<T>(ctx, (const T*)dy, rows, d->cin, dbias, accumulate, part));
     if (rc) return rc;
   }
   return RCGAN_OK;

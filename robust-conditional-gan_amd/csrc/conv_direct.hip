@@ -7,6 +7,7 @@
 // conv2d_backprop_filter with SAME padding (reference call sites: mnist/ops.py:62,78;
 // cifar10/common/ops/conv2d.py:181-187).
 #include "common.h"
+#include <type_traits>
 
 struct ConvGeom {
   int N, H, W, Cin;      // logical conv input (post-upsample)
@@ -54,6 +55,39 @@ template <typename T> struct FwdOp {
   long M, N, R, r_chunk;
   __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, i, r); }
   __device__ __forceinline__ float b(long r, long j) const { return w[r * g.Cout + j]; }
+  // fast operand fetch: the row (output pixel) is decoded once per thread, the 8 consecutive reduction indices of a
+  // K-step are walked incrementally ((kh,kw,ci) with ci fastest) -- one 32-bit division per 8 elements instead of six
+  // 64-bit ones per element
+  static constexpr bool FAST = true;
+  struct Row { int n, ih0, iw0, ok; };
+  __device__ __forceinline__ Row row(long i) const {
+    Row rw;
+    rw.ok = i < M;
+    const unsigned ii = rw.ok ? (unsigned)i : 0u;
+    const unsigned ow = ii % (unsigned)g.OW, t = ii / (unsigned)g.OW;
+    rw.n = (int)(t / (unsigned)g.OH);
+    rw.ih0 = (int)(t % (unsigned)g.OH) * g.S - g.PT;
+    rw.iw0 = (int)ow * g.S - g.PL;
+    return rw;
+  }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+    unsigned kk = (unsigned)r / (unsigned)g.Cin;
+    int ci = (int)((unsigned)r - kk * (unsigned)g.Cin);
+    int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
+    const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      const int ih = rw.ih0 + kh, iw = rw.iw0 + kw;
+      if (rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
+        const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
+        v = Elem<T>::ld(x + (((long)rw.n * Hs + sh) * Ws + sw) * g.Cin + ci);
+        if (g.relu_in) v = v > 0.f ? v : 0.f;
+      }
+      out[q] = v;
+      if (++ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+    }
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     T* p = y + i * g.Cout + j;
@@ -86,6 +120,37 @@ template <typename T> struct DgradOp {
     long co = r % g.Cout, kk = r / g.Cout;
     return w[(kk * g.Cin + j) * g.Cout + co];
   }
+  static constexpr bool FAST = true;
+  struct Row { int n, ih, iw, ok; };
+  __device__ __forceinline__ Row row(long i) const {
+    Row rw;
+    rw.ok = i < M;
+    const unsigned ii = rw.ok ? (unsigned)i : 0u;
+    rw.iw = (int)(ii % (unsigned)g.W);
+    const unsigned t = ii / (unsigned)g.W;
+    rw.ih = (int)(t % (unsigned)g.H);
+    rw.n = (int)(t / (unsigned)g.H);
+    return rw;
+  }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+    unsigned kk = (unsigned)r / (unsigned)g.Cout;
+    int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
+    int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      const int th = rw.ih + g.PT - kh, tw = rw.iw + g.PL - kw;
+      if (rw.ok && r + q < r_end && th >= 0 && tw >= 0) {
+        int oh = th, ow = tw;
+        bool ok = true;
+        if (g.S == 2) { ok = !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
+        else if (g.S > 2) { ok = (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
+        if (ok && oh < g.OH && ow < g.OW) v = Elem<T>::ld(dy + (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co);
+      }
+      out[q] = v;
+      if (++co == g.Cout) { co = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+    }
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];          // used by the transposed-conv forward
     long off = i * g.Cin + j;
@@ -103,6 +168,37 @@ template <typename T> struct WgradOp {
   long M, N, R, r_chunk;
   __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, r, i); }
   __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * g.Cout + j); }
+  // fast fetch: the row is a (kh,kw,ci) filter position, the reduction walks 8 consecutive output pixels
+  static constexpr bool FAST = true;
+  struct Row { int kh, kw, ci, ok; };
+  __device__ __forceinline__ Row row(long i) const {
+    Row rw;
+    rw.ok = i < M;
+    const unsigned ii = rw.ok ? (unsigned)i : 0u;
+    const unsigned kk = ii / (unsigned)g.Cin;
+    rw.ci = (int)(ii - kk * (unsigned)g.Cin);
+    rw.kh = (int)(kk / (unsigned)g.KW);
+    rw.kw = (int)(kk - (unsigned)rw.kh * (unsigned)g.KW);
+    return rw;
+  }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+    unsigned t = (unsigned)r / (unsigned)g.OW;
+    int ow = (int)((unsigned)r - t * (unsigned)g.OW);
+    int n = (int)(t / (unsigned)g.OH), oh = (int)(t - (unsigned)n * (unsigned)g.OH);
+    const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      const int ih = oh * g.S + rw.kh - g.PT, iw = ow * g.S + rw.kw - g.PL;
+      if (rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
+        const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
+        v = Elem<T>::ld(x + (((long)n * Hs + sh) * Ws + sw) * g.Cin + rw.ci);
+        if (g.relu_in) v = v > 0.f ? v : 0.f;
+      }
+      out[q] = v;
+      if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++n; } }
+    }
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     slab[(long)z * M * N + i * N + j] = v;
   }
@@ -150,6 +246,13 @@ template <typename T> struct LinWgradOp {
 // 64 x 64 output tile, K-step 32, fp32 FMA.  The operand elements of step s+1 are fetched into registers before
 // the FMAs of step s and written to the other LDS buffer after them: one barrier per step, and the (gather)
 // load latency -- what bounds the few-workgroup dense layers of the nets -- overlaps the arithmetic.
+template <class Op, class = void> struct has_fast : std::false_type {};
+template <class Op> struct has_fast<Op, std::void_t<decltype(Op::FAST)>> : std::true_type {};
+template <class Op> __device__ __forceinline__ auto row_of(const Op& op, long i) {
+  if constexpr (has_fast<Op>::value) return op.row(i);
+  else return 0;
+}
+
 template <class Op>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   __shared__ float As[2][32][68];
@@ -173,11 +276,16 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   const int br = tid >> 4;
   const long bj = j0 + (tid & 15) * 4;
   float ra[8], rb[8];
+  const auto arow = row_of(op, ai);
   auto fetch = [&](long r0) {
+    if constexpr (has_fast<Op>::value) {
+      op.a8(arow, r0 + ar, r_end, ra);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const long r = r0 + ar + q;
-      ra[q] = (ai < op.M && r < r_end) ? op.a(ai, r) : 0.f;
+      for (int q = 0; q < 8; ++q) {
+        const long r = r0 + ar + q;
+        ra[q] = (ai < op.M && r < r_end) ? op.a(ai, r) : 0.f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -271,6 +379,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, long ro
     partial[(long)blockIdx.y * c + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// narrow matrices (c <= 8, e.g. the single-channel image bias of the MNIST generator): every thread walks whole rows,
+// the 256 row lanes are reduced through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_narrow_partial_kernel(const T* x, long rows, int c, long rows_per_blk, float* partial) {
+  __shared__ float red[4];
+  const long rb = (long)blockIdx.x * rows_per_blk;
+  long re = rb + rows_per_blk;
+  if (re > rows) re = rows;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long r = rb + threadIdx.x; r < re; r += 256)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < c) s[j] += Elem<T>::ld(x + r * c + j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j >= c) break;
+    const float v = block_sum256(s[j], red);
+    if (threadIdx.x == 0) partial[(long)blockIdx.x * c + j] = v;
+    __syncthreads();
+  }
+}
+
 // vectorised partial column sums: each thread owns 8 consecutive columns (one 16-B bf16 / two 16-B fp32
 // loads per row), row lanes reduced through LDS.  Requires c % 8 == 0 and (c/8) | 256.
 __device__ __forceinline__ void load8(const float* p, float* v) {
@@ -345,6 +475,16 @@ int colsum_launch(rcgan_ctx* ctx, const T* x, long rows, int c, float* out, int 
     while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
     int nb = cdiv(rows, rpb);          // <= 1024 <= the cdiv(rows, 2048)*... slots? see colsum_ws_rows()
     hipLaunchKernelGGL(colsum_vec_partial_kernel<T>, dim3(nb), dim3(256), 0, ctx->stream, x, rows, c, rpb, partial_ws);
+    RC_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, (const float*)partial_ws, (long)nb, c, out, accumulate);
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
+  if (partial_ws != nullptr && rows >= 4096 && c <= 8) {
+    long rpb = 1024;
+    while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
+    int nb = cdiv(rows, rpb);
+    hipLaunchKernelGGL(colsum_narrow_partial_kernel<T>, dim3(nb), dim3(256), 0, ctx->stream, x, rows, c, rpb, partial_ws);
     RC_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(c, 64)), dim3(256), 0, ctx->stream, (const float*)partial_ws, (long)nb, c, out, accumulate);
     RC_LAUNCH_CHECK(ctx);
