@@ -161,6 +161,63 @@ template <typename T> struct DgradOp {
   }
 };
 
+// ---- data gradient of a stride-2 conv (= the MNIST transposed convs and the backward of its 5x5 stride-2 convs),
+//      one input-pixel PARITY CLASS (ih % 2, iw % 2) per launch.  For a pixel of class (ph, pw) only the taps with
+//      kh = kh0 + 2*jh, kw = kw0 + 2*jw (kh0 = (ph + PT) % 2) reach an output pixel, so the reduction runs over
+//      ceil(KH/2) x ceil(KW/2) x Cout instead of KH x KW x Cout with three quarters of the gathers returning zero.
+//      i = (n, ih/2, iw/2) inside the class, j = ci, r = (jh, jw, co).
+template <typename T> struct DgradS2Op {
+  ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
+  const float* wscale;
+  long M, N, R, r_chunk;
+  int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
+  __device__ __forceinline__ float a(long, long) const { return 0.f; }
+  __device__ __forceinline__ float b(long r, long j) const {
+    const unsigned jj = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - jj * (unsigned)g.Cout;
+    const int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    const int kh = kh0 + 2 * jh, kw = kw0 + 2 * jw;
+    return w[((long)(kh * g.KW + kw) * g.Cin + j) * g.Cout + co];
+  }
+  static constexpr bool FAST = true;
+  struct Row { int n, ih2, iw2, ok; };
+  __device__ __forceinline__ Row row(long i) const {
+    Row rw;
+    rw.ok = i < M;
+    const unsigned ii = rw.ok ? (unsigned)i : 0u;
+    rw.iw2 = (int)(ii % (unsigned)Wp);
+    const unsigned t = ii / (unsigned)Wp;
+    rw.ih2 = (int)(t % (unsigned)Hp);
+    rw.n = (int)(t / (unsigned)Hp);
+    return rw;
+  }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+    unsigned jj = (unsigned)r / (unsigned)g.Cout;
+    int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
+    int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      const int oh = rw.ih2 + dh - jh, ow = rw.iw2 + dwc - jw;
+      if (rw.ok && r + q < r_end && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW)
+        v = Elem<T>::ld(dy + (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co);
+      out[q] = v;
+      if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
+    }
+  }
+  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+    const unsigned ii = (unsigned)i;
+    const int iw2 = (int)(ii % (unsigned)Wp);
+    const unsigned t = ii / (unsigned)Wp;
+    const int ih2 = (int)(t % (unsigned)Hp), n = (int)(t / (unsigned)Hp);
+    if (bias) v += bias[j];
+    const long off = (((long)n * g.H + 2 * ih2 + ph) * g.W + 2 * iw2 + pw) * g.Cin + j;
+    if (xmask) { float xv = Elem<T>::ld(xmask + off); if (!(xv > 0.f)) v = 0.f; }
+    T* p = dx + off;
+    if (accumulate) v += Elem<T>::ld(p);
+    Elem<T>::st(p, v);
+  }
+};
+
 // ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs ----
 template <typename T> struct WgradOp {
   ConvGeom g; const T* x; const T* dy; float* slab;
@@ -708,6 +765,27 @@ template int direct_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t
 template <typename T>
 int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const float* w, const float* wscale, const float* bias,
                  const T* xmask, T* dx, int accumulate) {
+  {
+    ConvGeom g = make_geom(d);
+    if (g.S == 2) {                      // one launch per input-pixel parity class
+      for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+          DgradS2Op<T> op;
+          op.g = g; op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
+          op.ph = ph; op.pw = pw; op.Hp = (g.H - ph + 1) / 2; op.Wp = (g.W - pw + 1) / 2;
+          if (op.Hp <= 0 || op.Wp <= 0) continue;
+          op.kh0 = (ph + g.PT) % 2; op.kw0 = (pw + g.PL) % 2;
+          op.nkh = g.KH > op.kh0 ? (g.KH - op.kh0 + 1) / 2 : 0;
+          op.nkw = g.KW > op.kw0 ? (g.KW - op.kw0 + 1) / 2 : 0;
+          op.dh = (ph + g.PT - op.kh0) / 2; op.dwc = (pw + g.PL - op.kw0) / 2;
+          if (op.nkw == 0) { op.nkw = 1; op.nkh = 0; }          // keeps the divisions defined; R = 0: outputs are bias / 0
+          op.M = (long)g.N * op.Hp * op.Wp; op.N = g.Cin; op.R = (long)op.nkh * op.nkw * g.Cout; op.r_chunk = op.R;
+          int rc = launch_gemm(ctx, op, 1);
+          if (rc) return rc;
+        }
+      return RCGAN_OK;
+    }
+  }
   DgradOp<T> op;
   op.g = make_geom(d); op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
   op.M = (long)op.g.N * op.g.H * op.g.W; op.N = op.g.Cin; op.R = (long)op.g.KH * op.g.KW * op.g.Cout; op.r_chunk = op.R;
