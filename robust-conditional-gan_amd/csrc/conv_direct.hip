@@ -300,9 +300,13 @@ template <typename T> struct LinWgradOp {
   }
 };
 
-// 64 x 64 output tile, K-step 32, fp32 FMA.  The operand elements of step s+1 are fetched into registers before
-// the FMAs of step s and written to the other LDS buffer after them: one barrier per step, and the (gather)
-// load latency -- what bounds the few-workgroup dense layers of the nets -- overlaps the arithmetic.
+// 64 x 64 output tile, K-step 32, fp32 matrix cores (v_mfma_f32_32x32x2_f32: IEEE fp32 products and sums, only the
+// summation order differs from a scalar loop).  Four waves, one 32x32 quadrant each: per K-step a wave reads its
+// operands with 4 ds_read_b128 + 16 ds_read_b32 and issues 16 MFMAs -- 8 KB of LDS traffic per wave-step where the
+// FMA formulation moved 64 KB and stalled on every LDS->FMA dependency at the one-wave-per-SIMD occupancy of the
+// few-workgroup dense layers.  The K-slot a lane feeds to MFMA s is 16*(lane>>5)+s, so the A operand of all 16 steps is
+// one contiguous 64-byte run per lane.  The operand elements of step s+1 are fetched into registers before the MFMAs of
+// step s and written to the other LDS buffer after them: one barrier per step.
 template <class Op, class = void> struct has_fast : std::false_type {};
 template <class Op> struct has_fast<Op, std::void_t<decltype(Op::FAST)>> : std::true_type {};
 template <class Op> __device__ __forceinline__ auto row_of(const Op& op, long i) {
@@ -312,19 +316,18 @@ template <class Op> __device__ __forceinline__ auto row_of(const Op& op, long i)
 
 template <class Op>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
-  __shared__ float As[2][32][68];
-  __shared__ float Bs[2][32][68];
+  __shared__ __attribute__((aligned(16))) float As[2][64][36];   // [row][k]
+  __shared__ __attribute__((aligned(16))) float Bs[2][32][68];                                 // [k][col]
   const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, l31 = lane & 31, hh = lane >> 5;
   const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
   const long r_begin = (long)blockIdx.z * op.r_chunk;
   long r_end = r_begin + op.r_chunk;
   if (r_end > op.R) r_end = op.R;
-  float acc[4][4];
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 acc;
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[p][q] = 0.f;
+  for (int p = 0; p < 16; ++p) acc[p] = 0.f;
 
   // spectral-norm division W / sigma: sigma is loaded once per thread, not once per operand element
   const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
@@ -351,10 +354,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
     }
   };
   auto stash = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) As[buf][ar + q][tid >> 2] = ra[q];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) Bs[buf][br + 16 * (q >> 2)][(tid & 15) * 4 + (q & 3)] = rb[q];
+    *(float4*)&As[buf][tid >> 2][ar] = make_float4(ra[0], ra[1], ra[2], ra[3]);
+    *(float4*)&As[buf][tid >> 2][ar + 4] = make_float4(ra[4], ra[5], ra[6], ra[7]);
+    *(float4*)&Bs[buf][br][(tid & 15) * 4] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    *(float4*)&Bs[buf][br + 16][(tid & 15) * 4] = make_float4(rb[4], rb[5], rb[6], rb[7]);
   };
   if (r_begin < r_end) { fetch(r_begin); stash(0); }
   __syncthreads();
@@ -362,30 +365,26 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   for (long r0 = r_begin; r0 < r_end; r0 += 32) {
     const bool more = r0 + 32 < r_end;
     if (more) fetch(r0 + 32);
+    float av[16], bv[16];
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-      float a4[4], b4[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) a4[p] = As[buf][kk][ty * 4 + p];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b4[q] = Bs[buf][kk][tx * 4 + q];
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] = fmaf(a4[p], b4[q], acc[p][q]);
+    for (int v = 0; v < 4; ++v) {
+      const float4 t = *(const float4*)&As[buf][wr * 32 + l31][16 * hh + 4 * v];
+      av[4 * v] = t.x; av[4 * v + 1] = t.y; av[4 * v + 2] = t.z; av[4 * v + 3] = t.w;
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bv[q] = Bs[buf][16 * hh + q][wc * 32 + l31];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
     if (more) stash(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
+  const long j = j0 + wc * 32 + l31;
+  if (j < op.N) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    long i = i0 + ty * 4 + p;
-    if (i >= op.M) continue;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      long j = j0 + tx * 4 + q;
-      if (j < op.N) op.store(i, j, acc[p][q], blockIdx.z);
+    for (int p = 0; p < 16; ++p) {
+      const long i = i0 + wr * 32 + 8 * (p >> 2) + 4 * hh + (p & 3);
+      if (i < op.M) op.store(i, j, acc[p], blockIdx.z);
     }
   }
 }
