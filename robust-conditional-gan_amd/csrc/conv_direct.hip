@@ -70,21 +70,20 @@ template <typename T> struct FwdOp {
     rw.iw0 = (int)ow * g.S - g.PL;
     return rw;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+  __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
     unsigned kk = (unsigned)r / (unsigned)g.Cin;
     int ci = (int)((unsigned)r - kk * (unsigned)g.Cin);
     int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
     const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
+    mask = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = 0.f;
       const int ih = rw.ih0 + kh, iw = rw.iw0 + kw;
-      if (rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
-        const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
-        v = Elem<T>::ld(x + (((long)rw.n * Hs + sh) * Ws + sw) * g.Cin + ci);
-        if (g.relu_in) v = v > 0.f ? v : 0.f;
-      }
-      out[q] = v;
+      const bool ok = rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+      const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
+      raw[q] = x[ok ? (((long)rw.n * Hs + sh) * Ws + sw) * g.Cin + ci : 0];
+      mask |= (unsigned)ok << q;
       if (++ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
     }
   }
@@ -132,22 +131,22 @@ template <typename T> struct DgradOp {
     rw.n = (int)(t / (unsigned)g.H);
     return rw;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+  __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
     unsigned kk = (unsigned)r / (unsigned)g.Cout;
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
     int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
+    mask = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = 0.f;
       const int th = rw.ih + g.PT - kh, tw = rw.iw + g.PL - kw;
-      if (rw.ok && r + q < r_end && th >= 0 && tw >= 0) {
-        int oh = th, ow = tw;
-        bool ok = true;
-        if (g.S == 2) { ok = !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
-        else if (g.S > 2) { ok = (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
-        if (ok && oh < g.OH && ow < g.OW) v = Elem<T>::ld(dy + (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co);
-      }
-      out[q] = v;
+      bool ok = rw.ok && r + q < r_end && th >= 0 && tw >= 0;
+      int oh = th, ow = tw;
+      if (g.S == 2) { ok = ok && !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
+      else if (g.S > 2) { ok = ok && (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
+      ok = ok && oh < g.OH && ow < g.OW;
+      raw[q] = dy[ok ? (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co : 0];
+      mask |= (unsigned)ok << q;
       if (++co == g.Cout) { co = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
     }
   }
@@ -190,17 +189,18 @@ template <typename T> struct DgradS2Op {
     rw.n = (int)(t / (unsigned)Hp);
     return rw;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+  __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
     unsigned jj = (unsigned)r / (unsigned)g.Cout;
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
     int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    mask = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = 0.f;
       const int oh = rw.ih2 + dh - jh, ow = rw.iw2 + dwc - jw;
-      if (rw.ok && r + q < r_end && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW)
-        v = Elem<T>::ld(dy + (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co);
-      out[q] = v;
+      const bool ok = rw.ok && r + q < r_end && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+      raw[q] = dy[ok ? (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co : 0];
+      mask |= (unsigned)ok << q;
       if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
     }
   }
@@ -238,21 +238,20 @@ template <typename T> struct WgradOp {
     rw.kw = (int)(kk - (unsigned)rw.kh * (unsigned)g.KW);
     return rw;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, float* out) const {
+  __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
     unsigned t = (unsigned)r / (unsigned)g.OW;
     int ow = (int)((unsigned)r - t * (unsigned)g.OW);
     int n = (int)(t / (unsigned)g.OH), oh = (int)(t - (unsigned)n * (unsigned)g.OH);
     const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
+    mask = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = 0.f;
       const int ih = oh * g.S + rw.kh - g.PT, iw = ow * g.S + rw.kw - g.PL;
-      if (rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
-        const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
-        v = Elem<T>::ld(x + (((long)n * Hs + sh) * Ws + sw) * g.Cin + rw.ci);
-        if (g.relu_in) v = v > 0.f ? v : 0.f;
-      }
-      out[q] = v;
+      const bool ok = rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+      const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
+      raw[q] = x[ok ? (((long)n * Hs + sh) * Ws + sw) * g.Cin + rw.ci : 0];
+      mask |= (unsigned)ok << q;
       if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++n; } }
     }
   }
@@ -309,6 +308,11 @@ template <typename T> struct LinWgradOp {
 // step s and written to the other LDS buffer after them: one barrier per step.
 template <class Op, class = void> struct has_fast : std::false_type {};
 template <class Op> struct has_fast<Op, std::void_t<decltype(Op::FAST)>> : std::true_type {};
+template <typename T> __device__ T a_elem(const FwdOp<T>&);
+template <typename T> __device__ T a_elem(const DgradOp<T>&);
+template <typename T> __device__ T a_elem(const DgradS2Op<T>&);
+template <typename T> __device__ T a_elem(const WgradOp<T>&);
+template <class Op> __device__ float a_elem(const Op&);
 template <class Op> __device__ __forceinline__ auto row_of(const Op& op, long i) {
   if constexpr (has_fast<Op>::value) return op.row(i);
   else return 0;
@@ -335,29 +339,54 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   const int ar = (tid & 3) * 8;
   const int br = tid >> 4;
   const long bj = j0 + (tid & 15) * 4;
-  float ra[8], rb[8];
+  // Operand fetch is branch-free (clamped addresses, validity kept in bit masks) and the zero-fill / ReLU / sigma scale
+  // are applied at the LDS write: every load of a step is in flight together and nothing waits on them until after the
+  // MFMAs (a select or max right behind each guarded load serialised the eight load latencies of a step).
+  typename std::conditional<has_fast<Op>::value, decltype(a_elem(op)), float>::type ra[8];
+  float rb[8];
+  unsigned amask = 0, bmask = 0;
   const auto arow = row_of(op, ai);
   auto fetch = [&](long r0) {
     if constexpr (has_fast<Op>::value) {
-      op.a8(arow, r0 + ar, r_end, ra);
+      op.a8(arow, r0 + ar, r_end, ra, amask);
     } else {
+      amask = 0;
+      const long aic = ai < op.M ? ai : op.M - 1;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const long r = r0 + ar + q;
-        ra[q] = (ai < op.M && r < r_end) ? op.a(ai, r) : 0.f;
+        const bool ok = ai < op.M && r < r_end;
+        ra[q] = op.a(aic, ok ? r : r_end - 1);
+        amask |= (unsigned)ok << q;
       }
     }
+    bmask = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const long r = r0 + br + 16 * (q >> 2), j = bj + (q & 3);
-      rb[q] = (r < r_end && j < op.N) ? op.b(r, j) * bscale : 0.f;
+      const bool ok = r < r_end && j < op.N;
+      rb[q] = op.b(r < r_end ? r : r_end - 1, j < op.N ? j : op.N - 1);
+      bmask |= (unsigned)ok << q;
     }
   };
   auto stash = [&](int buf) {
-    *(float4*)&As[buf][tid >> 2][ar] = make_float4(ra[0], ra[1], ra[2], ra[3]);
-    *(float4*)&As[buf][tid >> 2][ar + 4] = make_float4(ra[4], ra[5], ra[6], ra[7]);
-    *(float4*)&Bs[buf][br][(tid & 15) * 4] = make_float4(rb[0], rb[1], rb[2], rb[3]);
-    *(float4*)&Bs[buf][br + 16][(tid & 15) * 4] = make_float4(rb[4], rb[5], rb[6], rb[7]);
+    float fa[8], fb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v;
+      if constexpr (has_fast<Op>::value) {
+        v = Elem<decltype(a_elem(op))>::ld(&ra[q]);
+        if (op.a_relu()) v = v > 0.f ? v : 0.f;
+      } else {
+        v = ra[q];
+      }
+      fa[q] = ((amask >> q) & 1u) ? v : 0.f;
+      fb[q] = ((bmask >> q) & 1u) ? rb[q] * bscale : 0.f;
+    }
+    *(float4*)&As[buf][tid >> 2][ar] = make_float4(fa[0], fa[1], fa[2], fa[3]);
+    *(float4*)&As[buf][tid >> 2][ar + 4] = make_float4(fa[4], fa[5], fa[6], fa[7]);
+    *(float4*)&Bs[buf][br][(tid & 15) * 4] = make_float4(fb[0], fb[1], fb[2], fb[3]);
+    *(float4*)&Bs[buf][br + 16][(tid & 15) * 4] = make_float4(fb[4], fb[5], fb[6], fb[7]);
   };
   if (r_begin < r_end) { fetch(r_begin); stash(0); }
   __syncthreads();
