@@ -28,37 +28,30 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
   return g;
 }
 
-// value of the (virtually padded / upsampled / relu'd) conv input at pixel m=(n,oh,ow), tap index k=(kh,kw,ci)
-template <typename T>
-__device__ __forceinline__ float gather_in(const ConvGeom& g, const T* x, long m, long k) {
-  int ow = (int)(m % g.OW);
-  long t = m / g.OW;
-  int oh = (int)(t % g.OH);
-  int n = (int)(t / g.OH);
-  int ci = (int)(k % g.Cin);
-  int kk = (int)(k / g.Cin);
-  int kw = kk % g.KW, kh = kk / g.KW;
-  int ih = oh * g.S + kh - g.PT, iw = ow * g.S + kw - g.PL;
-  if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
-  long off;
-  if (g.up) off = (((long)n * (g.H >> 1) + (ih >> 1)) * (g.W >> 1) + (iw >> 1)) * g.Cin + ci;
-  else off = (((long)n * g.H + ih) * g.W + iw) * g.Cin + ci;
-  float v = Elem<T>::ld(x + off);
-  if (g.relu_in) v = v > 0.f ? v : 0.f;
-  return v;
+// Operand functors of the gather GEMM  C[i][j] = sum_r A(i,r) * B(r,j).  Each provides
+//   Row row(i)                          the row decoded once per thread (a thread fetches one row of A for the whole launch)
+//   a8(row, r, r_end, raw[8], mask)     8 consecutive reduction indices of that row: raw element loads from addresses
+//                                       that are always inside the tensor + a validity bit mask (zero-fill, ReLU and
+//                                       conversion happen at the LDS write, after the MFMAs of the previous step)
+//   bbase(r, stride)                    B(r, j) = bbase[j * stride]
+//   store(i, j, v, z)
+// Pixel indices are 32-bit (a tensor has < 2^32 pixels); the element offset is one 64-bit multiply-add.  When the run
+// dimension (channels) is >= 8 a run of 8 touches at most two filter taps, so the tap decode, the bounds test and the
+// pixel address are computed twice per run instead of eight times.
+__device__ __forceinline__ unsigned run_mask(bool okA, bool okB, int nA, long r, long r_end) {
+  const unsigned mA = nA >= 8 ? 0xffu : ((1u << nA) - 1u);
+  unsigned m = (okA ? mA : 0u) | (okB ? (0xffu & ~mA) : 0u);
+  const long left = r_end - r;
+  m &= left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u);
+  return m;
 }
 
 // ---- forward: i = output pixel, j = cout, r = (kh,kw,ci) ---------------------------------------
 template <typename T> struct FwdOp {
+  typedef T AT; typedef float BT;
   ConvGeom g; const T* x; const float* w; const float* bias; T* y; int accumulate;
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
   long M, N, R, r_chunk;
-  __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, i, r); }
-  __device__ __forceinline__ float b(long r, long j) const { return w[r * g.Cout + j]; }
-  // fast operand fetch: the row (output pixel) is decoded once per thread, the 8 consecutive reduction indices of a
-  // K-step are walked incrementally ((kh,kw,ci) with ci fastest) -- one 32-bit division per 8 elements instead of six
-  // 64-bit ones per element
-  static constexpr bool FAST = true;
   struct Row { int n, ih0, iw0, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -71,22 +64,43 @@ template <typename T> struct FwdOp {
     return rw;
   }
   __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
+  // element pointer of tap (kh,kw), channel offset c0 (may be negative: the second tap of a run is addressed at q >= nA)
+  __device__ __forceinline__ const T* tap(const Row& rw, int kh, int kw, int c0, bool& ok) const {
+    const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
+    const int ih = rw.ih0 + kh, iw = rw.iw0 + kw;
+    ok = rw.ok && kh < g.KH && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+    const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
+    const unsigned pix = ((unsigned)rw.n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
+    return ok ? x + ((long)pix * g.Cin + c0) : x;
+  }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    unsigned kk = (unsigned)r / (unsigned)g.Cin;
+    const unsigned kk = (unsigned)r / (unsigned)g.Cin;
     int ci = (int)((unsigned)r - kk * (unsigned)g.Cin);
     int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
-    const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
-    mask = 0;
+    if (g.Cin >= 8) {
+      const int nA = g.Cin - ci;
+      bool okA, okB;
+      const T* pA = tap(rw, kh, kw, ci, okA);
+      int kw2 = kw + 1, kh2 = kh;
+      if (kw2 == g.KW) { kw2 = 0; ++kh2; }
+      const T* pB = tap(rw, kh2, kw2, -nA, okB);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int ih = rw.ih0 + kh, iw = rw.iw0 + kw;
-      const bool ok = rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-      const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
-      raw[q] = x[ok ? (((long)rw.n * Hs + sh) * Ws + sw) * g.Cin + ci : 0];
-      mask |= (unsigned)ok << q;
-      if (++ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      mask = run_mask(okA, okB, nA, r, r_end);
+    } else {
+      mask = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bool ok;
+        const T* p = tap(rw, kh, kw, ci, ok);
+        ok = ok && r + q < r_end;
+        raw[q] = *(ok ? p : x);
+        mask |= (unsigned)ok << q;
+        if (++ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+      }
     }
   }
+  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = 1; return w + r * g.Cout; }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     T* p = y + i * g.Cout + j;
@@ -97,29 +111,10 @@ template <typename T> struct FwdOp {
 
 // ---- data gradient: i = input pixel (n,ih,iw) at the logical resolution, j = ci, r = (kh,kw,co) ---
 template <typename T> struct DgradOp {
+  typedef T AT; typedef float BT;
   ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
   const float* wscale;
   long M, N, R, r_chunk;
-  __device__ __forceinline__ float a(long i, long r) const {
-    int iw = (int)(i % g.W);
-    long t = i / g.W;
-    int ih = (int)(t % g.H);
-    int n = (int)(t / g.H);
-    int co = (int)(r % g.Cout);
-    int kk = (int)(r / g.Cout);
-    int kw = kk % g.KW, kh = kk / g.KW;
-    int th = ih + g.PT - kh, tw = iw + g.PL - kw;
-    if (th < 0 || tw < 0) return 0.f;
-    if (g.S > 1 && ((th % g.S) || (tw % g.S))) return 0.f;
-    int oh = th / g.S, ow = tw / g.S;
-    if (oh >= g.OH || ow >= g.OW) return 0.f;
-    return Elem<T>::ld(dy + (((long)n * g.OH + oh) * g.OW + ow) * g.Cout + co);
-  }
-  __device__ __forceinline__ float b(long r, long j) const {
-    long co = r % g.Cout, kk = r / g.Cout;
-    return w[(kk * g.Cin + j) * g.Cout + co];
-  }
-  static constexpr bool FAST = true;
   struct Row { int n, ih, iw, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -132,23 +127,47 @@ template <typename T> struct DgradOp {
     return rw;
   }
   __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ const T* tap(const Row& rw, int kh, int kw, int c0, bool& ok) const {
+    const int th = rw.ih + g.PT - kh, tw = rw.iw + g.PL - kw;
+    ok = rw.ok && kh < g.KH && th >= 0 && tw >= 0;
+    int oh = th, ow = tw;
+    if (g.S == 2) { ok = ok && !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
+    else if (g.S > 2) { ok = ok && (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
+    ok = ok && oh < g.OH && ow < g.OW;
+    const unsigned pix = ((unsigned)rw.n * (unsigned)g.OH + (unsigned)oh) * (unsigned)g.OW + (unsigned)ow;
+    return ok ? dy + ((long)pix * g.Cout + c0) : dy;
+  }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    unsigned kk = (unsigned)r / (unsigned)g.Cout;
+    const unsigned kk = (unsigned)r / (unsigned)g.Cout;
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
     int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
-    mask = 0;
+    if (g.Cout >= 8) {
+      const int nA = g.Cout - co;
+      bool okA, okB;
+      const T* pA = tap(rw, kh, kw, co, okA);
+      int kw2 = kw + 1, kh2 = kh;
+      if (kw2 == g.KW) { kw2 = 0; ++kh2; }
+      const T* pB = tap(rw, kh2, kw2, -nA, okB);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int th = rw.ih + g.PT - kh, tw = rw.iw + g.PL - kw;
-      bool ok = rw.ok && r + q < r_end && th >= 0 && tw >= 0;
-      int oh = th, ow = tw;
-      if (g.S == 2) { ok = ok && !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
-      else if (g.S > 2) { ok = ok && (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
-      ok = ok && oh < g.OH && ow < g.OW;
-      raw[q] = dy[ok ? (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co : 0];
-      mask |= (unsigned)ok << q;
-      if (++co == g.Cout) { co = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      mask = run_mask(okA, okB, nA, r, r_end);
+    } else {
+      mask = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bool ok;
+        const T* p = tap(rw, kh, kw, co, ok);
+        ok = ok && r + q < r_end;
+        raw[q] = *(ok ? p : dy);
+        mask |= (unsigned)ok << q;
+        if (++co == g.Cout) { co = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+      }
     }
+  }
+  __device__ __forceinline__ const float* bbase(long r, long& stride) const {
+    const unsigned kk = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - kk * (unsigned)g.Cout;
+    stride = g.Cout;
+    return w + ((long)kk * g.Cin * g.Cout + co);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];          // used by the transposed-conv forward
@@ -166,18 +185,11 @@ template <typename T> struct DgradOp {
 //      ceil(KH/2) x ceil(KW/2) x Cout instead of KH x KW x Cout with three quarters of the gathers returning zero.
 //      i = (n, ih/2, iw/2) inside the class, j = ci, r = (jh, jw, co).
 template <typename T> struct DgradS2Op {
+  typedef T AT; typedef float BT;
   ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
   const float* wscale;
   long M, N, R, r_chunk;
   int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
-  __device__ __forceinline__ float a(long, long) const { return 0.f; }
-  __device__ __forceinline__ float b(long r, long j) const {
-    const unsigned jj = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - jj * (unsigned)g.Cout;
-    const int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
-    const int kh = kh0 + 2 * jh, kw = kw0 + 2 * jw;
-    return w[((long)(kh * g.KW + kw) * g.Cin + j) * g.Cout + co];
-  }
-  static constexpr bool FAST = true;
   struct Row { int n, ih2, iw2, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -190,19 +202,45 @@ template <typename T> struct DgradS2Op {
     return rw;
   }
   __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ const T* tap(const Row& rw, int jh, int jw, int c0, bool& ok) const {
+    const int oh = rw.ih2 + dh - jh, ow = rw.iw2 + dwc - jw;
+    ok = rw.ok && jh < nkh && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+    const unsigned pix = ((unsigned)rw.n * (unsigned)g.OH + (unsigned)oh) * (unsigned)g.OW + (unsigned)ow;
+    return ok ? dy + ((long)pix * g.Cout + c0) : dy;
+  }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    unsigned jj = (unsigned)r / (unsigned)g.Cout;
+    const unsigned jj = (unsigned)r / (unsigned)g.Cout;
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
     int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
-    mask = 0;
+    if (g.Cout >= 8) {
+      const int nA = g.Cout - co;
+      bool okA, okB;
+      const T* pA = tap(rw, jh, jw, co, okA);
+      int jw2 = jw + 1, jh2 = jh;
+      if (jw2 == nkw) { jw2 = 0; ++jh2; }
+      const T* pB = tap(rw, jh2, jw2, -nA, okB);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int oh = rw.ih2 + dh - jh, ow = rw.iw2 + dwc - jw;
-      const bool ok = rw.ok && r + q < r_end && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-      raw[q] = dy[ok ? (((long)rw.n * g.OH + oh) * g.OW + ow) * g.Cout + co : 0];
-      mask |= (unsigned)ok << q;
-      if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
+      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      mask = run_mask(okA, okB, nA, r, r_end);
+    } else {
+      mask = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bool ok;
+        const T* p = tap(rw, jh, jw, co, ok);
+        ok = ok && r + q < r_end;
+        raw[q] = *(ok ? p : dy);
+        mask |= (unsigned)ok << q;
+        if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
+      }
     }
+  }
+  __device__ __forceinline__ const float* bbase(long r, long& stride) const {
+    const unsigned jj = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - jj * (unsigned)g.Cout;
+    const int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    const int kh = kh0 + 2 * jh, kw = kw0 + 2 * jw;
+    stride = g.Cout;
+    return w + ((long)(kh * g.KW + kw) * g.Cin * g.Cout + co);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     const unsigned ii = (unsigned)i;
@@ -220,13 +258,11 @@ template <typename T> struct DgradS2Op {
 
 // ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs ----
 template <typename T> struct WgradOp {
+  typedef T AT; typedef T BT;
   ConvGeom g; const T* x; const T* dy; float* slab;
   const float* wscale;   // always null (the filter gradient has no filter operand)
   long M, N, R, r_chunk;
-  __device__ __forceinline__ float a(long i, long r) const { return gather_in<T>(g, x, r, i); }
-  __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * g.Cout + j); }
-  // fast fetch: the row is a (kh,kw,ci) filter position, the reduction walks 8 consecutive output pixels
-  static constexpr bool FAST = true;
+  // the row is a (kh,kw,ci) filter position, the reduction walks 8 consecutive output pixels
   struct Row { int kh, kw, ci, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -240,7 +276,7 @@ template <typename T> struct WgradOp {
   }
   __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    unsigned t = (unsigned)r / (unsigned)g.OW;
+    const unsigned t = (unsigned)r / (unsigned)g.OW;
     int ow = (int)((unsigned)r - t * (unsigned)g.OW);
     int n = (int)(t / (unsigned)g.OH), oh = (int)(t - (unsigned)n * (unsigned)g.OH);
     const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
@@ -250,34 +286,55 @@ template <typename T> struct WgradOp {
       const int ih = oh * g.S + rw.kh - g.PT, iw = ow * g.S + rw.kw - g.PL;
       const bool ok = rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
       const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
-      raw[q] = x[ok ? (((long)n * Hs + sh) * Ws + sw) * g.Cin + rw.ci : 0];
+      const unsigned pix = ((unsigned)n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
+      raw[q] = x[ok ? (long)pix * g.Cin + rw.ci : 0];
       mask |= (unsigned)ok << q;
       if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++n; } }
     }
   }
+  __device__ __forceinline__ const T* bbase(long r, long& stride) const { stride = 1; return dy + r * g.Cout; }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     slab[(long)z * M * N + i * N + j] = v;
   }
 };
 
-// ---- fully connected layers: the same GEMM core with plain row-major operands (no pixel decode, no
-//      integer division per element): y[m][n] = x[m][:] . w[:][n];  dx[m][k] = dy[m][:] . w[k][:];
-//      dw[k][n] = x[:][k] . dy[:][n]
+// ---- fully connected layers: the same GEMM core with plain row-major operands:
+//      y[m][n] = x[m][:] . w[:][n];  dx[m][k] = dy[m][:] . w[k][:];  dw[k][n] = x[:][k] . dy[:][n]
+__device__ __forceinline__ unsigned tail_mask(bool ok, long r, long r_end) {
+  const long left = r_end - r;
+  return ok ? (left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u)) : 0u;
+}
 template <typename T> struct LinFwdOp {
+  typedef T AT; typedef float BT;
   const T* x; const float* w; const float* bias; T* y; const float* wscale;
   long M, N, R, r_chunk;
-  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(x + i * R + r); }
-  __device__ __forceinline__ float b(long r, long j) const { return w[r * N + j]; }
+  struct Row { const T* p; int ok; };
+  __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = x + (rw.ok ? i : 0) * R; return rw; }
+  __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = rw.p[r + q < r_end ? r + q : r_end - 1];
+    mask = tail_mask(rw.ok, r, r_end);
+  }
+  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = 1; return w + r * N; }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     Elem<T>::st(y + i * N + j, v);
   }
 };
 template <typename T> struct LinDgradOp {
+  typedef T AT; typedef float BT;
   const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
   long M, N, R, r_chunk;          // N = in features, R = out features
-  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(dy + i * R + r); }
-  __device__ __forceinline__ float b(long r, long j) const { return w[j * R + r]; }
+  struct Row { const T* p; int ok; };
+  __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = dy + (rw.ok ? i : 0) * R; return rw; }
+  __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = rw.p[r + q < r_end ? r + q : r_end - 1];
+    mask = tail_mask(rw.ok, r, r_end);
+  }
+  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = R; return w + r; }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     T* p = dx + i * N + j;
     if (accumulate) v += Elem<T>::ld(p);
@@ -285,10 +342,18 @@ template <typename T> struct LinDgradOp {
   }
 };
 template <typename T> struct LinWgradOp {
+  typedef T AT; typedef T BT;
   const T* x; const T* dy; float* out; int accumulate; int direct; const float* wscale;
   long M, N, R, r_chunk;          // M = in features, N = out features, R = batch rows
-  __device__ __forceinline__ float a(long i, long r) const { return Elem<T>::ld(x + r * M + i); }
-  __device__ __forceinline__ float b(long r, long j) const { return Elem<T>::ld(dy + r * N + j); }
+  struct Row { const T* p; int ok; };
+  __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = x + (rw.ok ? i : 0); return rw; }
+  __device__ __forceinline__ bool a_relu() const { return false; }
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = rw.p[(r + q < r_end ? r + q : r_end - 1) * M];
+    mask = tail_mask(rw.ok, r, r_end);
+  }
+  __device__ __forceinline__ const T* bbase(long r, long& stride) const { stride = 1; return dy + r * N; }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     if (direct) {                  // single r-chunk: straight into the gradient
       float* p = out + i * N + j;
@@ -306,23 +371,18 @@ template <typename T> struct LinWgradOp {
 // few-workgroup dense layers.  The K-slot a lane feeds to MFMA s is 16*(lane>>5)+s, so the A operand of all 16 steps is
 // one contiguous 64-byte run per lane.  The operand elements of step s+1 are fetched into registers before the MFMAs of
 // step s and written to the other LDS buffer after them: one barrier per step.
-template <class Op, class = void> struct has_fast : std::false_type {};
-template <class Op> struct has_fast<Op, std::void_t<decltype(Op::FAST)>> : std::true_type {};
-template <typename T> __device__ T a_elem(const FwdOp<T>&);
-template <typename T> __device__ T a_elem(const DgradOp<T>&);
-template <typename T> __device__ T a_elem(const DgradS2Op<T>&);
-template <typename T> __device__ T a_elem(const WgradOp<T>&);
-template <class Op> __device__ float a_elem(const Op&);
-template <class Op> __device__ __forceinline__ auto row_of(const Op& op, long i) {
-  if constexpr (has_fast<Op>::value) return op.row(i);
-  else return 0;
-}
-
-template <class Op>
-__global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
-  __shared__ __attribute__((aligned(16))) float As[2][64][36];   // [row][k]
-  __shared__ __attribute__((aligned(16))) float Bs[2][32][68];                                 // [k][col]
-  const int tid = threadIdx.x;
+// KS groups of four waves walk interleaved K-steps (group g takes steps g, g+KS, ...) on private LDS buffers and their
+// accumulators are summed through LDS at the end: the dense layers of the MNIST nets launch 16..400 workgroups with
+// 50..200 sequential K-steps each, and a step is latency (address decode -> loads -> LDS -> MFMA chain), not throughput.
+template <class Op, int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
+  extern __shared__ __attribute__((aligned(16))) float gg_smem[];
+  const int kg = threadIdx.x >> 8;
+  typedef float AsT[2][64][36];   // [buf][row][k]
+  typedef float BsT[2][32][68];   // [buf][k][col]
+  AsT& As = *(AsT*)(gg_smem + (size_t)kg * (2 * 64 * 36 + 2 * 32 * 68));
+  BsT& Bs = *(BsT*)(gg_smem + (size_t)kg * (2 * 64 * 36 + 2 * 32 * 68) + 2 * 64 * 36);
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, l31 = lane & 31, hh = lane >> 5;
   const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
   const long r_begin = (long)blockIdx.z * op.r_chunk;
@@ -339,66 +399,57 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
   const int ar = (tid & 3) * 8;
   const int br = tid >> 4;
   const long bj = j0 + (tid & 15) * 4;
-  // Operand fetch is branch-free (clamped addresses, validity kept in bit masks) and the zero-fill / ReLU / sigma scale
-  // are applied at the LDS write: every load of a step is in flight together and nothing waits on them until after the
-  // MFMAs (a select or max right behind each guarded load serialised the eight load latencies of a step).
-  typename std::conditional<has_fast<Op>::value, decltype(a_elem(op)), float>::type ra[8];
-  float rb[8];
+  // Operand fetch is branch-free (addresses always inside the tensors, validity kept in bit masks) and the zero-fill /
+  // ReLU / sigma scale are applied at the LDS write: every load of a step is in flight together and nothing waits on
+  // them until after the MFMAs (a select or max right behind each guarded load serialised the load latencies).
+  typename Op::AT ra[8];
+  typename Op::BT rb[8];
   unsigned amask = 0, bmask = 0;
-  const auto arow = row_of(op, ai);
+  const auto arow = op.row(ai);
   auto fetch = [&](long r0) {
-    if constexpr (has_fast<Op>::value) {
-      op.a8(arow, r0 + ar, r_end, ra, amask);
-    } else {
-      amask = 0;
-      const long aic = ai < op.M ? ai : op.M - 1;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const long r = r0 + ar + q;
-        const bool ok = ai < op.M && r < r_end;
-        ra[q] = op.a(aic, ok ? r : r_end - 1);
-        amask |= (unsigned)ok << q;
-      }
-    }
+    op.a8(arow, r0 + ar, r_end, ra, amask);
     bmask = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const long r = r0 + br + 16 * (q >> 2), j = bj + (q & 3);
-      const bool ok = r < r_end && j < op.N;
-      rb[q] = op.b(r < r_end ? r : r_end - 1, j < op.N ? j : op.N - 1);
-      bmask |= (unsigned)ok << q;
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const long r = r0 + br + 16 * h2;
+      long st;
+      const typename Op::BT* pb = op.bbase(r < r_end ? r : r_end - 1, st);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long j = bj + c;
+        rb[h2 * 4 + c] = pb[(j < op.N ? j : op.N - 1) * st];
+        bmask |= (unsigned)(r < r_end && j < op.N) << (h2 * 4 + c);
+      }
     }
   };
   auto stash = [&](int buf) {
     float fa[8], fb[8];
+    const bool relu = op.a_relu();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v;
-      if constexpr (has_fast<Op>::value) {
-        v = Elem<decltype(a_elem(op))>::ld(&ra[q]);
-        if (op.a_relu()) v = v > 0.f ? v : 0.f;
-      } else {
-        v = ra[q];
-      }
+      float v = Elem<typename Op::AT>::ld(&ra[q]);
+      if (relu) v = v > 0.f ? v : 0.f;
       fa[q] = ((amask >> q) & 1u) ? v : 0.f;
-      fb[q] = ((bmask >> q) & 1u) ? rb[q] * bscale : 0.f;
+      fb[q] = ((bmask >> q) & 1u) ? Elem<typename Op::BT>::ld(&rb[q]) * bscale : 0.f;
     }
     *(float4*)&As[buf][tid >> 2][ar] = make_float4(fa[0], fa[1], fa[2], fa[3]);
     *(float4*)&As[buf][tid >> 2][ar + 4] = make_float4(fa[4], fa[5], fa[6], fa[7]);
     *(float4*)&Bs[buf][br][(tid & 15) * 4] = make_float4(fb[0], fb[1], fb[2], fb[3]);
     *(float4*)&Bs[buf][br + 16][(tid & 15) * 4] = make_float4(fb[4], fb[5], fb[6], fb[7]);
   };
-  if (r_begin < r_end) { fetch(r_begin); stash(0); }
+  const long nsteps = (r_end - r_begin + 31) / 32;
+  const long T = (nsteps + KS - 1) / KS;          // per-group steps (same for every group: the barriers are block-wide)
+  if (T > 0) { fetch(r_begin + 32 * kg); stash(0); }
   __syncthreads();
   int buf = 0;
-  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
-    const bool more = r0 + 32 < r_end;
-    if (more) fetch(r0 + 32);
+  for (long t = 0; t < T; ++t) {
+    const bool more = t + 1 < T;
+    if (more) fetch(r_begin + 32 * (kg + KS * (t + 1)));
     float av[16], bv[16];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const float4 t = *(const float4*)&As[buf][wr * 32 + l31][16 * hh + 4 * v];
-      av[4 * v] = t.x; av[4 * v + 1] = t.y; av[4 * v + 2] = t.z; av[4 * v + 3] = t.w;
+      const float4 t4 = *(const float4*)&As[buf][wr * 32 + l31][16 * hh + 4 * v];
+      av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) bv[q] = Bs[buf][16 * hh + q][wc * 32 + l31];
@@ -407,6 +458,19 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(Op op) {
     if (more) stash(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (KS > 1) {                          // sum the groups' accumulators: [group-1][wave][reg][lane]
+    float* red = gg_smem;
+    if (kg > 0) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) red[(((kg - 1) * 4 + wv) * 16 + p) * 64 + lane] = acc[p];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g2 = 0; g2 < KS - 1; ++g2)
+#pragma unroll
+      for (int p = 0; p < 16; ++p) acc[p] += red[((g2 * 4 + wv) * 16 + p) * 64 + lane];
   }
   const long j = j0 + wc * 32 + l31;
   if (j < op.N) {
@@ -525,13 +589,32 @@ __global__ __launch_bounds__(256) void colsum_vec_partial_kernel(const T* x, lon
   }
 }
 
+static int gg_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+template <class Op, int KS>
+static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)KS * (2 * 64 * 36 + 2 * 32 * 68) * sizeof(float);
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)gemm_gather_kernel<Op, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_gather_kernel<Op, KS>), grid, dim3(256 * KS), lds, ctx->stream, op);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 template <class Op>
 static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz) {
   dim3 grid(cdiv(op.N, 64), cdiv(op.M, 64), nz);
   if (grid.y > 65535u || grid.z > 65535u) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "M too large");
-  hipLaunchKernelGGL(gemm_gather_kernel<Op>, grid, dim3(256), 0, ctx->stream, op);
-  RC_LAUNCH_CHECK(ctx);
-  return RCGAN_OK;
+  static const int ks_min_steps = gg_env_int("RCGAN_GG_KS_MINSTEPS", 8);
+  const long steps = (op.r_chunk + 31) / 32;
+  if (steps >= ks_min_steps) return launch_gemm_ks<Op, 4>(ctx, op, grid);
+  return launch_gemm_ks<Op, 1>(ctx, op, grid);
 }
 
 // pick the number of r-splits for a filter-gradient GEMM so the grid fills the chip
