@@ -28,16 +28,59 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
   return g;
 }
 
-// Operand functors of the gather GEMM  C[i][j] = sum_r A(i,r) * B(r,j).  Each provides
-//   Row row(i)                          the row decoded once per thread (a thread fetches one row of A for the whole launch)
-//   a8(row, r, r_end, raw[8], mask)     8 consecutive reduction indices of that row: raw element loads from addresses
-//                                       that are always inside the tensor + a validity bit mask (zero-fill, ReLU and
-//                                       conversion happen at the LDS write, after the MFMAs of the previous step)
-//   bbase(r, stride)                    B(r, j) = bbase[j * stride]
-//   store(i, j, v, z)
+// Operand functors of the gather GEMM  C[i][j] = sum_r A(i,r) * B(r,j).  An operand is fetched along the dimension
+// it is contiguous in, in 8- or 16-byte vectors where the channel count and the base pointer allow:
+//   K-major (X_KMAJOR = true):  a thread owns one row (col) of the tile and fetches runs of 8 consecutive reduction
+//       indices.  row(i) / brow(j) decode the row once per launch; a8 / b8 produce raw elements + a validity mask.
+//       LDS layout [row][k], the MFMA operand is read with ds_read_b128.
+//   N-major (X_KMAJOR = false): a thread fetches 4 consecutive rows (cols) at one reduction index (two per K-step).
+//       arun(i) decodes the 4-row group once; a4 / b4 produce raw elements + mask.  LDS layout [k][row], operand read
+//       with ds_read_b32.
+// Loads are branch-free: addresses always lie inside the tensors (invalid elements point at the tensor base) and the
+// zero-fill, ReLU and fp32 conversion happen at the LDS write, after the MFMAs of the previous step.
 // Pixel indices are 32-bit (a tensor has < 2^32 pixels); the element offset is one 64-bit multiply-add.  When the run
 // dimension (channels) is >= 8 a run of 8 touches at most two filter taps, so the tap decode, the bounds test and the
 // pixel address are computed twice per run instead of eight times.
+template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+template <typename T> struct alignas(2 * sizeof(T)) Vec2 { T v[2]; };
+
+template <typename T> static int vec_of(const T* p, long c) {
+  const uintptr_t a = (uintptr_t)p;
+  if (c % 4 == 0 && a % (4 * sizeof(T)) == 0) return 4;
+  if (c % 2 == 0 && a % (2 * sizeof(T)) == 0) return 2;
+  return 1;
+}
+
+// 4 contiguous elements
+template <typename T> __device__ __forceinline__ void ld4(const T* p, int vec, T* out) {
+  if (vec == 4) {
+    const Vec4<T> t = *(const Vec4<T>*)p;
+    out[0] = t.v[0]; out[1] = t.v[1]; out[2] = t.v[2]; out[3] = t.v[3];
+  } else if (vec == 2) {
+    const Vec2<T> a = *(const Vec2<T>*)p, b = *(const Vec2<T>*)(p + 2);
+    out[0] = a.v[0]; out[1] = a.v[1]; out[2] = b.v[0]; out[3] = b.v[1];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = p[q];
+  }
+}
+// 8 elements: element q comes from pA[q] while q < nA, from pB[q] after (nA is a multiple of vec)
+template <typename T> __device__ __forceinline__ void ld_run8(const T* pA, const T* pB, int nA, int vec, T* raw) {
+  if (vec == 4) {
+    const Vec4<T> a = *(const Vec4<T>*)pA, b = *(const Vec4<T>*)((nA >= 8 ? pA : pB) + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { raw[q] = a.v[q]; raw[4 + q] = b.v[q]; }
+  } else if (vec == 2) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Vec2<T> t = *(const Vec2<T>*)((2 * k < nA ? pA : pB) + 2 * k);
+      raw[2 * k] = t.v[0]; raw[2 * k + 1] = t.v[1];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+  }
+}
 __device__ __forceinline__ unsigned run_mask(bool okA, bool okB, int nA, long r, long r_end) {
   const unsigned mA = nA >= 8 ? 0xffu : ((1u << nA) - 1u);
   unsigned m = (okA ? mA : 0u) | (okB ? (0xffu & ~mA) : 0u);
@@ -45,13 +88,42 @@ __device__ __forceinline__ unsigned run_mask(bool okA, bool okB, int nA, long r,
   m &= left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u);
   return m;
 }
+// plain row-major rows (dense layers): 8 consecutive elements of row p, clamped at the row end
+template <typename T> __device__ __forceinline__ void lin_run8(const T* p, bool ok, long r, long r_end, int vec, T* raw, unsigned& mask) {
+  const long left = r_end - r;
+  if (left >= 8 && vec > 1) {
+    ld_run8<T>(p + r, p + r, 8, vec, raw);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = p[r + q < r_end ? r + q : r_end - 1];
+  }
+  mask = ok ? (left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u)) : 0u;
+}
+// 4 consecutive columns j..j+3 of row-major matrix row p (n columns)
+template <typename T> __device__ __forceinline__ void lin_run4(const T* p, bool rok, long j, long n, int vec, T* raw, unsigned& mask) {
+  if ((n & 3) == 0) {
+    const bool ok = rok && j < n;
+    ld4<T>(p + (j < n ? j : 0), vec, raw);
+    mask = ok ? 0xfu : 0u;
+  } else {
+    mask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long jj = j + c;
+      raw[c] = p[jj < n ? jj : 0];
+      mask |= (unsigned)(rok && jj < n) << c;
+    }
+  }
+}
 
 // ---- forward: i = output pixel, j = cout, r = (kh,kw,ci) ---------------------------------------
 template <typename T> struct FwdOp {
   typedef T AT; typedef float BT;
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
   ConvGeom g; const T* x; const float* w; const float* bias; T* y; int accumulate;
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
   long M, N, R, r_chunk;
+  int avec, bvec;
   struct Row { int n, ih0, iw0, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -84,8 +156,7 @@ template <typename T> struct FwdOp {
       int kw2 = kw + 1, kh2 = kh;
       if (kw2 == g.KW) { kw2 = 0; ++kh2; }
       const T* pB = tap(rw, kh2, kw2, -nA, okB);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
       mask = 0;
@@ -100,7 +171,10 @@ template <typename T> struct FwdOp {
       }
     }
   }
-  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = 1; return w + r * g.Cout; }
+  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    lin_run4<float>(w + (rok ? r : 0) * g.Cout, rok, j, N, bvec, raw, mask);
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     T* p = y + i * g.Cout + j;
@@ -109,12 +183,17 @@ template <typename T> struct FwdOp {
   }
 };
 
+// filter element run for the data gradients: B(r, j) = w[tap(r)][j][co(r)], contiguous along co for a fixed ci = j
+struct WRow { long j; int ok; };
+
 // ---- data gradient: i = input pixel (n,ih,iw) at the logical resolution, j = ci, r = (kh,kw,co) ---
 template <typename T> struct DgradOp {
   typedef T AT; typedef float BT;
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
   const float* wscale;
   long M, N, R, r_chunk;
+  int avec, bvec;
   struct Row { int n, ih, iw, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -148,8 +227,7 @@ template <typename T> struct DgradOp {
       int kw2 = kw + 1, kh2 = kh;
       if (kw2 == g.KW) { kw2 = 0; ++kh2; }
       const T* pB = tap(rw, kh2, kw2, -nA, okB);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
       mask = 0;
@@ -164,10 +242,34 @@ template <typename T> struct DgradOp {
       }
     }
   }
-  __device__ __forceinline__ const float* bbase(long r, long& stride) const {
-    const unsigned kk = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - kk * (unsigned)g.Cout;
-    stride = g.Cout;
-    return w + ((long)kk * g.Cin * g.Cout + co);
+  __device__ __forceinline__ WRow brow(long j) const { WRow b; b.ok = j < N; b.j = b.ok ? j : 0; return b; }
+  __device__ __forceinline__ const float* wtap(const WRow& b, unsigned kk, int c0, bool& ok) const {
+    ok = b.ok && kk < (unsigned)(g.KH * g.KW);
+    return ok ? w + (((long)kk * g.Cin + b.j) * g.Cout + c0) : w;
+  }
+  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
+    const unsigned kk = (unsigned)r / (unsigned)g.Cout;
+    int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
+    if (g.Cout >= 8) {
+      const int nA = g.Cout - co;
+      bool okA, okB;
+      const float* pA = wtap(b, kk, co, okA);
+      const float* pB = wtap(b, kk + 1, -nA, okB);
+      ld_run8<float>(pA, pB, nA, bvec, raw);
+      mask = run_mask(okA, okB, nA, r, r_end);
+    } else {
+      mask = 0;
+      unsigned k2 = kk;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bool ok;
+        const float* p = wtap(b, k2, co, ok);
+        ok = ok && r + q < r_end;
+        raw[q] = *(ok ? p : w);
+        mask |= (unsigned)ok << q;
+        if (++co == g.Cout) { co = 0; ++k2; }
+      }
+    }
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];          // used by the transposed-conv forward
@@ -186,9 +288,11 @@ template <typename T> struct DgradOp {
 //      i = (n, ih/2, iw/2) inside the class, j = ci, r = (jh, jw, co).
 template <typename T> struct DgradS2Op {
   typedef T AT; typedef float BT;
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
   const float* wscale;
   long M, N, R, r_chunk;
+  int avec, bvec;
   int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
   struct Row { int n, ih2, iw2, ok; };
   __device__ __forceinline__ Row row(long i) const {
@@ -219,8 +323,7 @@ template <typename T> struct DgradS2Op {
       int jw2 = jw + 1, jh2 = jh;
       if (jw2 == nkw) { jw2 = 0; ++jh2; }
       const T* pB = tap(rw, jh2, jw2, -nA, okB);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
+      ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
       mask = 0;
@@ -235,12 +338,37 @@ template <typename T> struct DgradS2Op {
       }
     }
   }
-  __device__ __forceinline__ const float* bbase(long r, long& stride) const {
-    const unsigned jj = (unsigned)r / (unsigned)g.Cout, co = (unsigned)r - jj * (unsigned)g.Cout;
-    const int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+  __device__ __forceinline__ WRow brow(long j) const { WRow b; b.ok = j < N; b.j = b.ok ? j : 0; return b; }
+  __device__ __forceinline__ const float* wtap(const WRow& b, int jh, int jw, int c0, bool& ok) const {
+    ok = b.ok && jh < nkh;
     const int kh = kh0 + 2 * jh, kw = kw0 + 2 * jw;
-    stride = g.Cout;
-    return w + ((long)(kh * g.KW + kw) * g.Cin * g.Cout + co);
+    return ok ? w + (((long)(kh * g.KW + kw) * g.Cin + b.j) * g.Cout + c0) : w;
+  }
+  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
+    const unsigned jj = (unsigned)r / (unsigned)g.Cout;
+    int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
+    int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    if (g.Cout >= 8) {
+      const int nA = g.Cout - co;
+      bool okA, okB;
+      const float* pA = wtap(b, jh, jw, co, okA);
+      int jw2 = jw + 1, jh2 = jh;
+      if (jw2 == nkw) { jw2 = 0; ++jh2; }
+      const float* pB = wtap(b, jh2, jw2, -nA, okB);
+      ld_run8<float>(pA, pB, nA, bvec, raw);
+      mask = run_mask(okA, okB, nA, r, r_end);
+    } else {
+      mask = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bool ok;
+        const float* p = wtap(b, jh, jw, co, ok);
+        ok = ok && r + q < r_end;
+        raw[q] = *(ok ? p : w);
+        mask |= (unsigned)ok << q;
+        if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
+      }
+    }
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     const unsigned ii = (unsigned)i;
@@ -256,43 +384,63 @@ template <typename T> struct DgradS2Op {
   }
 };
 
-// ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs ----
+// ---- filter gradient: i = (kh,kw,ci), j = cout, r = output pixel; split over r into fp32 slabs.
+//      Both operands are contiguous along the tile dimensions (ci / cout), strided along r: N-major fetch.
 template <typename T> struct WgradOp {
   typedef T AT; typedef T BT;
+  static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
   ConvGeom g; const T* x; const T* dy; float* slab;
   const float* wscale;   // always null (the filter gradient has no filter operand)
   long M, N, R, r_chunk;
-  // the row is a (kh,kw,ci) filter position, the reduction walks 8 consecutive output pixels
-  struct Row { int kh, kw, ci, ok; };
-  __device__ __forceinline__ Row row(long i) const {
-    Row rw;
-    rw.ok = i < M;
-    const unsigned ii = rw.ok ? (unsigned)i : 0u;
-    const unsigned kk = ii / (unsigned)g.Cin;
-    rw.ci = (int)(ii - kk * (unsigned)g.Cin);
-    rw.kh = (int)(kk / (unsigned)g.KW);
-    rw.kw = (int)(kk - (unsigned)rw.kh * (unsigned)g.KW);
-    return rw;
+  int avec, bvec;
+  // four consecutive filter positions (kh,kw,ci); with Cin % 4 == 0 they share the tap and only e[0] is used
+  struct ARun { unsigned e[4]; };     // kh | kw << 8 | ci << 16 | valid << 31
+  __device__ __forceinline__ ARun arun(long i) const {
+    ARun a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = i + q < M;
+      const unsigned ii = ok ? (unsigned)(i + q) : 0u;
+      const unsigned kk = ii / (unsigned)g.Cin, ci = ii - kk * (unsigned)g.Cin;
+      const unsigned kh = kk / (unsigned)g.KW, kw = kk - kh * (unsigned)g.KW;
+      a.e[q] = kh | (kw << 8) | (ci << 16) | ((unsigned)ok << 31);
+    }
+    return a;
   }
   __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    const unsigned t = (unsigned)r / (unsigned)g.OW;
-    int ow = (int)((unsigned)r - t * (unsigned)g.OW);
-    int n = (int)(t / (unsigned)g.OH), oh = (int)(t - (unsigned)n * (unsigned)g.OH);
+  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    const unsigned rr = rok ? (unsigned)r : 0u;
+    const unsigned t = rr / (unsigned)g.OW, ow = rr - t * (unsigned)g.OW;
+    const unsigned n = t / (unsigned)g.OH, oh = t - n * (unsigned)g.OH;
     const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
-    mask = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int ih = oh * g.S + rw.kh - g.PT, iw = ow * g.S + rw.kw - g.PL;
-      const bool ok = rw.ok && r + q < r_end && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+    const int ihb = (int)oh * g.S - g.PT, iwb = (int)ow * g.S - g.PL;
+    auto elem = [&](unsigned e, bool& ok) -> const T* {
+      const int ih = ihb + (int)(e & 0xff), iw = iwb + (int)((e >> 8) & 0xff);
+      ok = rok && (e >> 31) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
       const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
-      const unsigned pix = ((unsigned)n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
-      raw[q] = x[ok ? (long)pix * g.Cin + rw.ci : 0];
-      mask |= (unsigned)ok << q;
-      if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++n; } }
+      const unsigned pix = (n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
+      return ok ? x + ((long)pix * g.Cin + ((e >> 16) & 0x7fff)) : x;
+    };
+    if ((g.Cin & 3) == 0) {
+      bool ok;
+      const T* p = elem(a.e[0], ok);
+      ld4<T>(p, avec, raw);
+      mask = ok ? 0xfu : 0u;
+    } else {
+      mask = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bool ok;
+        raw[q] = *elem(a.e[q], ok);
+        mask |= (unsigned)ok << q;
+      }
     }
   }
-  __device__ __forceinline__ const T* bbase(long r, long& stride) const { stride = 1; return dy + r * g.Cout; }
+  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    lin_run4<T>(dy + (rok ? r : 0) * g.Cout, rok, j, N, bvec, raw, mask);
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     slab[(long)z * M * N + i * N + j] = v;
   }
@@ -300,23 +448,23 @@ template <typename T> struct WgradOp {
 
 // ---- fully connected layers: the same GEMM core with plain row-major operands:
 //      y[m][n] = x[m][:] . w[:][n];  dx[m][k] = dy[m][:] . w[k][:];  dw[k][n] = x[:][k] . dy[:][n]
-__device__ __forceinline__ unsigned tail_mask(bool ok, long r, long r_end) {
-  const long left = r_end - r;
-  return ok ? (left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u)) : 0u;
-}
+template <typename T> struct LinRow { const T* p; int ok; };
 template <typename T> struct LinFwdOp {
   typedef T AT; typedef float BT;
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
   const T* x; const float* w; const float* bias; T* y; const float* wscale;
   long M, N, R, r_chunk;
-  struct Row { const T* p; int ok; };
+  int avec, bvec;
+  typedef LinRow<T> Row;
   __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = x + (rw.ok ? i : 0) * R; return rw; }
   __device__ __forceinline__ bool a_relu() const { return false; }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) raw[q] = rw.p[r + q < r_end ? r + q : r_end - 1];
-    mask = tail_mask(rw.ok, r, r_end);
+    lin_run8<T>(rw.p, rw.ok, r, r_end, avec, raw, mask);
   }
-  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = 1; return w + r * N; }
+  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    lin_run4<float>(w + (rok ? r : 0) * N, rok, j, N, bvec, raw, mask);
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
     Elem<T>::st(y + i * N + j, v);
@@ -324,17 +472,20 @@ template <typename T> struct LinFwdOp {
 };
 template <typename T> struct LinDgradOp {
   typedef T AT; typedef float BT;
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
   long M, N, R, r_chunk;          // N = in features, R = out features
-  struct Row { const T* p; int ok; };
+  int avec, bvec;
+  typedef LinRow<T> Row;
   __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = dy + (rw.ok ? i : 0) * R; return rw; }
   __device__ __forceinline__ bool a_relu() const { return false; }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) raw[q] = rw.p[r + q < r_end ? r + q : r_end - 1];
-    mask = tail_mask(rw.ok, r, r_end);
+    lin_run8<T>(rw.p, rw.ok, r, r_end, avec, raw, mask);
   }
-  __device__ __forceinline__ const float* bbase(long r, long& stride) const { stride = R; return w + r; }
+  __device__ __forceinline__ LinRow<float> brow(long j) const { LinRow<float> b; b.ok = j < N; b.p = w + (b.ok ? j : 0) * R; return b; }
+  __device__ __forceinline__ void b8(const LinRow<float>& b, long r, long r_end, float* raw, unsigned& mask) const {
+    lin_run8<float>(b.p, b.ok, r, r_end, bvec, raw, mask);
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     T* p = dx + i * N + j;
     if (accumulate) v += Elem<T>::ld(p);
@@ -343,17 +494,21 @@ template <typename T> struct LinDgradOp {
 };
 template <typename T> struct LinWgradOp {
   typedef T AT; typedef T BT;
+  static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
   const T* x; const T* dy; float* out; int accumulate; int direct; const float* wscale;
   long M, N, R, r_chunk;          // M = in features, N = out features, R = batch rows
-  struct Row { const T* p; int ok; };
-  __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = x + (rw.ok ? i : 0); return rw; }
+  int avec, bvec;
+  struct ARun { long i; };
+  __device__ __forceinline__ ARun arun(long i) const { ARun a; a.i = i; return a; }
   __device__ __forceinline__ bool a_relu() const { return false; }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) raw[q] = rw.p[(r + q < r_end ? r + q : r_end - 1) * M];
-    mask = tail_mask(rw.ok, r, r_end);
+  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    lin_run4<T>(x + (rok ? r : 0) * M, rok, a.i, M, avec, raw, mask);
   }
-  __device__ __forceinline__ const T* bbase(long r, long& stride) const { stride = 1; return dy + r * N; }
+  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw, unsigned& mask) const {
+    const bool rok = r < r_end;
+    lin_run4<T>(dy + (rok ? r : 0) * N, rok, j, N, bvec, raw, mask);
+  }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     if (direct) {                  // single r-chunk: straight into the gradient
       float* p = out + i * N + j;
@@ -366,22 +521,28 @@ template <typename T> struct LinWgradOp {
 
 // 64 x 64 output tile, K-step 32, fp32 matrix cores (v_mfma_f32_32x32x2_f32: IEEE fp32 products and sums, only the
 // summation order differs from a scalar loop).  Four waves, one 32x32 quadrant each: per K-step a wave reads its
-// operands with 4 ds_read_b128 + 16 ds_read_b32 and issues 16 MFMAs -- 8 KB of LDS traffic per wave-step where the
-// FMA formulation moved 64 KB and stalled on every LDS->FMA dependency at the one-wave-per-SIMD occupancy of the
-// few-workgroup dense layers.  The K-slot a lane feeds to MFMA s is 16*(lane>>5)+s, so the A operand of all 16 steps is
-// one contiguous 64-byte run per lane.  The operand elements of step s+1 are fetched into registers before the MFMAs of
-// step s and written to the other LDS buffer after them: one barrier per step.
+// operands from LDS and issues 16 MFMAs.  The K-slot a lane feeds to MFMA s is 16*(lane>>5)+s, so a K-major operand
+// of all 16 steps is one contiguous 64-byte run per lane.  The operand elements of step s+1 are fetched into registers
+// before the MFMAs of step s and written to the other LDS buffer after them: one barrier per step.
 // KS groups of four waves walk interleaved K-steps (group g takes steps g, g+KS, ...) on private LDS buffers and their
 // accumulators are summed through LDS at the end: the dense layers of the MNIST nets launch 16..400 workgroups with
-// 50..200 sequential K-steps each, and a step is latency (address decode -> loads -> LDS -> MFMA chain), not throughput.
+// 50..200 sequential K-steps each.
+template <class Op> __device__ __forceinline__ auto a_init(const Op& op, long i0, int tid) {
+  if constexpr (Op::A_KMAJOR) return op.row(i0 + (tid >> 2));
+  else return op.arun(i0 + (tid & 15) * 4);
+}
+template <class Op> __device__ __forceinline__ auto b_init(const Op& op, long j0, int tid) {
+  if constexpr (Op::B_KMAJOR) return op.brow(j0 + (tid >> 2));
+  else return j0 + (tid & 15) * 4;
+}
+
+#define GG_XBUF 2304   /* floats per operand buffer: max(64 x 36 K-major, 32 x 68 N-major) */
+
 template <class Op, int KS>
 __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
   extern __shared__ __attribute__((aligned(16))) float gg_smem[];
   const int kg = threadIdx.x >> 8;
-  typedef float AsT[2][64][36];   // [buf][row][k]
-  typedef float BsT[2][32][68];   // [buf][k][col]
-  AsT& As = *(AsT*)(gg_smem + (size_t)kg * (2 * 64 * 36 + 2 * 32 * 68));
-  BsT& Bs = *(BsT*)(gg_smem + (size_t)kg * (2 * 64 * 36 + 2 * 32 * 68) + 2 * 64 * 36);
+  float* const lds = gg_smem + (size_t)kg * 4 * GG_XBUF;      // A buf 0/1, B buf 0/1
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, l31 = lane & 31, hh = lane >> 5;
   const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
@@ -395,31 +556,38 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
 
   // spectral-norm division W / sigma: sigma is loaded once per thread, not once per operand element
   const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
-  const long ai = i0 + (tid >> 2);
-  const int ar = (tid & 3) * 8;
-  const int br = tid >> 4;
-  const long bj = j0 + (tid & 15) * 4;
-  // Operand fetch is branch-free (addresses always inside the tensors, validity kept in bit masks) and the zero-fill /
-  // ReLU / sigma scale are applied at the LDS write: every load of a step is in flight together and nothing waits on
-  // them until after the MFMAs (a select or max right behind each guarded load serialised the load latencies).
   typename Op::AT ra[8];
   typename Op::BT rb[8];
   unsigned amask = 0, bmask = 0;
-  const auto arow = op.row(ai);
+  const auto ast = a_init(op, i0, tid);
+  const auto bst = b_init(op, j0, tid);
   auto fetch = [&](long r0) {
-    op.a8(arow, r0 + ar, r_end, ra, amask);
-    bmask = 0;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const long r = r0 + br + 16 * h2;
-      long st;
-      const typename Op::BT* pb = op.bbase(r < r_end ? r : r_end - 1, st);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const long j = bj + c;
-        rb[h2 * 4 + c] = pb[(j < op.N ? j : op.N - 1) * st];
-        bmask |= (unsigned)(r < r_end && j < op.N) << (h2 * 4 + c);
-      }
+    if constexpr (Op::A_KMAJOR) {
+      op.a8(ast, r0 + (tid & 3) * 8, r_end, ra, amask);
+    } else {
+      unsigned m0, m1;
+      op.a4(ast, r0 + (tid >> 4), r_end, ra, m0);
+      op.a4(ast, r0 + (tid >> 4) + 16, r_end, ra + 4, m1);
+      amask = m0 | (m1 << 4);
+    }
+    if constexpr (Op::B_KMAJOR) {
+      op.b8(bst, r0 + (tid & 3) * 8, r_end, rb, bmask);
+    } else {
+      unsigned m0, m1;
+      op.b4(r0 + (tid >> 4), r_end, bst, rb, m0);
+      op.b4(r0 + (tid >> 4) + 16, r_end, bst, rb + 4, m1);
+      bmask = m0 | (m1 << 4);
+    }
+  };
+  auto put = [&](float* xb, bool kmajor, const float* f) {
+    if (kmajor) {
+      float* p = xb + (tid >> 2) * 36 + (tid & 3) * 8;
+      *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+      float* p = xb + (tid >> 4) * 68 + (tid & 15) * 4;
+      *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)(p + 16 * 68) = make_float4(f[4], f[5], f[6], f[7]);
     }
   };
   auto stash = [&](int buf) {
@@ -432,10 +600,20 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
       fa[q] = ((amask >> q) & 1u) ? v : 0.f;
       fb[q] = ((bmask >> q) & 1u) ? Elem<typename Op::BT>::ld(&rb[q]) * bscale : 0.f;
     }
-    *(float4*)&As[buf][tid >> 2][ar] = make_float4(fa[0], fa[1], fa[2], fa[3]);
-    *(float4*)&As[buf][tid >> 2][ar + 4] = make_float4(fa[4], fa[5], fa[6], fa[7]);
-    *(float4*)&Bs[buf][br][(tid & 15) * 4] = make_float4(fb[0], fb[1], fb[2], fb[3]);
-    *(float4*)&Bs[buf][br + 16][(tid & 15) * 4] = make_float4(fb[4], fb[5], fb[6], fb[7]);
+    put(lds + buf * GG_XBUF, Op::A_KMAJOR, fa);
+    put(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, fb);
+  };
+  auto get = [&](const float* xb, bool kmajor, int w32, float* v) {
+    if (kmajor) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t4 = *(const float4*)(xb + (w32 + l31) * 36 + 16 * hh + 4 * c);
+        v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = xb[(16 * hh + q) * 68 + w32 + l31];
+    }
   };
   const long nsteps = (r_end - r_begin + 31) / 32;
   const long T = (nsteps + KS - 1) / KS;          // per-group steps (same for every group: the barriers are block-wide)
@@ -446,13 +624,8 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
     const bool more = t + 1 < T;
     if (more) fetch(r_begin + 32 * (kg + KS * (t + 1)));
     float av[16], bv[16];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float4 t4 = *(const float4*)&As[buf][wr * 32 + l31][16 * hh + 4 * v];
-      av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) bv[q] = Bs[buf][16 * hh + q][wc * 32 + l31];
+    get(lds + buf * GG_XBUF, Op::A_KMAJOR, wr * 32, av);
+    get(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, wc * 32, bv);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
     if (more) stash(buf ^ 1);
@@ -480,6 +653,64 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
       if (i < op.M) op.store(i, j, acc[p], blockIdx.z);
     }
   }
+}
+
+// Stride-2 data gradient / transposed conv with 1..4 output channels (the MNIST generator's image layer, Cout = 1):
+// a 64-column GEMM tile would be 1/64 occupied.  Sixteen lanes share an output pixel and split the channel runs of its
+// reachable taps (coalesced, VEC elements per lane), the filter slice lives in LDS, the lane partials meet in a
+// 4-step butterfly.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dgrad_s2_narrow_kernel(DgradS2Op<T> op) {
+  extern __shared__ __attribute__((aligned(16))) float nw_smem[];     // [tap][j][Cout]
+  const int C = op.g.Cout, NJ = (int)op.N, ntaps = op.nkh * op.nkw;
+  const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
+  for (int e = threadIdx.x; e < ntaps * NJ * C; e += 256) {
+    const int co = e % C, t = e / C, j = t % NJ, tp = t / NJ;
+    const int kh = op.kh0 + 2 * (tp / op.nkw), kw = op.kw0 + 2 * (tp % op.nkw);
+    nw_smem[e] = op.w[((long)(kh * op.g.KW + kw) * op.g.Cin + j) * C + co] * bscale;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const auto rw = op.row(i);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int jh = 0; jh < op.nkh; ++jh)
+    for (int jw = 0; jw < op.nkw; ++jw) {
+      bool ok;
+      const T* p = op.tap(rw, jh, jw, 0, ok);
+      if (!ok) continue;
+      const float* wl = nw_smem + (size_t)(jh * op.nkw + jw) * NJ * C;
+      for (int c0 = sub * VEC; c0 < C; c0 += 16 * VEC) {
+        T raw[VEC];
+        if constexpr (VEC == 4) { const Vec4<T> t4 = *(const Vec4<T>*)(p + c0); raw[0] = t4.v[0]; raw[1] = t4.v[1]; raw[2] = t4.v[2]; raw[3] = t4.v[3]; }
+        else if constexpr (VEC == 2) { const Vec2<T> t2 = *(const Vec2<T>*)(p + c0); raw[0] = t2.v[0]; raw[1] = t2.v[1]; }
+        else raw[0] = p[c0];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float a = Elem<T>::ld(&raw[q]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < NJ) acc[j] = fmaf(a, wl[j * C + c0 + q], acc[j]);
+        }
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = acc[j];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    if (sub == 0 && j < NJ && i < op.M) op.store(i, j, v, 0);
+  }
+}
+
+template <typename T>
+static int launch_dgrad_s2_narrow(rcgan_ctx* ctx, DgradS2Op<T>& op) {
+  const size_t lds = (size_t)op.nkh * op.nkw * op.N * op.g.Cout * sizeof(float);
+  dim3 grid(cdiv(op.M, 16));
+  if (op.avec == 4) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 4>), grid, dim3(256), lds, ctx->stream, op);
+  else if (op.avec == 2) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 2>), grid, dim3(256), lds, ctx->stream, op);
+  else hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 1>), grid, dim3(256), lds, ctx->stream, op);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
 }
 
 // out[i] (= or +=) sum_z slab[z][i]
@@ -597,7 +828,7 @@ static int gg_env_int(const char* name, int dflt) {
 template <class Op, int KS>
 static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid) {
   static bool attr_set = false;
-  const size_t lds = (size_t)KS * (2 * 64 * 36 + 2 * 32 * 68) * sizeof(float);
+  const size_t lds = (size_t)KS * 4 * GG_XBUF * sizeof(float);
   if (!attr_set) {
     RC_HIP(ctx, hipFuncSetAttribute((const void*)gemm_gather_kernel<Op, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -795,6 +1026,7 @@ int linear_fwd(rcgan_ctx* ctx, long m, long k, long n, const T* x, const float* 
   LinFwdOp<T> op;
   op.x = x; op.w = w; op.bias = bias; op.y = y; op.wscale = wscale;
   op.M = m; op.N = n; op.R = k; op.r_chunk = k;
+  op.avec = vec_of(x, k); op.bvec = vec_of(w, n);
   return launch_gemm(ctx, op, 1);
 }
 template int linear_fwd<float>(rcgan_ctx*, long, long, long, const float*, const float*, const float*, const float*, float*);
@@ -811,6 +1043,7 @@ int linear_dgrad(rcgan_ctx* ctx, long m, long k, long n, const T* dy, const floa
   LinDgradOp<T> op;
   op.dy = dy; op.w = w; op.dx = dx; op.accumulate = accumulate; op.wscale = wscale;
   op.M = m; op.N = k; op.R = n; op.r_chunk = n;
+  op.avec = vec_of(dy, n); op.bvec = vec_of(w, n);
   return launch_gemm(ctx, op, 1);
 }
 template int linear_dgrad<float>(rcgan_ctx*, long, long, long, const float*, const float*, const float*, float*, int);
@@ -835,6 +1068,7 @@ int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy
   LinWgradOp<T> op;
   op.x = x; op.dy = dy; op.wscale = nullptr; op.accumulate = accumulate;
   op.M = k; op.N = n; op.R = m;
+  op.avec = vec_of(x, k); op.bvec = vec_of(dy, n);
   int nz = m <= 1024 ? 1 : wgrad_splits(k, n, m);
   size_t slab_bytes = (size_t)(nz > 1 ? nz : 0) * k * n * sizeof(float);
   if (ws_bytes < linear_wgrad_ws_bytes(m, k, n)) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", linear_wgrad_ws_bytes(m, k, n), ws_bytes);
@@ -867,6 +1101,7 @@ int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float
   op.g = make_geom(d); op.x = x; op.w = w; op.wscale = wscale; op.bias = bias; op.y = y;
   op.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
   op.M = (long)op.g.N * op.g.OH * op.g.OW; op.N = op.g.Cout; op.R = (long)op.g.KH * op.g.KW * op.g.Cin; op.r_chunk = op.R;
+  op.avec = vec_of(x, op.g.Cin); op.bvec = vec_of(w, op.g.Cout);
   return launch_gemm(ctx, op, 1);
 }
 template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*);
@@ -891,7 +1126,10 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
           op.dh = (ph + g.PT - op.kh0) / 2; op.dwc = (pw + g.PL - op.kw0) / 2;
           if (op.nkw == 0) { op.nkw = 1; op.nkh = 0; }          // keeps the divisions defined; R = 0: outputs are bias / 0
           op.M = (long)g.N * op.Hp * op.Wp; op.N = g.Cin; op.R = (long)op.nkh * op.nkw * g.Cout; op.r_chunk = op.R;
-          int rc = launch_gemm(ctx, op, 1);
+          op.avec = vec_of(dy, g.Cout); op.bvec = vec_of(w, g.Cout);
+          int rc;
+          if (op.N <= 4 && op.R > 0 && (size_t)op.R * op.N * sizeof(float) <= 48 * 1024) rc = launch_dgrad_s2_narrow(ctx, op);
+          else rc = launch_gemm(ctx, op, 1);
           if (rc) return rc;
         }
       return RCGAN_OK;
@@ -900,6 +1138,7 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
   DgradOp<T> op;
   op.g = make_geom(d); op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
   op.M = (long)op.g.N * op.g.H * op.g.W; op.N = op.g.Cin; op.R = (long)op.g.KH * op.g.KW * op.g.Cout; op.r_chunk = op.R;
+  op.avec = vec_of(dy, op.g.Cout); op.bvec = vec_of(w, op.g.Cout);
   return launch_gemm(ctx, op, 1);
 }
 template int direct_dgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, const float*, float*, int);
@@ -916,6 +1155,7 @@ int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* 
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   op.slab = (float*)ws;
   op.M = K; op.N = op.g.Cout; op.R = M;
+  op.avec = vec_of(x, op.g.Cin); op.bvec = vec_of(dy, op.g.Cout);
   op.r_chunk = ((M + nz - 1) / nz + 15) / 16 * 16;
   nz = cdiv(M, op.r_chunk);
   int rc = launch_gemm(ctx, op, nz);
