@@ -9,12 +9,38 @@
 #include "common.h"
 #include <type_traits>
 
+// Division by a launch-invariant 32-bit divisor as multiply-high + shifts (Granlund-Montgomery, branch-free form):
+// the operand decode of every K-step divides by the channel count and the filter width, ~30 VALU ops each when the
+// compiler has to expand a general division.
+struct FastDiv {
+  unsigned d, m, s;
+  __host__ __device__ __forceinline__ unsigned div(unsigned n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned t = __umulhi(n, m);
+#else
+    const unsigned t = (unsigned)(((unsigned long long)n * m) >> 32);
+#endif
+    const unsigned q = (t + ((n - t) >> 1)) >> s;
+    return d == 1 ? n : q;
+  }
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f; f.d = d; f.m = 0; f.s = 0;
+  if (d <= 1) return f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                       // ceil(log2 d)
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s = l - 1;
+  return f;
+}
+
 struct ConvGeom {
   int N, H, W, Cin;      // logical conv input (post-upsample)
   int OH, OW, Cout;
   int KH, KW, S, PT, PL;
   int up;                // input tensor is stored at (H/2, W/2) and read through nearest upsample
   int relu_in;
+  FastDiv dCin, dCout, dKW, dOW, dOH;
 };
 
 static ConvGeom make_geom(const rcgan_conv_desc* d) {
@@ -25,6 +51,8 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
   same_pad(d->w, d->kw, d->stride, &g.OW, &g.PL);
   g.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
   g.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+  g.dCin = make_fastdiv(g.Cin); g.dCout = make_fastdiv(g.Cout); g.dKW = make_fastdiv(g.KW);
+  g.dOW = make_fastdiv(g.OW); g.dOH = make_fastdiv(g.OH);
   return g;
 }
 
@@ -41,8 +69,16 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
 // Pixel indices are 32-bit (a tensor has < 2^32 pixels); the element offset is one 64-bit multiply-add.  When the run
 // dimension (channels) is >= 8 a run of 8 touches at most two filter taps, so the tap decode, the bounds test and the
 // pixel address are computed twice per run instead of eight times.
-template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
-template <typename T> struct alignas(2 * sizeof(T)) Vec2 { T v[2]; };
+// real vector types: a struct of four scalars is split into four scalar loads by SROA and never re-vectorised
+template <typename T> struct VecOf { typedef T v4 __attribute__((ext_vector_type(4))); typedef T v2 __attribute__((ext_vector_type(2))); };
+template <typename T> struct Vec4 {
+  typename VecOf<T>::v4 v;
+  __device__ __forceinline__ static Vec4 load(const T* p) { Vec4 r; r.v = *(const typename VecOf<T>::v4*)p; return r; }
+};
+template <typename T> struct Vec2 {
+  typename VecOf<T>::v2 v;
+  __device__ __forceinline__ static Vec2 load(const T* p) { Vec2 r; r.v = *(const typename VecOf<T>::v2*)p; return r; }
+};
 
 template <typename T> static int vec_of(const T* p, long c) {
   const uintptr_t a = (uintptr_t)p;
@@ -54,10 +90,10 @@ template <typename T> static int vec_of(const T* p, long c) {
 // 4 contiguous elements
 template <typename T> __device__ __forceinline__ void ld4(const T* p, int vec, T* out) {
   if (vec == 4) {
-    const Vec4<T> t = *(const Vec4<T>*)p;
+    const Vec4<T> t = Vec4<T>::load(p);
     out[0] = t.v[0]; out[1] = t.v[1]; out[2] = t.v[2]; out[3] = t.v[3];
   } else if (vec == 2) {
-    const Vec2<T> a = *(const Vec2<T>*)p, b = *(const Vec2<T>*)(p + 2);
+    const Vec2<T> a = Vec2<T>::load(p), b = Vec2<T>::load(p + 2);
     out[0] = a.v[0]; out[1] = a.v[1]; out[2] = b.v[0]; out[3] = b.v[1];
   } else {
 #pragma unroll
@@ -67,13 +103,13 @@ template <typename T> __device__ __forceinline__ void ld4(const T* p, int vec, T
 // 8 elements: element q comes from pA[q] while q < nA, from pB[q] after (nA is a multiple of vec)
 template <typename T> __device__ __forceinline__ void ld_run8(const T* pA, const T* pB, int nA, int vec, T* raw) {
   if (vec == 4) {
-    const Vec4<T> a = *(const Vec4<T>*)pA, b = *(const Vec4<T>*)((nA >= 8 ? pA : pB) + 4);
+    const Vec4<T> a = Vec4<T>::load(pA), b = Vec4<T>::load((nA >= 8 ? pA : pB) + 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { raw[q] = a.v[q]; raw[4 + q] = b.v[q]; }
   } else if (vec == 2) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const Vec2<T> t = *(const Vec2<T>*)((2 * k < nA ? pA : pB) + 2 * k);
+      const Vec2<T> t = Vec2<T>::load((2 * k < nA ? pA : pB) + 2 * k);
       raw[2 * k] = t.v[0]; raw[2 * k + 1] = t.v[1];
     }
   } else {
@@ -146,16 +182,20 @@ template <typename T> struct FwdOp {
     return ok ? x + ((long)pix * g.Cin + c0) : x;
   }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    const unsigned kk = (unsigned)r / (unsigned)g.Cin;
+    const unsigned kk = g.dCin.div((unsigned)r);
     int ci = (int)((unsigned)r - kk * (unsigned)g.Cin);
-    int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
+    int kh = (int)g.dKW.div(kk), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
     if (g.Cin >= 8) {
       const int nA = g.Cin - ci;
       bool okA, okB;
       const T* pA = tap(rw, kh, kw, ci, okA);
-      int kw2 = kw + 1, kh2 = kh;
-      if (kw2 == g.KW) { kw2 = 0; ++kh2; }
-      const T* pB = tap(rw, kh2, kw2, -nA, okB);
+      const T* pB = pA;
+      okB = false;
+      if (nA < 8) {                        // second tap only for the runs that cross into it
+        int kw2 = kw + 1, kh2 = kh;
+        if (kw2 == g.KW) { kw2 = 0; ++kh2; }
+        pB = tap(rw, kh2, kw2, -nA, okB);
+      }
       ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
@@ -217,16 +257,20 @@ template <typename T> struct DgradOp {
     return ok ? dy + ((long)pix * g.Cout + c0) : dy;
   }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    const unsigned kk = (unsigned)r / (unsigned)g.Cout;
+    const unsigned kk = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
-    int kh = (int)(kk / (unsigned)g.KW), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
+    int kh = (int)g.dKW.div(kk), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
     if (g.Cout >= 8) {
       const int nA = g.Cout - co;
       bool okA, okB;
       const T* pA = tap(rw, kh, kw, co, okA);
-      int kw2 = kw + 1, kh2 = kh;
-      if (kw2 == g.KW) { kw2 = 0; ++kh2; }
-      const T* pB = tap(rw, kh2, kw2, -nA, okB);
+      const T* pB = pA;
+      okB = false;
+      if (nA < 8) {
+        int kw2 = kw + 1, kh2 = kh;
+        if (kw2 == g.KW) { kw2 = 0; ++kh2; }
+        pB = tap(rw, kh2, kw2, -nA, okB);
+      }
       ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
@@ -248,13 +292,15 @@ template <typename T> struct DgradOp {
     return ok ? w + (((long)kk * g.Cin + b.j) * g.Cout + c0) : w;
   }
   __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
-    const unsigned kk = (unsigned)r / (unsigned)g.Cout;
+    const unsigned kk = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
     if (g.Cout >= 8) {
       const int nA = g.Cout - co;
       bool okA, okB;
       const float* pA = wtap(b, kk, co, okA);
-      const float* pB = wtap(b, kk + 1, -nA, okB);
+      const float* pB = pA;
+      okB = false;
+      if (nA < 8) pB = wtap(b, kk + 1, -nA, okB);
       ld_run8<float>(pA, pB, nA, bvec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
@@ -294,6 +340,7 @@ template <typename T> struct DgradS2Op {
   long M, N, R, r_chunk;
   int avec, bvec;
   int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
+  FastDiv dnkw;
   struct Row { int n, ih2, iw2, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -313,16 +360,20 @@ template <typename T> struct DgradS2Op {
     return ok ? dy + ((long)pix * g.Cout + c0) : dy;
   }
   __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    const unsigned jj = (unsigned)r / (unsigned)g.Cout;
+    const unsigned jj = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
-    int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    int jh = (int)dnkw.div(jj), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
     if (g.Cout >= 8) {
       const int nA = g.Cout - co;
       bool okA, okB;
       const T* pA = tap(rw, jh, jw, co, okA);
-      int jw2 = jw + 1, jh2 = jh;
-      if (jw2 == nkw) { jw2 = 0; ++jh2; }
-      const T* pB = tap(rw, jh2, jw2, -nA, okB);
+      const T* pB = pA;
+      okB = false;
+      if (nA < 8) {
+        int jw2 = jw + 1, jh2 = jh;
+        if (jw2 == nkw) { jw2 = 0; ++jh2; }
+        pB = tap(rw, jh2, jw2, -nA, okB);
+      }
       ld_run8<T>(pA, pB, nA, avec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
@@ -345,16 +396,20 @@ template <typename T> struct DgradS2Op {
     return ok ? w + (((long)(kh * g.KW + kw) * g.Cin + b.j) * g.Cout + c0) : w;
   }
   __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
-    const unsigned jj = (unsigned)r / (unsigned)g.Cout;
+    const unsigned jj = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
-    int jh = (int)(jj / (unsigned)nkw), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
+    int jh = (int)dnkw.div(jj), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
     if (g.Cout >= 8) {
       const int nA = g.Cout - co;
       bool okA, okB;
       const float* pA = wtap(b, jh, jw, co, okA);
-      int jw2 = jw + 1, jh2 = jh;
-      if (jw2 == nkw) { jw2 = 0; ++jh2; }
-      const float* pB = wtap(b, jh2, jw2, -nA, okB);
+      const float* pB = pA;
+      okB = false;
+      if (nA < 8) {
+        int jw2 = jw + 1, jh2 = jh;
+        if (jw2 == nkw) { jw2 = 0; ++jh2; }
+        pB = wtap(b, jh2, jw2, -nA, okB);
+      }
       ld_run8<float>(pA, pB, nA, bvec, raw);
       mask = run_mask(okA, okB, nA, r, r_end);
     } else {
@@ -411,8 +466,8 @@ template <typename T> struct WgradOp {
   __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw, unsigned& mask) const {
     const bool rok = r < r_end;
     const unsigned rr = rok ? (unsigned)r : 0u;
-    const unsigned t = rr / (unsigned)g.OW, ow = rr - t * (unsigned)g.OW;
-    const unsigned n = t / (unsigned)g.OH, oh = t - n * (unsigned)g.OH;
+    const unsigned t = g.dOW.div(rr), ow = rr - t * (unsigned)g.OW;
+    const unsigned n = g.dOH.div(t), oh = t - n * (unsigned)g.OH;
     const int Hs = g.up ? (g.H >> 1) : g.H, Ws = g.up ? (g.W >> 1) : g.W;
     const int ihb = (int)oh * g.S - g.PT, iwb = (int)ow * g.S - g.PL;
     auto elem = [&](unsigned e, bool& ok) -> const T* {
@@ -592,11 +647,10 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
   };
   auto stash = [&](int buf) {
     float fa[8], fb[8];
-    const bool relu = op.a_relu();
+    const float lo = op.a_relu() ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = Elem<typename Op::AT>::ld(&ra[q]);
-      if (relu) v = v > 0.f ? v : 0.f;
+      float v = fmaxf(Elem<typename Op::AT>::ld(&ra[q]), lo);
       fa[q] = ((amask >> q) & 1u) ? v : 0.f;
       fb[q] = ((bmask >> q) & 1u) ? Elem<typename Op::BT>::ld(&rb[q]) * bscale : 0.f;
     }
@@ -682,8 +736,8 @@ __global__ __launch_bounds__(256) void dgrad_s2_narrow_kernel(DgradS2Op<T> op) {
       const float* wl = nw_smem + (size_t)(jh * op.nkw + jw) * NJ * C;
       for (int c0 = sub * VEC; c0 < C; c0 += 16 * VEC) {
         T raw[VEC];
-        if constexpr (VEC == 4) { const Vec4<T> t4 = *(const Vec4<T>*)(p + c0); raw[0] = t4.v[0]; raw[1] = t4.v[1]; raw[2] = t4.v[2]; raw[3] = t4.v[3]; }
-        else if constexpr (VEC == 2) { const Vec2<T> t2 = *(const Vec2<T>*)(p + c0); raw[0] = t2.v[0]; raw[1] = t2.v[1]; }
+        if constexpr (VEC == 4) { const Vec4<T> t4 = Vec4<T>::load(p + c0); raw[0] = t4.v[0]; raw[1] = t4.v[1]; raw[2] = t4.v[2]; raw[3] = t4.v[3]; }
+        else if constexpr (VEC == 2) { const Vec2<T> t2 = Vec2<T>::load(p + c0); raw[0] = t2.v[0]; raw[1] = t2.v[1]; }
         else raw[0] = p[c0];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -1124,7 +1178,8 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
           op.nkh = g.KH > op.kh0 ? (g.KH - op.kh0 + 1) / 2 : 0;
           op.nkw = g.KW > op.kw0 ? (g.KW - op.kw0 + 1) / 2 : 0;
           op.dh = (ph + g.PT - op.kh0) / 2; op.dwc = (pw + g.PL - op.kw0) / 2;
-          if (op.nkw == 0) { op.nkw = 1; op.nkh = 0; }          // keeps the divisions defined; R = 0: outputs are bias / 0
+          if (op.nkw == 0) { op.nkw = 1; op.nkh = 0; }
+          op.dnkw = make_fastdiv(op.nkw);          // keeps the divisions defined; R = 0: outputs are bias / 0
           op.M = (long)g.N * op.Hp * op.Wp; op.N = g.Cin; op.R = (long)op.nkh * op.nkw * g.Cout; op.r_chunk = op.R;
           op.avec = vec_of(dy, g.Cout); op.bvec = vec_of(w, g.Cout);
           int rc;
