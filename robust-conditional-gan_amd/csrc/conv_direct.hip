@@ -69,6 +69,7 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
 // Pixel indices are 32-bit (a tensor has < 2^32 pixels); the element offset is one 64-bit multiply-add.  When the run
 // dimension (channels) is >= 8 a run of 8 touches at most two filter taps, so the tap decode, the bounds test and the
 // pixel address are computed twice per run instead of eight times.
+struct NoAux {};
 // real vector types: a struct of four scalars is split into four scalar loads by SROA and never re-vectorised
 template <typename T> struct VecOf { typedef T v4 __attribute__((ext_vector_type(4))); typedef T v2 __attribute__((ext_vector_type(2))); };
 template <typename T> struct Vec4 {
@@ -155,6 +156,7 @@ template <typename T> __device__ __forceinline__ void lin_run4(const T* p, bool 
 // ---- forward: i = output pixel, j = cout, r = (kh,kw,ci) ---------------------------------------
 template <typename T> struct FwdOp {
   typedef T AT; typedef float BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
   ConvGeom g; const T* x; const float* w; const float* bias; T* y; int accumulate;
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
@@ -229,6 +231,7 @@ struct WRow { long j; int ok; };
 // ---- data gradient: i = input pixel (n,ih,iw) at the logical resolution, j = ci, r = (kh,kw,co) ---
 template <typename T> struct DgradOp {
   typedef T AT; typedef float BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   ConvGeom g; const T* dy; const float* w; const float* bias; T* dx; const T* xmask; int accumulate;
   const float* wscale;
@@ -332,6 +335,8 @@ template <typename T> struct DgradOp {
 //      kh = kh0 + 2*jh, kw = kw0 + 2*jw (kh0 = (ph + PT) % 2) reach an output pixel, so the reduction runs over
 //      ceil(KH/2) x ceil(KW/2) x Cout instead of KH x KW x Cout with three quarters of the gathers returning zero.
 //      i = (n, ih/2, iw/2) inside the class, j = ci, r = (jh, jw, co).
+struct S2Cls { int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc; long M, R; FastDiv dnkw; };
+struct S2Table { S2Cls cls[4]; };
 template <typename T> struct DgradS2Op {
   typedef T AT; typedef float BT;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
@@ -341,6 +346,14 @@ template <typename T> struct DgradS2Op {
   int avec, bvec;
   int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
   FastDiv dnkw;
+  // the (up to) four parity classes of one layer run in ONE launch, class = blockIdx.z.  The class table is its own
+  // kernel argument: a dynamically indexed array inside the functor would push the whole by-value copy into scratch.
+  typedef S2Table Aux;
+  __device__ __forceinline__ void select(const S2Table& tab, int z) {
+    const S2Cls& c = tab.cls[z];
+    ph = c.ph; pw = c.pw; Hp = c.Hp; Wp = c.Wp; kh0 = c.kh0; kw0 = c.kw0; nkh = c.nkh; nkw = c.nkw; dh = c.dh; dwc = c.dwc;
+    M = c.M; R = c.R; r_chunk = c.R; dnkw = c.dnkw;
+  }
   struct Row { int n, ih2, iw2, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -443,6 +456,7 @@ template <typename T> struct DgradS2Op {
 //      Both operands are contiguous along the tile dimensions (ci / cout), strided along r: N-major fetch.
 template <typename T> struct WgradOp {
   typedef T AT; typedef T BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
   ConvGeom g; const T* x; const T* dy; float* slab;
   const float* wscale;   // always null (the filter gradient has no filter operand)
@@ -506,6 +520,7 @@ template <typename T> struct WgradOp {
 template <typename T> struct LinRow { const T* p; int ok; };
 template <typename T> struct LinFwdOp {
   typedef T AT; typedef float BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
   const T* x; const float* w; const float* bias; T* y; const float* wscale;
   long M, N, R, r_chunk;
@@ -527,6 +542,7 @@ template <typename T> struct LinFwdOp {
 };
 template <typename T> struct LinDgradOp {
   typedef T AT; typedef float BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
   long M, N, R, r_chunk;          // N = in features, R = out features
@@ -549,6 +565,7 @@ template <typename T> struct LinDgradOp {
 };
 template <typename T> struct LinWgradOp {
   typedef T AT; typedef T BT;
+  typedef NoAux Aux;
   static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
   const T* x; const T* dy; float* out; int accumulate; int direct; const float* wscale;
   long M, N, R, r_chunk;          // M = in features, N = out features, R = batch rows
@@ -582,6 +599,12 @@ template <typename T> struct LinWgradOp {
 // KS groups of four waves walk interleaved K-steps (group g takes steps g, g+KS, ...) on private LDS buffers and their
 // accumulators are summed through LDS at the end: the dense layers of the MNIST nets launch 16..400 workgroups with
 // 50..200 sequential K-steps each.
+template <class Op, class = void> struct has_select : std::false_type {};
+template <class Op> struct has_select<Op, std::void_t<decltype(&Op::select)>> : std::true_type {};
+template <class Op> __device__ __forceinline__ int gg_select(Op& op, const typename Op::Aux& aux, int z) {
+  if constexpr (has_select<Op>::value) { op.select(aux, z); return 0; }
+  else return z;
+}
 template <class Op> __device__ __forceinline__ auto a_init(const Op& op, long i0, int tid) {
   if constexpr (Op::A_KMAJOR) return op.row(i0 + (tid >> 2));
   else return op.arun(i0 + (tid & 15) * 4);
@@ -594,14 +617,17 @@ template <class Op> __device__ __forceinline__ auto b_init(const Op& op, long j0
 #define GG_XBUF 2304   /* floats per operand buffer: max(64 x 36 K-major, 32 x 68 N-major) */
 
 template <class Op, int KS>
-__global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
+__global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typename Op::Aux aux) {
   extern __shared__ __attribute__((aligned(16))) float gg_smem[];
+  Op op = op_in;
+  const int zc = gg_select(op, aux, (int)blockIdx.z);      // r-chunk index (ops that use grid.z for something else return 0)
+  if ((long)blockIdx.y * 64 >= op.M) return;
   const int kg = threadIdx.x >> 8;
   float* const lds = gg_smem + (size_t)kg * 4 * GG_XBUF;      // A buf 0/1, B buf 0/1
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, l31 = lane & 31, hh = lane >> 5;
   const long i0 = (long)blockIdx.y * 64, j0 = (long)blockIdx.x * 64;
-  const long r_begin = (long)blockIdx.z * op.r_chunk;
+  const long r_begin = (long)zc * op.r_chunk;
   long r_end = r_begin + op.r_chunk;
   if (r_end > op.R) r_end = op.R;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -680,8 +706,14 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
     float av[16], bv[16];
     get(lds + buf * GG_XBUF, Op::A_KMAJOR, wr * 32, av);
     get(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, wc * 32, bv);
+    // all operand reads land before the MFMA chain starts: left alone the scheduler feeds every second MFMA from an
+    // LDS read issued right before it and the chain pays the LDS latency sixteen times
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (more) stash(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const long i = i0 + wr * 32 + 8 * (p >> 2) + 4 * hh + (p & 3);
-      if (i < op.M) op.store(i, j, acc[p], blockIdx.z);
+      if (i < op.M) op.store(i, j, acc[p], zc);
     }
   }
 }
@@ -714,8 +746,11 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op) {
 // reachable taps (coalesced, VEC elements per lane), the filter slice lives in LDS, the lane partials meet in a
 // 4-step butterfly.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void dgrad_s2_narrow_kernel(DgradS2Op<T> op) {
+__global__ __launch_bounds__(256) void dgrad_s2_narrow_kernel(DgradS2Op<T> op_in, S2Table tab) {
   extern __shared__ __attribute__((aligned(16))) float nw_smem[];     // [tap][j][Cout]
+  DgradS2Op<T> op = op_in;
+  op.select(tab, (int)blockIdx.y);
+  if ((long)blockIdx.x * 16 >= op.M) return;
   const int C = op.g.Cout, NJ = (int)op.N, ntaps = op.nkh * op.nkw;
   const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
   for (int e = threadIdx.x; e < ntaps * NJ * C; e += 256) {
@@ -757,12 +792,12 @@ __global__ __launch_bounds__(256) void dgrad_s2_narrow_kernel(DgradS2Op<T> op) {
 }
 
 template <typename T>
-static int launch_dgrad_s2_narrow(rcgan_ctx* ctx, DgradS2Op<T>& op) {
-  const size_t lds = (size_t)op.nkh * op.nkw * op.N * op.g.Cout * sizeof(float);
-  dim3 grid(cdiv(op.M, 16));
-  if (op.avec == 4) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 4>), grid, dim3(256), lds, ctx->stream, op);
-  else if (op.avec == 2) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 2>), grid, dim3(256), lds, ctx->stream, op);
-  else hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 1>), grid, dim3(256), lds, ctx->stream, op);
+static int launch_dgrad_s2_narrow(rcgan_ctx* ctx, DgradS2Op<T>& op, const S2Table& tab, int ncls, long maxM, long maxR) {
+  const size_t lds = (size_t)maxR * op.N * sizeof(float);
+  dim3 grid(cdiv(maxM, 16), ncls);
+  if (op.avec == 4) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 4>), grid, dim3(256), lds, ctx->stream, op, tab);
+  else if (op.avec == 2) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 2>), grid, dim3(256), lds, ctx->stream, op, tab);
+  else hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 1>), grid, dim3(256), lds, ctx->stream, op, tab);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
@@ -880,26 +915,29 @@ static int gg_env_int(const char* name, int dflt) {
 }
 
 template <class Op, int KS>
-static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid) {
+static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid, const typename Op::Aux& aux) {
   static bool attr_set = false;
   const size_t lds = (size_t)KS * 4 * GG_XBUF * sizeof(float);
   if (!attr_set) {
     RC_HIP(ctx, hipFuncSetAttribute((const void*)gemm_gather_kernel<Op, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_gather_kernel<Op, KS>), grid, dim3(256 * KS), lds, ctx->stream, op);
+  hipLaunchKernelGGL((gemm_gather_kernel<Op, KS>), grid, dim3(256 * KS), lds, ctx->stream, op, aux);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
 
 template <class Op>
-static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz) {
+static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz, const typename Op::Aux& aux = typename Op::Aux()) {
   dim3 grid(cdiv(op.N, 64), cdiv(op.M, 64), nz);
   if (grid.y > 65535u || grid.z > 65535u) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "M too large");
   static const int ks_min_steps = gg_env_int("RCGAN_GG_KS_MINSTEPS", 8);
   const long steps = (op.r_chunk + 31) / 32;
-  if (steps >= ks_min_steps) return launch_gemm_ks<Op, 4>(ctx, op, grid);
-  return launch_gemm_ks<Op, 1>(ctx, op, grid);
+  static const int ks_force = gg_env_int("RCGAN_GG_KS", 0);
+  if (ks_force == 2) return launch_gemm_ks<Op, 2>(ctx, op, grid, aux);
+  if (ks_force == 1) return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
+  if (steps >= ks_min_steps) return launch_gemm_ks<Op, 4>(ctx, op, grid, aux);
+  return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
 }
 
 // pick the number of r-splits for a filter-gradient GEMM so the grid fills the chip
@@ -1167,27 +1205,38 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
                  const T* xmask, T* dx, int accumulate) {
   {
     ConvGeom g = make_geom(d);
-    if (g.S == 2) {                      // one launch per input-pixel parity class
+    if (g.S == 2) {                      // the four input-pixel parity classes, one launch (class = grid.z)
+      DgradS2Op<T> op;
+      op.g = g; op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
+      op.N = g.Cin;
+      op.avec = vec_of(dy, g.Cout); op.bvec = vec_of(w, g.Cout);
+      S2Table tab;
+      int ncls = 0;
+      long maxM = 0, maxR = 0;
       for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
-          DgradS2Op<T> op;
-          op.g = g; op.g.up = 0; op.dy = dy; op.w = w; op.wscale = wscale; op.bias = bias; op.dx = dx; op.xmask = xmask; op.accumulate = accumulate;
-          op.ph = ph; op.pw = pw; op.Hp = (g.H - ph + 1) / 2; op.Wp = (g.W - pw + 1) / 2;
-          if (op.Hp <= 0 || op.Wp <= 0) continue;
-          op.kh0 = (ph + g.PT) % 2; op.kw0 = (pw + g.PL) % 2;
-          op.nkh = g.KH > op.kh0 ? (g.KH - op.kh0 + 1) / 2 : 0;
-          op.nkw = g.KW > op.kw0 ? (g.KW - op.kw0 + 1) / 2 : 0;
-          op.dh = (ph + g.PT - op.kh0) / 2; op.dwc = (pw + g.PL - op.kw0) / 2;
-          if (op.nkw == 0) { op.nkw = 1; op.nkh = 0; }
-          op.dnkw = make_fastdiv(op.nkw);          // keeps the divisions defined; R = 0: outputs are bias / 0
-          op.M = (long)g.N * op.Hp * op.Wp; op.N = g.Cin; op.R = (long)op.nkh * op.nkw * g.Cout; op.r_chunk = op.R;
-          op.avec = vec_of(dy, g.Cout); op.bvec = vec_of(w, g.Cout);
-          int rc;
-          if (op.N <= 4 && op.R > 0 && (size_t)op.R * op.N * sizeof(float) <= 48 * 1024) rc = launch_dgrad_s2_narrow(ctx, op);
-          else rc = launch_gemm(ctx, op, 1);
-          if (rc) return rc;
+          S2Cls c;
+          c.ph = ph; c.pw = pw; c.Hp = (g.H - ph + 1) / 2; c.Wp = (g.W - pw + 1) / 2;
+          if (c.Hp <= 0 || c.Wp <= 0) continue;
+          c.kh0 = (ph + g.PT) % 2; c.kw0 = (pw + g.PL) % 2;
+          c.nkh = g.KH > c.kh0 ? (g.KH - c.kh0 + 1) / 2 : 0;
+          c.nkw = g.KW > c.kw0 ? (g.KW - c.kw0 + 1) / 2 : 0;
+          c.dh = (ph + g.PT - c.kh0) / 2; c.dwc = (pw + g.PL - c.kw0) / 2;
+          if (c.nkw == 0) { c.nkw = 1; c.nkh = 0; }          // keeps the divisions defined; R = 0: outputs are bias / 0
+          c.dnkw = make_fastdiv(c.nkw);
+          c.M = (long)g.N * c.Hp * c.Wp; c.R = (long)c.nkh * c.nkw * g.Cout;
+          if (c.M > maxM) maxM = c.M;
+          if (c.R > maxR) maxR = c.R;
+          tab.cls[ncls++] = c;
         }
-      return RCGAN_OK;
+      if (ncls == 0) return RCGAN_OK;
+      for (int q = ncls; q < 4; ++q) tab.cls[q] = tab.cls[0];
+      // launch-shape fields (the kernel re-selects per class)
+      op.M = maxM; op.R = maxR; op.r_chunk = maxR;
+      { const auto& c = tab.cls[0]; op.ph = c.ph; op.pw = c.pw; op.Hp = c.Hp; op.Wp = c.Wp; op.kh0 = c.kh0; op.kw0 = c.kw0;
+        op.nkh = c.nkh; op.nkw = c.nkw; op.dh = c.dh; op.dwc = c.dwc; op.dnkw = c.dnkw; }
+      if (op.N <= 4 && maxR > 0 && (size_t)maxR * op.N * sizeof(float) <= 48 * 1024) return launch_dgrad_s2_narrow(ctx, op, tab, ncls, maxM, maxR);
+      return launch_gemm(ctx, op, ncls, tab);
     }
   }
   DgradOp<T> op;
