@@ -59,13 +59,13 @@ static ConvGeom make_geom(const rcgan_conv_desc* d) {
 // Operand functors of the gather GEMM  C[i][j] = sum_r A(i,r) * B(r,j).  An operand is fetched along the dimension
 // it is contiguous in, in 8- or 16-byte vectors where the channel count and the base pointer allow:
 //   K-major (X_KMAJOR = true):  a thread owns one row (col) of the tile and fetches runs of 8 consecutive reduction
-//       indices.  row(i) / brow(j) decode the row once per launch; a8 / b8 produce raw elements + a validity mask.
+//       indices.  row(i) / brow(j) decode the row once per launch; a8 / b8 produce the raw elements.
 //       LDS layout [row][k], the MFMA operand is read with ds_read_b128.
 //   N-major (X_KMAJOR = false): a thread fetches 4 consecutive rows (cols) at one reduction index (two per K-step).
-//       arun(i) decodes the 4-row group once; a4 / b4 produce raw elements + mask.  LDS layout [k][row], operand read
+//       arun(i) decodes the 4-row group once; a4 / b4 produce the raw elements.  LDS layout [k][row], operand read
 //       with ds_read_b32.
-// Loads are branch-free: addresses always lie inside the tensors (invalid elements point at the tensor base) and the
-// zero-fill, ReLU and fp32 conversion happen at the LDS write, after the MFMAs of the previous step.
+// Loads are branch-free and mask-free: an invalid element (padding tap, row / column / reduction index past the end)
+// is read from a page of zeros, so the LDS write after the MFMAs of the previous step is a plain fp32 conversion (+ReLU).
 // Pixel indices are 32-bit (a tensor has < 2^32 pixels); the element offset is one 64-bit multiply-add.  When the run
 // dimension (channels) is >= 8 a run of 8 touches at most two filter taps, so the tap decode, the bounds test and the
 // pixel address are computed twice per run instead of eight times.
@@ -118,38 +118,31 @@ template <typename T> __device__ __forceinline__ void ld_run8(const T* pA, const
     for (int q = 0; q < 8; ++q) raw[q] = (q < nA ? pA : pB)[q];
   }
 }
-__device__ __forceinline__ unsigned run_mask(bool okA, bool okB, int nA, long r, long r_end) {
-  const unsigned mA = nA >= 8 ? 0xffu : ((1u << nA) - 1u);
-  unsigned m = (okA ? mA : 0u) | (okB ? (0xffu & ~mA) : 0u);
-  const long left = r_end - r;
-  m &= left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u);
-  return m;
-}
-// plain row-major rows (dense layers): 8 consecutive elements of row p, clamped at the row end
-template <typename T> __device__ __forceinline__ void lin_run8(const T* p, bool ok, long r, long r_end, int vec, T* raw, unsigned& mask) {
+// plain row-major rows (dense layers): 8 consecutive elements of row p.  The tail of the reduction is clamped (A operand:
+// the matching B elements are zero) or read from the zero page (B operand)
+template <typename T> __device__ __forceinline__ void lin_run8(const T* p, long r, long r_end, int vec, const T* zp, bool zero_tail, T* raw) {
   const long left = r_end - r;
   if (left >= 8 && vec > 1) {
     ld_run8<T>(p + r, p + r, 8, vec, raw);
+  } else if (zero_tail) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw[q] = *(r + q < r_end ? p + r + q : zp);
   } else {
 #pragma unroll
     for (int q = 0; q < 8; ++q) raw[q] = p[r + q < r_end ? r + q : r_end - 1];
   }
-  mask = ok ? (left >= 8 ? 0xffu : (left > 0 ? ((1u << (int)left) - 1u) : 0u)) : 0u;
 }
-// 4 consecutive columns j..j+3 of row-major matrix row p (n columns)
-template <typename T> __device__ __forceinline__ void lin_run4(const T* p, bool rok, long j, long n, int vec, T* raw, unsigned& mask) {
+// 4 consecutive columns j..j+3 of a row-major matrix row p (n columns); rows past the reduction end and columns past n
+// read the zero page
+template <typename T> __device__ __forceinline__ void lin_run4(const T* p, bool rok, long j, long n, int vec, const T* zp, T* raw) {
   if ((n & 3) == 0) {
-    const bool ok = rok && j < n;
-    ld4<T>(p + (j < n ? j : 0), vec, raw);
-    mask = ok ? 0xfu : 0u;
+    ld4<T>(rok && j < n ? p + j : zp, vec, raw);
+  } else if ((n & 1) == 0 && vec >= 2) {
+    const Vec2<T> a = Vec2<T>::load(rok && j < n ? p + j : zp), b = Vec2<T>::load(rok && j + 2 < n ? p + j + 2 : zp);
+    raw[0] = a.v[0]; raw[1] = a.v[1]; raw[2] = b.v[0]; raw[3] = b.v[1];
   } else {
-    mask = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const long jj = j + c;
-      raw[c] = p[jj < n ? jj : 0];
-      mask |= (unsigned)(rok && jj < n) << c;
-    }
+    for (int c = 0; c < 4; ++c) raw[c] = *(rok && j + c < n ? p + j + c : zp);
   }
 }
 
@@ -162,6 +155,7 @@ template <typename T> struct FwdOp {
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
   long M, N, R, r_chunk;
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   struct Row { int n, ih0, iw0, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -181,9 +175,9 @@ template <typename T> struct FwdOp {
     ok = rw.ok && kh < g.KH && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
     const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
     const unsigned pix = ((unsigned)rw.n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
-    return ok ? x + ((long)pix * g.Cin + c0) : x;
+    return ok ? x + ((long)pix * g.Cin + c0) : (const T*)zp;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw) const {
     const unsigned kk = g.dCin.div((unsigned)r);
     int ci = (int)((unsigned)r - kk * (unsigned)g.Cin);
     int kh = (int)g.dKW.div(kk), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
@@ -199,23 +193,18 @@ template <typename T> struct FwdOp {
         pB = tap(rw, kh2, kw2, -nA, okB);
       }
       ld_run8<T>(pA, pB, nA, avec, raw);
-      mask = run_mask(okA, okB, nA, r, r_end);
     } else {
-      mask = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         bool ok;
-        const T* p = tap(rw, kh, kw, ci, ok);
-        ok = ok && r + q < r_end;
-        raw[q] = *(ok ? p : x);
-        mask |= (unsigned)ok << q;
+        raw[q] = *tap(rw, kh, kw, ci, ok);
         if (++ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
       }
     }
   }
-  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw) const {
     const bool rok = r < r_end;
-    lin_run4<float>(w + (rok ? r : 0) * g.Cout, rok, j, N, bvec, raw, mask);
+    lin_run4<float>(w + (rok ? r : 0) * g.Cout, rok, j, N, bvec, (const float*)zp, raw);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
@@ -237,6 +226,7 @@ template <typename T> struct DgradOp {
   const float* wscale;
   long M, N, R, r_chunk;
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   struct Row { int n, ih, iw, ok; };
   __device__ __forceinline__ Row row(long i) const {
     Row rw;
@@ -257,9 +247,9 @@ template <typename T> struct DgradOp {
     else if (g.S > 2) { ok = ok && (th % g.S == 0) && (tw % g.S == 0); oh = th / g.S; ow = tw / g.S; }
     ok = ok && oh < g.OH && ow < g.OW;
     const unsigned pix = ((unsigned)rw.n * (unsigned)g.OH + (unsigned)oh) * (unsigned)g.OW + (unsigned)ow;
-    return ok ? dy + ((long)pix * g.Cout + c0) : dy;
+    return ok ? dy + ((long)pix * g.Cout + c0) : (const T*)zp;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw) const {
     const unsigned kk = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
     int kh = (int)g.dKW.div(kk), kw = (int)(kk - (unsigned)kh * (unsigned)g.KW);
@@ -275,16 +265,11 @@ template <typename T> struct DgradOp {
         pB = tap(rw, kh2, kw2, -nA, okB);
       }
       ld_run8<T>(pA, pB, nA, avec, raw);
-      mask = run_mask(okA, okB, nA, r, r_end);
     } else {
-      mask = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         bool ok;
-        const T* p = tap(rw, kh, kw, co, ok);
-        ok = ok && r + q < r_end;
-        raw[q] = *(ok ? p : dy);
-        mask |= (unsigned)ok << q;
+        raw[q] = *tap(rw, kh, kw, co, ok);
         if (++co == g.Cout) { co = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
       }
     }
@@ -292,9 +277,9 @@ template <typename T> struct DgradOp {
   __device__ __forceinline__ WRow brow(long j) const { WRow b; b.ok = j < N; b.j = b.ok ? j : 0; return b; }
   __device__ __forceinline__ const float* wtap(const WRow& b, unsigned kk, int c0, bool& ok) const {
     ok = b.ok && kk < (unsigned)(g.KH * g.KW);
-    return ok ? w + (((long)kk * g.Cin + b.j) * g.Cout + c0) : w;
+    return ok ? w + (((long)kk * g.Cin + b.j) * g.Cout + c0) : (const float*)zp;
   }
-  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw) const {
     const unsigned kk = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - kk * (unsigned)g.Cout);
     if (g.Cout >= 8) {
@@ -305,17 +290,12 @@ template <typename T> struct DgradOp {
       okB = false;
       if (nA < 8) pB = wtap(b, kk + 1, -nA, okB);
       ld_run8<float>(pA, pB, nA, bvec, raw);
-      mask = run_mask(okA, okB, nA, r, r_end);
     } else {
-      mask = 0;
       unsigned k2 = kk;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         bool ok;
-        const float* p = wtap(b, k2, co, ok);
-        ok = ok && r + q < r_end;
-        raw[q] = *(ok ? p : w);
-        mask |= (unsigned)ok << q;
+        raw[q] = *wtap(b, k2, co, ok);
         if (++co == g.Cout) { co = 0; ++k2; }
       }
     }
@@ -344,6 +324,7 @@ template <typename T> struct DgradS2Op {
   const float* wscale;
   long M, N, R, r_chunk;
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   int ph, pw, Hp, Wp, kh0, kw0, nkh, nkw, dh, dwc;
   FastDiv dnkw;
   // the (up to) four parity classes of one layer run in ONE launch, class = blockIdx.z.  The class table is its own
@@ -370,9 +351,9 @@ template <typename T> struct DgradS2Op {
     const int oh = rw.ih2 + dh - jh, ow = rw.iw2 + dwc - jw;
     ok = rw.ok && jh < nkh && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
     const unsigned pix = ((unsigned)rw.n * (unsigned)g.OH + (unsigned)oh) * (unsigned)g.OW + (unsigned)ow;
-    return ok ? dy + ((long)pix * g.Cout + c0) : dy;
+    return ok ? dy + ((long)pix * g.Cout + c0) : (const T*)zp;
   }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw) const {
     const unsigned jj = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
     int jh = (int)dnkw.div(jj), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
@@ -388,16 +369,11 @@ template <typename T> struct DgradS2Op {
         pB = tap(rw, jh2, jw2, -nA, okB);
       }
       ld_run8<T>(pA, pB, nA, avec, raw);
-      mask = run_mask(okA, okB, nA, r, r_end);
     } else {
-      mask = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         bool ok;
-        const T* p = tap(rw, jh, jw, co, ok);
-        ok = ok && r + q < r_end;
-        raw[q] = *(ok ? p : dy);
-        mask |= (unsigned)ok << q;
+        raw[q] = *tap(rw, jh, jw, co, ok);
         if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
       }
     }
@@ -406,9 +382,9 @@ template <typename T> struct DgradS2Op {
   __device__ __forceinline__ const float* wtap(const WRow& b, int jh, int jw, int c0, bool& ok) const {
     ok = b.ok && jh < nkh;
     const int kh = kh0 + 2 * jh, kw = kw0 + 2 * jw;
-    return ok ? w + (((long)(kh * g.KW + kw) * g.Cin + b.j) * g.Cout + c0) : w;
+    return ok ? w + (((long)(kh * g.KW + kw) * g.Cin + b.j) * g.Cout + c0) : (const float*)zp;
   }
-  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b8(const WRow& b, long r, long r_end, float* raw) const {
     const unsigned jj = g.dCout.div((unsigned)r);
     int co = (int)((unsigned)r - jj * (unsigned)g.Cout);
     int jh = (int)dnkw.div(jj), jw = (int)(jj - (unsigned)jh * (unsigned)nkw);
@@ -424,16 +400,11 @@ template <typename T> struct DgradS2Op {
         pB = wtap(b, jh2, jw2, -nA, okB);
       }
       ld_run8<float>(pA, pB, nA, bvec, raw);
-      mask = run_mask(okA, okB, nA, r, r_end);
     } else {
-      mask = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         bool ok;
-        const float* p = wtap(b, jh, jw, co, ok);
-        ok = ok && r + q < r_end;
-        raw[q] = *(ok ? p : w);
-        mask |= (unsigned)ok << q;
+        raw[q] = *wtap(b, jh, jw, co, ok);
         if (++co == g.Cout) { co = 0; if (++jw == nkw) { jw = 0; ++jh; } }
       }
     }
@@ -462,6 +433,7 @@ template <typename T> struct WgradOp {
   const float* wscale;   // always null (the filter gradient has no filter operand)
   long M, N, R, r_chunk;
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   // four consecutive filter positions (kh,kw,ci); with Cin % 4 == 0 they share the tap and only e[0] is used
   struct ARun { unsigned e[4]; };     // kh | kw << 8 | ci << 16 | valid << 31
   __device__ __forceinline__ ARun arun(long i) const {
@@ -477,7 +449,7 @@ template <typename T> struct WgradOp {
     return a;
   }
   __device__ __forceinline__ bool a_relu() const { return g.relu_in; }
-  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw) const {
     const bool rok = r < r_end;
     const unsigned rr = rok ? (unsigned)r : 0u;
     const unsigned t = g.dOW.div(rr), ow = rr - t * (unsigned)g.OW;
@@ -489,26 +461,22 @@ template <typename T> struct WgradOp {
       ok = rok && (e >> 31) && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
       const int sh = g.up ? (ih >> 1) : ih, sw = g.up ? (iw >> 1) : iw;
       const unsigned pix = (n * (unsigned)Hs + (unsigned)sh) * (unsigned)Ws + (unsigned)sw;
-      return ok ? x + ((long)pix * g.Cin + ((e >> 16) & 0x7fff)) : x;
+      return ok ? x + ((long)pix * g.Cin + ((e >> 16) & 0x7fff)) : (const T*)zp;
     };
     if ((g.Cin & 3) == 0) {
       bool ok;
-      const T* p = elem(a.e[0], ok);
-      ld4<T>(p, avec, raw);
-      mask = ok ? 0xfu : 0u;
+      ld4<T>(elem(a.e[0], ok), avec, raw);
     } else {
-      mask = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bool ok;
         raw[q] = *elem(a.e[q], ok);
-        mask |= (unsigned)ok << q;
       }
     }
   }
-  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw) const {
     const bool rok = r < r_end;
-    lin_run4<T>(dy + (rok ? r : 0) * g.Cout, rok, j, N, bvec, raw, mask);
+    lin_run4<T>(dy + (rok ? r : 0) * g.Cout, rok, j, N, bvec, (const T*)zp, raw);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     slab[(long)z * M * N + i * N + j] = v;
@@ -525,15 +493,16 @@ template <typename T> struct LinFwdOp {
   const T* x; const float* w; const float* bias; T* y; const float* wscale;
   long M, N, R, r_chunk;
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   typedef LinRow<T> Row;
   __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = x + (rw.ok ? i : 0) * R; return rw; }
   __device__ __forceinline__ bool a_relu() const { return false; }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    lin_run8<T>(rw.p, rw.ok, r, r_end, avec, raw, mask);
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw) const {
+    lin_run8<T>(rw.p, r, r_end, avec, (const T*)zp, false, raw);
   }
-  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b4(long r, long r_end, long j, float* raw) const {
     const bool rok = r < r_end;
-    lin_run4<float>(w + (rok ? r : 0) * N, rok, j, N, bvec, raw, mask);
+    lin_run4<float>(w + (rok ? r : 0) * N, rok, j, N, bvec, (const float*)zp, raw);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
@@ -547,15 +516,16 @@ template <typename T> struct LinDgradOp {
   const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
   long M, N, R, r_chunk;          // N = in features, R = out features
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   typedef LinRow<T> Row;
   __device__ __forceinline__ Row row(long i) const { Row rw; rw.ok = i < M; rw.p = dy + (rw.ok ? i : 0) * R; return rw; }
   __device__ __forceinline__ bool a_relu() const { return false; }
-  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw, unsigned& mask) const {
-    lin_run8<T>(rw.p, rw.ok, r, r_end, avec, raw, mask);
+  __device__ __forceinline__ void a8(const Row& rw, long r, long r_end, T* raw) const {
+    lin_run8<T>(rw.p, r, r_end, avec, (const T*)zp, false, raw);
   }
   __device__ __forceinline__ LinRow<float> brow(long j) const { LinRow<float> b; b.ok = j < N; b.p = w + (b.ok ? j : 0) * R; return b; }
-  __device__ __forceinline__ void b8(const LinRow<float>& b, long r, long r_end, float* raw, unsigned& mask) const {
-    lin_run8<float>(b.p, b.ok, r, r_end, bvec, raw, mask);
+  __device__ __forceinline__ void b8(const LinRow<float>& b, long r, long r_end, float* raw) const {
+    lin_run8<float>(b.p, r, r_end, bvec, (const float*)zp, true, raw);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     T* p = dx + i * N + j;
@@ -570,16 +540,17 @@ template <typename T> struct LinWgradOp {
   const T* x; const T* dy; float* out; int accumulate; int direct; const float* wscale;
   long M, N, R, r_chunk;          // M = in features, N = out features, R = batch rows
   int avec, bvec;
+  const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   struct ARun { long i; };
   __device__ __forceinline__ ARun arun(long i) const { ARun a; a.i = i; return a; }
   __device__ __forceinline__ bool a_relu() const { return false; }
-  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void a4(const ARun& a, long r, long r_end, T* raw) const {
     const bool rok = r < r_end;
-    lin_run4<T>(x + (rok ? r : 0) * M, rok, a.i, M, avec, raw, mask);
+    lin_run4<T>(x + (rok ? r : 0) * M, rok, a.i, M, avec, (const T*)zp, raw);
   }
-  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw, unsigned& mask) const {
+  __device__ __forceinline__ void b4(long r, long r_end, long j, T* raw) const {
     const bool rok = r < r_end;
-    lin_run4<T>(dy + (rok ? r : 0) * N, rok, j, N, bvec, raw, mask);
+    lin_run4<T>(dy + (rok ? r : 0) * N, rok, j, N, bvec, (const T*)zp, raw);
   }
   __device__ __forceinline__ void store(long i, long j, float v, int z) const {
     if (direct) {                  // single r-chunk: straight into the gradient
@@ -639,25 +610,20 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
   const float bscale = op.wscale ? 1.f / *op.wscale : 1.f;
   typename Op::AT ra[8];
   typename Op::BT rb[8];
-  unsigned amask = 0, bmask = 0;
   const auto ast = a_init(op, i0, tid);
   const auto bst = b_init(op, j0, tid);
   auto fetch = [&](long r0) {
     if constexpr (Op::A_KMAJOR) {
-      op.a8(ast, r0 + (tid & 3) * 8, r_end, ra, amask);
+      op.a8(ast, r0 + (tid & 3) * 8, r_end, ra);
     } else {
-      unsigned m0, m1;
-      op.a4(ast, r0 + (tid >> 4), r_end, ra, m0);
-      op.a4(ast, r0 + (tid >> 4) + 16, r_end, ra + 4, m1);
-      amask = m0 | (m1 << 4);
+      op.a4(ast, r0 + (tid >> 4), r_end, ra);
+      op.a4(ast, r0 + (tid >> 4) + 16, r_end, ra + 4);
     }
     if constexpr (Op::B_KMAJOR) {
-      op.b8(bst, r0 + (tid & 3) * 8, r_end, rb, bmask);
+      op.b8(bst, r0 + (tid & 3) * 8, r_end, rb);
     } else {
-      unsigned m0, m1;
-      op.b4(r0 + (tid >> 4), r_end, bst, rb, m0);
-      op.b4(r0 + (tid >> 4) + 16, r_end, bst, rb + 4, m1);
-      bmask = m0 | (m1 << 4);
+      op.b4(r0 + (tid >> 4), r_end, bst, rb);
+      op.b4(r0 + (tid >> 4) + 16, r_end, bst, rb + 4);
     }
   };
   auto put = [&](float* xb, bool kmajor, const float* f) {
@@ -671,14 +637,20 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
       *(float4*)(p + 16 * 68) = make_float4(f[4], f[5], f[6], f[7]);
     }
   };
+  // Invalid operand elements (padding taps, rows / columns / reduction indices past the end) were READ as zeros from the
+  // zero page, so the LDS write is a plain conversion: no masks.  B is exactly zero past the end of the reduction, which
+  // covers the (finite) A elements there; rows and columns past M / N are never stored.
+  const bool relu = op.a_relu();
   auto stash = [&](int buf) {
     float fa[8], fb[8];
-    const float lo = op.a_relu() ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = fmaxf(Elem<typename Op::AT>::ld(&ra[q]), lo);
-      fa[q] = ((amask >> q) & 1u) ? v : 0.f;
-      fb[q] = ((bmask >> q) & 1u) ? Elem<typename Op::BT>::ld(&rb[q]) * bscale : 0.f;
+      fa[q] = Elem<typename Op::AT>::ld(&ra[q]);
+      fb[q] = Elem<typename Op::BT>::ld(&rb[q]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fa[q] = fmaxf(fa[q], 0.f);
     }
     put(lds + buf * GG_XBUF, Op::A_KMAJOR, fa);
     put(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, fb);
@@ -736,7 +708,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const long i = i0 + wr * 32 + 8 * (p >> 2) + 4 * hh + (p & 3);
-      if (i < op.M) op.store(i, j, acc[p], zc);
+      if (i < op.M) op.store(i, j, acc[p] * bscale, zc);      // the filter's 1/sigma, applied once per output
     }
   }
 }
@@ -795,6 +767,7 @@ template <typename T>
 static int launch_dgrad_s2_narrow(rcgan_ctx* ctx, DgradS2Op<T>& op, const S2Table& tab, int ncls, long maxM, long maxR) {
   const size_t lds = (size_t)maxR * op.N * sizeof(float);
   dim3 grid(cdiv(maxM, 16), ncls);
+  op.zp = ctx->zero_page;
   if (op.avec == 4) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 4>), grid, dim3(256), lds, ctx->stream, op, tab);
   else if (op.avec == 2) hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 2>), grid, dim3(256), lds, ctx->stream, op, tab);
   else hipLaunchKernelGGL((dgrad_s2_narrow_kernel<T, 1>), grid, dim3(256), lds, ctx->stream, op, tab);
@@ -929,6 +902,7 @@ static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid, const typename Op::
 
 template <class Op>
 static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz, const typename Op::Aux& aux = typename Op::Aux()) {
+  op.zp = ctx->zero_page;
   dim3 grid(cdiv(op.N, 64), cdiv(op.M, 64), nz);
   if (grid.y > 65535u || grid.z > 65535u) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "M too large");
   static const int ks_min_steps = gg_env_int("RCGAN_GG_KS_MINSTEPS", 8);
