@@ -669,12 +669,8 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
   };
   const long nsteps = (r_end - r_begin + 31) / 32;
   const long T = (nsteps + KS - 1) / KS;          // per-group steps (same for every group: the barriers are block-wide)
-  if (T > 0) { fetch(r_begin + 32 * kg); stash(0); }
-  __syncthreads();
-  int buf = 0;
-  for (long t = 0; t < T; ++t) {
-    const bool more = t + 1 < T;
-    if (more) fetch(r_begin + 32 * (kg + KS * (t + 1)));
+  auto step_r = [&](long t) { return r_begin + 32 * (kg + KS * t); };
+  auto mfma_step = [&](int buf) {
     float av[16], bv[16];
     get(lds + buf * GG_XBUF, Op::A_KMAJOR, wr * 32, av);
     get(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, wc * 32, bv);
@@ -683,12 +679,38 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) stash(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+  };
+  // The waves that share a SIMD belong to different K-groups and run the same fetch -> MFMA -> LDS-write cycle; left
+  // in phase they all decode addresses together (matrix core idle) and then queue on the matrix core together (vector
+  // ALU idle).  Odd groups run the cycle rotated by one stage (MFMA first, then write + fetch two steps ahead), so one
+  // half of a SIMD's waves is in its MFMA chain while the other half does the vector work.
+  const bool rotated = KS > 1 && (kg & 1);
+  if (T > 0) { fetch(step_r(0)); stash(0); }
+  if (rotated && T > 1) fetch(step_r(1));
+  __syncthreads();
+  int buf = 0;
+  if (!rotated) {
+    for (long t = 0; t < T; ++t) {
+      const bool more = t + 1 < T;
+      if (more) fetch(step_r(t + 1));
+      mfma_step(buf);
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    for (long t = 0; t < T; ++t) {
+      mfma_step(buf);
+      if (t + 1 < T) stash(buf ^ 1);
+      if (t + 2 < T) fetch(step_r(t + 2));
+      __syncthreads();
+      buf ^= 1;
+    }
   }
   if constexpr (KS > 1) {                          // sum the groups' accumulators: [group-1][wave][reg][lane]
     float* red = gg_smem;
