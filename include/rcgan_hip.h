@@ -54,6 +54,10 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream);
 int rcgan_destroy(rcgan_ctx* ctx);
 const char* rcgan_last_error(rcgan_ctx* ctx);
 const char* rcgan_version(void);
+/* CRC-32C (Castagnoli, reflected 0x82F63B78), host-side, no GPU needed: crc of `n` bytes continuing from `crc`
+ * (pass 0 to start).  The checksum TensorFlow's V2 checkpoint bundles carry per tensor and per table block
+ * (tf.train.Saver at cifar10/gan_resnet.py:906, mnist/model.py:265); used by the bundle reader/writer of the host layer. */
+unsigned rcgan_crc32c(unsigned crc, const void* data, size_t n);
 int rcgan_set_stream(rcgan_ctx* ctx, void* stream);
 /* Fork/join onto the context's second stream: launches between side_begin and side_end run on it, ordered after
  * everything issued before the fork; side_join makes the main stream wait for them.  Used to run a layer's filter

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rcgan_destroy": (I, [P]),
     "rcgan_last_error": (C.c_char_p, [P]),
     "rcgan_version": (C.c_char_p, []),
+    "rcgan_crc32c": (C.c_uint, [C.c_uint, P, SZ]),
     "rcgan_set_stream": (I, [P, P]),
     "rcgan_side_begin": (I, [P]),
     "rcgan_side_end": (I, [P]),

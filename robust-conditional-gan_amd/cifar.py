@@ -538,6 +538,10 @@ class CifarRCGAN:
         for k, v in self.get_state().items():
             out[k] = v
         out["_iteration"] = np.array([self.iteration], np.int64)
+        # AdamOptimizer's own step state, in the reference's creation order: disc_opt, gen_opt, confusion (:802-817)
+        from .host import adam_power_tensors
+        opts = [(self.PD.t, 0.0, 0.9), (self.PG.t, 0.0, 0.9)] + ([(self.PC.t, 0.0, 0.9)] if self.PC is not None else [])
+        out.update(adam_power_tensors(opts))
         return out
 
     def load_state_dict(self, sd):
@@ -551,7 +555,14 @@ class CifarRCGAN:
                     grp.set(n, sd[n + "/Adam_1"], "v")
             key = "_opt/%s/step" % gname
             if key in sd:
-                grp.t = int(sd[key][0])
+                grp.t = int(np.asarray(sd[key]).reshape(-1)[0])
+            else:                        # a bundle written by TensorFlow: recover the step from beta2_power
+                from .host import steps_from_beta_power
+                sfx = {"Discriminator": "", "Generator": "_1", "confusion": "_2"}[gname]
+                if "beta2_power" + sfx in sd:
+                    grp.t = steps_from_beta_power(float(np.asarray(sd["beta2_power" + sfx])), 0.9)
+        if "_iteration" in sd:
+            self.iteration = int(np.asarray(sd["_iteration"]).reshape(-1)[0])
         ctx = self.ctx
         for k, t in self.state.items():
             if k in sd:

@@ -118,6 +118,34 @@ int rcgan_destroy(rcgan_ctx* ctx) {
 
 const char* rcgan_last_error(rcgan_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// CRC-32C, slice-by-8 tables built on first use (host only)
+unsigned rcgan_crc32c(unsigned crc, const void* data, size_t n) {
+  static uint32_t tab[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xff];
+    ready = true;
+  }
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = tab[7][lo & 0xff] ^ tab[6][(lo >> 8) & 0xff] ^ tab[5][(lo >> 16) & 0xff] ^ tab[4][lo >> 24] ^
+        tab[3][hi & 0xff] ^ tab[2][(hi >> 8) & 0xff] ^ tab[1][(hi >> 16) & 0xff] ^ tab[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) c = (c >> 8) ^ tab[0][(c ^ *p++) & 0xff];
+  return ~c;
+}
+
 int rcgan_set_stream(rcgan_ctx* ctx, void* stream) {
   RC_REQUIRE(ctx, !ctx->on_side, "set_stream inside a side section");
   ctx->stream = ctx->main_stream = (hipStream_t)stream;

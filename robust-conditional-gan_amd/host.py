@@ -143,24 +143,50 @@ def record_setting(out, src_dir=None):
 
 
 # ------------------------------------------------------------------------------------------------------
-# checkpoints: <dir>/<prefix>-<step>.npz + a TF-style `checkpoint` index file, max_to_keep newest kept.
-# Tensor names are the TF variable names plus Adam slots "<var>/Adam", "<var>/Adam_1"
-# and "<group>/beta_step".  (Genuine TF-bundle bytes are a "next" item, SURVEY 8f #2.)
+# checkpoints: TensorFlow V2 bundles <dir>/<prefix>-<step>.index + .data-00000-of-00001 (tf_bundle.py) + the
+# CheckpointState text file `checkpoint`, max_to_keep newest kept -- what tf.train.Saver writes in the reference
+# (cifar10/gan_resnet.py:906-925, mnist/model.py:398-425).  Tensor names are the TF variable names
+# plus the Adam slots "<var>/Adam", "<var>/Adam_1" and the optimisers' "beta1_power" / "beta2_power" scalars
+# (suffixes _1, _2 in optimiser creation order); "_opt/<group>/step" and "_iteration" are this engine's own exact
+# integer counters (TensorFlow ignores names it does not ask for).  ".npz" files of earlier runs still load.
 # ------------------------------------------------------------------------------------------------------
+def adam_power_tensors(optimisers):
+    """optimisers: [(steps taken, beta1, beta2)] in the reference's AdamOptimizer creation order ->
+    {"beta1_power": beta1**(t+1), "beta2_power": ..., "beta1_power_1": ...}: the non-slot variables AdamOptimizer keeps
+    (initialised to beta, multiplied by beta after every apply_gradients)."""
+    out = {}
+    for i, (t, b1, b2) in enumerate(optimisers):
+        sfx = "" if i == 0 else "_%d" % i
+        out["beta1_power" + sfx] = np.float32(float(b1) ** (t + 1))
+        out["beta2_power" + sfx] = np.float32(float(b2) ** (t + 1))
+    return out
+
+
+def steps_from_beta_power(power, beta):
+    """Inverse of adam_power_tensors for one optimiser (a checkpoint written by TensorFlow has no integer counter)."""
+    if not 0.0 < beta < 1.0 or not power > 0.0:
+        return 0
+    return max(int(round(np.log(float(power)) / np.log(float(beta)))) - 1, 0)
+
+
 class Saver:
     def __init__(self, max_to_keep=5):
         self.max_to_keep = max_to_keep
         self.kept = []
 
     def save(self, tensors, directory, prefix, global_step):
+        from . import tf_bundle
         os.makedirs(directory, exist_ok=True)
         path = os.path.join(directory, "%s-%d" % (prefix, global_step))
-        np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in tensors.items()})
+        tf_bundle.write_bundle(path, tensors)
+        if path in self.kept:
+            self.kept.remove(path)
         self.kept.append(path)
         while len(self.kept) > self.max_to_keep:
             old = self.kept.pop(0)
-            if os.path.exists(old + ".npz"):
-                os.remove(old + ".npz")
+            for ext in (".index", ".data-00000-of-00001", ".npz"):
+                if os.path.exists(old + ext):
+                    os.remove(old + ext)
         with open(os.path.join(directory, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
             for p in self.kept:
@@ -169,6 +195,7 @@ class Saver:
 
 
 def latest_checkpoint(directory):
+    from . import tf_bundle
     idx = os.path.join(directory, "checkpoint")
     if not os.path.exists(idx):
         return None
@@ -176,11 +203,14 @@ def latest_checkpoint(directory):
         for line in f:
             if line.startswith("model_checkpoint_path:"):
                 name = line.split(":", 1)[1].strip().strip('"')
-                p = os.path.join(directory, name)
-                return p if os.path.exists(p + ".npz") else None
+                p = name if os.path.isabs(name) else os.path.join(directory, name)
+                return p if tf_bundle.exists(p) or os.path.exists(p + ".npz") else None
     return None
 
 
 def load_checkpoint(path):
+    from . import tf_bundle
+    if tf_bundle.exists(path):
+        return tf_bundle.read_bundle(path)
     with np.load(path + ".npz") as z:
         return {k.replace("|", "/"): z[k] for k in z.files}

@@ -456,6 +456,12 @@ class MnistRCGAN:
                 sd[n + "/Adam_1"] = grp.get(n, "v")
             sd["_opt/%s/step" % gname] = np.array([grp.t], np.int64)
         sd.update(self.get_state())
+        # AdamOptimizer's own step state, in the reference's creation order: d_optim, g_optim, c_optim (model.py:250-262)
+        from .host import adam_power_tensors
+        opts = [(self.PD.t, self.beta1, 0.999), (self.PG.t, self.beta1, 0.999)]
+        if getattr(self, "PC", None) is not None:
+            opts.append((self.PC.t, self.beta1, 0.999))
+        sd.update(adam_power_tensors(opts))
         return sd
 
     def load_state_dict(self, sd):
@@ -469,7 +475,12 @@ class MnistRCGAN:
                     grp.set(n, sd[n + "/Adam_1"], "v")
             key = "_opt/%s/step" % gname
             if key in sd:
-                grp.t = int(sd[key][0])
+                grp.t = int(np.asarray(sd[key]).reshape(-1)[0])
+            else:                        # a bundle written by TensorFlow: recover the step from beta2_power
+                from .host import steps_from_beta_power
+                sfx = {"discriminator": "", "generator": "_1", "confusion": "_2"}[gname]
+                if "beta2_power" + sfx in sd:
+                    grp.t = steps_from_beta_power(float(np.asarray(sd["beta2_power" + sfx])), 0.999)
         ctx = self.ctx
         with torch.cuda.stream(ctx.stream):
             for k, t in self.state.items():

@@ -5,7 +5,7 @@
       script/{*.py, <script_file>, command.txt}        utils.dump_script
       samples/train_EE_IIII.png                        10x10 grid every 700 updates (fixed z, 10 per class)
       samples/samples_<epoch>.npy                      100 x [100,28,28,1] every 5th epoch (previous one removed)
-      mnist_<batch>_28_28/DCGAN.model-<step>.npz       every 700 updates (+ TF-style `checkpoint` index)
+      mnist_<batch>_28_28/DCGAN.model-<step>.{index,data-00000-of-00001}   every 700 updates (TF V2 bundle + `checkpoint`)
 
 Per batch: one D update, two G (+ confusion-matrix) updates on the same z (model.py:347-372).  Deviations, all
 logging-only: the console metrics are evaluated only for the lines that are printed; the generated-label accuracy
