@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_CRITIC = 5
-PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 (= fp16) MFMA peak, MI355X_MICROARCH.md
 POOL = 8                      # synthetic batches resident on the device
 
 
@@ -87,7 +87,7 @@ def iteration(m, pool, it, dcount):
         m.d_step(iteration=it)
 
 
-def kernel_roofline(m, pool):
+def kernel_roofline(m, pool, default_workload=True):
     """One eager (un-captured) iteration with every conv_mfma_p8_kernel launch (the dominant kernel: forward and data
     gradient of the 256-channel 3x3 / 1x1 convolutions, 256 x 256 tiles) bracketed by HIP events on the launch stream."""
     from rcgan_amd import _lib as L
@@ -106,7 +106,7 @@ def kernel_roofline(m, pool):
     # WRITE_SIZE cannot share a pass; corrections as MI355X_MICROARCH.md prescribes) and committed with the profile
     traffic = None
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv_p8.json")
-    if os.path.exists(tf):
+    if default_workload and os.path.exists(tf):          # the counters were collected on the default workload only
         with open(tf) as f:
             traffic = float(json.load(f)["traffic_bytes_per_launch"])
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    default_wl = args.batch == 64 and args.dtype == "bf16" and args.algorithm == "rcgan"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,12 +219,12 @@ def main():
                           "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
                           "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
                           "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}
-        out["roofline"] = kernel_roofline(m, pool) if args.dtype == "bf16" else None
+        out["roofline"] = kernel_roofline(m, pool, default_wl) if args.dtype in ("bf16", "f16") else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alpha)
     else:
-        if args.dtype == "bf16":
-            kernel_roofline(m, pool)      # keep ranks in lock-step through the extra (all-reducing) iteration
+        if args.dtype in ("bf16", "f16"):
+            kernel_roofline(m, pool, default_wl)      # keep ranks in lock-step through the extra (all-reducing) iteration
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

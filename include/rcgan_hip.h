@@ -37,6 +37,7 @@ extern "C" {
 
 #define RCGAN_F32 0
 #define RCGAN_BF16 1
+#define RCGAN_F16 2   /* IEEE half: only in the fp16 build of the library (librcgan_hip_f16.so), which has no bf16 */
 
 /* activation codes shared by several entry points */
 #define RCGAN_ACT_NONE 0
@@ -54,6 +55,10 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream);
 int rcgan_destroy(rcgan_ctx* ctx);
 const char* rcgan_last_error(rcgan_ctx* ctx);
 const char* rcgan_version(void);
+/* The 16-bit activation dtype this build of the library computes in: RCGAN_BF16 (librcgan_hip.so) or RCGAN_F16
+ * (librcgan_hip_f16.so, the same sources compiled with -DRCGAN_HALF_FP16=1: v_mfma_f32_16x16x32_f16, v_cvt_f16_f32).
+ * The other 16-bit dtype is rejected with RCGAN_EINVALID_ARG.  (The reference computes in fp32; BASELINE configs 3 / 5.) */
+int rcgan_half_dtype(void);
 /* CRC-32C (Castagnoli, reflected 0x82F63B78), host-side, no GPU needed: crc of `n` bytes continuing from `crc`
  * (pass 0 to start).  The checksum TensorFlow's V2 checkpoint bundles carry per tensor and per table block
  * (tf.train.Saver at cifar10/gan_resnet.py:906, mnist/model.py:265); used by the bundle reader/writer of the host layer. */
@@ -96,7 +101,7 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
 typedef struct rcgan_conv_desc {
   int n, h, w, cin;   /* logical conv input: after the 2x upsample when IN_UPSAMPLE2X is set */
   int cout, kh, kw, stride;
-  int dtype;          /* RCGAN_F32 / RCGAN_BF16: activations and activation gradients */
+  int dtype;          /* RCGAN_F32 or the build's 16-bit dtype (rcgan_half_dtype()): activations and activation gradients */
   int flags;
 } rcgan_conv_desc;
 

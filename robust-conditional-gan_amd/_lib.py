@@ -8,8 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCGAN_LIB_PATH") or os.path.join(_HERE, "librcgan_hip.so")   # override: kernel probes only
+# the same sources built with -DRCGAN_HALF_FP16=1: its 16-bit activation dtype is IEEE half instead of bf16
+LIB_PATH_F16 = os.environ.get("RCGAN_LIB_PATH_F16") or os.path.join(_HERE, "librcgan_hip_f16.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_IN_UPSAMPLE2X, CONV_IN_RELU, CONV_ACCUMULATE, CONV_FORCE_DIRECT = 1, 2, 4, 8
 LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_CE_ONES, LOSS_CE_ZEROS = 0, 1, 2, 3, 4
@@ -54,6 +56,7 @@ SIGNATURES = {
     "rcgan_destroy": (I, [P]),
     "rcgan_last_error": (C.c_char_p, [P]),
     "rcgan_version": (C.c_char_p, []),
+    "rcgan_half_dtype": (I, []),
     "rcgan_crc32c": (C.c_uint, [C.c_uint, P, SZ]),
     "rcgan_set_stream": (I, [P, P]),
     "rcgan_side_begin": (I, [P]),
@@ -125,25 +128,29 @@ SIGNATURES = {
     "rcgan_query": (I, [P, I]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the shared library (once).  Loading needs no GPU; compute calls do."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(half="bf16"):
+    """Load the shared library (once per 16-bit format).  Loading needs no GPU; compute calls do.
+    ``half``: "bf16" (librcgan_hip.so, also serves fp32) or "f16" (librcgan_hip_f16.so)."""
+    if half in _libs:
+        return _libs[half]
+    path = LIB_PATH_F16 if half == "f16" else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            "librcgan_hip.so is missing (%s): build it with robust-conditional-gan_amd/csrc/build.sh "
-            "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+            "%s is missing (%s): build it with robust-conditional-gan_amd/csrc/build.sh "
+            "or __graft_entry__.build(); there is no CPU fallback" % (os.path.basename(path), path))
     # torch first: it bundles its own libamdhip64.so.7 and librcgan_hip.so must bind to the SAME HIP
     # runtime (one SONAME, first loader wins); two runtimes in a process cannot share streams or pointers
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    want = F16 if half == "f16" else BF16
+    if lib.rcgan_half_dtype() != want:
+        raise RuntimeError("%s was built for 16-bit dtype %d, expected %d" % (path, lib.rcgan_half_dtype(), want))
+    _libs[half] = lib
     return lib

@@ -237,7 +237,7 @@ class CifarRCGAN:
                  perm_classifier=False, perm_multiplier=1.0, perm_type="linear",
                  confuse_init=False, confuse_init_diag=0.2, confuse_multiplier=1.0, confuse_lr_decay=False,
                  device=0, use_graphs=True, device_rng=True, arena_bytes=None, world_size=1, rank=0,
-                 variables=None):
+                 variables=None, loss_scale=None):
         if algorithm not in ALGORITHMS:
             raise ValueError("Unknown algorithm %s" % algorithm)
         self.alg, self.alpha, self.B, self.lr = algorithm, alpha, int(batch_size), lr
@@ -249,6 +249,10 @@ class CifarRCGAN:
             arena_bytes = int(2.5e6 * 4 * self.B * 2) + (1 << 30)      # ~20 MB/sample fp32-equivalent + slack
         self.ctx = Context(device, dtype, arena_bytes=arena_bytes)
         ctx = self.ctx
+        # Static loss scaling for fp16 activations (5 exponent bits: activation gradients of ~1e-5 and below would go
+        # subnormal): every loss term -- hence every activation and filter gradient -- is multiplied by a power of two,
+        # the fp32 filter gradients are divided by it inside the Adam kernel (grad_scale).  1 for bf16 / fp32.
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if ctx.act_dtype == L.F16 else 1.0)
         if variables is None:
             variables = create_variables(seed, algorithm, perm_classifier, perm_type, confuse_init, confuse_init_diag)
         gs, ds, cs, U = variables
@@ -388,7 +392,7 @@ class CifarRCGAN:
             real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
         ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
         fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)                 # :540-546
-        w = 1.0
+        w = self.loss_scale
         if self.alg == "rcgan-u":
             feat, wgan = Discriminator(real, inp["labels"], update_collection=None)
             emb = Discriminator_projection(inp["labels"], update_collection=None)
@@ -417,7 +421,7 @@ class CifarRCGAN:
                 O.loss_term(ctx, L.LOSS_HINGE_FAKE, disc_fake, w, self.loss_d)           # :639,648
         if self.perm:
             logits = perm_classifier(real, self.perm_type)                               # :692
-            O.bce_onehot_term(ctx, logits, inp["labels"], 1.0, self.loss_d)              # :693-695
+            O.bce_onehot_term(ctx, logits, inp["labels"], self.loss_scale, self.loss_d)              # :693-695
         ctx.backward()
 
     # ---------------------------------------------------------------------------------- G step
@@ -443,14 +447,14 @@ class CifarRCGAN:
             E = Discriminator_projection(inp["arange"], update_collection=None)                      # :736
             disc_fake = O.proj_logit_all(ctx, feat, wgan, E)
             y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random_G"], n)          # :757-758
-            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g, wts=y_conf)               # :751,759
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, self.loss_scale, self.loss_g, wts=y_conf)               # :751,759
         else:
             emb = Discriminator_projection(lab, update_collection=None)                              # :725,731
             disc_fake = O.proj_logit(ctx, feat, wgan, emb)                                           # :763
-            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g)                           # :773
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, self.loss_scale, self.loss_g)                        # :773
         if self.perm:
             logits = perm_classifier(fake, self.perm_type)                                           # :781
-            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult, self.loss_g)      # :782-784
+            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult * self.loss_scale, self.loss_g)      # :782-784
         ctx.backward()
 
     # ---------------------------------------------------------------------------------- stepping
@@ -484,7 +488,7 @@ class CifarRCGAN:
         self._allreduce(self.PD)
         self.PD.t += 1
         self.PD.set_hyper(self.lr * lr_decay(it), self.PD.t)
-        self.PD.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+        self.PD.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
 
     def g_step(self, iteration=None):
         """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op
@@ -495,19 +499,19 @@ class CifarRCGAN:
         self._allreduce(self.PG)
         self.PG.t += 1
         self.PG.set_hyper(self.lr * lr_decay(it), self.PG.t)
-        self.PG.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+        self.PG.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
         self._refresh_generator_filters()
         if self.PC is not None:
             self._allreduce(self.PC)
             self.PC.t += 1
             clr = self.lr * self.confuse_multiplier * (lr_decay(it) if self.confuse_lr_decay else 1.0)
             self.PC.set_hyper(clr, self.PC.t)
-            self.PC.adam(0.0, 0.9, grad_scale=1.0 / self.world)
+            self.PC.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
 
     def losses(self):
         ctx = self.ctx
-        d = float(ctx.download(self.loss_d)[0])
-        g = float(ctx.download(self.loss_g)[0])
+        d = float(ctx.download(self.loss_d)[0]) / self.loss_scale
+        g = float(ctx.download(self.loss_g)[0]) / self.loss_scale
         return d, g
 
     # ---------------------------------------------------------------------------------- inspection
@@ -519,7 +523,8 @@ class CifarRCGAN:
         return out
 
     def get_grads(self, group):
-        return {n: group.get(n, "grad") for n in group.names}
+        """Gradients of the last step (the loss scale of the fp16 build divided out; a power of two, exact)."""
+        return {n: group.get(n, "grad") / np.float32(self.loss_scale) for n in group.names}
 
     def get_state(self):
         return {k: self.ctx.download(v).reshape(1, -1) for k, v in self.state.items()}

@@ -70,7 +70,7 @@ static int ensure_selftest(rcgan_ctx* ctx) {
 
 extern "C" {
 
-const char* rcgan_version(void) { return "rcgan_hip 0.1 (gfx950)"; }
+const char* rcgan_version(void) { return RCGAN_HALF_FP16 ? "rcgan_hip 0.1 (gfx950, fp16 build)" : "rcgan_hip 0.1 (gfx950, bf16 build)"; }
 
 int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   if (!out) return RCGAN_EINVALID_ARG;
@@ -117,6 +117,7 @@ int rcgan_destroy(rcgan_ctx* ctx) {
 }
 
 const char* rcgan_last_error(rcgan_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int rcgan_half_dtype(void) { return RCGAN_H16; }
 
 // CRC-32C, slice-by-8 tables built on first use (host only)
 unsigned rcgan_crc32c(unsigned crc, const void* data, size_t n) {
@@ -278,7 +279,7 @@ static int check_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d) {
   RC_REQUIRE(ctx, d != nullptr, "null desc");
   RC_REQUIRE(ctx, d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad dims");
   RC_REQUIRE(ctx, d->kh > 0 && d->kw > 0 && d->stride > 0, "bad kernel/stride");
-  RC_REQUIRE(ctx, d->dtype == RCGAN_F32 || d->dtype == RCGAN_BF16, "bad dtype");
+  RC_REQUIRE(ctx, d->dtype == RCGAN_F32 || d->dtype == RCGAN_H16, "bad dtype");
   if (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) RC_REQUIRE(ctx, d->h % 2 == 0 && d->w % 2 == 0, "upsampled size must be even");
   return RCGAN_OK;
 }
@@ -524,7 +525,7 @@ int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
 // ------------------------------------------------------------------------------------------------
 static int check_lin(rcgan_ctx* ctx, int m, int k, int n, int dtype) {
   RC_REQUIRE(ctx, m > 0 && k > 0 && n > 0, "bad linear shape [%d,%d]x[%d,%d]", m, k, k, n);
-  RC_REQUIRE(ctx, dtype == RCGAN_F32 || dtype == RCGAN_BF16, "bad dtype %d", dtype);
+  RC_REQUIRE(ctx, dtype == RCGAN_F32 || dtype == RCGAN_H16, "bad dtype %d", dtype);
   return RCGAN_OK;
 }
 

@@ -82,10 +82,20 @@ struct ProfScope {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// bf16 storage helpers (round-to-nearest-even, as v_cvt_pk_bf16_f32 does)
+// 16-bit storage helpers.  One source tree, two builds: bf16 (default) or IEEE fp16 (-DRCGAN_HALF_FP16=1).  Every
+// kernel goes through these two conversions, the MFMA wrapper and the constants in mfma_util.h, so the format is a
+// compile-time property of the library; the type keeps its historical name.  Both round to nearest even.
 // ---------------------------------------------------------------------------------------------
+#ifndef RCGAN_HALF_FP16
+#define RCGAN_HALF_FP16 0
+#endif
+#define RCGAN_H16 (RCGAN_HALF_FP16 ? RCGAN_F16 : RCGAN_BF16)
 typedef uint16_t bf16_t;
 
+#if RCGAN_HALF_FP16
+__host__ __device__ inline float bf16_to_f32(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__host__ __device__ inline bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }   // v_cvt_f16_f32
+#else
 __host__ __device__ inline float bf16_to_f32(bf16_t h) {
   uint32_t u = ((uint32_t)h) << 16;
   float f;
@@ -108,6 +118,7 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 #endif
 }
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -119,13 +130,13 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-static inline size_t dtype_size(int dtype) { return dtype == RCGAN_BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dtype) { return dtype == RCGAN_H16 ? 2 : 4; }
 
 // dispatch a templated launcher over the activation dtype
 #define RC_DISPATCH_DTYPE(ctx, dtype, ...)                              \
   do {                                                                  \
     if ((dtype) == RCGAN_F32) { typedef float T; __VA_ARGS__; }         \
-    else if ((dtype) == RCGAN_BF16) { typedef bf16_t T; __VA_ARGS__; }  \
+    else if ((dtype) == RCGAN_H16) { typedef bf16_t T; __VA_ARGS__; }   \
     else RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtype %d", (int)(dtype)); \
   } while (0)
 

@@ -16,7 +16,7 @@
 // eligibility + prepared-filter layouts
 // ---------------------------------------------------------------------------------------------------------
 int img_side(const rcgan_conv_desc* d) {
-  if (d->dtype != RCGAN_BF16 || d->stride != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3)) return 0;
+  if (d->dtype != RCGAN_H16 || d->stride != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3)) return 0;
   if (d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_FORCE_DIRECT)) return 0;
   const int lw = ilog2_exact(d->w), lh = ilog2_exact(d->h);
   if (lw < 3 || lw > 5 || lh < 0 || d->h * d->w < 256) return 0;      // W in {8,16,32}; whole 256-pixel bands
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void conv_img_small_red_kernel(ImgKArgs a) {
 #pragma unroll
       for (int q = 0; q < NF / 2; ++q) {
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * q], xf, z, 0, 0, 0);
-        const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * q + 1], xf, z, 0, 0, 0);
+        const f32x4_t lo = mfma16(wf[2 * q], xf, z);
+        const f32x4_t hi = mfma16(wf[2 * q + 1], xf, z);
         float o[8] = {lo[0] + bv[q][0], lo[1] + bv[q][1], lo[2] + bv[q][2], lo[3] + bv[q][3],
                       hi[0] + bv[q][4], hi[1] + bv[q][5], hi[2] + bv[q][6], hi[3] + bv[q][7]};
         uint4* dst = (uint4*)(orow + q * 32);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
           const int tr = tr0[f] + dtr;
           uint4 v = *(const uint4*)(xs + tr * 128 + ((kc ^ (tr & 7)) << 4));
           v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
-          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, v), acc[f], 0, 0, 0);
+          acc[f] = mfma16(wf, __builtin_bit_cast(bf16x8_t, v), acc[f]);
         }
       }
     }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const long m = m0 + pg * (PB / 8) + j * 8 + e;
-        v[e] = ones ? (m < a.g.M ? 0x3F80u : 0u) : col_load(a.g, m, dh, dw, c);
+        v[e] = ones ? (m < a.g.M ? H16_ONE : 0u) : col_load(a.g, m, dh, dw, c);
       }
       *(uint4*)(cols + k * CPITCH + (pg * (PB / 8) + j * 8) * 2) =
           make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
   const unsigned char* bh = bigs + (chw / 128) * PB * 256;
   const int slotw = (chw % 128) / 8;
   const uint32_t relu_lb = a.relu_big ? 0u : 0x80008000u;
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(H16_ONE_X2, H16_ONE_X2, H16_ONE_X2, H16_ONE_X2));
   f32x4_t acc[NFW][2], accs[2];
 #pragma unroll
   for (int i = 0; i < NFW; ++i) { acc[i][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
       cf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
     }
     if (wave == 0) {
-      accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, cf[0], accs[0], 0, 0, 0);
-      accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, cf[1], accs[1], 0, 0, 0);
+      accs[0] = mfma16(ones, cf[0], accs[0]);
+      accs[1] = mfma16(ones, cf[1], accs[1]);
     }
 #pragma unroll
     for (int i = 0; i < NFW; ++i) {
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
       uint4 v = __builtin_bit_cast(uint4, tr_pair(p, 16 * 256));
       v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
       const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, v);
-      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, cf[0], acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, cf[1], acc[i][1], 0, 0, 0);
+      acc[i][0] = mfma16(bf, cf[0], acc[i][0]);
+      acc[i][1] = mfma16(bf, cf[1], acc[i][1]);
     }
   }
   // D[row = channel (4*g4 + r)][col = im2col column li (+16 j)]

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
     }
     if (kt + 1 < KT) store_tile(buf ^ 1);
     __syncthreads();
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
       }
     }
     if (++buf == NS) buf = 0;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgradArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16(yf[i], xf[j], acc[i][j]);
     }
     if (t + 1 < ntile) store_tile(buf ^ 1);
     __syncthreads();
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const bool do_bias = a.want_bias && tap == 0 && cit == 0 && wi == 0;     // see conv_mfma_wgrad3_kernel
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(H16_ONE_X2, H16_ONE_X2, H16_ONE_X2, H16_ONE_X2));
   f32x4_t accb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -639,13 +639,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
     for (int j = 0; j < 4; ++j) xf[j] = frag_tr_swz(Xb, 0, wi * 8 + j * 2, lane, a.use_tr, a.relu_in);
     if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) accb[i] = mfma16(yf[i], ones, accb[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16(yf[i], xf[j], acc[i][j]);
     if (++buf == NS) buf = 0;
   }
   float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
@@ -708,7 +708,7 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
     const int slot0 = wave * 4 + i * 2;
     offy[i] = row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
   }
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(H16_ONE_X2, H16_ONE_X2, H16_ONE_X2, H16_ONE_X2));
   f32x4_t accb[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
   const int KT = (int)((me - mb + 31) / 32);
 #pragma unroll
@@ -725,7 +725,7 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
         const unsigned char* sb = smem + sidx * YT;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(sb + offy[i], 16 * 256), ones, accb[i], 0, 0, 0);
+          accb[i] = mfma16(tr_pair(sb + offy[i], 16 * 256), ones, accb[i]);
       }
     }
   }
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[t][i][j], 0, 0, 0);
+              acc[t][i][j] = mfma16(yf[i], xf[j], acc[t][i][j]);
         }
       }
     }
@@ -996,7 +996,7 @@ __global__ void conv_prepare_direct_kernel(const float* w, const float* sigma, f
 // host side
 // ---------------------------------------------------------------------------------------------
 bool mfma_eligible(const rcgan_conv_desc* d) {
-  if (d->dtype != RCGAN_BF16) return false;
+  if (d->dtype != RCGAN_H16) return false;
   if (d->flags & RCGAN_CONV_FORCE_DIRECT) return false;
   if (d->stride != 1) return false;
   if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return false;
@@ -1207,7 +1207,7 @@ __global__ void selftest_kernel(int* result /* [0]=mfma mismatches, [1]=tr misma
   bf16x8_t af = *(const bf16x8_t*)(A + (lane & 15) * 32 + (lane >> 4) * 8);
   bf16x8_t bf = *(const bf16x8_t*)(B + (lane & 15) * 32 + (lane >> 4) * 8);
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+  acc = mfma16(af, bf, acc);
   int bad = 0;
   for (int r = 0; r < 4; ++r) {
     int row = (lane >> 4) * 4 + r, col = lane & 15;

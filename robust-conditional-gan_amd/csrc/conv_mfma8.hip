@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
-          acc[ch * 2 + g][ph * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f], 0, 0, 0);
+          acc[ch * 2 + g][ph * 4 + f] = mfma16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f]);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
-          acc[g][ph * 2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][g], xf[ks][f], acc[g][ph * 2 + f], 0, 0, 0);
+          acc[g][ph * 2 + f] = mfma16(wf[ks][g], xf[ks][f], acc[g][ph * 2 + f]);
     __builtin_amdgcn_s_setprio(0);
   };
 

@@ -336,10 +336,10 @@ int rcgan_axpby(rcgan_ctx* ctx, size_t count, int dtype, float alpha, const void
 
 int rcgan_cast(rcgan_ctx* ctx, size_t count, int sd, const void* s, int dd, void* d) {
   dim3 g(ew_grid(count)), b(EW_BLOCK);
-  if (sd == RCGAN_F32 && dd == RCGAN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, ctx->stream, count, (const float*)s, (bf16_t*)d);
-  else if (sd == RCGAN_BF16 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (float*)d);
+  if (sd == RCGAN_F32 && dd == RCGAN_H16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, ctx->stream, count, (const float*)s, (bf16_t*)d);
+  else if (sd == RCGAN_H16 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (float*)d);
   else if (sd == RCGAN_F32 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, ctx->stream, count, (const float*)s, (float*)d);
-  else if (sd == RCGAN_BF16 && dd == RCGAN_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (bf16_t*)d);
+  else if (sd == RCGAN_H16 && dd == RCGAN_H16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (bf16_t*)d);
   else RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtypes %d %d", sd, dd);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;

@@ -3,10 +3,26 @@
 #pragma once
 #include "common.h"
 
+#if RCGAN_HALF_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;      // (historical name: eight 16-bit operand elements)
+#define H16_ONE 0x3C00u                                             /* 1.0 */
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define H16_ONE 0x3F80u
+#endif
+#define H16_ONE_X2 (H16_ONE | (H16_ONE << 16))
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+// D = A(16x32) * B(32x16) + C on the matrix cores in the build's 16-bit format, fp32 accumulate
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+#if RCGAN_HALF_FP16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 
 // packed signed-16 max on bf16 bit patterns (v_pk_max_i16): with bound 0 this is ReLU (every negative bf16,

@@ -106,7 +106,10 @@ class Context:
     def __init__(self, device=0, dtype="bf16", arena_bytes=6 << 30, ws_bytes=1 << 30):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the RCGAN engine has no CPU fallback")
-        self.lib = L.load()
+        if dtype in ("f16", "fp16", L.F16):
+            self.act_dtype, self.lib = L.F16, L.load("f16")       # the fp16 build of the same kernels
+        else:
+            self.act_dtype, self.lib = (L.BF16 if dtype in ("bf16", L.BF16) else L.F32), L.load()
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
@@ -115,7 +118,6 @@ class Context:
         if rc != 0:
             raise L.RcganError(rc, "rcgan_create failed")
         self.h = h
-        self.act_dtype = L.BF16 if dtype in ("bf16", L.BF16) else L.F32
         self.arena = Arena(arena_bytes, self.device)
         self.ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device)
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), int(ws_bytes)
@@ -152,7 +154,7 @@ class Context:
 
     def persistent(self, shape, dtype=L.F32, fill=None):
         """A buffer outside the arena (survives arena resets)."""
-        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, "i32": torch.int32}[dtype]
+        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16, "i32": torch.int32}[dtype]
         t = torch.empty(tuple(int(s) for s in shape) or (1,), dtype=tdt, device=self.device)
         if fill is not None:
             with torch.cuda.stream(self.stream):
@@ -162,7 +164,7 @@ class Context:
 
     def view(self, t):
         """torch tensor aliasing a DT (for uploads, downloads and RCCL)."""
-        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, "i32": torch.int32}[t.dtype]
+        tdt = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16, "i32": torch.int32}[t.dtype]
         if isinstance(t.base, torch.Tensor):
             base = t.base
             off = t.ptr - base.data_ptr()

@@ -48,7 +48,7 @@ def define_flags():
     f.DEFINE_boolean("perm_gen_label_acc", False, "min. over label permutations of the generated label accuracy")
     f.DEFINE_string("log_level", 'info', "logging level [info, debug]")
     # this build's additions (absent flags keep the reference behaviour)
-    f.DEFINE_string("dtype", 'bf16', "activation dtype [bf16, f32]")
+    f.DEFINE_string("dtype", 'bf16', "activation dtype [bf16, f16 (static loss scale 1024), f32]")
     f.DEFINE_boolean("synthetic", False, "train on the SURVEY 8(d) synthetic data instead of ../data/cifar10")
     f.DEFINE_integer("seed", 0, "variable-initialisation seed")
     f.DEFINE_string("data_dir", DATA_DIR, "CIFAR-10 python batches")

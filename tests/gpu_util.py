@@ -7,6 +7,18 @@ def bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32))).bfloat16().float().numpy()
 
 
+def f16_round(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+HALF = ("bf16", "f16")
+
+
+def half_round(mode, a):
+    """Round to the 16-bit activation format of ``mode`` (identity for f32)."""
+    return bf16_round(a) if mode == "bf16" else (f16_round(a) if mode == "f16" else np.asarray(a, np.float32))
+
+
 def rel_err(a, ref):
     a = np.asarray(a, np.float64)
     ref = np.asarray(ref, np.float64)

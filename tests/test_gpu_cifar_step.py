@@ -61,7 +61,8 @@ def _check(m, P, Uo, alg, perm, raw, gb, C, tol_kind):
     conditioned -- and the HIP fp32 path lands at the same distance, see tests/tools/debug_gstep.py.)"""
     from rcgan_amd import _lib as L
     cfg = dict(algorithm=alg, C=C, perm_classifier=perm, perm_multiplier=1.0)
-    bf16 = m.ctx.act_dtype == L.BF16
+    bf16 = m.ctx.act_dtype in (L.BF16, L.F16)      # 16-bit activations (the fp16 build scales its losses: losses() and
+                                                    # get_grads() report unscaled values)
 
     def cmp_all(tag, got, grads, bf16_tol):
         gmax = max(float(np.abs(g).max()) for g in grads.values())
@@ -162,6 +163,22 @@ def test_step_parity_bf16(alg, perm):
     m_init = {k: v.copy() for k, v in P.items()}
     try:
         _check(m, P, Uo, alg, perm, raw, gb, C, "bf16")
+    finally:
+        m.ctx.close()
+
+
+def test_step_parity_f16():
+    """The fp16 build of the library (BASELINE config 5: v_mfma_f32_16x16x32_f16, static loss scale 1024) against the
+    same float64 oracle step, at the bf16 tolerances (fp16 keeps three more significand bits)."""
+    global m_init
+    rs = np.random.RandomState(22)
+    B = B_CUR
+    C, raw, gb = _batches(rs, B)
+    m, P, Uo = _make("rcgan", False, B, "f16")
+    assert m.loss_scale == 1024.0
+    m_init = {k: v.copy() for k, v in P.items()}
+    try:
+        _check(m, P, Uo, "rcgan", False, raw, gb, C, "bf16")
     finally:
         m.ctx.close()
 

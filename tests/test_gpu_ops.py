@@ -8,14 +8,14 @@ import pytest
 import torch
 
 from oracle import nn
-from tests.gpu_util import FakeParam, assert_close, bf16_round, make_ctx
+from tests.gpu_util import HALF, FakeParam, assert_close, half_round, make_ctx
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 2e-5, "bf16": 1e-2}
+TOL = {"f32": 2e-5, "bf16": 1e-2, "f16": 3e-3}     # fp16: 11 significand bits, half-ulp 2^-12 = 0.02 %
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16"])
+@pytest.fixture(scope="module", params=["f32", "bf16", "f16"])
 def dev(request):
     ctx = make_ctx(request.param)
     yield ctx, request.param
@@ -23,7 +23,7 @@ def dev(request):
 
 
 def _prep(a, mode):
-    return bf16_round(a) if mode == "bf16" else np.asarray(a, np.float32)
+    return half_round(mode, a)
 
 
 def test_selftest_layouts(dev):
@@ -83,9 +83,9 @@ def test_conv2d_fwd_bwd(dev, case):
     W = O.Weight(ctx, wp.t, sg)
     y = O.conv2d(ctx, xd, W, bp.t, k, s, in_up=up, in_relu=relu)
     # oracle: same bf16-rounded filter the MFMA path uses (direct path keeps the filter in fp32)
-    mf = mode == "bf16" and s == 1 and k in (1, 3) and cin % 64 == 0 and cout % 64 == 0
+    mf = mode in HALF and s == 1 and k in (1, 3) and cin % 64 == 0 and cout % 64 == 0
     w_eff = (wgt / sigma)
-    w_eff = bf16_round(w_eff) if mf else w_eff
+    w_eff = half_round(mode, w_eff) if mf else w_eff
     xin = np.maximum(x, 0) if relu else x
     xin = nn.upsample2(xin) if up else xin
     ref = nn.conv2d_fwd(xin.astype(np.float64), w_eff.astype(np.float64), s) + b
@@ -100,7 +100,7 @@ def test_conv2d_fwd_bwd(dev, case):
         dxin = dxin * (x > 0)
     assert_close(ctx.download(xd.grad), dxin, TOL[mode], "conv dgrad %s" % (case,))
     dw_bar = nn.conv2d_bwd_filter(xin.astype(np.float64), dy.astype(np.float64), wgt.shape, s)
-    assert_close(ctx.download(W.dwbar), dw_bar, 2e-4 if mode == "bf16" else TOL[mode], "conv wgrad %s" % (case,))
+    assert_close(ctx.download(W.dwbar), dw_bar, 2e-4 if mode in HALF else TOL[mode], "conv wgrad %s" % (case,))
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "conv dbias %s" % (case,))
 
 
@@ -120,11 +120,11 @@ def test_conv_residual_block(dev, cin):
     p1, p2 = FakeParam(ctx, w1), FakeParam(ctx, w2)
     h = O.conv2d(ctx, xd, O.Weight(ctx, p1.t), None, 3, in_relu=True)
     y = O.conv2d(ctx, h, O.Weight(ctx, p2.t), None, 3, in_relu=True, residual=xd)
-    mf = mode == "bf16" and cin % 64 == 0
-    q = (lambda a: bf16_round(a)) if mf else (lambda a: a)
+    mf = mode in HALF and cin % 64 == 0
+    q = (lambda a: half_round(mode, a)) if mf else (lambda a: a)
     x64 = x.astype(np.float64)
     h_ref = nn.conv2d_fwd(np.maximum(x64, 0), q(w1).astype(np.float64))
-    hq = bf16_round(h_ref).astype(np.float64) if mode == "bf16" else h_ref
+    hq = half_round(mode, h_ref).astype(np.float64) if mode in HALF else h_ref
     ref = x64 + nn.conv2d_fwd(np.maximum(hq, 0), q(w2).astype(np.float64))
     assert_close(ctx.download(y), ref, TOL[mode] * 2, "residual conv fwd")
     dy = _prep(rs.randn(*ref.shape), mode)
@@ -132,7 +132,7 @@ def test_conv_residual_block(dev, cin):
     ctx.backward()
     dy64 = dy.astype(np.float64)
     dh = nn.conv2d_bwd_input(dy64, q(w2).astype(np.float64), hq.shape) * (hq > 0)
-    dhq = bf16_round(dh).astype(np.float64) if mode == "bf16" else dh
+    dhq = half_round(mode, dh).astype(np.float64) if mode in HALF else dh
     dx = dy64 + nn.conv2d_bwd_input(dhq, q(w1).astype(np.float64), x.shape) * (x64 > 0)
     assert_close(ctx.download(xd.grad), dx, TOL[mode] * 3, "residual conv dx")
 
@@ -153,7 +153,7 @@ def test_conv_accumulate_and_force_direct(dev):
     t2 = O.conv2d(ctx, xd, O.Weight(ctx, p3.t), None, 3, accumulate_into=t2, force_direct=True)
     ref = nn.conv2d_fwd(x.astype(np.float64), w1.astype(np.float64)) + nn.conv2d_fwd(x.astype(np.float64), w3.astype(np.float64))
     assert_close(ctx.download(t2), ref, TOL[mode], "direct accumulate")
-    assert_close(ctx.download(t), ref, 2e-2 if mode == "bf16" else TOL[mode], "mfma accumulate")
+    assert_close(ctx.download(t), ref, 2e-2 if mode in HALF else TOL[mode], "mfma accumulate")
 
 
 @pytest.mark.parametrize("hin,cin,cout", [(7, 10, 6), (14, 138, 1), (7, 138, 128)])
@@ -244,7 +244,7 @@ def test_batch_norm(dev, shape, cond):
     dy = _prep(rs.randn(*shape), mode)
     y.grad = ctx.upload(dy)
     ctx.backward()
-    yq = bf16_round(ref) if mode == "bf16" else ref      # the kernel takes the activation mask from the stored y
+    yq = half_round(mode, ref) if mode in HALF else ref      # the kernel takes the activation mask from the stored y
     dpre = dy.astype(np.float64).reshape(x4.shape) * (np.where(yq > 0, 1.0, 0.0) if cond else np.where(yq > 0, 1.0, 0.2))
     if cond:
         dx, dg, db = nn.cond_batchnorm_bwd(dpre, x4, labels, gamma.astype(np.float64), st)
@@ -275,7 +275,7 @@ def test_spectral_norm(dev, shape):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
     ctx, mode = dev
-    if mode == "bf16":
+    if mode in HALF:
         pytest.skip("spectral norm is fp32 regardless of the activation dtype")
     rs = np.random.RandomState(shape[0] * 13 + shape[-1])
     w = (rs.randn(*shape) * 0.1).astype(np.float32)
@@ -321,7 +321,7 @@ def test_elementwise_and_resampling(dev):
         assert_close(ctx.download(y), ref, TOL[mode], "act %d" % kind)
         y.grad = ctx.upload(dy_full)
         ctx.backward()
-        yq = bf16_round(ref) if mode == "bf16" else ref
+        yq = half_round(mode, ref) if mode in HALF else ref
         assert_close(ctx.download(xd.grad), dy_full * df(x.astype(np.float64), yq), TOL[mode], "act bwd %d" % kind)
     ctx.new_step()
     xd = ctx.upload(x)
@@ -372,7 +372,7 @@ def test_preprocess_cifar(dev):
     ctx.new_step()
     out = ctx.empty((4, 3072))
     ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, 4, ctx.upload(img).ptr, ctx.upload(noise, 0).ptr, out.dtype, out.ptr))
-    assert_close(ctx.download(out), oc.preprocess_real(img, noise), 4e-3 if mode == "bf16" else 1e-6, "preprocess")
+    assert_close(ctx.download(out), oc.preprocess_real(img, noise), 4e-3 if mode in HALF else 1e-6, "preprocess")
 
 
 def test_head_and_losses(dev):
@@ -478,7 +478,7 @@ def test_adam_tf(dev):
     from rcgan_amd import _lib as L
     from rcgan_amd.runtime import ParamGroup
     ctx, mode = dev
-    if mode == "bf16":
+    if mode in HALF:
         pytest.skip("optimiser state is fp32 regardless of the activation dtype")
     rs = np.random.RandomState(2)
     w0 = rs.randn(1000).astype(np.float32)
@@ -500,7 +500,7 @@ def test_rng_and_graph_replay(dev):
     import ctypes as C
     from rcgan_amd import _lib as L
     ctx, mode = dev
-    if mode == "bf16":
+    if mode in HALF:
         pytest.skip("one dtype is enough")
     n = 1 << 16
     buf = ctx.persistent((n,), L.F32)

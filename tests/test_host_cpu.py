@@ -29,6 +29,14 @@ def test_abi_exports_every_declared_symbol():
     d = _lib.ConvDesc(128, 32, 32, 256, 256, 3, 3, 1, _lib.BF16, 0)
     assert lib.rcgan_conv_prepared_bytes(d) >= 2 * 2 * 9 * 256 * 256
     assert lib.rcgan_sn_save_floats(1152, 128) == 3 * 1152 + 4 * 128 + 4 + 36 * (128 + 2)
+    assert lib.rcgan_half_dtype() == _lib.BF16
+    # the fp16 build of the same sources exports the same ABI and reports its 16-bit dtype
+    lib16 = _lib.load("f16")
+    for name in declared:
+        assert hasattr(lib16, name), name
+    assert lib16.rcgan_half_dtype() == _lib.F16 and b"fp16" in lib16.rcgan_version()
+    d16 = _lib.ConvDesc(128, 32, 32, 256, 256, 3, 3, 1, _lib.F16, 0)
+    assert lib16.rcgan_conv_prepared_bytes(d16) == lib.rcgan_conv_prepared_bytes(d)
 
 
 def test_no_gpu_fails_loudly():
