@@ -97,3 +97,73 @@ def test_conv_adjoint_identity(dev, case):
     assert 0.3 * expect < yy < 2.0 * expect, (name, yy, expect)
     assert abs(yy - b) <= tol * yy, (name, "forward vs data gradient", yy, b)
     assert abs(yy - c) <= tol * yy, (name, "forward vs filter gradient", yy, c)
+
+
+# ---- conditional batch norm at full size: numpy (float64) restates it in seconds, and the backward has two exact
+#      invariants per channel: sum(dx) = 0 and sum(dx * xhat) = 0 (the batch statistics absorb both directions) -------
+BN_CASES = [
+    ("cfg3 G.Block3 condBN n=128 32x32x256 bf16", "bf16", 128, 1024, 256, 10),
+    ("cfg5 G.Block3 condBN n=256 32x32x256 fp16", "f16", 256, 1024, 256, 10),
+    ("cfg2 MNIST g_bn2 n=256 14x14x128 fp32", "f32", 256, 196, 128, 1),
+]
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=[c[0] for c in BN_CASES])
+def test_batch_norm_full_size(dev, case):
+    from rcgan_amd import _lib as L
+    ctx, mode = dev
+    name, dtype, n, rps, c, nl = case
+    if dtype != mode:
+        pytest.skip("runs in the %s context" % dtype)
+    lib, hd = ctx.lib, ctx.h
+    ctx.new_step()
+    rows = n * rps
+    rs = np.random.RandomState(5)
+    x, y, dy, dx = (ctx.empty((rows, c)) for _ in range(4))
+    ctx.check(lib.rcgan_rng_fill(hd, x.size, x.dtype, 1, 1.5, 3.0, 21, None, C.c_void_p(x.ptr)))
+    ctx.check(lib.rcgan_rng_fill(hd, dy.size, dy.dtype, 1, 0.0, 1.0, 22, None, C.c_void_p(dy.ptr)))
+    labels = rs.randint(nl, size=n).astype(np.int32)
+    gamma = (1.0 + 0.3 * rs.randn(nl, c)).astype(np.float32)
+    beta = (0.5 * rs.randn(nl, c)).astype(np.float32)
+    d_lab = ctx.upload(labels) if nl > 1 else None
+    d_g, d_b = ctx.upload(gamma, dtype=L.F32), ctx.upload(beta, dtype=L.F32)
+    mean, rstd = ctx.empty((c,), L.F32), ctx.empty((c,), L.F32)
+    dgam, dbet = ctx.zeros((nl, c), L.F32), ctx.zeros((nl, c), L.F32)
+    eps = 1e-5
+    lp = C.c_void_p(d_lab.ptr) if d_lab is not None else None
+    ws, wsb = C.c_void_p(ctx.ws_ptr), ctx.ws_bytes
+    ctx.check(lib.rcgan_bn_stats(hd, rows, c, ctx.act_dtype, C.c_void_p(x.ptr), eps, C.c_void_p(mean.ptr), C.c_void_p(rstd.ptr),
+                                 None, None, 0.9, ws, wsb))
+    ctx.check(lib.rcgan_bn_apply_fwd(hd, n, rps, c, nl, ctx.act_dtype, C.c_void_p(x.ptr), lp, C.c_void_p(d_g.ptr), C.c_void_p(d_b.ptr),
+                                     C.c_void_p(mean.ptr), C.c_void_p(rstd.ptr), L.ACT_NONE, C.c_void_p(y.ptr), ws, wsb))
+    ctx.check(lib.rcgan_bn_bwd(hd, n, rps, c, nl, ctx.act_dtype, C.c_void_p(x.ptr), C.c_void_p(y.ptr), C.c_void_p(dy.ptr), lp,
+                               C.c_void_p(d_g.ptr), C.c_void_p(mean.ptr), C.c_void_p(rstd.ptr), L.ACT_NONE,
+                               C.c_void_p(dx.ptr), 0, C.c_void_p(dgam.ptr), C.c_void_p(dbet.ptr), 0, ws, wsb))
+    X = ctx.download(x).astype(np.float64)
+    m_ref, v_ref = X.mean(0), X.var(0)
+    r_ref = 1.0 / np.sqrt(v_ref + eps)
+    tol = {"f32": 2e-5, "f16": 2e-3, "bf16": 1e-2}[mode]
+    assert np.abs(ctx.download(mean) - m_ref).max() <= 1e-5 * np.abs(m_ref).max() + 1e-6
+    assert np.abs(ctx.download(rstd) / r_ref - 1).max() <= 2e-5
+    xhat = (X - m_ref) * r_ref
+    lab_rows = np.repeat(labels, rps)
+    y_ref = gamma[lab_rows].astype(np.float64) * xhat + beta[lab_rows]
+    Y = ctx.download(y)
+    assert np.abs(Y - y_ref).max() <= tol * np.abs(y_ref).max(), name
+    DY = ctx.download(dy).astype(np.float64)
+    DX = ctx.download(dx).astype(np.float64)
+    # parameter gradients against the float64 restatement
+    dg_ref = np.zeros((nl, c))
+    db_ref = np.zeros((nl, c))
+    np.add.at(dg_ref, lab_rows, DY * xhat)
+    np.add.at(db_ref, lab_rows, DY)
+    assert np.abs(ctx.download(dgam) - dg_ref).max() <= 2e-4 * np.abs(dg_ref).max(), name
+    assert np.abs(ctx.download(dbet) - db_ref).max() <= 2e-4 * np.abs(db_ref).max(), name
+    # data gradient: the float64 formula, and the two invariants
+    g_rows = gamma[lab_rows].astype(np.float64) * DY
+    dx_ref = r_ref * (g_rows - g_rows.mean(0) - xhat * (g_rows * xhat).mean(0))
+    assert np.abs(DX - dx_ref).max() <= tol * np.abs(dx_ref).max(), name
+    size = np.sqrt((DX ** 2).sum(0) * rows)          # |dx|_2 * sqrt(rows) bounds |sum dx| per channel
+    inv_tol = {"f32": 1e-5, "f16": 2e-4, "bf16": 1e-3}[mode]
+    assert (np.abs(DX.sum(0)) <= inv_tol * size).all(), name
+    assert (np.abs((DX * xhat).sum(0)) <= inv_tol * size).all(), name
