@@ -12,6 +12,7 @@ struct MfmaConvArgs {
   const bf16_t* zero;     // >= 16 zero bytes (halo source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;
   int up, relu_in, accumulate;
+  int cm;                 // eight-wave kernels: channel-major K order (all taps of a 64-channel chunk, then the next chunk)
   int lw, lh;             // log2(W), log2(H) when both are powers of two (pixel decode by shifts), else -1
   long M;
 };

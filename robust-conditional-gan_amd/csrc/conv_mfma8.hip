@@ -108,12 +108,21 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       for (int j = 0; j < 2; ++j)
         glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
       if (which == 3) {
-        i_k0 += 64;
-        i_c0 += 64;
-        if (i_c0 == a.Cin) {
-          i_c0 = 0;
-          if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+        if (a.cm) {
+          // channel-major: the taps of one 64-channel chunk back to back.  They read the same 128-byte line of every
+          // pixel (shifted by a pixel or a row), so eight of the nine passes over the tile are L2 hits instead of
+          // coming back from the fabric after the other workgroups of the XCD have swept the 4 MB L2.
+          if (++i_kw == a.KW) { i_kw = 0; if (++i_kh == a.KH) { i_kh = 0; i_c0 += 64; } }
+          i_k0 = (i_kh * a.KW + i_kw) * a.Cin + i_c0;
           set_tap(i_kh, i_kw);
+        } else {
+          i_k0 += 64;
+          i_c0 += 64;
+          if (i_c0 == a.Cin) {
+            i_c0 = 0;
+            if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+            set_tap(i_kh, i_kw);
+          }
         }
       }
     } else {
@@ -470,11 +479,14 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 
 // wide = 256 output channels per workgroup (Cout % 256 == 0), else 128
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
-  static int swz = -1;
+  static int swz = -1, cm = -1;
   if (swz < 0) { const char* e = getenv("RCGAN_P8_XCD"); swz = e ? atoi(e) : 1; }
+  if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 0; }
   if (wide) {
-    if (swz) return a.relu_in ? launch8<true, true>(ctx, a) : launch8<false, true>(ctx, a);
-    return a.relu_in ? launch8<true, false>(ctx, a) : launch8<false, false>(ctx, a);
+    MfmaConvArgs b = a;
+    b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
+    if (swz) return b.relu_in ? launch8<true, true>(ctx, b) : launch8<false, true>(ctx, b);
+    return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }
   return a.relu_in ? launch8n<true>(ctx, a) : launch8n<false>(ctx, a);
 }
