@@ -54,9 +54,42 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int lrow = lane >> 3, pos = lane & 7;
 
+  // ---- tap-source table: T[tap][p] = element offset (into a.in) of the pixel that tile pixel p reads for that tap, or
+  //      ~0u where SAME padding applies.  Built once per workgroup behind the tile buffers (9 x 256 x 4 B); the K loop
+  //      then needs one ds_read_b32 + a select per DMA row when the tap changes instead of a bounds test and a pixel
+  //      address -- which is what makes a tap change per K-tile (channel-major order, a.cm) affordable.
+  unsigned* const tapt = (unsigned*)(smem + 2 * BUF);
+  const int ntaps = a.KH * a.KW;
+  for (int e = tid; e < ntaps * 256; e += 512) {
+    const int tap = e >> 8;
+    const long m = m0 + (e & 255);
+    unsigned off = ~0u;
+    if (m < a.M) {
+      int n, oh, ow;
+      const unsigned mm = (unsigned)m;
+      if (a.lw >= 0) {
+        ow = (int)(mm & (unsigned)(a.W - 1));
+        oh = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
+        n = (int)(mm >> (a.lw + a.lh));
+      } else {
+        ow = (int)(m % a.W);
+        oh = (int)((m / a.W) % a.H);
+        n = (int)(m / ((long)a.W * a.H));
+      }
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        if (a.up) { ih >>= 1; iw >>= 1; }
+        off = (((unsigned)n * Hs + ih) * Ws + iw) * a.Cin;
+      }
+    }
+    tapt[e] = off;
+  }
+  __syncthreads();
+
   // ---- DMA roles: per half-tile this wavefront deposits rows (wave*2 + j)*8 + lrow, j = 0,1 (of 128) ----------------
   // LDS row r of X half h  <->  tile pixel (r>>6)*128 + h*64 + (r&63);  W half h: channel (r>>5)*64 + h*32 + (r&31)
-  int p_n[4], p_oh[4], p_ow[4], a_coff[4];       // index = h*2 + j
+  int pix[4], a_coff[4];                          // index = h*2 + j
   const bf16_t* wsrc[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -64,22 +97,8 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
     for (int j = 0; j < 2; ++j) {
       const int r = (wave * 2 + j) * 8 + lrow;
       const int swz = (pos ^ ((r >> 1) & 7)) * 8;
-      const long m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      pix[h * 2 + j] = (r >> 6) * 128 + h * 64 + (r & 63);
       a_coff[h * 2 + j] = swz;
-      if (m < a.M) {
-        const unsigned mm = (unsigned)m;
-        if (a.lw >= 0) {
-          p_ow[h * 2 + j] = (int)(mm & (unsigned)(a.W - 1));
-          p_oh[h * 2 + j] = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
-          p_n[h * 2 + j] = (int)(mm >> (a.lw + a.lh));
-        } else {
-          p_ow[h * 2 + j] = (int)(m % a.W);
-          p_oh[h * 2 + j] = (int)((m / a.W) % a.H);
-          p_n[h * 2 + j] = (int)(m / ((long)a.W * a.H));
-        }
-      } else {
-        p_n[h * 2 + j] = 0; p_oh[h * 2 + j] = -100000; p_ow[h * 2 + j] = 0;
-      }
       const int co = co0 + (r >> 5) * 64 + h * 32 + (r & 31);
       wsrc[h * 2 + j] = a.wt + (long)co * K + swz;
     }
@@ -87,23 +106,29 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const bf16_t* rp[4];
   int rstep[4];
-  int i_c0 = 0, i_kh = 0, i_kw = 0, i_k0 = 0;
-  auto set_tap = [&](int kh, int kw) {
+  unsigned noff[4];                               // offsets of the NEXT tap, read ahead of their use
+  bool pend = false;
+  int i_c0 = 0, i_tap = 0, i_k0 = 0;
+  auto read_tap = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) noff[i] = tapt[tap * 256 + pix[i]];
+  };
+  auto use_tap = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
-      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      if (a.up) { ih >>= 1; iw >>= 1; }
-      rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
+      const bool ok = noff[i] != ~0u;
+      rp[i] = ok ? a.in + noff[i] + a_coff[i] : a.zero;
       rstep[i] = ok ? 1 : 0;
     }
   };
-  set_tap(0, 0);
+  read_tap(0);
+  use_tap();
   // half-tile ids: 0 = P0, 1 = C0, 2 = C1, 3 = P1 (issue order); the cursor moves on after P1
   auto issue = [&](int which, int buf) {
     const unsigned base = lds0 + buf * BUF;
     if (which == 0 || which == 3) {
       const int h = which == 0 ? 0 : 1;
+      if (which == 0 && pend) { use_tap(); pend = false; }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
@@ -112,16 +137,18 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
           // channel-major: the taps of one 64-channel chunk back to back.  They read the same 128-byte line of every
           // pixel (shifted by a pixel or a row), so eight of the nine passes over the tile are L2 hits instead of
           // coming back from the fabric after the other workgroups of the XCD have swept the 4 MB L2.
-          if (++i_kw == a.KW) { i_kw = 0; if (++i_kh == a.KH) { i_kh = 0; i_c0 += 64; } }
-          i_k0 = (i_kh * a.KW + i_kw) * a.Cin + i_c0;
-          set_tap(i_kh, i_kw);
+          if (++i_tap == ntaps) { i_tap = 0; i_c0 += 64; }
+          i_k0 = i_tap * a.Cin + i_c0;
+          read_tap(i_tap);
+          pend = true;
         } else {
           i_k0 += 64;
           i_c0 += 64;
           if (i_c0 == a.Cin) {
             i_c0 = 0;
-            if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
-            set_tap(i_kh, i_kw);
+            ++i_tap;
+            read_tap(i_tap < ntaps ? i_tap : 0);
+            pend = true;
           }
         }
       }
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
 template <bool RELU, bool XCDSWZ>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  const size_t lds = (size_t)2 * 4 * 128 * 128;
+  const size_t lds = (size_t)2 * 4 * 128 * 128 + 9 * 256 * sizeof(unsigned);      // tile buffers + tap-source table
   if (!attr_set) {
     RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -481,7 +508,7 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   static int swz = -1, cm = -1;
   if (swz < 0) { const char* e = getenv("RCGAN_P8_XCD"); swz = e ? atoi(e) : 1; }
-  if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 0; }
+  if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 1; }
   if (wide) {
     MfmaConvArgs b = a;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
