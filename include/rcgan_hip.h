@@ -177,6 +177,13 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
 int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
                        const int32_t* labels, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, int act, void* y, void* ws, size_t ws_bytes);
+/* rcgan_bn_stats + rcgan_bn_apply_fwd for `nseg` independent segments of n_per_seg samples stored back to back: each
+ * segment is normalised with its OWN batch statistics (= nseg separate Generator() calls of the reference, e.g. the
+ * N_CRITIC generator forwards of one iteration, gan_resnet.py:540-546,928-947, evaluated as one batch).  Forward only.
+ * mean / rstd: [nseg][c] outputs; ws: nseg * rcgan_bn_workspace_bytes(n_per_seg*rows_per_sample, c). */
+int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_sample, int c, int n_labels, int dtype,
+                          const void* x, const int32_t* labels, const float* gamma, const float* beta, float eps, int act,
+                          float* mean, float* rstd, void* y, void* ws, size_t ws_bytes);
 /* Backward of stats+apply (gradient flows through the batch statistics).  dgamma/dbeta: [n_labels][c]
  * (= or += by accumulate); dx = or += by accumulate_dx.  y is the forward output (activation mask). */
 int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "rcgan_bn_workspace_bytes": (SZ, [I, I]),
     "rcgan_bn_stats": (I, [P, I, I, I, P, F, P, P, P, P, F, P, SZ]),
     "rcgan_bn_apply_fwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, I, P, P, SZ]),
+    "rcgan_bn_fwd_segments": (I, [P, I, I, I, I, I, I, P, P, P, P, F, I, P, P, P, P, SZ]),
     "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, SZ]),
     "rcgan_bn_infer": (I, [P, I, I, I, P, P, P, P, P, F, I, P]),
     "rcgan_bn_infer_bwd": (I, [P, I, I, I, P, P, P, P, F, I, P, I]),

@@ -153,28 +153,30 @@ def UpsampleConv(inputs, output_dim, filter_size=3, name=None, spectral_normed=F
                   _in_upsample=True, _in_relu=_in_relu, _accumulate_into=_accumulate_into)
 
 
-def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels):
+def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels, segments=1):
     """ResidualBlock(resample='up') with conditional batch norm (gan_resnet.py:275-328)."""
     shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
     with variable_scope(name + '.N1'):
-        out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU)
+        out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
     out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1')
     with variable_scope(name + '.N2'):
-        out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU)
+        out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
     return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _accumulate_into=shortcut)
 
 
-def Generator(n_samples, labels, noise, out=None):
-    """gan_resnet.py:356-371.  noise: [n,128] device tensor; returns [n, 3072] (NHWC flattened) in (-1,1)."""
+def Generator(n_samples, labels, noise, out=None, segments=1):
+    """gan_resnet.py:356-371.  noise: [n,128] device tensor; returns [n, 3072] (NHWC flattened) in (-1,1).
+    segments > 1 (forward only): the n samples are that many independent Generator() batches back to back, each with
+    its own batch-norm statistics -- the convolutions run once on all of them."""
     ctx = _ctx()
     with variable_scope("Generator"):
         output = Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = O.reshape(ctx, output, (-1, 4, 4, DIM_G * 8))
-        output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels)
-        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels)
-        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels)
+        output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels, segments)
+        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels, segments)
+        output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels, segments)
         with variable_scope('G.OutputNorm'):
-            output = cond_batchnorm('G.OutputNorm', [0, 1, 2], output, labels=labels, n_labels=10, _act=L.ACT_RELU)
+            output = cond_batchnorm('G.OutputNorm', [0, 1, 2], output, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
         output = Conv2D(output, DIM_G * 2, IMG_DIM, 3, 1, 'G.Output', he_init=False)
         output = O.act(ctx, output, L.ACT_TANH, out=out.reshape(output.shape) if out is not None else None)
         return O.reshape(ctx, output, (-1, OUTPUT_DIM))
@@ -585,8 +587,9 @@ class CifarRCGAN:
         e = np.exp(logits - logits.max(axis=1, keepdims=True))
         return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
 
-    def sample(self, labels, z):
-        """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32."""
+    def sample(self, labels, z, segments=1):
+        """Generator forward only (fixed_noise_samples, gan_resnet.py:827); returns [n,3072] float32.
+        segments: evaluate that many independent batches (own batch-norm statistics each) in one pass."""
         ctx, g = self.ctx, self.graph
         self._refresh_generator_filters()
         ctx.new_step()
@@ -595,7 +598,7 @@ class CifarRCGAN:
         try:
             lab = ctx.upload(np.asarray(labels, np.int32))
             zz = ctx.upload(np.asarray(z, np.float32))
-            out = Generator(len(labels), lab, zz)
+            out = Generator(len(labels), lab, zz, segments=segments)
             res = ctx.download(out)
         finally:
             ctx.recording = rec

@@ -324,6 +324,7 @@ __global__ void bn_bwd_apply_vec_kernel(long nchunks, int rows_per_sample, int c
 // ------------------------------------------------------------------------------------------------
 struct BnFusedArgs {
   long rows; int c; long rows_per_group; int ngroups;
+  int nseg;                             // forward only: blockIdx.z = segment; x, partial, counter, mean, rstd advance per segment
   const void *x, *y, *dy;
   const float *mean_in, *rstd_in;       // backward only
   int act;
@@ -351,6 +352,13 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
   const long rb = (long)blockIdx.y * a.rows_per_group;
   long re = rb + a.rows_per_group;
   if (re > a.rows) re = a.rows;
+  if (MODE == 0 && a.nseg > 1) {        // independent statistics per segment of a.rows rows (batched generator forward)
+    const long sg = blockIdx.z;
+    a.x = (const T*)a.x + sg * a.rows * c;
+    a.partial += sg * (long)a.ngroups * 2 * c;
+    a.counter += sg * (c / 64);
+    a.mean += sg * c; a.rstd += sg * c;
+  }
   const T* x = (const T*)a.x; const T* y = (const T*)a.y; const T* dy = (const T*)a.dy;
   float s1[8], s2[8], mu[8], rs[8];
 #pragma unroll
@@ -525,7 +533,13 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_fused_kernel(long nchunks, int rows_per_sample, int c, const T* x, const int32_t* labels,
                                                              const float* gamma, const float* beta, const float* mean,
-                                                             const float* rstd, int act, T* y) {
+                                                             const float* rstd, int act, T* y, int n_per_seg) {
+  if (gridDim.y > 1) {                                // blockIdx.y = segment: nchunks / n_per_seg count ONE segment
+    const long sg = blockIdx.y;
+    x += sg * nchunks * 8; y += sg * nchunks * 8;
+    if (labels) labels += sg * n_per_seg;
+    mean += sg * c; rstd += sg * c;
+  }
   const unsigned cpr = (unsigned)c / 8u;              // a power of two on this path
   const int lcpr = __ffs((int)cpr) - 1;
   const int lrps = (rows_per_sample & (rows_per_sample - 1)) == 0 ? __ffs(rows_per_sample) - 1 : -1;
@@ -666,7 +680,7 @@ int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_
   if (bn_fused_ok(c)) {
     long nchunks = total / 8;
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
-                                                     nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y));
+                                                     nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y, 0));
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
   }
@@ -683,6 +697,46 @@ int rcgan_bn_apply_fwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_
   }
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fwd_kernel<T>, dim3(ew_grid2(total)), dim3(256), 0, ctx->stream, total,
                                                    rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// Forward batch norm of `nseg` independent segments of n_per_seg samples each (x = the segments back to back): every
+// segment gets its own batch statistics, exactly as nseg separate calls would, in two launches for all of them.
+// mean / rstd: [nseg][c] scratch outputs.
+int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
+                          const int32_t* labels, const float* gamma, const float* beta, float eps, int act,
+                          float* mean, float* rstd, void* y, void* ws, size_t ws_bytes) {
+  RC_REQUIRE(ctx, nseg >= 1 && n_per_seg >= 1, "segments %d x %d", nseg, n_per_seg);
+  const long rows = (long)n_per_seg * rows_per_sample;
+  if (!bn_fused_ok(c) || nseg * (c / 64) > 256) {       // other channel counts: one segment at a time
+    const size_t esz = dtype_size(dtype);
+    for (int sg = 0; sg < nseg; ++sg) {
+      const char* xs = (const char*)x + (size_t)sg * rows * c * esz;
+      char* ys = (char*)y + (size_t)sg * rows * c * esz;
+      int rc = rcgan_bn_stats(ctx, (int)rows, c, dtype, xs, eps, mean + (size_t)sg * c, rstd + (size_t)sg * c, nullptr, nullptr, 0.f, ws, ws_bytes);
+      if (rc) return rc;
+      rc = rcgan_bn_apply_fwd(ctx, n_per_seg, rows_per_sample, c, n_labels, dtype, xs, labels ? labels + (size_t)sg * n_per_seg : nullptr,
+                              gamma, beta, mean + (size_t)sg * c, rstd + (size_t)sg * c, act, ys, ws, ws_bytes);
+      if (rc) return rc;
+    }
+    return RCGAN_OK;
+  }
+  const long rpg = stats_group_rows(rows);
+  const int ng = cdiv(rows, rpg);
+  const size_t need = (size_t)nseg * ng * 2 * c * sizeof(float);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  BnFusedArgs a = {};
+  a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.nseg = nseg; a.x = x; a.partial = (float*)ws;
+  a.counter = ctx->counters() + RC_COUNTER_BNSEG;
+  a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = nullptr; a.mv = nullptr; a.decay = 0.f;
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), 0, ctx->stream, a));
+  RC_LAUNCH_CHECK(ctx);
+  const long nchunks = rows * c / 8;
+  int gx = apply_grid_fused(nchunks, c);
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(gx, nseg), dim3(256), 0, ctx->stream,
+                                                   nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, (const float*)mean, (const float*)rstd,
+                                                   act, (T*)y, n_per_seg));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

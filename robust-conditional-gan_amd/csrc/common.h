@@ -35,6 +35,7 @@ struct rcgan_ctx {
 };
 #define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
 #define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish
+#define RC_COUNTER_BNSEG 512   // [512,768): segmented forward batch norm, one per (segment, 64-channel column block)
 
 // brackets one launch with events when profiling is armed for kernel id `which`
 struct ProfScope {

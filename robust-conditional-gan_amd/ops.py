@@ -292,13 +292,23 @@ def _rows(x):
     return x.shape[0], 1, x.shape[1]
 
 
-def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1, moving=None, decay=0.9, eps=1e-5):
+def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1, moving=None, decay=0.9, eps=1e-5, segments=1):
     """Batch statistics + (conditional) affine + activation, one fused op.
     labels=None: tf.contrib.layers.batch_norm (mnist/ops.py:38-44), ``moving`` = (moving_mean, moving_var)
     DTs updated in place.  labels=int32 DT [n]: cond_batchnorm (cifar10/common/ops/normalization.py:27-59),
-    gamma/beta are [n_labels, c] tables."""
+    gamma/beta are [n_labels, c] tables.  segments > 1 (forward only): x holds that many independent batches back to
+    back, each normalised with its own statistics -- several Generator() calls of the reference evaluated as one."""
     n, rps, c = _rows(x)
     rows = n * rps
+    if segments > 1:
+        if (ctx.recording and (x.req or gamma.req or beta.req)) or moving is not None or n % segments:
+            raise NotImplementedError("segmented batch norm is forward-only (no gradient, no moving statistics)")
+        mean = ctx.empty((segments, c), L.F32)
+        rstd = ctx.empty((segments, c), L.F32)
+        y = ctx.empty(x.shape, x.dtype)
+        ctx.check(ctx.lib.rcgan_bn_fwd_segments(ctx.h, segments, n // segments, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma),
+                                                _p(beta), eps, act, _p(mean), _p(rstd), _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        return y
     mean = ctx.empty((c,), L.F32)
     rstd = ctx.empty((c,), L.F32)
     mm, mv = moving if moving is not None else (None, None)

@@ -183,6 +183,25 @@ def test_step_parity_f16():
         m.ctx.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_segmented_generator_forward_equals_separate_calls(dtype, tol):
+    """Generator(segments=k) on k batches stored back to back == k separate Generator() calls: the convolutions see one
+    big batch, every conditional batch norm takes its statistics per segment (rcgan_bn_fwd_segments)."""
+    rs = np.random.RandomState(31)
+    B, K = 6, 3
+    m, P, Uo = _make("rcgan", False, B, dtype)
+    try:
+        lab = rs.randint(10, size=K * B)
+        z = rs.randn(K * B, 128).astype(np.float32)
+        whole = m.sample(lab, z, segments=K)
+        parts = np.concatenate([m.sample(lab[k * B:(k + 1) * B], z[k * B:(k + 1) * B]) for k in range(K)])
+        pooled = m.sample(lab, z)                 # statistics over all K*B samples: must differ
+        assert_close(whole, parts, tol, "segmented generator forward")
+        assert np.abs(pooled - parts).max() > 10 * tol * np.abs(parts).max()
+    finally:
+        m.ctx.close()
+
+
 def test_graph_replay_matches_eager():
     """The captured hipGraph of a D step / G step must reproduce the eager launches bit for bit."""
     rs = np.random.RandomState(23)
