@@ -33,6 +33,7 @@ import torch  # noqa: E402
 N_CRITIC = 5
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 (= fp16) MFMA peak, MI355X_MICROARCH.md
 POOL = 8                      # synthetic batches resident on the device
+BATCH_CRITIC_FAKES = os.environ.get("RCGAN_BATCH_CRITIC_FAKES", "1") == "1"
 
 
 def build_pool(m, rank, alpha):
@@ -64,6 +65,10 @@ def build_pool(m, rank, alpha):
         fg.append(m.pack_feed("g", labels_random_G=host(pool["labels_random_G"][k]), labels_biased_G=host(pool["labels_biased_G"][k])))
     pool["feed_d"] = torch.from_numpy(np.stack(fd)).to(dev)
     pool["feed_g"] = torch.from_numpy(np.stack(fg)).to(dev)
+    # generator labels of N_CRITIC consecutive critic steps starting at pool index s (any s: dcount walks the pool cyclically)
+    lr = host(pool["labels_random"])
+    pool["feed_gf"] = torch.from_numpy(np.stack([
+        m.pack_feed("gf", labels_random_all=np.concatenate([lr[(s0 + t) % POOL] for t in range(N_CRITIC)])) for s0 in range(POOL)])).to(dev)
     torch.cuda.synchronize()
     return pool
 
@@ -81,6 +86,11 @@ def iteration(m, pool, it, dcount):
     if it > 0:
         feed_g(m, pool, it)
         m.g_step(iteration=it)
+    if BATCH_CRITIC_FAKES:
+        # the N_CRITIC generator forwards of this iteration's critic steps as one pass (same G weights, own z / labels /
+        # batch-norm statistics each)
+        m.set_feed("gf", pool["feed_gf"][dcount[0] % POOL])
+        m.prepare_critic_fakes()
     for _ in range(N_CRITIC):
         feed_d(m, pool, dcount[0])
         dcount[0] += 1
@@ -216,6 +226,8 @@ def main():
                "config": {"workload": "CIFAR-10 32x32 SNGAN-projection ResNet %s, per-GPU batch %d, iteration = 1 G step (2B fakes) + 5 D steps (B real + B fake)"
                                       % (args.algorithm.upper(), args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
+                          "critic_generator_forwards": ("one pass over N_CRITIC x B samples, batch-norm statistics per critic step"
+                                                        if BATCH_CRITIC_FAKES else "inside every critic step"),
                           "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
                           "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
                           "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}

@@ -276,7 +276,9 @@ class CifarRCGAN:
         self.feed_layout = {
             "d": [("images", (B, OUTPUT_DIM), i32), ("labels", (B,), i32), ("labels_random", (B,), i32), ("labels_biased", (B,), i32),
                   ("inv_weights", (B, VOCAB_SIZE), f32), ("labels_all", (2 * B,), i32)],
-            "g": [("labels_random_G", (2 * B,), i32), ("labels_biased_G", (2 * B,), i32)]}
+            "g": [("labels_random_G", (2 * B,), i32), ("labels_biased_G", (2 * B,), i32)],
+            # generator labels of the N_CRITIC critic steps of one iteration (prepare_critic_fakes)
+            "gf": [("labels_random_all", (N_CRITIC * B,), i32)]}
         self.feed, self.inp = {}, {}
         for key, fields in self.feed_layout.items():
             words = sum(int(np.prod(shp)) for _, shp, _ in fields)
@@ -287,9 +289,15 @@ class CifarRCGAN:
                 self.inp[name] = DT(slab.data_ptr() + 4 * off, shp, dt, slab, name)
                 off += int(np.prod(shp))
         self.inp.update(noise=P((B, OUTPUT_DIM), f32), z=P((B, Z_DIM), act), z_G=P((2 * B, Z_DIM), act),
+                        z_all=P((N_CRITIC * B, Z_DIM), act),
                         arange=P((VOCAB_SIZE,), i32), C_const=P((VOCAB_SIZE, VOCAB_SIZE), f32))
         ctx.view(self.inp["arange"]).copy_(torch.arange(VOCAB_SIZE, dtype=torch.int32))
         ctx.view(self.inp["C_const"]).copy_(torch.from_numpy(C_ALPHA(alpha).astype(np.float32)))
+        # the critic steps' generator forwards evaluated as one batch (prepare_critic_fakes): fakes of all N_CRITIC steps,
+        # and the discriminator input [real ; fake] of a step at a fixed address the fake rows are copied into
+        self.fakes_all = P((N_CRITIC * B, OUTPUT_DIM), act)
+        self.x_all = P((2 * B, OUTPUT_DIM), act)
+        self._fakes_left = 0
         self.loss_d = P((1,), f32, fill=0.0)
         self.loss_g = P((1,), f32, fill=0.0)
         self.rng_state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
@@ -373,8 +381,9 @@ class CifarRCGAN:
         return self.inp["C_const"]                                               # gan_resnet.py:524
 
     # ---------------------------------------------------------------------------------- D step
-    def _d_body(self):
-        """Forward + backward of disc_cost (gan_resnet.py:557-697) on this rank's shard."""
+    def _d_body(self, fakes_ready=False):
+        """Forward + backward of disc_cost (gan_resnet.py:557-697) on this rank's shard.  fakes_ready: the generator
+        forward of this step was evaluated by prepare_critic_fakes; its images are in the fake rows of self.x_all."""
         ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
         self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
@@ -383,17 +392,21 @@ class CifarRCGAN:
         ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss_d.ptr, 0.0))
         if self.device_rng:
             self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
-            self._rng(inp["z"], 1, 0.0, 1.0)
+            if not fakes_ready:
+                self._rng(inp["z"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(True, True))
-        self._prepare_all((self.PG, self.PD))
+        self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD))
         fake_dst = None
         if self.alg == "rcgan-u":
             real = ctx.empty((B, OUTPUT_DIM))
         else:
-            x_all = ctx.empty((2 * B, OUTPUT_DIM))
+            x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
             real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
         ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
-        fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)                 # :540-546
+        if fakes_ready:
+            fake = self.x_all.rows(B, 2 * B)
+        else:
+            fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)             # :540-546
         w = self.loss_scale
         if self.alg == "rcgan-u":
             feat, wgan = Discriminator(real, inp["labels"], update_collection=None)
@@ -482,11 +495,43 @@ class CifarRCGAN:
             from .dp import allreduce_sum_
             allreduce_sum_(group.grad, self.ctx.stream)
 
+    def _gf_body(self):
+        ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
+        self._refresh_generator_filters()
+        ctx.new_step()
+        g.begin_step(set())
+        rec, ctx.recording = ctx.recording, False
+        try:
+            if self.device_rng:
+                self._rng(inp["z_all"], 1, 0.0, 1.0)
+            self._prepare_all((self.PG,))
+            Generator(N_CRITIC * B, inp["labels_random_all"], inp["z_all"], out=self.fakes_all, segments=N_CRITIC)
+        finally:
+            ctx.recording = rec
+
+    def prepare_critic_fakes(self):
+        """The generator does not change during the N_CRITIC critic updates of an iteration (gan_resnet.py:928-947), so their
+        N_CRITIC Generator() calls (:540-546, one fresh z and label draw each) are evaluated here as ONE pass over
+        N_CRITIC*B samples -- same values: the convolutions are per-sample, every conditional batch norm takes its
+        statistics per step's batch (segments) -- and the next N_CRITIC d_step() calls consume one slice each.
+        Inputs: labels_random_all [N_CRITIC*B] (feed "gf"; slice k must equal step k's labels_random), z_all (drawn on the
+        device unless device_rng=False)."""
+        self._run("gf", self._gf_body)
+        self._fakes_left = N_CRITIC
+
     def d_step(self, iteration=None):
         """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""
         it = self.iteration if iteration is None else iteration
         self._refresh_generator_filters()
-        self._run("d", self._d_body)
+        if self._fakes_left > 0:
+            k = N_CRITIC - self._fakes_left
+            self._fakes_left -= 1
+            ctx = self.ctx
+            with torch.cuda.stream(ctx.stream):
+                ctx.view(self.x_all.rows(self.B, 2 * self.B)).copy_(ctx.view(self.fakes_all.rows(k * self.B, (k + 1) * self.B)), non_blocking=True)
+            self._run("d_fakes", lambda: self._d_body(True))
+        else:
+            self._run("d", self._d_body)
         self._allreduce(self.PD)
         self.PD.t += 1
         self.PD.set_hyper(self.lr * lr_decay(it), self.PD.t)

@@ -162,8 +162,13 @@ def main(argv=None):
             _random_labels_G, _labels_biased_G = next(gen_G)
             m.set_inputs(labels_random_G=sh(_random_labels_G), labels_biased_G=sh(_labels_biased_G))
             m.g_step(iteration=iteration)
-        for _ in range(N_CRITIC):
-            feed_d(next(gen))
+        # the generator is fixed during the critic updates: their N_CRITIC Generator() forwards run as one pass
+        # (prepare_critic_fakes), then every critic step consumes its slice
+        batches = [next(gen) for _ in range(N_CRITIC)]
+        m.set_inputs(labels_random_all=np.concatenate([sh(b[2]) for b in batches]))
+        m.prepare_critic_fakes()
+        for batch in batches:
+            feed_d(batch)
             m.d_step(iteration=iteration)
         m.iteration = iteration + 1
         if timed:

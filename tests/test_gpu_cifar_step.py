@@ -202,6 +202,42 @@ def test_segmented_generator_forward_equals_separate_calls(dtype, tol):
         m.ctx.close()
 
 
+@pytest.mark.parametrize("alg,dtype,tol", [("rcgan", "f32", 1e-3), ("rcgan", "bf16", 3e-2), ("rcgan-u", "f32", 1e-3)])
+def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
+    """prepare_critic_fakes() + N_CRITIC d_step() == N_CRITIC plain d_step() (the generator forward inside every critic
+    step, as the reference runs it) on the same z / labels / real batches: discriminator weights after the five Adam
+    updates and the last critic loss agree.  (Adam moves a weight whose gradient is ~0 by up to lr per step whatever the
+    gradient's size, so single elements may differ by a few 1e-6 absolute in fp32; the norm-relative error is ~1e-7.)"""
+    from rcgan_amd.cifar import N_CRITIC
+    rs = np.random.RandomState(41)
+    B = 4
+    steps = []
+    for _ in range(N_CRITIC):
+        C, raw, _ = _batches(rs, B)
+        steps.append(raw)
+    outs = []
+    for batched in (False, True):
+        m, P, Uo = _make(alg, alg == "rcgan-u", B, dtype)
+        try:
+            if batched:
+                m.set_inputs(labels_random_all=np.concatenate([r["labels_random"] for r in steps]),
+                             z_all=np.concatenate([r["z"] for r in steps]))
+                m.prepare_critic_fakes()
+            for it, raw in enumerate(steps):
+                m.set_inputs(labels_all=_labels_all(alg, raw), **raw)
+                m.d_step(iteration=0)
+            assert m._fakes_left == 0
+            outs.append((m.get_params(), m.losses()[0]))
+        finally:
+            m.ctx.close()
+    (pa, la), (pb, lb) = outs
+    assert abs(la - lb) <= tol * max(1.0, abs(la)), (la, lb)
+    for k in pa:
+        if k.startswith("Discriminator") or "D." in k:
+            assert_close(pb[k], pa[k], tol, "D weights after %d critic steps: %s" % (N_CRITIC, k))
+            assert rel_err(pb[k], pa[k]) <= (5e-3 if dtype == "bf16" else 2e-5), (k, rel_err(pb[k], pa[k]))
+
+
 def test_graph_replay_matches_eager():
     """The captured hipGraph of a D step / G step must reproduce the eager launches bit for bit."""
     rs = np.random.RandomState(23)
