@@ -396,12 +396,11 @@ class CifarRCGAN:
                 self._rng(inp["z"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(True, True))
         self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD))
-        fake_dst = None
-        if self.alg == "rcgan-u":
-            real = ctx.empty((B, OUTPUT_DIM))
-        else:
-            x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
-            real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
+        # [real ; fake] is ONE discriminator pass for every algorithm: there is no norm layer in D and the spectral-norm
+        # weights of a step are computed once (prefetch_sn above), so D(real) and D(fake) of the reference's rcgan-u graph
+        # (:654-660) see the same filters and the trunk is evaluated on the 2B rows together
+        x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
+        real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
         ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
         if fakes_ready:
             fake = self.x_all.rows(B, 2 * B)
@@ -409,10 +408,11 @@ class CifarRCGAN:
             fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)             # :540-546
         w = self.loss_scale
         if self.alg == "rcgan-u":
-            feat, wgan = Discriminator(real, inp["labels"], update_collection=None)
+            feat_a, wgan_a = Discriminator(x_all, None, update_collection=None)
+            feat, wgan = O.rows(ctx, feat_a, 0, B), O.rows(ctx, wgan_a, 0, B)
+            feat_f, wgan_f = O.rows(ctx, feat_a, B, 2 * B), O.rows(ctx, wgan_a, B, 2 * B)
             emb = Discriminator_projection(inp["labels"], update_collection=None)
             disc_real = O.proj_logit(ctx, feat, wgan, emb)
-            feat_f, wgan_f = Discriminator(fake, inp["labels_random"], update_collection=None)
             E = Discriminator_projection(inp["arange"], update_collection=None)
             disc_fake = O.proj_logit_all(ctx, feat_f, wgan_f, E)                         # :654-660
             y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random"], B)   # :682-683
