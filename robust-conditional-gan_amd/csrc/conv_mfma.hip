@@ -1076,7 +1076,11 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
   static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);         // 256 x 256 four-phase kernel (conv_mfma8.hip)
   const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);      // its tap-source table holds 32-bit element offsets
-  if (a.Cout % 256 == 0 && a.zero != nullptr && off32 && (long)cdiv(a.M, 256) * (a.Cout / 256) >= p8_min) return mfma_conv8_launch(ctx, a, true);
+  // one 256 x 256 workgroup per CU: a grid of 320 runs two rounds for 1.25 rounds of work -- such grids go to the
+  // 256 x 128 kernel (twice the workgroups, finer rounds) when less than 3/4 of the last round would be busy
+  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
+  const bool fit8 = 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
+  if (a.Cout % 256 == 0 && a.zero != nullptr && off32 && b8 >= p8_min && fit8) return mfma_conv8_launch(ctx, a, true);
   static const int p8n_min = env_int("RCGAN_P8N_MINBLK", 190);
   if (a.Cout % 128 == 0 && a.zero != nullptr && (long)cdiv(a.M, 256) * (a.Cout / 128) >= p8n_min) return mfma_conv8_launch(ctx, a, false);
   static const int t256_min = env_int("RCGAN_T256_MINBLK", 1 << 30);     // experiment: 256-pixel tiles (1 wave/SIMD)
