@@ -280,6 +280,7 @@ class CifarRCGAN:
             # generator labels of the N_CRITIC critic steps of one iteration (prepare_critic_fakes)
             "gf": [("labels_random_all", (N_CRITIC * B,), i32)]}
         self.feed, self.inp = {}, {}
+        self._feed_ring = {}
         for key, fields in self.feed_layout.items():
             words = sum(int(np.prod(shp)) for _, shp, _ in fields)
             slab = torch.zeros(words, dtype=torch.int32, device=ctx.device)
@@ -315,7 +316,9 @@ class CifarRCGAN:
             for k, a in arrays.items():
                 dst = ctx.view(self.inp[k])
                 src = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
-                dst.copy_(src.reshape(dst.shape).to(dst.dtype), non_blocking=False)
+                # pinned staging + asynchronous copy: a pageable (synchronous) copy would wait for every launch already
+                # queued on the device -- one full step per array -- and serialise the host loop with the GPU
+                dst.copy_(src.reshape(dst.shape).to(dst.dtype).pin_memory(), non_blocking=True)
 
     def pack_feed(self, key, **arrays):
         """Host-side packing of one step's batch into the feed layout (int32 words; float fields bit-cast): what a data
@@ -325,6 +328,35 @@ class CifarRCGAN:
             a = np.ascontiguousarray(np.asarray(arrays[name]).reshape(shp))
             parts.append(a.astype(np.float32).view(np.int32).reshape(-1) if dt == L.F32 else a.astype(np.int32).reshape(-1))
         return np.concatenate(parts)
+
+    def feed_host(self, key, **arrays):
+        """pack_feed + set_feed for a host-side loader: the batch is packed straight into a pinned staging slot (a ring of
+        8 per feed, guarded by events) and handed over with ONE asynchronous copy -- no per-array conversions, pinned
+        allocations or synchronous copies in the training loop."""
+        ring = self._feed_ring.setdefault(key, {"slots": [], "events": [], "next": 0})
+        words = self.feed[key].numel()
+        if not ring["slots"]:
+            ring["slots"] = [torch.empty(words, dtype=torch.int32).pin_memory() for _ in range(8)]
+            ring["events"] = [None] * 8
+        i = ring["next"]
+        ring["next"] = (i + 1) % 8
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()              # the copy that last read this slot has finished
+        dst = ring["slots"][i].numpy()
+        off = 0
+        for name, shp, dt in self.feed_layout[key]:
+            n = int(np.prod(shp))
+            a = np.asarray(arrays[name]).reshape(-1)
+            if dt == L.F32:
+                dst[off:off + n].view(np.float32)[:] = a
+            else:
+                dst[off:off + n] = a
+            off += n
+        with torch.cuda.stream(self.ctx.stream):
+            self.feed[key].copy_(ring["slots"][i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.ctx.stream)
+        ring["events"][i] = ev
 
     def set_feed(self, key, blob):
         """One copy of a packed batch (numpy int32 array or device / pinned int32 tensor) into the D-step ("d") or G-step

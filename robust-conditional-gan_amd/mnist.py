@@ -351,7 +351,8 @@ class MnistRCGAN:
                     continue
                 dst = ctx.view(self.inp[k])
                 src = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
-                dst.copy_(src.reshape(dst.shape).to(dst.dtype))
+                # pinned staging + asynchronous copy (a pageable copy waits for all queued device work)
+                dst.copy_(src.reshape(dst.shape).to(dst.dtype).pin_memory(), non_blocking=True)
 
     def losses(self):
         out = {k: float(self.ctx.download(v)[0]) for k, v in self.loss.items()}

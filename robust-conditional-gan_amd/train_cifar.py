@@ -130,8 +130,8 @@ def main(argv=None):
     def feed_d(batch):
         images, labels, rnd, bia, inv = batch
         second = rnd if ALGORITHM in ("biased", "unbiased") else bia
-        m.set_inputs(images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
-                     inv_weights=sh(inv), labels_all=np.concatenate([sh(labels), sh(second)]))
+        m.feed_host("d", images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
+                    inv_weights=sh(inv), labels_all=np.concatenate([sh(labels), sh(second)]))
 
     # generated-label accuracy (gan_resnet.py:424-455, 847-861): 1000 samples, 100 per class, ONE classifier batch
     label_100_list = [label for label in range(10) for _ in range(10)]
@@ -160,12 +160,12 @@ def main(argv=None):
         t0 = time.time()
         if 0 < iteration:
             _random_labels_G, _labels_biased_G = next(gen_G)
-            m.set_inputs(labels_random_G=sh(_random_labels_G), labels_biased_G=sh(_labels_biased_G))
+            m.feed_host("g", labels_random_G=sh(_random_labels_G), labels_biased_G=sh(_labels_biased_G))
             m.g_step(iteration=iteration)
         # the generator is fixed during the critic updates: their N_CRITIC Generator() forwards run as one pass
         # (prepare_critic_fakes), then every critic step consumes its slice
         batches = [next(gen) for _ in range(N_CRITIC)]
-        m.set_inputs(labels_random_all=np.concatenate([sh(b[2]) for b in batches]))
+        m.feed_host("gf", labels_random_all=np.concatenate([sh(b[2]) for b in batches]))
         m.prepare_critic_fakes()
         for batch in batches:
             feed_d(batch)
