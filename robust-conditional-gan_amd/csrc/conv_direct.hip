@@ -1,11 +1,10 @@
-// Generic fp32-accumulate implicit-GEMM convolution on the vector ALUs ("direct" path).
+// Generic fp32 implicit-GEMM convolution ("direct" path): a gather GEMM on the fp32 matrix cores.
 //
-// One LDS-tiled 64x64x16 GEMM skeleton, C[i][j] = sum_r A(i,r) * B(r,j), with the operand fetch
-// expressed as gather functors.  It serves every shape the MFMA path does not take: fp32 parity
-// mode, the 3-channel ends of the CIFAR nets (Cin=3 / Cout=3), the MNIST 5x5 stride-2 convs and
-// transposed convs, and all dense layers.  Same math as tf.nn.conv2d / conv2d_backprop_input /
-// conv2d_backprop_filter with SAME padding (reference call sites: mnist/ops.py:62,78;
-// cifar10/common/ops/conv2d.py:181-187).
+// One LDS-tiled 64x64x32 GEMM skeleton, C[i][j] = sum_r A(i,r) * B(r,j), on v_mfma_f32_32x32x2_f32, with the operand
+// fetch expressed as functors.  It serves every shape the 16-bit MFMA path does not take: fp32 mode (MNIST config 2 and
+// the fp32 parity runs), the MNIST 5x5 stride-2 convs and transposed convs, and all dense layers.  Same math as
+// tf.nn.conv2d / conv2d_backprop_input / conv2d_backprop_filter with SAME padding (reference call sites:
+// mnist/ops.py:62,78; cifar10/common/ops/conv2d.py:181-187).
 #include "common.h"
 #include <type_traits>
 
