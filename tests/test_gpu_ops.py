@@ -61,7 +61,27 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+def _random_conv_cases(count=36, seed=2024):
+    """Seeded sweep over shapes the fixed list does not pin down: odd / non-square sizes, channel counts that are not
+    multiples of 2, 4 or 8 (scalar / 8-byte / 16-byte operand loads, runs of 8 that straddle two filter taps), 1x1 / 3x3 /
+    5x5 filters at stride 1 and 2 (parity-class data gradient, narrow outputs), folded ReLU."""
+    rs = np.random.RandomState(seed)
+    chans = [1, 2, 3, 5, 8, 9, 10, 12, 16, 20, 33, 64, 70, 138]
+    cases = []
+    while len(cases) < count:
+        k = int(rs.choice([1, 3, 5]))
+        s = int(rs.choice([1, 2]))
+        h, w = int(rs.randint(2, 15)), int(rs.randint(2, 15))
+        cin, cout = int(rs.choice(chans)), int(rs.choice(chans))
+        n = int(rs.randint(1, 5))
+        relu = bool(rs.randint(2))
+        if n * h * w * cin * cout * k * k > 3e7:
+            continue
+        cases.append((n, h, w, cin, cout, k, s, False, relu))
+    return cases
+
+
+@pytest.mark.parametrize("case", CONV_CASES + _random_conv_cases())
 def test_conv2d_fwd_bwd(dev, case):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
