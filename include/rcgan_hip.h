@@ -139,6 +139,12 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
  * Replaces tf.nn.conv2d_backprop_filter + BiasAddGrad. */
 int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
                             float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
+/* The filter gradients of `n` layers in one call (all x / dy available: the end of a backward pass).  Same results as n
+ * rcgan_conv2d_bwd_weight calls; the layers the three-tap matrix-core kernel takes share ONE launch (+ one slab reduction):
+ * the discriminator's 8x8 / 16x16 layers are launch-latency-bound one by one.  dbiases[i] may be NULL.
+ * ws: at least twice the largest rcgan_conv2d_workspace_bytes of the layers plus the sum of their slab sizes. */
+int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* xs, const void* const* dys,
+                                  float* const* dws, float* const* dbiases, int accumulate, void* ws, size_t ws_bytes);
 
 /* Transposed convolution, filter [kh][kw][Cout][Cin] used as-is (no preparation, fp32).
  * d describes the *forward conv* it is the gradient of: n,h,w,cin = deconv OUTPUT (n,H,W,Cout_deconv),

@@ -34,6 +34,23 @@ __global__ void slab_reduce2_kernel(const float* slab, long stride, float* out, 
   *o = s;
 }
 
+// the same reduction for several filter gradients in one launch (blockIdx.y = problem)
+#define REDUCE_GROUP_MAX 12
+struct SlabReduceGroup {
+  struct Item { const float* slab; long stride; float* out; long count; float* bias_out; int nbias, nz, accumulate; } it[REDUCE_GROUP_MAX];
+};
+__global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
+  const SlabReduceGroup::Item& r = g.it[blockIdx.y];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r.count + r.nbias) return;
+  float s = 0.f;
+#pragma unroll 4
+  for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + i];
+  float* o = i < r.count ? r.out + i : r.bias_out + (i - r.count);
+  if (r.accumulate) s += *o;
+  *o = s;
+}
+
 __global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
                                float beta2, float eps, float clip, float grad_scale) {
   // the arithmetic form of TF's ApplyAdam kernel: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
@@ -480,6 +497,75 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     RC_DISPATCH_DTYPE(ctx, d->dtype, return small_wgrad<T>(ctx, d, kind, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
   }
   RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_wgrad<T>(ctx, d, (const T*)x, (const T*)dy, dw, dbias, accumulate, ws, ws_bytes));
+  return RCGAN_OK;
+}
+
+// Filter gradients of several layers whose x / dy are all available (the end of a backward pass): the layers the
+// three-tap matrix-core kernel takes run as ONE grouped launch per input-ReLU flavour + ONE grouped slab reduction; every
+// other layer goes through rcgan_conv2d_bwd_weight as usual.
+int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* xs, const void* const* dys,
+                                  float* const* dws, float* const* dbiases, int accumulate, void* ws, size_t ws_bytes) {
+  RC_REQUIRE(ctx, n >= 0 && (n == 0 || (descs && xs && dys && dws && dbiases)), "null argument");
+  std::vector<MfmaWgradArgs> args[2];
+  std::vector<unsigned> gxs[2], gys[2];
+  std::vector<SlabReduceGroup::Item> red;
+  size_t used = 0;
+  for (int i = 0; i < n; ++i) {
+    const rcgan_conv_desc* d = descs + i;
+    int rc = check_desc(ctx, d);
+    if (rc) return rc;
+    bool grouped = false;
+    if (mfma_wgrad_eligible(d)) {
+      rc = ensure_selftest(ctx);
+      if (rc) return rc;
+      MfmaWgradArgs a;
+      int oh, ow, pt, pl;
+      same_pad(d->h, d->kh, 1, &oh, &pt);
+      same_pad(d->w, d->kw, 1, &ow, &pl);
+      a.x = (const bf16_t*)xs[i]; a.dy = (const bf16_t*)dys[i];
+      a.zero = (const bf16_t*)ctx->zero_page;
+      a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
+      a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+      a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+      a.use_tr = g_use_tr;
+      a.M = (long)d->n * d->h * d->w;
+      a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
+      if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
+      const int nz = mfma_wgrad_splits(d, a.M);
+      const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
+      a.slab_stride = cnt + d->cout;
+      a.want_bias = dbiases[i] ? 1 : 0;
+      unsigned gx = 0, gy = 0;
+      const size_t need = (size_t)nz * a.slab_stride * sizeof(float);
+      if (mfma_wgrad3_plan(a, nz, &gx, &gy) && used + need <= ws_bytes / 2) {
+        a.slab = (float*)((char*)ws + used);
+        used += (need + 255) / 256 * 256;
+        const int f = a.relu_in ? 1 : 0;
+        args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
+        SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate};
+        red.push_back(it);
+        grouped = true;
+      }
+    }
+    if (!grouped) {          // its own launches, with the workspace half the grouped slabs do not use
+      rc = rcgan_conv2d_bwd_weight(ctx, d, xs[i], dys[i], dws[i], dbiases[i], accumulate, (char*)ws + ws_bytes / 2, ws_bytes - ws_bytes / 2);
+      if (rc) return rc;
+    }
+  }
+  for (int f = 0; f < 2; ++f)
+    if (!args[f].empty()) {
+      int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data());
+      if (rc) return rc;
+    }
+  for (size_t i0 = 0; i0 < red.size(); i0 += REDUCE_GROUP_MAX) {
+    SlabReduceGroup g;
+    const int m = (int)((red.size() - i0 < REDUCE_GROUP_MAX) ? red.size() - i0 : REDUCE_GROUP_MAX);
+    long maxc = 0;
+    for (int q = 0; q < m; ++q) { g.it[q] = red[i0 + q]; if (g.it[q].count + g.it[q].nbias > maxc) maxc = g.it[q].count + g.it[q].nbias; }
+    for (int q = m; q < REDUCE_GROUP_MAX; ++q) g.it[q] = red[i0];
+    hipLaunchKernelGGL(slab_reduce2_group_kernel, dim3(cdiv(maxc, 256), m), dim3(256), 0, ctx->stream, g);
+    RC_LAUNCH_CHECK(ctx);
+  }
   return RCGAN_OK;
 }
 

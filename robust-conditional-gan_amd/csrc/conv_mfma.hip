@@ -738,21 +738,21 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
 }
 
 template <int NS, bool RELU>
-__global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) {
+__device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsigned bx, const unsigned by) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int XT = 40 * 128, YT = 32 * 256, STAGE = XT + YT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wo = wave >> 1;
   const int nci = a.Cin / 64, nco = a.Cout / 128;
-  const long mb = (long)blockIdx.y * a.m_chunk;
+  const long mb = (long)by * a.m_chunk;
   long me = mb + a.m_chunk;
   if (me > a.M) me = a.M;
-  if ((int)blockIdx.x >= a.KH * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
-    wgrad_bias_block<NS>(a, smem, (int)blockIdx.x - a.KH * nci * nco, mb, me, a.slab + (long)blockIdx.y * a.slab_stride);
+  if ((int)bx >= a.KH * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
+    wgrad_bias_block<NS>(a, smem, (int)bx - a.KH * nci * nco, mb, me, a.slab + (long)by * a.slab_stride);
     return;
   }
-  int b = blockIdx.x;
+  int b = (int)bx;
   const int cot = b % nco; b /= nco;
   const int cit = b % nci; b /= nci;
   const int kh = b;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
     }
   }
   // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
-  float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
+  float* slab = a.slab + (long)by * a.slab_stride;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -894,6 +894,35 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
         float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
         *(float4*)(slab + ((long)(kh * 3 + t) * a.Cin + ci) * a.Cout + co) = v;
       }
+}
+
+
+template <int NS, bool RELU>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) {
+  wgrad3_body<NS, RELU>(a, blockIdx.x, blockIdx.y);
+}
+
+// Several layers' filter gradients in ONE launch: workgroup b belongs to the problem p with first[p] <= b < first[p+1]
+// and plays (b - first[p]) % gx[p], (b - first[p]) / gx[p] of that problem's own grid.  The 8x8 / 16x16 discriminator layers
+// launch 224..602 workgroups each and are latency-bound alone; together their workgroups share the CUs (3 fit per CU).
+#define WGRAD_GROUP_MAX 12
+struct WgradGroup {
+  int n;
+  unsigned first[WGRAD_GROUP_MAX + 1];
+  unsigned gx[WGRAD_GROUP_MAX];
+  MfmaWgradArgs a[WGRAD_GROUP_MAX];
+};
+
+template <int NS, bool RELU>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup g) {
+  const unsigned b = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < WGRAD_GROUP_MAX; ++q)
+    if (q < g.n && b >= g.first[q]) p = q;
+  const unsigned l = b - g.first[p];
+  const unsigned gxp = g.gx[p];
+  wgrad3_body<NS, RELU>(g.a[p], l % gxp, l / gxp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1179,6 +1208,57 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
   }
   RC_LAUNCH_CHECK(ctx);
   return nzz;
+}
+
+// the three-tap kernel's plan for one problem (also what mfma_wgrad_launch does): grid and pixel chunk, or false
+bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy) {
+  if (!(wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1)) return false;
+  long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
+  int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
+  if (want > nz) want = nz;
+  a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
+  *gx = (unsigned)(tiles3 + (a.want_bias ? a.Cout / 128 : 0));
+  *gy = (unsigned)cdiv(a.M, a.m_chunk);
+  return true;
+}
+
+template <bool RELU>
+static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
+  constexpr int NS = 4;
+  static bool attr = false;
+  size_t lds = (size_t)NS * (40 * 128 + 32 * 256);
+  if (!attr) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad3_group_kernel<NS, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  double fl = 0;
+  for (int p = 0; p < g.n; ++p) fl += 2.0 * (double)g.a[p].M * g.a[p].KH * g.a[p].KW * g.a[p].Cin * g.a[p].Cout;
+  {
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl);
+    hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.first[g.n]), dim3(256), lds, ctx->stream, g);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// args[i] planned by mfma_wgrad3_plan (gx, gy); all with the same relu_in
+int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy) {
+  for (int i0 = 0; i0 < n; i0 += WGRAD_GROUP_MAX) {
+    WgradGroup g;
+    g.n = (n - i0 < WGRAD_GROUP_MAX) ? n - i0 : WGRAD_GROUP_MAX;
+    unsigned tot = 0;
+    for (int p = 0; p < g.n; ++p) {
+      g.a[p] = args[i0 + p];
+      g.gx[p] = gx[i0 + p];
+      g.first[p] = tot;
+      tot += gx[i0 + p] * gy[i0 + p];
+    }
+    for (int p = g.n; p <= WGRAD_GROUP_MAX; ++p) g.first[p] = tot;
+    for (int p = g.n; p < WGRAD_GROUP_MAX; ++p) { g.gx[p] = 1; g.a[p] = args[i0]; }
+    int rc = args[i0].relu_in ? launch_wgrad3_group<true>(ctx, g) : launch_wgrad3_group<false>(ctx, g);
+    if (rc) return rc;
+  }
+  return RCGAN_OK;
 }
 
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout) {

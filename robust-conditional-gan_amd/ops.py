@@ -144,6 +144,7 @@ def spectral_norm_batch(ctx, entries):
                 off += (w.param.size + 63) // 64 * 64
 
     def bw():
+        ctx.flush_wgrads()          # the deferred filter gradients write the dW_bar this closure consumes
         todo = [(w, s) for w, s in zip(weights, saves) if w.dwbar is not None and w.param.req]
         if not todo:
             return
@@ -201,7 +202,14 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
             # filter gradient and data gradient only share their inputs: run them side by side on two streams (most
             # layers of these nets leave the chip half empty); the filter gradient gets its own workspace
             fork = bool(xr and wr and ctx.overlap)
-            if wr:
+            defer = bool(wr and ctx.group_wgrads and not fork and x.dtype != L.F32)
+            if wr and defer:
+                # computed with the other layers' filter gradients in one grouped launch (Context.flush_wgrads: before the
+                # spectral-norm backward reads dW_bar, at the latest at the end of the backward pass).  x is a forward
+                # activation and dy is final here; the one place that would write into dy later is the residual adoption
+                # below, which copies instead when this layer's gradient is deferred
+                ctx.defer_wgrad(desc, x, dy, weight.grad_target(), bias.grad if br else None)
+            elif wr:
                 dw = weight.grad_target()
                 if fork:
                     ctx.check(ctx.lib.rcgan_side_begin(ctx.h))
@@ -220,8 +228,11 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
             if residual is not None and residual.req:
                 # d(residual) = dy.  dy is dead after this closure: a residual without a gradient yet adopts the
                 # buffer (later contributions accumulate into it in place), otherwise one accumulate
-                if residual.grad is None:
+                if residual.grad is None and not defer:
                     residual.grad = dy
+                elif residual.grad is None:
+                    residual.grad = ctx.empty(residual.shape, residual.dtype)        # dy must survive until flush_wgrads
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, residual.size, residual.dtype, 1.0, _p(dy), 0.0, _p(residual.grad)))
                 else:
                     ctx.check(ctx.lib.rcgan_axpby(ctx.h, residual.size, residual.dtype, 1.0, _p(dy), 1.0, _p(residual.grad)))
         ctx.record(bw)

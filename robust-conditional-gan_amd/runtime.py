@@ -128,6 +128,8 @@ class Context:
         self.ws2 = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device) if self.overlap else None
         self.ws2_ptr = self.ws2.data_ptr() if self.overlap else 0
         self.tape = []
+        self.pending_wgrads = []
+        self.group_wgrads = os.environ.get("RCGAN_GROUP_WGRAD", "1") == "1"     # see defer_wgrad
         self.recording = True
         self._keep = []
         self.check(self.lib.rcgan_selftest(self.h))
@@ -213,9 +215,28 @@ class Context:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.flush_wgrads()
+
+    # ------------------------------------------------------------------ grouped filter gradients
+    def defer_wgrad(self, desc, x, dy, dw, dbias):
+        """Queue one conv layer's filter gradient; flush_wgrads() computes all queued ones in one grouped call.
+        The caller guarantees x and dy stay untouched until then."""
+        self.pending_wgrads.append((desc, x, dy, dw, dbias))
+
+    def flush_wgrads(self):
+        pend = self.pending_wgrads
+        if not pend:
+            return
+        self.pending_wgrads = []
+        n = len(pend)
+        descs = (L.ConvDesc * n)(*[p[0] for p in pend])
+        arr = lambda k: (C.c_void_p * n)(*[(p[k].ptr if p[k] is not None else None) for p in pend])
+        xs, dys, dws, dbs = arr(1), arr(2), arr(3), arr(4)
+        self.check(self.lib.rcgan_conv2d_bwd_weight_group(self.h, n, descs, xs, dys, dws, dbs, 1, C.c_void_p(self.ws_ptr), self.ws_bytes))
 
     def new_step(self):
         self.tape = []
+        self.pending_wgrads = []
         self.arena.reset()
 
     # ------------------------------------------------------------------ graphs

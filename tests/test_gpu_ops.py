@@ -542,3 +542,42 @@ def test_rng_and_graph_replay(dev):
     ctx.graph_launch(gid)
     b = ctx.download(buf).copy()
     assert not np.array_equal(a, b) and not np.array_equal(a, z)
+
+
+def test_grouped_filter_gradients_equal_single_calls():
+    """rcgan_conv2d_bwd_weight_group == one rcgan_conv2d_bwd_weight per layer, bit for bit: the grouped launch runs every
+    layer's own grid inside one kernel (plus one grouped slab reduction); layers the three-tap kernel does not take (here
+    the 3-channel and the 1x1 layer) fall back to their own launches inside the call."""
+    import ctypes as C
+    from rcgan_amd import _lib as L
+    ctx = make_ctx("bf16")
+    try:
+        lib, h = ctx.lib, ctx.h
+        ctx.new_step()
+        shapes = [(128, 8, 8, 128, 128, 3, L.CONV_IN_RELU), (16, 16, 16, 128, 128, 3, L.CONV_IN_RELU), (6, 8, 8, 256, 128, 3, 0),
+                  (4, 32, 32, 3, 128, 3, 0), (8, 8, 8, 128, 128, 1, 0), (3, 32, 32, 128, 256, 3, L.CONV_IN_RELU)]
+        items = []
+        for i, (n, hh, ww, cin, cout, k, fl) in enumerate(shapes):
+            x, dy = ctx.empty((n, hh, ww, cin)), ctx.empty((n, hh, ww, cout))
+            ctx.check(lib.rcgan_rng_fill(h, x.size, x.dtype, 1, 0.0, 1.0, 100 + i, None, C.c_void_p(x.ptr)))
+            ctx.check(lib.rcgan_rng_fill(h, dy.size, dy.dtype, 1, 0.0, 1.0, 200 + i, None, C.c_void_p(dy.ptr)))
+            dws = [ctx.zeros((k, k, cin, cout), L.F32) for _ in range(2)]
+            dbs = [ctx.zeros((cout,), L.F32) for _ in range(2)] if i % 2 == 0 else [None, None]
+            items.append((L.ConvDesc(n, hh, ww, cin, cout, k, k, 1, L.BF16, fl), x, dy, dws, dbs))
+        ws, wsb = C.c_void_p(ctx.ws_ptr), ctx.ws_bytes
+        for d, x, dy, dws, dbs in items:
+            ctx.check(lib.rcgan_conv2d_bwd_weight(h, C.byref(d), C.c_void_p(x.ptr), C.c_void_p(dy.ptr), C.c_void_p(dws[0].ptr),
+                                                  C.c_void_p(dbs[0].ptr) if dbs[0] else None, 1, ws, wsb))
+        n = len(items)
+        descs = (L.ConvDesc * n)(*[it[0] for it in items])
+        arr = lambda f: (C.c_void_p * n)(*[f(it) for it in items])
+        ctx.check(lib.rcgan_conv2d_bwd_weight_group(h, n, descs, arr(lambda it: it[1].ptr), arr(lambda it: it[2].ptr),
+                                                    arr(lambda it: it[3][1].ptr), arr(lambda it: it[4][1].ptr if it[4][1] else None),
+                                                    1, ws, wsb))
+        for i, (d, x, dy, dws, dbs) in enumerate(items):
+            a, b = ctx.download(dws[0]), ctx.download(dws[1])
+            assert np.abs(a).max() > 0 and np.array_equal(a, b), "layer %d filter gradient" % i
+            if dbs[0] is not None:
+                assert np.array_equal(ctx.download(dbs[0]), ctx.download(dbs[1])), "layer %d bias gradient" % i
+    finally:
+        ctx.close()
