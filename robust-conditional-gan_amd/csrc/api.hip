@@ -506,49 +506,69 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
 int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* xs, const void* const* dys,
                                   float* const* dws, float* const* dbiases, int accumulate, void* ws, size_t ws_bytes) {
   RC_REQUIRE(ctx, n >= 0 && (n == 0 || (descs && xs && dys && dws && dbiases)), "null argument");
+  static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 512; }();
+  std::vector<MfmaWgradArgs> cand(n);
+  std::vector<char> takes(n, 0);
+  // pass 1: which layers the grouped kernel takes, and the pixels per workgroup that gives ~target_blocks workgroups in all
+  double work = 0;
+  for (int i = 0; i < n; ++i) {
+    const rcgan_conv_desc* d = descs + i;
+    int rc = check_desc(ctx, d);
+    if (rc) return rc;
+    if (!mfma_wgrad_eligible(d)) continue;
+    rc = ensure_selftest(ctx);
+    if (rc) return rc;
+    MfmaWgradArgs& a = cand[i];
+    int oh, ow, pt, pl;
+    same_pad(d->h, d->kh, 1, &oh, &pt);
+    same_pad(d->w, d->kw, 1, &ow, &pl);
+    a.x = (const bf16_t*)xs[i]; a.dy = (const bf16_t*)dys[i]; a.slab = nullptr;
+    a.zero = (const bf16_t*)ctx->zero_page;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
+    a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    a.use_tr = g_use_tr;
+    a.M = (long)d->n * d->h * d->w;
+    a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
+    if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
+    a.slab_stride = (long)d->kh * d->kw * d->cin * d->cout + d->cout;
+    a.want_bias = dbiases[i] ? 1 : 0;
+    if (mfma_wgrad3_takes(a)) {
+      takes[i] = 1;
+      work += (double)a.M * a.KH * (a.Cin / 64) * (a.Cout / 128);
+    }
+  }
+  long px = (long)(work / target_blocks);
+  px = (px + 63) / 64 * 64;
+  if (px < 256) px = 256;
+  // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
   std::vector<MfmaWgradArgs> args[2];
   std::vector<unsigned> gxs[2], gys[2];
   std::vector<SlabReduceGroup::Item> red;
   size_t used = 0;
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
-    int rc = check_desc(ctx, d);
-    if (rc) return rc;
     bool grouped = false;
-    if (mfma_wgrad_eligible(d)) {
-      rc = ensure_selftest(ctx);
-      if (rc) return rc;
-      MfmaWgradArgs a;
-      int oh, ow, pt, pl;
-      same_pad(d->h, d->kh, 1, &oh, &pt);
-      same_pad(d->w, d->kw, 1, &ow, &pl);
-      a.x = (const bf16_t*)xs[i]; a.dy = (const bf16_t*)dys[i];
-      a.zero = (const bf16_t*)ctx->zero_page;
-      a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
-      a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
-      a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
-      a.use_tr = g_use_tr;
-      a.M = (long)d->n * d->h * d->w;
-      a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
-      if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
+    if (takes[i]) {
+      MfmaWgradArgs a = cand[i];
       const int nz = mfma_wgrad_splits(d, a.M);
-      const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-      a.slab_stride = cnt + d->cout;
-      a.want_bias = dbiases[i] ? 1 : 0;
       unsigned gx = 0, gy = 0;
-      const size_t need = (size_t)nz * a.slab_stride * sizeof(float);
-      if (mfma_wgrad3_plan(a, nz, &gx, &gy) && used + need <= ws_bytes / 2) {
-        a.slab = (float*)((char*)ws + used);
-        used += (need + 255) / 256 * 256;
-        const int f = a.relu_in ? 1 : 0;
-        args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
-        SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate};
-        red.push_back(it);
-        grouped = true;
+      if (mfma_wgrad3_plan(a, nz, &gx, &gy, px)) {
+        const size_t need = ((size_t)gy * a.slab_stride * sizeof(float) + 255) / 256 * 256;
+        if (used + need <= ws_bytes / 2) {
+          a.slab = (float*)((char*)ws + used);
+          used += need;
+          const int f = a.relu_in ? 1 : 0;
+          args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
+          const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
+          SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate};
+          red.push_back(it);
+          grouped = true;
+        }
       }
     }
     if (!grouped) {          // its own launches, with the workspace half the grouped slabs do not use
-      rc = rcgan_conv2d_bwd_weight(ctx, d, xs[i], dys[i], dws[i], dbiases[i], accumulate, (char*)ws + ws_bytes / 2, ws_bytes - ws_bytes / 2);
+      int rc = rcgan_conv2d_bwd_weight(ctx, d, xs[i], dys[i], dws[i], dbiases[i], accumulate, (char*)ws + ws_bytes / 2, ws_bytes - ws_bytes / 2);
       if (rc) return rc;
     }
   }

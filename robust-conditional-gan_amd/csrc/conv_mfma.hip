@@ -1211,11 +1211,19 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
 }
 
 // the three-tap kernel's plan for one problem (also what mfma_wgrad_launch does): grid and pixel chunk, or false
-bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy) {
+bool mfma_wgrad3_takes(const MfmaWgradArgs& a) {
+  return wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1;
+}
+
+bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block) {
   if (!(wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1)) return false;
   long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
-  int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
+  // pixel chunks: alone, enough of them for ~512 workgroups; in a group the caller fixes the pixels per workgroup for all
+  // layers (equal workgroup run times, and far fewer fp32 slabs to write and reduce than 512 workgroups per layer)
+  int want = px_per_block > 0 ? (int)wgrad_clamp_splits(cdiv(a.M, px_per_block), a.M)
+                              : (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
   if (want > nz) want = nz;
+  if (want < 1) want = 1;
   a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
   *gx = (unsigned)(tiles3 + (a.want_bias ? a.Cout / 128 : 0));
   *gy = (unsigned)cdiv(a.M, a.m_chunk);

@@ -545,9 +545,10 @@ def test_rng_and_graph_replay(dev):
 
 
 def test_grouped_filter_gradients_equal_single_calls():
-    """rcgan_conv2d_bwd_weight_group == one rcgan_conv2d_bwd_weight per layer, bit for bit: the grouped launch runs every
-    layer's own grid inside one kernel (plus one grouped slab reduction); layers the three-tap kernel does not take (here
-    the 3-channel and the 1x1 layer) fall back to their own launches inside the call."""
+    """rcgan_conv2d_bwd_weight_group == one rcgan_conv2d_bwd_weight per layer: the grouped launch runs every layer's grid
+    inside one kernel (plus one grouped slab reduction), with the pixels per workgroup chosen for the group as a whole, so
+    the fp32 partial sums are cut differently (1e-6 relative); layers the three-tap kernel does not take (here the
+    3-channel and the 1x1 layer) go through their own launches inside the call and are bit-identical."""
     import ctypes as C
     from rcgan_amd import _lib as L
     ctx = make_ctx("bf16")
@@ -576,8 +577,13 @@ def test_grouped_filter_gradients_equal_single_calls():
                                                     1, ws, wsb))
         for i, (d, x, dy, dws, dbs) in enumerate(items):
             a, b = ctx.download(dws[0]), ctx.download(dws[1])
-            assert np.abs(a).max() > 0 and np.array_equal(a, b), "layer %d filter gradient" % i
+            assert np.abs(a).max() > 0
+            own = d.kh != 3 or d.cin % 128 != 0
+            if own:
+                assert np.array_equal(a, b), "layer %d filter gradient" % i
+            else:
+                assert_close(b, a, 2e-6, "layer %d filter gradient" % i)
             if dbs[0] is not None:
-                assert np.array_equal(ctx.download(dbs[0]), ctx.download(dbs[1])), "layer %d bias gradient" % i
+                assert_close(ctx.download(dbs[1]), ctx.download(dbs[0]), 2e-6, "layer %d bias gradient" % i)
     finally:
         ctx.close()
