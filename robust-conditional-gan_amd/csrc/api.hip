@@ -538,9 +538,11 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       work += (double)a.M * a.KH * (a.Cin / 64) * (a.Cout / 128);
     }
   }
+  static const int px_max = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_PXMAX"); return e ? atoi(e) : 6144; }();
   long px = (long)(work / target_blocks);
   px = (px + 63) / 64 * 64;
   if (px < 256) px = 256;
+  if (px > px_max) px = px_max;      // big groups (the generator step): more workgroups rather than ever longer ones
   // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
   std::vector<MfmaWgradArgs> args[2];
   std::vector<unsigned> gxs[2], gys[2];
