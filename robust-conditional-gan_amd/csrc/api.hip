@@ -544,23 +544,24 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   if (px < 256) px = 256;
   if (px > px_max) px = px_max;      // big groups (the generator step): more workgroups rather than ever longer ones
   // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
-  std::vector<MfmaWgradArgs> args[2];
-  std::vector<unsigned> gxs[2], gys[2];
+  std::vector<MfmaWgradArgs> args[3];            // three-tap kernel without / with input ReLU, per-tap kernel
+  std::vector<unsigned> gxs[3], gys[3];
   std::vector<SlabReduceGroup::Item> red;
   size_t used = 0;
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
     bool grouped = false;
-    if (takes[i]) {
+    if (mfma_wgrad_eligible(d)) {
       MfmaWgradArgs a = cand[i];
       const int nz = mfma_wgrad_splits(d, a.M);
       unsigned gx = 0, gy = 0;
-      if (mfma_wgrad3_plan(a, nz, &gx, &gy, px)) {
+      const bool three = takes[i] && mfma_wgrad3_plan(a, nz, &gx, &gy, px);
+      if (three || mfma_wgrad_tap_plan(a, nz, &gx, &gy)) {
         const size_t need = ((size_t)gy * a.slab_stride * sizeof(float) + 255) / 256 * 256;
         if (used + need <= ws_bytes / 2) {
           a.slab = (float*)((char*)ws + used);
           used += need;
-          const int f = a.relu_in ? 1 : 0;
+          const int f = three ? (a.relu_in ? 1 : 0) : 2;
           args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
           const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
           SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate};
@@ -574,9 +575,9 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       if (rc) return rc;
     }
   }
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < 3; ++f)
     if (!args[f].empty()) {
-      int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data());
+      int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data(), f == 2 ? 1 : 0);
       if (rc) return rc;
     }
   for (size_t i0 = 0; i0 < red.size(); i0 += REDUCE_GROUP_MAX) {

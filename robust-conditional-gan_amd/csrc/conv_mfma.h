@@ -42,7 +42,8 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
 bool mfma_wgrad3_takes(const MfmaWgradArgs& a);
-int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy);
+int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family);
+bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);

@@ -550,7 +550,7 @@ __device__ __forceinline__ bf16x8_t frag_tr_swz(const unsigned char* tile, int r
 }
 
 template <int NS>
-__global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs a) {
+__device__ __forceinline__ void wgrad_glds_body(const MfmaWgradArgs& a, const unsigned bx, const unsigned by) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = 32 * 256;                 // bytes per operand per stage: 32 pixels x 128 channels
   constexpr int STAGE = 2 * TILE;
@@ -558,13 +558,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wo = wave >> 1;
   const int nci = a.Cin / 128, nco = a.Cout / 128;
-  int b = blockIdx.x;
+  int b = (int)bx;
   const int cot = b % nco; b /= nco;
   const int cit = b % nci; b /= nci;
   const int tap = b;
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int ci0 = cit * 128, co0 = cot * 128;
-  const long mb = (long)blockIdx.y * a.m_chunk;
+  const long mb = (long)by * a.m_chunk;
   long me = mb + a.m_chunk;
   if (me > a.M) me = a.M;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
         acc[i][j] = mfma16(yf[i], xf[j], acc[i][j]);
     if (++buf == NS) buf = 0;
   }
-  float* slab = a.slab + (long)blockIdx.y * a.slab_stride;
+  float* slab = a.slab + (long)by * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -664,6 +664,11 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs
     for (int i = 0; i < 4; ++i)
       *(float4*)(bs + co0 + wo * 64 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
   }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_kernel(MfmaWgradArgs a) {
+  wgrad_glds_body<NS>(a, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -923,6 +928,19 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup 
   const unsigned l = b - g.first[p];
   const unsigned gxp = g.gx[p];
   wgrad3_body<NS, RELU>(g.a[p], l % gxp, l / gxp);
+}
+
+// the same grouping for the per-tap kernel (1x1 shortcuts and the shapes the three-tap kernel does not take)
+template <int NS>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_group_kernel(WgradGroup g) {
+  const unsigned b = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < WGRAD_GROUP_MAX; ++q)
+    if (q < g.n && b >= g.first[q]) p = q;
+  const unsigned l = b - g.first[p];
+  const unsigned gxp = g.gx[p];
+  wgrad_glds_body<NS>(g.a[p], l % gxp, l / gxp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1249,8 +1267,37 @@ static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
   return RCGAN_OK;
 }
 
-// args[i] planned by mfma_wgrad3_plan (gx, gy); all with the same relu_in
-int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy) {
+static int launch_wgrad_glds_group(rcgan_ctx* ctx, const WgradGroup& g) {
+  constexpr int NS = 4;
+  static bool attr = false;
+  size_t lds = (size_t)NS * 2 * 32 * 256;
+  if (!attr) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad_glds_group_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  double fl = 0;
+  for (int p = 0; p < g.n; ++p) fl += 2.0 * (double)g.a[p].M * g.a[p].KH * g.a[p].KW * g.a[p].Cin * g.a[p].Cout;
+  {
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl);
+    hipLaunchKernelGGL(conv_mfma_wgrad_glds_group_kernel<NS>, dim3(g.first[g.n]), dim3(256), lds, ctx->stream, g);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// the per-tap kernel's plan for one problem inside a group (its own pixel chunking rule, as mfma_wgrad_launch)
+bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy) {
+  static int wg_glds = -1;
+  if (wg_glds < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); wg_glds = (e && e[0] == 'r') ? 0 : 1; }
+  if (!(wg_glds == 1 && a.zero != nullptr && a.Cin % 128 == 0 && a.Cout % 128 == 0)) return false;
+  a.m_chunk = ((a.M + nz - 1) / nz + 63) / 64 * 64;
+  *gx = (unsigned)(a.KH * a.KW * (a.Cin / 128) * (a.Cout / 128));
+  *gy = (unsigned)cdiv(a.M, a.m_chunk);
+  return true;
+}
+
+// args[i] planned by mfma_wgrad3_plan (family 0; all with the same relu_in) or mfma_wgrad_tap_plan (family 1)
+int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family) {
   for (int i0 = 0; i0 < n; i0 += WGRAD_GROUP_MAX) {
     WgradGroup g;
     g.n = (n - i0 < WGRAD_GROUP_MAX) ? n - i0 : WGRAD_GROUP_MAX;
@@ -1263,7 +1310,8 @@ int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, c
     }
     for (int p = g.n; p <= WGRAD_GROUP_MAX; ++p) g.first[p] = tot;
     for (int p = g.n; p < WGRAD_GROUP_MAX; ++p) { g.gx[p] = 1; g.a[p] = args[i0]; }
-    int rc = args[i0].relu_in ? launch_wgrad3_group<true>(ctx, g) : launch_wgrad3_group<false>(ctx, g);
+    int rc = family == 1 ? launch_wgrad_glds_group(ctx, g)
+                         : (args[i0].relu_in ? launch_wgrad3_group<true>(ctx, g) : launch_wgrad3_group<false>(ctx, g));
     if (rc) return rc;
   }
   return RCGAN_OK;
