@@ -5,6 +5,7 @@ Host-side mirror of /root/reference mnist/model.py: generator :705-731, gen_samp
 (one D run, then TWO G runs on the same batch).  The reference's five logging-only ``.eval()`` passes per
 iteration (:374-398), which also mutate BN moving averages and SN ``u``, are not executed.
 """
+import os
 import time
 
 import numpy as np
@@ -136,6 +137,8 @@ class MnistRCGAN:
         self.d_bn1, self.d_bn2, self.d_bn3 = batch_norm(name='d_bn1'), batch_norm(name='d_bn2'), batch_norm(name='d_bn3')
         self.g_bn0, self.g_bn1, self.g_bn2 = batch_norm(name='g_bn0'), batch_norm(name='g_bn1'), batch_norm(name='g_bn2')
         self._graphs = {}
+        self.fuse_first_g = os.environ.get("RCGAN_MNIST_FUSE_G", "1") == "1"       # see _d_body_keep
+        self._fused_ready = False
         # clip range of the max_norm constraint inside the D slab
         self.clip_range = None
         if self.max_norm:
@@ -305,8 +308,7 @@ class MnistRCGAN:
             from .dp import allreduce_sum_
             allreduce_sum_(group.grad, self.ctx.stream)
 
-    def d_step(self):
-        self._run("d", self._d_body)
+    def _d_update(self):
         self._allreduce(self.PD)
         self.PD.t += 1
         self.PD.set_hyper(self.lr, self.PD.t)
@@ -319,8 +321,7 @@ class MnistRCGAN:
             self.PD.adam(self.beta1, 0.999, grad_scale=gs, clip=1.0, lo=lo, hi=hi)
             self.PD.adam(self.beta1, 0.999, grad_scale=gs, lo=hi, hi=self.PD.count)
 
-    def g_step(self):
-        self._run("g", self._g_body)
+    def _g_update(self):
         self._allreduce(self.PG)
         self.PG.t += 1
         self.PG.set_hyper(self.lr, self.PG.t)
@@ -331,11 +332,103 @@ class MnistRCGAN:
             self.PC.set_hyper(self.lr * self.confuse_multiplier, self.PC.t)
             self.PC.adam(self.beta1, 0.999, grad_scale=1.0 / self.world)
 
+    def d_step(self):
+        self._run("d", self._d_body)
+        self._d_update()
+
+    def g_step(self):
+        self._run("g", self._g_body)
+        self._g_update()
+
+    # The D update does not touch the generator, so the first generator step of an iteration (model.py:347-372: D once, then G
+    # twice on the SAME z / y_gen) would recompute exactly the forward pass the D step just ran.  The fused iteration runs
+    # that forward once: the D step records it on the tape and keeps its activations (the arena is not reset in between),
+    # the first G step only runs the (updated) discriminator on the kept images and back-propagates through the kept tape.
+    # The generator's batch-norm moving averages receive the two identical updates the reference applies as one update
+    # with the decay squared.
+    def _d_body_keep(self):
+        ctx, g, inp = self.ctx, self.graph, self.inp
+        ctx.new_step()
+        g.begin_step({0, 1})
+        bns = (self.g_bn0, self.g_bn1, self.g_bn2)
+        keep = [b.momentum for b in bns]
+        for b in bns:
+            b.momentum = b.momentum * b.momentum
+        try:
+            G = self.generator(inp["z"], inp["y_gen"])                               # taped: generator parameters are trainable
+        finally:
+            for b, m0 in zip(bns, keep):
+                b.momentum = m0
+        n_gen = len(ctx.tape)
+        G.req = False                                                               # this step's backward stops at the images
+        self.PD.zero_grad()
+        self._zero_losses(("d_loss_real", "d_loss_fake", "class_loss_real"))
+        self._sn_prefetch()
+        kr, kf, kg = self._kinds()
+        if self.alg in ("biased", "rcgan", "ambient"):
+            O.loss_term(ctx, kr, self.discriminator(inp["images"], inp["y_real"]), 1.0, self.loss["d_loss_real"])
+        else:
+            logits = self.discriminator_all_labels(inp["images"])
+            O.loss_term(ctx, kr, logits, 1.0, self.loss["d_loss_real"], wts=inp["y_real_weights"])
+        self._fake_branch(G, True)
+        if self.perm:
+            O.bce_onehot_term(ctx, self.classifier(inp["images"]), inp["lab_real"], 1.0, self.loss["class_loss_real"])
+        self._kept = (G, list(ctx.tape[:n_gen]))
+        ctx.tape = ctx.tape[n_gen:]
+        ctx.backward()
+
+    def _g_body_reuse(self):
+        ctx, g, inp = self.ctx, self.graph, self.inp
+        ctx.tape, ctx.pending_wgrads = [], []                                       # NOT new_step(): the arena keeps the D step's tensors
+        g.begin_step({0, 2} if self.PC is not None else {0})
+        self.PG.zero_grad()
+        if self.PC is not None:
+            self.PC.zero_grad()
+        self._zero_losses(("g_loss", "class_loss_fake"))
+        self._sn_prefetch()
+        G, gen_tape = self._kept
+        G.req, G.grad = True, None
+        self._fake_branch(G, False)
+        if self.perm:
+            O.bce_onehot_term(ctx, self.classifier(G), inp["lab_gen"], self.perm_mult, self.loss["class_loss_fake"])
+        ctx.tape = gen_tape + ctx.tape                                              # backward: discriminator first, then the kept generator tape
+        ctx.backward()
+
     def iteration(self):
         """model.py:347-372: D once, G twice on the same fed batch."""
-        self.d_step()
+        if not self.fuse_first_g:
+            self.d_step()
+            self.g_step()
+            self.g_step()
+            return
+        if not self._fused_ready:
+            # first iteration: the plain steps run eagerly once (module loads, LDS attributes) and capture their graphs;
+            # the fused bodies below are then captured WITHOUT an eager rehearsal -- they must execute exactly once per
+            # capture, because the first G step works on tensor objects the D step left behind.  (Same rule without
+            # graphs, so that graph replay and eager execution stay bit-identical.)
+            self.d_step()
+            self.g_step()
+            self.g_step()
+            self._fused_ready = True
+            return
+        self._run_once("d_keep", self._d_body_keep)
+        self._d_update()
+        self._run_once("g_reuse", self._g_body_reuse)
+        self._g_update()
         self.g_step()
-        self.g_step()
+
+    def _run_once(self, key, body):
+        ctx = self.ctx
+        if not self.use_graphs:
+            body()
+            return
+        if key not in self._graphs:
+            ctx.graph_begin()
+            try:
+                body()
+            finally:
+                self._graphs[key] = ctx.graph_end()
+        ctx.graph_launch(self._graphs[key])
 
     # ------------------------------------------------------------------------------------ io
     def set_inputs(self, images=None, z=None, y_real=None, y_fake=None, y_gen=None, y_real_weights=None):

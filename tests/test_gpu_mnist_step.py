@@ -7,7 +7,7 @@ import pytest
 
 from oracle import labels as LB
 from oracle import mnist as om
-from tests.gpu_util import assert_close
+from tests.gpu_util import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -191,3 +191,36 @@ def test_recover_labels_matches_oracle():
             m.recover_labels(images[:2], y_actual[:2], epochs=1)
     finally:
         m.ctx.close()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_fused_iteration_equals_separate_steps(graphs, monkeypatch):
+    """MnistRCGAN.iteration() with the first generator step reusing the D step's generator forward (same z, y_gen and
+    generator weights: model.py:347-372) == d_step(); g_step(); g_step() -- parameters, Adam state through the parameters
+    after three iterations, batch-norm moving averages (two identical updates == one with the decay squared) and losses."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.mnist import MnistRCGAN, create_variables
+    rs = np.random.RandomState(47)
+    B = 8
+    batches = [_batch(rs, B)[1] for _ in range(3)]
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("RCGAN_MNIST_FUSE_G", fuse)
+        variables = create_variables(0, "projection", True, True, True, ())
+        m = MnistRCGAN(algorithm="rcgan", batch_size=B, dtype="f32", estimate_confuse=True, use_graphs=graphs, variables=variables)
+        assert m.fuse_first_g == (fuse == "1")
+        try:
+            for b in batches:
+                m.set_inputs(**b)
+                m.iteration()
+            outs.append((m.get_params(), m.get_state(), m.losses()))
+        finally:
+            m.ctx.close()
+    (pa, sa, la), (pb, sb, lb) = outs
+    for k in pa:
+        assert_close(pb[k], pa[k], 2e-4, "parameter " + k)
+        assert rel_err(pb[k], pa[k]) <= 2e-5, (k, rel_err(pb[k], pa[k]))
+    for k in sa:
+        assert_close(sb[k], sa[k], 1e-5, "state " + k)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(la[k])), (k, la[k], lb[k])
