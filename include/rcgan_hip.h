@@ -135,6 +135,11 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
  * Replaces tf.nn.conv2d_backprop_input (autodiff of the above).  ws: rcgan_conv_workspace_bytes. */
 int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared,
                           const void* x /* needed with IN_RELU */, void* dx, void* ws, size_t ws_bytes);
+/* dx = conv2d_backprop_input(dy) (masked by x > 0 under RCGAN_CONV_IN_RELU) + residual, written out of place: the
+ * accumulate of a second gradient contribution without touching the buffer that holds the first one (needed when that
+ * buffer is still to be read, e.g. by a deferred filter gradient).  residual: [n, h, w, cin], must not alias dx. */
+int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared,
+                                   const void* x /* IN_RELU mask or NULL */, const void* residual, void* dx, void* ws, size_t ws_bytes);
 /* dw (fp32 HWIO) = d(conv)/dw (dw = or += by accumulate), dbias = sum dy (if non-NULL).
  * Replaces tf.nn.conv2d_backprop_filter + BiasAddGrad. */
 int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,

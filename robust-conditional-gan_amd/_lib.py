@@ -78,6 +78,7 @@ SIGNATURES = {
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv2d_fwd_residual": (I, [P, DP, P, P, P, P, P]),
     "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),
+    "rcgan_conv2d_bwd_data_residual": (I, [P, DP, P, P, P, P, P, P, SZ]),
     "rcgan_conv2d_bwd_weight": (I, [P, DP, P, P, P, P, I, P, SZ]),
     "rcgan_conv2d_bwd_weight_group": (I, [P, I, P, P, P, P, P, I, P, SZ]),
     "rcgan_deconv2d_fwd": (I, [P, DP, P, P, P, P]),

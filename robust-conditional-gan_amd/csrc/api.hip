@@ -408,8 +408,21 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
 
 int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, const void* x, void* dx,
                           void* ws, size_t ws_bytes) {
+  return rcgan_conv2d_bwd_data_residual(ctx, d, dy, prepared, x, nullptr, dx, ws, ws_bytes);
+}
+
+int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, const void* x,
+                                   const void* residual, void* dx, void* ws, size_t ws_bytes) {
   int rc = check_desc(ctx, d);
   if (rc) return rc;
+  if (residual != nullptr) {
+    RC_REQUIRE(ctx, residual != dx && !(d->flags & RCGAN_CONV_ACCUMULATE), "residual form is out of place and not accumulating");
+    if (!mfma_eligible(d) || (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) {      // other kernels: plain data gradient, then dx += residual
+      rc = rcgan_conv2d_bwd_data_residual(ctx, d, dy, prepared, x, nullptr, dx, ws, ws_bytes);
+      if (rc) return rc;
+      return rcgan_axpby(ctx, (size_t)d->n * d->h * d->w * d->cin, d->dtype, 1.f, residual, 1.f, dx);
+    }
+  }
   const bool up = d->flags & RCGAN_CONV_IN_UPSAMPLE2X;
   const bool relu = d->flags & RCGAN_CONV_IN_RELU;
   const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
@@ -427,7 +440,7 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
     fill_mfma_args(d, a);
     size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared + elems; a.bias = nullptr; a.mask = (const bf16_t*)mask;
-    a.resid = nullptr;
+    a.resid = (const bf16_t*)residual;
     a.out = (bf16_t*)target;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cout; a.Cout = d->cin;          // reduction over cout, output channels = cin

@@ -32,6 +32,11 @@ def grad_of(ctx, t):
     if t.grad is None:
         t.grad = ctx.empty(t.shape, t.dtype)
         return t.grad, 0
+    if getattr(t.grad, "frozen", False):
+        # the buffer is still to be read by a deferred filter gradient (conv2d's residual adoption): copy on write
+        fresh = ctx.empty(t.shape, t.dtype)
+        ctx.check(ctx.lib.rcgan_axpby(ctx.h, t.size, t.dtype, 1.0, _p(t.grad), 0.0, _p(fresh)))
+        t.grad = fresh
     return t.grad, 1
 
 
@@ -218,7 +223,14 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
                                                           C.c_void_p(ctx.ws2_ptr if fork else ctx.ws_ptr), ctx.ws_bytes))
                 if fork:
                     ctx.check(ctx.lib.rcgan_side_end(ctx.h))
-            if xr:
+            if xr and x.grad is not None and getattr(x.grad, "frozen", False):
+                # x.grad is a buffer a deferred filter gradient still has to read (see the residual adoption below): the
+                # second contribution is added out of place, in the data-gradient kernel's epilogue
+                dx = ctx.empty(x.shape, x.dtype)
+                ctx.check(ctx.lib.rcgan_conv2d_bwd_data_residual(ctx.h, C.byref(desc), _p(dy), _p(prep), _p(x) if in_relu else None,
+                                                                 _p(x.grad), _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                x.grad = dx
+            elif xr:
                 dx, acc = grad_of(ctx, x)
                 d2 = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_ACCUMULATE if acc else 0))
                 ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
@@ -228,11 +240,10 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
             if residual is not None and residual.req:
                 # d(residual) = dy.  dy is dead after this closure: a residual without a gradient yet adopts the
                 # buffer (later contributions accumulate into it in place), otherwise one accumulate
-                if residual.grad is None and not defer:
+                if residual.grad is None:
                     residual.grad = dy
-                elif residual.grad is None:
-                    residual.grad = ctx.empty(residual.shape, residual.dtype)        # dy must survive until flush_wgrads
-                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, residual.size, residual.dtype, 1.0, _p(dy), 0.0, _p(residual.grad)))
+                    if defer:
+                        dy.frozen = True        # read again by flush_wgrads: later contributions go out of place (above)
                 else:
                     ctx.check(ctx.lib.rcgan_axpby(ctx.h, residual.size, residual.dtype, 1.0, _p(dy), 1.0, _p(residual.grad)))
         ctx.record(bw)

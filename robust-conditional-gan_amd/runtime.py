@@ -31,7 +31,7 @@ def _np_dtype(code):
 
 class DT:
     """A device tensor: raw pointer + shape + dtype code.  ``base`` keeps the owning torch storage alive."""
-    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name")
+    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen")
 
     def __init__(self, ptr, shape, dtype, base=None, name=None):
         self.ptr = int(ptr)
@@ -41,6 +41,7 @@ class DT:
         self.grad = None
         self.req = False
         self.name = name
+        self.frozen = False        # a gradient buffer that must not be written any more (ops.grad_of copies on write)
 
     @property
     def size(self):
