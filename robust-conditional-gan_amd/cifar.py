@@ -573,6 +573,7 @@ class CifarRCGAN:
         """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op
         (gan_resnet.py:806-817)."""
         it = self.iteration if iteration is None else iteration
+        self._fakes_left = 0                 # images prepared by prepare_critic_fakes belong to the generator before this update
         self._refresh_generator_filters()
         self._run("g", self._g_body)
         self._allreduce(self.PG)
