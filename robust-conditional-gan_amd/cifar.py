@@ -630,6 +630,7 @@ class CifarRCGAN:
         return out
 
     def load_state_dict(self, sd):
+        self._fakes_left = 0
         for gname, grp in zip(("Generator", "Discriminator", "confusion"), self.groups):
             for n in grp.names:
                 if n not in sd:
