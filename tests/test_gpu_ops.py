@@ -176,7 +176,25 @@ def test_conv_accumulate_and_force_direct(dev):
     assert_close(ctx.download(t), ref, 2e-2 if mode in HALF else TOL[mode], "mfma accumulate")
 
 
-@pytest.mark.parametrize("hin,cin,cout", [(7, 10, 6), (14, 138, 1), (7, 138, 128)])
+def _random_cases(kind, count, seed):
+    """Seeded shape sweeps for the dense / transposed-conv / batch-norm tests (sizes the fixed lists do not pin down)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        if kind == "deconv":          # (input size, cin, cout): 5x5 stride-2 transposed conv, odd sizes and channel counts
+            out.append((int(rs.randint(2, 9)), int(rs.choice([1, 3, 8, 10, 33, 64, 138])), int(rs.choice([1, 2, 4, 5, 16, 70, 128]))))
+        elif kind == "linear":        # (m, k, n): tiny / skinny / tiled paths, unaligned sizes
+            out.append((int(rs.randint(1, 70)), int(rs.choice([1, 7, 64, 100, 110, 513, 1030, 4100])), int(rs.choice([1, 3, 10, 17, 64, 130, 1024]))))
+        else:                         # (shape, conditional): fused (power-of-two channels) and generic paths
+            c = int(rs.choice([8, 24, 64, 96, 128, 200, 256, 512]))
+            if rs.randint(2):
+                out.append(((int(rs.randint(2, 9)), int(rs.randint(1, 7)), int(rs.randint(1, 7)), c), bool(rs.randint(2))))
+            else:
+                out.append(((int(rs.randint(2, 40)), c), False))
+    return out
+
+
+@pytest.mark.parametrize("hin,cin,cout", [(7, 10, 6), (14, 138, 1), (7, 138, 128)] + _random_cases("deconv", 8, 11))
 def test_deconv(dev, hin, cin, cout):
     from rcgan_amd import ops as O
     ctx, mode = dev
@@ -201,7 +219,7 @@ def test_deconv(dev, hin, cin, cout):
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "deconv db")
 
 
-@pytest.mark.parametrize("m,k,n", [(5, 110, 1024), (64, 128, 16384), (7, 128, 1), (9, 300, 128), (4, 3072, 10)])
+@pytest.mark.parametrize("m,k,n", [(5, 110, 1024), (64, 128, 16384), (7, 128, 1), (9, 300, 128), (4, 3072, 10)] + _random_cases("linear", 12, 12))
 def test_linear(dev, m, k, n):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
@@ -229,7 +247,7 @@ def test_linear(dev, m, k, n):
 
 
 @pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False),
-                                        ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True)])
+                                        ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True)] + _random_cases("bn", 10, 13))
 def test_batch_norm(dev, shape, cond):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
