@@ -594,6 +594,45 @@ class CifarRCGAN:
         g = float(ctx.download(self.loss_g)[0]) / self.loss_scale
         return d, g
 
+    def enqueue_losses(self):
+        """Asynchronous read-back of (disc_cost, gen_cost) as they stand on the stream now: two device scalars -> one slot of a
+        pinned ring (1024 slots), no host-device synchronisation.  Returns a ticket for fetch_losses; a ticket must be
+        fetched before 1024 newer ones exist."""
+        if not hasattr(self, "_loss_ring"):
+            self._loss_ring = torch.zeros(1024, 2, dtype=torch.float32).pin_memory()
+            self._loss_tickets = 0
+        i = self._loss_tickets % 1024
+        self._loss_tickets += 1
+        ctx = self.ctx
+        with torch.cuda.stream(ctx.stream):
+            self._loss_ring[i, 0:1].copy_(ctx.view(self.loss_d), non_blocking=True)
+            self._loss_ring[i, 1:2].copy_(ctx.view(self.loss_g), non_blocking=True)
+        return self._loss_tickets - 1
+
+    def fetch_losses(self, tickets):
+        """[(disc_cost, gen_cost)] of the given tickets (one stream synchronisation for all of them)."""
+        if not tickets:
+            return []
+        assert self._loss_tickets - min(tickets) <= 1024, "loss ring overrun: fetch at least every 1024 tickets"
+        self.ctx.sync()
+        return [(float(self._loss_ring[t % 1024, 0]) / self.loss_scale, float(self._loss_ring[t % 1024, 1]) / self.loss_scale)
+                for t in tickets]
+
+    def eval_d_cost(self):
+        """disc_cost on the current D-step inputs, forward only -- the reference's dev-cost pass ``session.run([disc_cost])``
+        (gan_resnet.py:977-990).  As there it is a training-mode evaluation of the graph: a fresh Generator() batch, batch
+        statistics, and the spectral-norm ``u`` vectors take their power-iteration update (deterministic from W and u, so
+        ranks stay identical as long as every rank makes the same calls).  No gradient, no optimiser step."""
+        ctx = self.ctx
+        left, self._fakes_left = self._fakes_left, 0
+        rec, ctx.recording = ctx.recording, False
+        try:
+            self._d_body(False)
+        finally:
+            ctx.recording = rec
+            self._fakes_left = left
+        return float(ctx.download(self.loss_d)[0]) / self.loss_scale
+
     # ---------------------------------------------------------------------------------- inspection
     def get_params(self):
         out = {}

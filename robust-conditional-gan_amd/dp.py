@@ -36,3 +36,12 @@ def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def mean_over_ranks(value, device=None):
+    """Mean of a host scalar over the ranks (the reference averages tower costs, gan_resnet.py:697)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else None)
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()

@@ -84,6 +84,10 @@ class Plot:
     def plot(self, name, value):
         self.since_last_flush[name][self.iter] = value
 
+    def plot_at(self, name, iteration, value):
+        """plot() for a value that was read back later than the iteration it belongs to (asynchronous loss read-back)."""
+        self.since_last_flush[name][iteration] = value
+
     def dir_flush(self, d, log_pkl=False):
         prints = []
         try:
@@ -164,8 +168,13 @@ def adam_power_tensors(optimisers):
 
 def steps_from_beta_power(power, beta):
     """Inverse of adam_power_tensors for one optimiser (a checkpoint written by TensorFlow has no integer counter)."""
-    if not 0.0 < beta < 1.0 or not power > 0.0:
+    if not 0.0 < beta < 1.0:
         return 0
+    if not power >= float(np.finfo(np.float32).tiny):
+        # TensorFlow keeps beta**t in fp32: beta2 = 0.9 underflows after ~830 steps (a zero or subnormal says "many steps",
+        # not "none").  The count only feeds Adam's bias correction, which is 1 to fp32 precision long before that, so any
+        # large count restores the optimiser exactly where TensorFlow left it.
+        return 1 << 20
     return max(int(round(np.log(float(power)) / np.log(float(beta)))) - 1, 0)
 
 

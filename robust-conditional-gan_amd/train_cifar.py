@@ -52,7 +52,8 @@ def define_flags():
     f.DEFINE_boolean("synthetic", False, "train on the SURVEY 8(d) synthetic data instead of ../data/cifar10")
     f.DEFINE_integer("seed", 0, "variable-initialisation seed")
     f.DEFINE_string("data_dir", DATA_DIR, "CIFAR-10 python batches")
-    f.DEFINE_integer("sample_every", 100, "sample-grid period (the reference hard-codes 100 for cifar)")
+    f.DEFINE_integer("sample_every", 0, "if > 0: overrides --sample_freq (dev cost + sample grid period)")
+    f.DEFINE_integer("early_checkpoint_every", 1, "checkpoint period during the first 500 iterations (the reference: every one)")
     return f
 
 
@@ -90,7 +91,13 @@ def main(argv=None):
         os.makedirs(DIR, exist_ok=True)
         record_setting(os.path.join(DIR, 'scripts'))
     CHECKPOINT_DIR = os.path.join(DIR, 'checkpoint')
-    SAMPLE_FREQUENCY, SAMPLE_SAVE_FREQUENCY = FLAGS.sample_every, 0            # cifar branch, gan_resnet.py:111-114
+    # gan_resnet.py:129-132: the flags override the per-dataset constants of :111-114
+    INCEPTION_FREQUENCY = FLAGS.inception_freq
+    SAMPLE_FREQUENCY = FLAGS.sample_every if FLAGS.sample_every > 0 else FLAGS.sample_freq
+    SAMPLE_SAVE_FREQUENCY = FLAGS.sample_save_freq
+    if INCEPTION_FREQUENCY and INCEPTION_FREQUENCY <= FLAGS.niters:
+        logging.warning("--inception_freq %d: the Inception score needs the Inception-v3 graph the reference downloads at import "
+                        "(common/inception/inception_score_.py:24-48); it is not part of the checkout and is skipped", INCEPTION_FREQUENCY)
 
     if world > 1:
         import torch
@@ -152,12 +159,28 @@ def main(argv=None):
         logging.info('generated label accuracy: {}'.format(acc))
         return acc
 
+    from .dp import mean_over_ranks
+    pending = []                       # (iteration, ticket) of losses read back asynchronously
+
+    def drain_losses():
+        # d_cost / g_cost of EVERY iteration (gan_resnet.py:950-951) without a host-device synchronisation per iteration:
+        # the device scalars are copied into a pinned ring behind each iteration and collected here
+        for (it_, _), (dc, gc) in zip(pending, m.fetch_losses([t for _, t in pending])):
+            plot.plot_at('d_cost', it_, dc)
+            plot.plot_at('g_cost', it_, gc)
+        del pending[:]
+
     _random_labels_G, _labels_biased_G = next(gen_G)
     for iteration in range(ITERS):                                             # gan_resnet.py:919-1016
         timed = iteration % 10 == 0 or iteration < 5
         if timed:
             m.ctx.sync()               # launches are asynchronous: drain the queue so sec_per_iter times THIS iteration only
         t0 = time.time()
+        if ALGORITHM == 'rcgan-u' and (iteration % 100 == 0 or iteration < 500) and FLAGS.log_level == 'debug':   # :921-925
+            np.set_printoptions(precision=3, suppress=True)
+            logging.debug('confusion_matrix: ')
+            logging.debug('\n{}'.format(m.confusion_matrix_value()))
+            np.set_printoptions()
         if 0 < iteration:
             _random_labels_G, _labels_biased_G = next(gen_G)
             m.feed_host("g", labels_random_G=sh(_random_labels_G), labels_biased_G=sh(_labels_biased_G))
@@ -171,12 +194,30 @@ def main(argv=None):
             feed_d(batch)
             m.d_step(iteration=iteration)
         m.iteration = iteration + 1
+        pending.append((iteration, m.enqueue_losses()))
         if timed:
-            d_cost, g_cost = m.losses()
-            plot.plot('d_cost', d_cost)
-            plot.plot('g_cost', g_cost)
+            drain_losses()
             plot.plot('sec_per_iter', time.time() - t0)
-        if rank == 0 and iteration % SAMPLE_FREQUENCY == SAMPLE_FREQUENCY - 1:
+        elif len(pending) >= 512:
+            drain_losses()
+        if rank == 0 and SAMPLE_SAVE_FREQUENCY and iteration % SAMPLE_SAVE_FREQUENCY == SAMPLE_SAVE_FREQUENCY - 1:   # :965-969
+            logging.info('starting saving samples.')
+            samples_for_save, _ = save_samples(10000)
+            np.save(os.path.join(DIR, '_samples_{}'.format(iteration)), samples_for_save)
+            logging.info('finished saving samples.')
+        if SAMPLE_FREQUENCY and iteration % SAMPLE_FREQUENCY == SAMPLE_FREQUENCY - 1:
+            # dev cost (gan_resnet.py:972-990): disc_cost, forward only, over the whole dev set; every rank evaluates its
+            # shard of every dev batch (the pass updates the spectral-norm u vectors exactly as the reference's does, so all
+            # ranks have to make it), the cost is the mean over towers and batches
+            logging.info('starting calculating dev cost.')
+            dev_disc_costs = []
+            for batch in dev_gen():
+                feed_d(batch)
+                dev_disc_costs.append(m.eval_d_cost())
+            if dev_disc_costs:
+                plot.plot('dev_cost', mean_over_ranks(np.mean(dev_disc_costs), m.ctx.device))
+            logging.info('finished calculating dev cost.')
+        if rank == 0 and SAMPLE_FREQUENCY and iteration % SAMPLE_FREQUENCY == SAMPLE_FREQUENCY - 1:
             samples = m.sample(fixed_labels, fixed_noise)
             samples = ((samples + 1.) * (255. / 2)).astype('int32')             # gan_resnet.py:831
             save_images(samples.reshape((100, 32, 32, 3)), os.path.join(DIR, 'samples_{}.png'.format(iteration)))
@@ -187,7 +228,9 @@ def main(argv=None):
             plot.plot('gen_label_acc', accuracy)
             plot.plot('gen_label_acc_max', acc_state["max"])
             logging.info('finished calculating generated label accuracy.')
-        if rank == 0 and ((iteration < 500 and iteration % 100 == 99) or (iteration % 1000 == 999)):
+        ECE = max(FLAGS.early_checkpoint_every, 1)
+        if rank == 0 and ((iteration < 500 and iteration % ECE == ECE - 1) or (iteration % 1000 == 999)):      # :1007-1014
+            drain_losses()
             plot.dir_flush(DIR)
             saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', iteration)
         plot.tick()
@@ -196,6 +239,7 @@ def main(argv=None):
         logging.info('starting calculating %sgenerated label accuracy.' % ('min. permuted ' if cm is not None else ''))
         plot.plot('gen_label_acc', label_accuracy(cm))
         logging.info('finished calculating generated label accuracy.')
+    drain_losses()
     if rank == 0 and ITERS:
         plot.dir_flush(DIR)
         saver.save(m.state_dict(), CHECKPOINT_DIR, 'model.ckpt', max(ITERS - 1, 0))

@@ -152,23 +152,27 @@ def main(argv=None):
     saver = Saver(max_to_keep=5)
 
     counter = 1
+    loaded = False
     if not FLAGS.train:                                                        # main.py:133-138
         print(" [*] Reading checkpoints...")
         ck = latest_checkpoint(model_dir)
         if ck:
             m.load_state_dict(load_checkpoint(ck))
             counter = int(ck.rsplit("-", 1)[1])
+            loaded = True
             print(" [*] Success to read {}".format(os.path.basename(ck)))
         else:
             print(" [*] Failed to find a checkpoint")
             print("[!] Training a model first, then run test mode")
+    # test mode with a restored model goes straight to recover_labels (main.py:136-140): no update, no new checkpoint
+    do_train = FLAGS.train or not loaded
 
     # ---- DCGAN.train (model.py:270-492) ------------------------------------------------------------------------
     sample_z = np.random.uniform(-1, 1, size=(B, Z_DIM))
     picks = [i for c in range(10) for i in np.where(y_gen[:, c] == 1)[0][0:10]]
     sample_inputs, sample_labels = data_X[picks[0:100]], y_gen[picks[0:100]]
     start_time = time.time()
-    for epoch in range(FLAGS.epoch):
+    for epoch in range(FLAGS.epoch if do_train else 0):
         batch_idxs = int(min(len(data_X), FLAGS.train_size)) // B
         cur_real, cur_fake = y_real, y_fake
         if FLAGS.add_noise:                                                    # model.py:293-333
@@ -181,13 +185,16 @@ def main(argv=None):
                          y_fake=sh(cur_fake[lo:hi]), y_real_weights=sh(y_w[lo:hi]))
             m.iteration()                                                      # D once, G (+C) twice: model.py:347-372
             counter += 1
-            if rank == 0 and ((epoch < 1 and idx < 20) or idx % 350 == 0):
+            if (epoch < 1 and idx < 20) or idx % 350 == 0:
+                # every rank evaluates: like each sess.run of the reference the pass runs D and G in training mode (power
+                # iteration of u, moving averages), so a rank that skipped it would drift away from the others' weights
                 ev = m.evaluate()
                 pr, pf = ev["prob_real"], ev["prob_fake"]
-                print("Epoch: [%2d] [%4d/%4d] time: %4.2f, d_loss: %.3f, g_loss: %.3f, "
-                      "d_real: %2d, %.3f, %.3f, d_fake: %2d, %.3f, %.3f"
-                      % (epoch, idx, batch_idxs, time.time() - start_time, ev["d_loss_fake"] + ev["d_loss_real"], ev["g_loss"],
-                         int((pr >= 0.5).sum()), pr.min(), pr.max(), int((pf <= 0.5).sum()), pf.min(), pf.max()))
+                if rank == 0:
+                    print("Epoch: [%2d] [%4d/%4d] time: %4.2f, d_loss: %.3f, g_loss: %.3f, "
+                          "d_real: %2d, %.3f, %.3f, d_fake: %2d, %.3f, %.3f"
+                          % (epoch, idx, batch_idxs, time.time() - start_time, ev["d_loss_fake"] + ev["d_loss_real"], ev["g_loss"],
+                             int((pr >= 0.5).sum()), pr.min(), pr.max(), int((pf <= 0.5).sum()), pf.min(), pf.max()))
             if rank == 0 and np.mod(counter, FLAGS.save_every) == 1:
                 n = min(len(sample_labels), B)
                 if n == B and world == 1:
@@ -211,7 +218,8 @@ def main(argv=None):
     final_state = None
     if rank == 0:
         final_state = m.state_dict()
-        saver.save(final_state, model_dir, "DCGAN.model", counter)
+        if do_train:
+            saver.save(final_state, model_dir, "DCGAN.model", counter)
     m.ctx.close()
 
     # ---- dcgan.recover_labels(FLAGS) (main.py:140, model.py:494-640): label recovery through the frozen sampler ------------

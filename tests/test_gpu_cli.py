@@ -16,7 +16,7 @@ def test_train_cli_layout_and_restore(tmp_path, caplog):
     parent = str(tmp_path)
     argv = ["--dataset", "cifar", "--algorithm", "rcgan-u", "--alpha", "0.6", "--run", "0", "--log_file", os.path.join(parent, "log.txt"),
             "--parent_dir", parent, "--expt_dir", "e1", "--ngpus", "1", "--multi_gpu_multi_batch", "--perm_classifier", "--confuse_init",
-            "--niters", "3", "--batch_size", "8", "--synthetic", "--sample_every", "2", "--noaux_classifier", "--bogus_flag", "7",
+            "--niters", "3", "--batch_size", "8", "--synthetic", "--sample_freq", "2", "--inception_freq", "2", "--noaux_classifier", "--bogus_flag", "7",
             "--generated_label_accuracy_freq", "2", "--perm_gen_label_acc"]
     import logging
     with caplog.at_level(logging.INFO):
@@ -34,7 +34,11 @@ def test_train_cli_layout_and_restore(tmp_path, caplog):
     assert sd["Generator/G.Block.3.Conv2/Filters"].shape == (3, 3, 256, 256)
     assert "Discriminator/D.Block.1.Conv1/filters/spectral_norm/u" in sd and "confusion_logits" in sd
     assert "Generator/G.Input/W/Adam_1" in sd and np.isfinite(sd["Generator/G.Input/W"]).all()
-    assert glob.glob(os.path.join(d, "d_cost.jpg"))
+    assert glob.glob(os.path.join(d, "d_cost.jpg")) and glob.glob(os.path.join(d, "g_cost.jpg"))
+    # dev cost over the dev generator at --sample_freq (gan_resnet.py:972-990); the unsupported Inception score is announced
+    assert "finished calculating dev cost." in log and glob.glob(os.path.join(d, "dev_cost.jpg"))
+    assert "Inception score needs the Inception-v3 graph" in log
+    assert ck.endswith("model.ckpt-2") and os.path.exists(os.path.join(d, "checkpoint", "model.ckpt-0.index"))   # every early iteration
     # second launch restores the newest checkpoint (gan_resnet.py:910-914) and keeps training
     d2 = main(argv)
     assert d2 == d
@@ -78,11 +82,23 @@ def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     assert "discriminator/d_h0_conv/w/Adam_1" in sd and np.isfinite(sd["generator/g_h3/w"]).all()
     steps = int(sd["_opt/discriminator/step"][0])
     assert steps == 10 and int(sd["_opt/generator/step"][0]) == 20
-    # test mode (no --train): restores, then trains on (main.py:133-138)
+    # test mode (no --train): a successful restore skips training and goes straight to recover_labels (main.py:133-140);
+    # the checkpoint directory is left exactly as it was
+    before = {f: os.path.getmtime(os.path.join(mdir, f)) for f in sorted(os.listdir(mdir))}
     d2 = main([a for a in argv if a != "--train"])
-    assert d2 == d and " [*] Success to read DCGAN.model-11" in capsys.readouterr().out
+    out2 = capsys.readouterr().out
+    assert d2 == d and " [*] Success to read DCGAN.model-11" in out2
+    assert "Epoch: [ 0]" not in out2 and "Recover Epoch: [199] time:" in out2
+    assert {f: os.path.getmtime(os.path.join(mdir, f)) for f in sorted(os.listdir(mdir))} == before
     sd2 = load_checkpoint(latest_checkpoint(mdir))
-    assert int(sd2["_opt/discriminator/step"][0]) == 2 * steps
+    assert int(sd2["_opt/discriminator/step"][0]) == steps
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
+    assert len(glob.glob(os.path.join(d, "recover_bs6_epoch200_lr50", "*", "recover.npz"))) == 2
+    # test mode without a checkpoint trains first (main.py:137-138)
+    d4 = main([("e4" if a == "e1" else a) for a in argv if a != "--train"])
+    out4 = capsys.readouterr().out
+    assert " [*] Failed to find a checkpoint" in out4 and "Epoch: [ 0] [   0/   5]" in out4
+    assert latest_checkpoint(os.path.join(d4, "mnist_100_28_28")) is not None
     # biased preset: vanilla D, CE loss, real_match, no SN / max-norm; plus the --add_noise schedule
     d3 = main(["--algorithm", "biased", "--alpha", "0.6", "--disc_type", "vanilla", "--loss_fn", "ce", "--real_match",
                "--noestimate_confuse", "--add_noise", "--noise_alpha", "0.3", "--noise_start", "1", "--noise_end", "2",

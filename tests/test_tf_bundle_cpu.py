@@ -152,3 +152,7 @@ def test_adam_power_tensors_round_trip():
     assert host.steps_from_beta_power(float(pw["beta2_power"]), 0.9) == 0
     assert host.steps_from_beta_power(float(pw["beta2_power_1"]), 0.999) == 41
     assert host.steps_from_beta_power(float(pw["beta2_power_2"]), 0.9) == 7
+    # a bundle written by TensorFlow after > ~830 steps holds an underflowed fp32 beta2_power: "many steps", never 0
+    old = host.adam_power_tensors([(5000, 0.0, 0.9)])
+    assert float(old["beta2_power"]) == 0.0 and host.steps_from_beta_power(float(old["beta2_power"]), 0.9) >= 100000
+    assert host.steps_from_beta_power(float(np.float32(0.9) ** np.float32(850)), 0.9) >= 100000      # subnormal
