@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--algorithm", default="rcgan")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=2e-4, help="Adam learning rate (reference: 2e-4, gan_resnet.py:--lr)")
     args = ap.parse_args()
     default_wl = args.batch == 64 and args.dtype == "bf16" and args.algorithm == "rcgan"
 
@@ -177,7 +178,7 @@ def main():
     from rcgan_amd.cifar import CifarRCGAN
 
     alpha = 0.6
-    m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0,
+    m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0, lr=args.lr,
                    device=local, use_graphs=not args.no_graphs, device_rng=True, world_size=world, rank=rank)
     if force_dist:
         m.world = 2          # take the all-reduce branch; grad_scale 1/2 cancels against the doubled "sum" below

@@ -93,7 +93,6 @@ def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     sd2 = load_checkpoint(latest_checkpoint(mdir))
     assert int(sd2["_opt/discriminator/step"][0]) == steps
     assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
-    assert len(glob.glob(os.path.join(d, "recover_bs6_epoch200_lr50", "*", "recover.npz"))) == 2
     # test mode without a checkpoint trains first (main.py:137-138)
     d4 = main([("e4" if a == "e1" else a) for a in argv if a != "--train"])
     out4 = capsys.readouterr().out
