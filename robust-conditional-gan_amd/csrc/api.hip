@@ -109,6 +109,11 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
     delete c;
     return RCGAN_EHIP;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    c->num_cus = cus;
+  }
   c->zero_page = nullptr;
   if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
     delete c;

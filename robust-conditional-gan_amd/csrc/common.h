@@ -29,6 +29,7 @@ struct rcgan_ctx {
   hipStream_t main_stream, side_stream;
   hipEvent_t fork_ev, join_ev;
   bool on_side;
+  int num_cus;         // compute units of the device (grid size of the persistent kernels)
   void* zero_page;     // 4 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
                        // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels
   unsigned* counters() const { return (unsigned*)((char*)zero_page + 1024); }

@@ -142,42 +142,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
   }
 
   // epilogue: lane holds out[m][co..co+3], m = pixel (lane&15), co = 4*(lane>>4)
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const long m = m0 + wm * TM + j * 16 + (lane & 15);
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int co = co0 + wn * TN + i * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (a.bias) {
-        const float4 b = *(const float4*)(a.bias + co);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const long off = m * a.Cout + co;
-      if (a.mask) {
-        const uint2 mk = *(const uint2*)(a.mask + off);
-        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
-      }
-      if (a.accumulate) {
-        const uint2 o = *(const uint2*)(a.out + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      if (a.resid) {
-        const uint2 o = *(const uint2*)(a.resid + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *(uint2*)(a.out + off) = pk;
-    }
-  }
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
 }
 
 
@@ -360,42 +325,7 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
     }
   }
 
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const long m = m0 + wm * TM + j * 16 + (lane & 15);
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int co = co0 + wn * TN + i * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (a.bias) {
-        const float4 b = *(const float4*)(a.bias + co);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const long off = m * a.Cout + co;
-      if (a.mask) {
-        const uint2 mk = *(const uint2*)(a.mask + off);
-        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
-      }
-      if (a.accumulate) {
-        const uint2 o = *(const uint2*)(a.out + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      if (a.resid) {
-        const uint2 o = *(const uint2*)(a.resid + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *(uint2*)(a.out + off) = pk;
-    }
-  }
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -242,41 +242,242 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   }
 
   // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the 256 x 256 kernel: one workgroup per CU walks its tiles in ONE continuous K-tile stream.
+//
+// Measured on the one-tile-per-workgroup kernel above (scripts/exp_p8_fixed_cost.py, 32x32 convs, Cout 256):
+// time per round of 256 workgroups = 12-16 us + 1.59 us per K-tile.  The K loop itself runs at 1.35 PFLOP/s; the fixed
+// part -- tap table, the first K-tile's round trip, and 256 CUs storing their 128 KB of output at the same moment with
+// nothing left to multiply (one workgroup per CU: LDS) -- is a fifth of a 36-K-tile tile and half of a 1x1 shortcut's.
+// Here a workgroup takes tiles b, b+P, b+2P, ...: the LDS-DMA cursor runs one K-tile ahead of the MFMAs ACROSS tile
+// boundaries (the last K-tile of a tile issues the first K-tile of the next), the epilogue's stores are issued and left
+// to drain under the next tile's MFMAs (stores only count in vmcnt: the counted waits stay sufficient, they then also
+// cover the older stores), and the tap-source table of tile i+2 is built in the shadow of the tile i -> i+1 boundary
+// (two tables, alternating).  Cost of a tile boundary: the epilogue's own issue time.
+// ---------------------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(512) void conv_mfma_p8p_kernel(MfmaConvArgs a, int tiles_m, int xcd_swz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HALF = 128 * 128;
+  constexpr int XOFF = 0, WOFF = 2 * HALF, BUF = 4 * HALF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int co0 = blockIdx.y * 256;
+  const int K = a.KH * a.KW * a.Cin;
+  const int KT = K / 64;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  const int lrow = lane >> 3, pos = lane & 7;
+  const int ntaps = a.KH * a.KW;
+  const int P = gridDim.x;
+  const int my_tiles = (tiles_m - (int)blockIdx.x + P - 1) / P;          // >= 1 (grid <= tiles)
+  // virtual block id v -> pixel tile: each XCD (v % 8 == blockIdx.x % 8 as P % 8 == 0) owns a contiguous run of tiles
+  auto tile_of = [&](int i) __attribute__((always_inline)) -> int {
+    const int v = (int)blockIdx.x + i * P;
+    return xcd_swz ? (v & 7) * (tiles_m >> 3) + (v >> 3) : v;
+  };
+
+  unsigned* const tapt = (unsigned*)(smem + 2 * BUF);                   // two tables of ntaps x 256 offsets
+  const int tab_words = ntaps * 256;
+  auto build_table = [&](int slot, long m0) __attribute__((always_inline)) {
+    unsigned* const T = tapt + slot * tab_words;
+    for (int e = tid; e < tab_words; e += 512) {
+      const int tap = e >> 8;
+      const long m = m0 + (e & 255);
+      unsigned off = ~0u;
+      if (m < a.M) {
+        int n, oh, ow;
+        const unsigned mm = (unsigned)m;
+        if (a.lw >= 0) {
+          ow = (int)(mm & (unsigned)(a.W - 1));
+          oh = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
+          n = (int)(mm >> (a.lw + a.lh));
+        } else {
+          ow = (int)(m % a.W);
+          oh = (int)((m / a.W) % a.H);
+          n = (int)(m / ((long)a.W * a.H));
+        }
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+          if (a.up) { ih >>= 1; iw >>= 1; }
+          off = (((unsigned)n * Hs + ih) * Ws + iw) * a.Cin;
+        }
+      }
+      T[e] = off;
+    }
+  };
+  build_table(0, (long)tile_of(0) * 256);
+  if (my_tiles > 1) build_table(1, (long)tile_of(1) * 256);
+  __syncthreads();
+
+  int pix[4], a_coff[4];
+  const bf16_t* wsrc[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const long m = m0 + wm * 128 + j * 16 + (lane & 15);
-    if (m >= a.M) continue;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wave * 2 + j) * 8 + lrow;
+      const int swz = (pos ^ ((r >> 1) & 7)) * 8;
+      pix[h * 2 + j] = (r >> 6) * 128 + h * 64 + (r & 63);
+      a_coff[h * 2 + j] = swz;
+      const int co = co0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      wsrc[h * 2 + j] = a.wt + (long)co * K + swz;
+    }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const bf16_t* rp[4];
+  int rstep[4];
+  unsigned noff[4];
+  bool pend = false;
+  int i_c0 = 0, i_tap = 0, i_k0 = 0, i_slot = 0;          // DMA cursor: (tile parity, tap, channel chunk) of the NEXT K-tile to issue
+  auto read_tap = [&](int slot, int tap) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) noff[i] = tapt[slot * tab_words + tap * 256 + pix[i]];
+  };
+  auto use_tap = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (a.bias) {
-        const float4 b = *(const float4*)(a.bias + co);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const long off = m * a.Cout + co;
-      if (a.mask) {
-        const uint2 mk = *(const uint2*)(a.mask + off);
-        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
-      }
-      if (a.accumulate) {
-        const uint2 o = *(const uint2*)(a.out + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      if (a.resid) {
-        const uint2 o = *(const uint2*)(a.resid + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *(uint2*)(a.out + off) = pk;
+      const bool ok = noff[i] != ~0u;
+      rp[i] = ok ? a.in + noff[i] + a_coff[i] : a.zero;
+      rstep[i] = ok ? 1 : 0;
     }
+  };
+  read_tap(0, 0);
+  use_tap();
+  auto issue = [&](int which, int buf) __attribute__((always_inline)) {
+    const unsigned base = lds0 + buf * BUF;
+    if (which == 0 || which == 3) {
+      const int h = which == 0 ? 0 : 1;
+      if (which == 0 && pend) { use_tap(); pend = false; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
+      if (which == 3) {
+        // advance the cursor by one K-tile; past a tile's last K-tile it moves on to the next tile's table
+        // (computed on copies and written back unconditionally: stores to i_tap / i_c0 in both arms of a branch are merged
+        // by the optimiser into a store through a selected POINTER, which pins both cursors in scratch memory)
+        const int cin = a.Cin, cmaj = a.cm;
+        int nt = i_tap + (cmaj ? 1 : 0), nc = i_c0 + (cmaj ? 0 : 64);
+        const bool tap_wrap = nt == ntaps, c_wrap = nc == cin;
+        if (cmaj) { nc += tap_wrap ? 64 : 0; nt = tap_wrap ? 0 : nt; }
+        else { nt += c_wrap ? 1 : 0; nc = c_wrap ? 0 : nc; }
+        const bool tile_wrap = cmaj ? (nc == cin) : (nt == ntaps);
+        const bool tapchg = cmaj || c_wrap || tile_wrap;
+        nt = tile_wrap ? 0 : nt;
+        nc = tile_wrap ? 0 : nc;
+        i_tap = nt;
+        i_c0 = nc;
+        i_slot ^= tile_wrap ? 1 : 0;
+        i_k0 = nt * cin + nc;
+        if (tapchg) { read_tap(i_slot, nt); pend = true; }
+      }
+    } else {
+      const int h = which - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16_asm(wsrc[h * 2 + j] + i_k0, base + WOFF + h * HALF + (wave * 2 + j) * 1024);
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
+  const int xrow0 = wm * 64 * 128;
+  const int wrow0 = wn * 32 * 128;
+
+  bf16x8_t xf[2][4], wfc[2][2][2];
+  auto load_x = [&](const unsigned char* bufp, int h) __attribute__((always_inline)) {
+    const unsigned char* p = bufp + XOFF + h * HALF + xrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        uint4 v = *(const uint4*)(p + f * 16 * 128 + (ks ? foff1 : foff0));
+        if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+        xf[ks][f] = __builtin_bit_cast(bf16x8_t, v);
+      }
+  };
+  auto load_w = [&](const unsigned char* bufp, int h) __attribute__((always_inline)) {
+    const unsigned char* p = bufp + WOFF + h * HALF + wrow0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) wfc[h][ks][g] = *(const bf16x8_t*)(p + g * 16 * 128 + (ks ? foff1 : foff0));
+  };
+  auto mma = [&](int ph, int ch) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          acc[ch * 2 + g][ph * 4 + f] = mfma16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: the whole first K-tile of the first tile
+#pragma unroll
+  for (int w = 0; w < 4; ++w) issue(w, 0);
+  wait_vm<0>();
+  wg_barrier();
+
+  int gk = 0;                                     // K-tiles multiplied so far (LDS buffer parity)
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const bool last_tile = ti + 1 == my_tiles;
+    for (int t = 0; t < KT; ++t, ++gk) {
+      const unsigned char* bufp = smem + (gk & 1) * BUF;
+      const int nb = (gk + 1) & 1;
+      const bool more = !(last_tile && t + 1 == KT);
+      // phase 1: (P0, C0)
+      load_x(bufp, 0);
+      load_w(bufp, 0);
+      if (more) issue(0, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, 0);
+      if (more) wait_vm<4>(); else wait_vm<2>();
+      wg_barrier();
+      // phase 2: (P0, C1)
+      load_w(bufp, 1);
+      if (more) issue(1, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, 1);
+      if (more) wait_vm<4>(); else wait_vm<0>();
+      wg_barrier();
+      // phase 3: (P1, C1)
+      load_x(bufp, 1);
+      if (more) issue(2, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, 1);
+      wg_barrier();
+      // phase 4: (P1, C0)
+      if (more) issue(3, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, 0);
+      if (more) wait_vm<4>();
+      wg_barrier();
+    }
+
+    // ---- tile boundary: store this tile (the next tile's first K-tile is already landing), clear the accumulators,
+    //      build the table of the tile after next in the slot this tile's table occupied (dead since its last K-tile
+    //      was issued, one K-tile ago; first read a whole tile from now, with >= 4 barriers in between)
+    const long m0 = (long)tile_of(ti) * 256;
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (ti + 2 < my_tiles) build_table(ti & 1, (long)tile_of(ti + 2) * 256);
   }
 }
 
@@ -432,42 +633,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
     wg_barrier();
   }
 
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long m = m0 + wm * 64 + j * 16 + (lane & 15);
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (a.bias) {
-        const float4 b = *(const float4*)(a.bias + co);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const long off = m * a.Cout + co;
-      if (a.mask) {
-        const uint2 mk = *(const uint2*)(a.mask + off);
-        if (!(bf16_to_f32((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
-        if (!(bf16_to_f32((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
-      }
-      if (a.accumulate) {
-        const uint2 o = *(const uint2*)(a.out + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      if (a.resid) {
-        const uint2 o = *(const uint2*)(a.resid + off);
-        v[0] += bf16_to_f32((bf16_t)(o.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(o.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(o.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(o.y >> 16));
-      }
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *(uint2*)(a.out + off) = pk;
-    }
-  }
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane);
 }
 
 template <bool RELU, bool XCDSWZ>
@@ -482,6 +648,30 @@ static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
     hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ>), grid, dim3(512), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+template <bool RELU>
+static int launch8p(rcgan_ctx* ctx, const MfmaConvArgs& a, int swz) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 4 * 128 * 128 + 2 * 9 * 256 * sizeof(unsigned);  // tile buffers + two tap-source tables
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8p_kernel<RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles = (int)cdiv(a.M, 256), ny = a.Cout / 256;
+  // one workgroup per CU (LDS): P workgroups per channel column walk the pixel tiles; P a multiple of 8 keeps a
+  // workgroup's tiles on its own XCD's run of the swizzled order
+  int P = ctx->num_cus / ny;
+  if (P > tiles) P = tiles;
+  if (P >= 8) P &= ~7;
+  const int xs = (swz && (tiles & 7) == 0 && (P & 7) == 0) ? 1 : 0;
+  dim3 grid(P, ny);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL(conv_mfma_p8p_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a, tiles, xs);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -509,9 +699,14 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   static int swz = -1, cm = -1;
   if (swz < 0) { const char* e = getenv("RCGAN_P8_XCD"); swz = e ? atoi(e) : 1; }
   if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 1; }
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("RCGAN_P8_PERSIST"); persist = e ? atoi(e) : 0; }
   if (wide) {
     MfmaConvArgs b = a;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
+    // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
+    if (persist && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
+      return b.relu_in ? launch8p<true>(ctx, b, swz) : launch8p<false>(ctx, b, swz);
     if (swz) return b.relu_in ? launch8<true, true>(ctx, b) : launch8<false, true>(ctx, b);
     return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }

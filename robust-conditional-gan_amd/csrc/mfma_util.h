@@ -72,6 +72,118 @@ __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p, int hi_off) 
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Shared epilogue of the MFMA convolution kernels: a wavefront's accumulators acc[NI][NJ] (NI channel fragments of 16,
+// NJ pixel fragments of 16; lane holds pixel lane&15, channels 4*(lane>>4) .. +3 of every fragment) -> bias, optional
+// ReLU-backward mask / accumulate / residual, 16-bit rounding, store to out[m][Cout].
+//
+// Why it looks like this (scripts/probes/epilogue_store.hip, MI355X, 256 x 256 tile per CU):
+//   * one 8-byte store per fragment is bound by store ISSUE at ~7.5 B/clk/CU (8.1 us per tile); pairing two channel
+//     fragments with v_permlane16_swap gives every lane 8 consecutive channels = one 16-byte store (5.3 us: 6.3 TB/s,
+//     the chip's write bandwidth); non-temporal stores are slower.
+//   * the per-fragment `if (bias) load; if (mask) load; ...` form this replaces made every fragment wait vmcnt(0) for its
+//     own loads AND for the previous fragment's store (CDNA4 counts stores in vmcnt): 32 dependent memory round trips
+//     per wavefront.  Here the bias is read once, and the extra operands of pixel row j+1 are requested BEFORE row j is
+//     stored, so a wait for them never covers a store younger than one row.
+// The swap: rows (16-lane groups) 1,3 of fragment i trade places with rows 0,2 of fragment i+1; afterwards row r holds
+// channels (r>>1)*8 .. +7 of fragment i + (r&1) -- x[] the first four, y[] the last four.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  // (through named scalars: __builtin_bit_cast applied to the vector ELEMENT r[1] reads element 0 with this clang)
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float h16_lo(uint32_t w) { return bf16_to_f32((bf16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(uint32_t w) { return bf16_to_f32((bf16_t)(w >> 16)); }
+
+template <int NI, int NJ>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const float* __restrict__ bias, const bf16_t* mask,
+                                              const bf16_t* resid, bf16_t* out, int accumulate, long M, int Cout,
+                                              long m_wave /* first pixel of the wavefront's rows */,
+                                              int co_wave /* first channel of the wavefront's columns */, int lane) {
+  static_assert(NI % 2 == 0, "channel fragments are stored in pairs");
+  constexpr int NP = NI / 2;
+  const int row = lane >> 4;
+  float4 b4[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    b4[i] = bias ? *(const float4*)(bias + co_wave + i * 16 + row * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // element offset of this lane's 8-channel run of pair p in pixel row j
+  auto offs = [&](int j, int p) __attribute__((always_inline)) -> long {
+    return (m_wave + j * 16 + (lane & 15)) * Cout + co_wave + (2 * p + (row & 1)) * 16 + (row >> 1) * 8;
+  };
+  auto valid = [&](int j) __attribute__((always_inline)) -> bool { return m_wave + j * 16 + (lane & 15) < M; };
+  const bool extras = mask != nullptr || resid != nullptr || accumulate != 0;
+  uint4 e_mask[NP], e_acc[NP], e_res[NP];
+  auto fetch = [&](int j) __attribute__((always_inline)) {
+    if (!valid(j)) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const long o = offs(j, p);
+      if (mask) e_mask[p] = *(const uint4*)(mask + o);
+      if (accumulate) e_acc[p] = *(const uint4*)(out + o);
+      if (resid) e_res[p] = *(const uint4*)(resid + o);
+    }
+  };
+  if (extras) fetch(0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    uint4 c_mask[NP], c_acc[NP], c_res[NP];
+    if (extras) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { c_mask[p] = e_mask[p]; c_acc[p] = e_acc[p]; c_res[p] = e_res[p]; }
+      if (j + 1 < NJ) fetch(j + 1);            // requested before row j is stored (see above)
+    }
+    const bool ok = valid(j);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float x[4], y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = acc[2 * p][j][e] + (&b4[2 * p].x)[e];
+        y[e] = acc[2 * p + 1][j][e] + (&b4[2 * p + 1].x)[e];
+        swap16(x[e], y[e]);
+      }
+      if (extras) {
+        if (mask) {
+          const uint32_t mw[4] = {c_mask[p].x, c_mask[p].y, c_mask[p].z, c_mask[p].w};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (!(h16_lo(mw[q]) > 0.f)) x[2 * q] = 0.f;
+            if (!(h16_hi(mw[q]) > 0.f)) x[2 * q + 1] = 0.f;
+            if (!(h16_lo(mw[2 + q]) > 0.f)) y[2 * q] = 0.f;
+            if (!(h16_hi(mw[2 + q]) > 0.f)) y[2 * q + 1] = 0.f;
+          }
+        }
+        if (accumulate) {
+          const uint32_t w[4] = {c_acc[p].x, c_acc[p].y, c_acc[p].z, c_acc[p].w};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            x[2 * q] += h16_lo(w[q]); x[2 * q + 1] += h16_hi(w[q]);
+            y[2 * q] += h16_lo(w[2 + q]); y[2 * q + 1] += h16_hi(w[2 + q]);
+          }
+        }
+        if (resid) {
+          const uint32_t w[4] = {c_res[p].x, c_res[p].y, c_res[p].z, c_res[p].w};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            x[2 * q] += h16_lo(w[q]); x[2 * q + 1] += h16_hi(w[q]);
+            y[2 * q] += h16_lo(w[2 + q]); y[2 * q + 1] += h16_hi(w[2 + q]);
+          }
+        }
+      }
+      if (ok) *(uint4*)(out + offs(j, p)) = make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(y[0], y[1]), pack_h16x2(y[2], y[3]));
+    }
+  }
+}
+
 // ---- prepared-filter layouts of the image-end kernels (conv_image.hip; also filled by the batched prepare) ----
 // element e of the extra region: wK[Cb][32] followed by wS[T][16][Cb]   (side 1: cin small, side 2: cout small)
 //   side 1:  wK[n][t*Cs+c] = W[t][c][n]        (forward)        wS[t][j][co] = W[T-1-t][j][co]   (dX from dY)

@@ -176,6 +176,82 @@ def test_conv_accumulate_and_force_direct(dev):
     assert_close(ctx.download(t), ref, 2e-2 if mode in HALF else TOL[mode], "mfma accumulate")
 
 
+def _torch_conv_ref(x, w, up=False, relu=False):
+    """fp32 CPU convolution (torch, SAME, stride 1) of NHWC x with HWIO w: the reference for shapes where the float64
+    numpy oracle would take minutes.  Both operands are already rounded to the 16-bit activation format."""
+    import torch.nn.functional as F
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+    if relu:
+        xt = xt.clamp_min(0)
+    if up:
+        xt = xt.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    wt = torch.from_numpy(np.ascontiguousarray(w)).permute(3, 2, 0, 1).contiguous()
+    return F.conv2d(xt, wt, padding=w.shape[0] // 2).permute(0, 2, 3, 1).contiguous().numpy()
+
+
+PERSISTENT_CASES = [
+    # n, h, w, cin, cout, k, up, relu, extra           tiles of 256 pixels -> persistent workgroups (256 CUs)
+    (400, 16, 16, 256, 256, 3, False, True, ""),        # 400 (XCD-swizzled): 144 workgroups walk 2 tiles, 112 walk 1; fwd + dgrad (mask)
+    (393, 16, 16, 64, 256, 3, True, False, ""),         # 393 (not a multiple of 8: plain order), folded upsample
+    (6201, 8, 8, 128, 256, 1, False, False, ""),        # 1551, the last one partial (64 of 256 pixels); 2 K-tiles per tile (minimum)
+    (400, 16, 16, 256, 256, 1, False, False, "acc"),    # accumulate into an existing tensor (shortcut + conv, gan_resnet.py:328)
+    (400, 16, 16, 256, 256, 1, False, True, "res"),     # residual added in the epilogue
+    (1280, 8, 8, 256, 256, 3, False, False, ""),        # 320 -> the 256 x 128 kernel (1.25 rounds of 256 x 256 tiles)
+]
+
+
+@pytest.mark.parametrize("case", PERSISTENT_CASES)
+def test_conv_persistent_tiles(dev, case):
+    """The persistent 256 x 256 kernel (one workgroup per CU walking several tiles in one K-tile stream: tile hand-over of
+    the LDS-DMA cursor, tap tables of two tiles alive at once, stores draining under the next tile) against an fp32 CPU
+    convolution, forward and -- where Cin is a multiple of 256 too -- data gradient."""
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("MFMA tile kernels run on 16-bit activations")
+    n, h, w, cin, cout, k, up, relu, extra = case
+    rs = np.random.RandomState(abs(hash(case)) % 2 ** 31)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = _prep(rs.randn(n, hs, ws, cin).astype(np.float32), mode)
+    wgt = half_round(mode, (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32))
+    b = rs.randn(cout).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    wp, bp = FakeParam(ctx, wgt), FakeParam(ctx, b)
+    W = O.Weight(ctx, wp.t)
+    ref = _torch_conv_ref(x, wgt, up, relu) + b
+    if extra == "acc":
+        t0 = _prep(rs.randn(n, h, w, cout).astype(np.float32), mode)
+        y = O.conv2d(ctx, xd, W, bp.t, k, in_up=up, in_relu=relu, accumulate_into=ctx.upload(t0))
+        ref = ref + t0
+    elif extra == "res":
+        r0 = _prep(rs.randn(n, h, w, cout).astype(np.float32), mode)
+        y = O.conv2d(ctx, xd, W, bp.t, k, in_up=up, in_relu=relu, residual=ctx.upload(r0))
+        ref = ref + r0
+    else:
+        y = O.conv2d(ctx, xd, W, bp.t, k, in_up=up, in_relu=relu)
+    got = ctx.download(y)
+    assert_close(got, ref, TOL[mode], "persistent conv fwd %s" % (case,))
+    # every tile individually (a misplaced tile would hide in a max over the whole tensor only if it were zero)
+    gt, rt = got.reshape(-1, cout), ref.reshape(-1, cout)
+    ntile = -(-gt.shape[0] // 256)
+    pad = ntile * 256 - gt.shape[0]
+    e = np.abs(np.pad(gt - rt, ((0, pad), (0, 0)))).reshape(ntile, -1).max(1)
+    assert e.max() <= TOL[mode] * np.abs(rt).max(), "tile %d off by %.3e" % (int(e.argmax()), float(e.max()))
+    if cin % 256 == 0 and not up:
+        dy = _prep(rs.randn(*ref.shape).astype(np.float32), mode)
+        y.grad = ctx.upload(dy)
+        ctx.group_wgrads, keep = True, ctx.group_wgrads
+        ctx.backward()
+        ctx.group_wgrads = keep
+        wf = np.ascontiguousarray(wgt[::-1, ::-1].transpose(0, 1, 3, 2))            # adjoint: 180-degree rotation, in/out swapped
+        dx = _torch_conv_ref(dy, wf)
+        if relu:
+            dx = dx * (x > 0)
+        assert_close(ctx.download(xd.grad), dx, TOL[mode], "persistent conv dgrad %s" % (case,))
+
+
 def _random_cases(kind, count, seed):
     """Seeded shape sweeps for the dense / transposed-conv / batch-norm tests (sizes the fixed lists do not pin down)."""
     rs = np.random.RandomState(seed)
