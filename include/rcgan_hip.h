@@ -85,6 +85,10 @@ int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* 
 #define RCGAN_PROF_CONV_P8N 5        /* conv_mfma_p8n_kernel: 256 x 128 tile */
 int rcgan_prof_begin(rcgan_ctx* ctx, int which);
 int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);
+/* Diagnostics: while `stamps` is non-null, every workgroup of the 256 x 256 convolution kernel writes 8 x uint64 to
+ * stamps[workgroup * 8 ..]: s_memtime at {start, tap table built, first K-tile landed, K loop done, stores issued,
+ * stores complete}, HW_ID, XCC_ID (scripts/exp_p8_timeline.py).  Pass null to switch it off. */
+int rcgan_debug_stamps(rcgan_ctx* ctx, void* stamps);
 /* hipGraph capture of everything launched on the ctx stream between begin/end; replay with launch.
  * Replaces the per-step sess.run dispatch (gan_resnet.py:931,938; mnist/model.py:347-372). */
 int rcgan_graph_begin(rcgan_ctx* ctx);
@@ -297,6 +301,23 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
                        float weight, float* loss_acc, float* dlogit, float* dwts);
 /* weight * mean over all rows*cols of sigmoid_cross_entropy_with_logits(x, onehot(labels))
  * (perm regulariser: gan_resnet.py:693-694,782-783; mnist/model.py:218-221). */
+/* Fused projection head: pooled features -> psi (D.Output, SN linear d -> 1), label embeddings E = table @ W_e / sigma_e + b_e
+ * (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421), logits psi + <feat, E[l]> (:588, :654-660), loss terms and ALL
+ * gradients in one launch.  Rows [0, rows_a) form part a, rows [rows_a, n) part b (real | fake of the critic step, :604-606);
+ * each part has its loss kind and EITHER int32 labels [rows] (one-hot weights) OR a weight matrix [rows, v] (confusion-matrix
+ * rows :682-684, C^-1 rows :647) with optional d/d(weights).  ws: (v*d + n*(v+1) + (v+1)*d + 256) floats of scratch.  loss_acc += weight * (mean over the part's rows);
+ * dfeat is written, the five parameter gradients are accumulated (+=); any output may be null. */
+typedef struct {
+  int n, d, v, e_dim;
+  int rows_a, kind_a, kind_b;
+  float weight;
+  const int32_t* labels_a; const float* wts_a; float* dwts_a;
+  const int32_t* labels_b; const float* wts_b; float* dwts_b;
+} rcgan_head_desc;
+int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
+                            const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,
+                            float* loss_acc, float* logits, float* dfeat, float* dw_out, float* db_out, float* dtable, float* dw_e,
+                            float* db_e, void* ws, size_t ws_bytes);
 int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels,
                              float weight, float* loss_acc, float* dx);
 /* recover_labels objective (mnist/model.py:533-537): gen [r*ydim, pix] = one generated image per (real sample r, label y),

@@ -37,6 +37,13 @@ class PrepareItem(C.Structure):
     _fields_ = [("desc", ConvDesc), ("w", C.c_void_p), ("sigma", C.c_void_p), ("prepared", C.c_void_p)]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("d", C.c_int), ("v", C.c_int), ("e_dim", C.c_int),
+                ("rows_a", C.c_int), ("kind_a", C.c_int), ("kind_b", C.c_int), ("weight", C.c_float),
+                ("labels_a", C.c_void_p), ("wts_a", C.c_void_p), ("dwts_a", C.c_void_p),
+                ("labels_b", C.c_void_p), ("wts_b", C.c_void_p), ("dwts_b", C.c_void_p)]
+
+
 class SnItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("sigma", C.c_void_p), ("save", C.c_void_p),
                 ("k", C.c_int), ("c", C.c_int), ("update", C.c_int)]
@@ -65,6 +72,7 @@ SIGNATURES = {
     "rcgan_stream_sync": (I, [P]),
     "rcgan_event_record": (I, [P, I]),
     "rcgan_event_elapsed_ms": (I, [P, I, I, C.POINTER(F)]),
+    "rcgan_debug_stamps": (I, [P, P]),
     "rcgan_prof_begin": (I, [P, I]),
     "rcgan_prof_end": (I, [P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rcgan_graph_begin": (I, [P]),
@@ -122,6 +130,7 @@ SIGNATURES = {
     "rcgan_proj_logit_all_bwd": (I, [P, I, I, I, P, P, P, P, P, P, I]),
     "rcgan_loss_fwd_bwd": (I, [P, I, I, I, P, P, F, P, P, P]),
     "rcgan_bce_onehot_fwd_bwd": (I, [P, I, I, P, P, F, P, P]),
+    "rcgan_proj_head_fwd_bwd": (I, [P, C.POINTER(HeadDesc)] + [P] * 16 + [P, SZ]),
     "rcgan_recover_mse_fwd_bwd": (I, [P, I, I, I, I, P, P, P, P, P, P, P, SZ]),
     "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),
     "rcgan_softmax_rows_bwd": (I, [P, I, I, P, P, P, I]),

@@ -7,15 +7,16 @@ one process per GPU, eager hand-written HIP kernels recorded on a tape, the whol
 captured into a hipGraph, gradients all-reduced over RCCL on flat slabs.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 
 from . import _lib as L
 from . import ops as O
-from .ops_cifar import NO_OPS, Conv2D, Linear, cond_batchnorm, embed_y
+from .ops_cifar import NO_OPS, Conv2D, Linear, cond_batchnorm, embed_y, spectral_normed_weight
 from .runtime import DT, Context, ParamGroup
-from .variables import Graph, variable_scope
+from .variables import Graph, scoped, variable_scope
 
 Z_DIM = 128
 DIM_G = 128
@@ -182,9 +183,10 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         return O.reshape(ctx, output, (-1, OUTPUT_DIM))
 
 
-def Discriminator(inputs, labels, update_collection=None):
+def Discriminator(inputs, labels, update_collection=None, _head=True):
     """gan_resnet.py:374-412 (+ OptimizedResBlockDisc1 :331-353, ResidualBlock :275-328).  No norm in D
-    (NORMALIZATION_D=False), so ``labels`` is unused exactly as in the reference."""
+    (NORMALIZATION_D=False), so ``labels`` is unused exactly as in the reference.  _head=False: return the pooled features
+    only (D.Output is then applied inside Discriminator_head's fused launch)."""
     ctx = _ctx()
     kw = dict(spectral_normed=True, update_collection=update_collection)
     with variable_scope("Discriminator"):
@@ -203,6 +205,8 @@ def Discriminator(inputs, labels, update_collection=None):
             h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
             x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv2' % blk, _in_relu=True, _residual=x, **kw)   # shortcut + output
         output = O.act_meanhw(ctx, x, L.ACT_RELU)                       # relu + reduce_mean over (1,2)
+        if not _head:
+            return output
         output_wgan = Linear(output, DIM_D, 1, 'D.Output', **kw)
         return output, O.reshape(ctx, output_wgan, (-1,))
 
@@ -213,6 +217,24 @@ def Discriminator_projection(labels, update_collection=None):
         e = embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
         return Linear(e, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
                       update_collection=update_collection, biases=True)
+
+
+def Discriminator_head(features, parts, weight, loss_acc, update_collection=None):
+    """The tail of Discriminator (D.Output, gan_resnet.py:408-411), Discriminator_projection (:414-421), the projection
+    logit (:588; every label's logit :654-660) and the loss terms built on it (:604-606, :647, :673-684, :751-773) as ONE
+    launch with all their gradients (ops.proj_head).  update_collection: that of D.Output's spectral norm (the projection's
+    is None at every call site of the reference).  parts: see ops.proj_head."""
+    g = Graph.current
+    with variable_scope("Discriminator"):
+        with variable_scope('D.Output'):
+            w_out = spectral_normed_weight(scoped('W'), update_collection=update_collection)
+            b_out = g.param(scoped('b'))
+        with variable_scope("Embedding.Label"):
+            table = g.param(scoped('embedding_map'))
+        with variable_scope('D.Embedding_y'):
+            w_e = spectral_normed_weight(scoped('W'), update_collection=None)
+            b_e = g.param(scoped('b'))
+    O.proj_head(g.ctx, features, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc)
 
 
 def perm_classifier(x, perm_type='linear'):
@@ -247,6 +269,8 @@ class CifarRCGAN:
         self.confuse_multiplier, self.confuse_lr_decay = confuse_multiplier, confuse_lr_decay
         self.world, self.rank = world_size, rank
         self.use_graphs, self.device_rng = use_graphs, device_rng
+        # the projection head + loss terms as one launch (Discriminator_head); RCGAN_FUSED_HEAD=0 keeps the op-by-op form
+        self.fused_head = os.environ.get("RCGAN_FUSED_HEAD", "1") == "1" and 2 * int(batch_size) <= O.HEAD_MAX_N
         if arena_bytes is None:
             arena_bytes = int(2.5e6 * 4 * self.B * 2) + (1 << 30)      # ~20 MB/sample fp32-equivalent + slack
         self.ctx = Context(device, dtype, arena_bytes=arena_bytes)
@@ -439,7 +463,18 @@ class CifarRCGAN:
         else:
             fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)             # :540-546
         w = self.loss_scale
-        if self.alg == "rcgan-u":
+        if self.fused_head:
+            feat = Discriminator(x_all, None, update_collection=None, _head=False)        # :584
+            lab_r, lab_f = inp["labels_all"].rows(0, B), inp["labels_all"].rows(B, 2 * B)
+            if self.alg == "rcgan-u":          # fake logits for every label, weighted by the confusion rows (:654-684)
+                y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random"], B)
+                parts = [(B, L.LOSS_HINGE_REAL, inp["labels"], None), (B, L.LOSS_HINGE_FAKE, None, y_conf)]
+            elif self.alg == "unbiased":       # real logits for every label, weighted by the C^-1 rows (:613-648)
+                parts = [(B, L.LOSS_HINGE_REAL, None, inp["inv_weights"]), (B, L.LOSS_HINGE_FAKE, inp["labels_random"], None)]
+            else:                              # biased / rcgan (:585-606): labels_all = [labels ; labels_random | labels_biased]
+                parts = [(B, L.LOSS_HINGE_REAL, lab_r, None), (B, L.LOSS_HINGE_FAKE, lab_f, None)]
+            Discriminator_head(feat, parts, w, self.loss_d, update_collection=None)
+        elif self.alg == "rcgan-u":
             feat_a, wgan_a = Discriminator(x_all, None, update_collection=None)
             feat, wgan = O.rows(ctx, feat_a, 0, B), O.rows(ctx, wgan_a, 0, B)
             feat_f, wgan_f = O.rows(ctx, feat_a, B, 2 * B), O.rows(ctx, wgan_a, B, 2 * B)
@@ -489,6 +524,23 @@ class CifarRCGAN:
         self._prepare_all((self.PG, self.PD))
         fake = Generator(n, inp["labels_random_G"], inp["z_G"])                                      # :719
         lab = inp["labels_random_G"] if self.alg in ("biased", "unbiased") else inp["labels_biased_G"]
+        if self.fused_head:
+            feat = Discriminator(fake, lab, update_collection=NO_OPS, _head=False)                   # :721-730
+            if self.alg == "rcgan-u":
+                y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random_G"], n)      # :757-758
+                parts = [(n, L.LOSS_NEG_MEAN, None, y_conf)]                                         # :751,759
+            else:
+                parts = [(n, L.LOSS_NEG_MEAN, lab, None)]                                            # :763,773
+            Discriminator_head(feat, parts, self.loss_scale, self.loss_g, update_collection=NO_OPS)
+        else:
+            self._g_head_unfused(fake, lab, n)
+        if self.perm:
+            logits = perm_classifier(fake, self.perm_type)                                           # :781
+            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult * self.loss_scale, self.loss_g)      # :782-784
+        ctx.backward()
+
+    def _g_head_unfused(self, fake, lab, n):
+        ctx, inp = self.ctx, self.inp
         feat, wgan = Discriminator(fake, lab, update_collection=NO_OPS)                              # :721-730
         if self.alg == "rcgan-u":
             E = Discriminator_projection(inp["arange"], update_collection=None)                      # :736
@@ -499,10 +551,6 @@ class CifarRCGAN:
             emb = Discriminator_projection(lab, update_collection=None)                              # :725,731
             disc_fake = O.proj_logit(ctx, feat, wgan, emb)                                           # :763
             O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, self.loss_scale, self.loss_g)                        # :773
-        if self.perm:
-            logits = perm_classifier(fake, self.perm_type)                                           # :781
-            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult * self.loss_scale, self.loss_g)      # :782-784
-        ctx.backward()
 
     # ---------------------------------------------------------------------------------- stepping
     def _run(self, key, body):

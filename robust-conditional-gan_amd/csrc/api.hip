@@ -114,6 +114,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     c->num_cus = cus;
   }
+  c->dbg_stamps = nullptr;
   c->zero_page = nullptr;
   if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
     delete c;
@@ -257,6 +258,12 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int id) {
   return RCGAN_OK;
 }
 
+int rcgan_debug_stamps(rcgan_ctx* ctx, void* stamps) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  ctx->dbg_stamps = stamps;
+  return RCGAN_OK;
+}
+
 int rcgan_prof_begin(rcgan_ctx* ctx, int which) {
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
   ctx->prof_ev.clear();
@@ -370,6 +377,7 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
   a.M = (long)d->n * d->h * d->w;
   a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
   if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
+  a.stamps = nullptr;
 }
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {

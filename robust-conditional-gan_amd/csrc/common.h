@@ -29,6 +29,7 @@ struct rcgan_ctx {
   hipStream_t main_stream, side_stream;
   hipEvent_t fork_ev, join_ev;
   bool on_side;
+  void* dbg_stamps;    // rcgan_debug_stamps
   int num_cus;         // compute units of the device (grid size of the persistent kernels)
   void* zero_page;     // 4 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
                        // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels
@@ -36,6 +37,7 @@ struct rcgan_ctx {
 };
 #define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
 #define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish
+#define RC_COUNTER_HEAD 500    // loss partials of the fused projection head
 #define RC_COUNTER_BNSEG 512   // [512,768): segmented forward batch norm, one per (segment, 64-channel column block)
 
 // brackets one launch with events when profiling is armed for kernel id `which`

@@ -15,6 +15,7 @@ struct MfmaConvArgs {
   int cm;                 // eight-wave kernels: channel-major K order (all taps of a 64-channel chunk, then the next chunk)
   int lw, lh;             // log2(W), log2(H) when both are powers of two (pixel decode by shifts), else -1
   long M;
+  unsigned long long* stamps;   // diagnostics (rcgan_debug_stamps), normally null
 };
 
 struct MfmaWgradArgs {

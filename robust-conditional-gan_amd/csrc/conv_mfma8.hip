@@ -58,6 +58,14 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   //      ~0u where SAME padding applies.  Built once per workgroup behind the tile buffers (9 x 256 x 4 B); the K loop
   //      then needs one ds_read_b32 + a select per DMA row when the tap changes instead of a bounds test and a pixel
   //      address -- which is what makes a tap change per K-tile (channel-major order, a.cm) affordable.
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  if (a.stamps && tid == 0) {
+    a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+    a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+  }
   unsigned* const tapt = (unsigned*)(smem + 2 * BUF);
   const int ntaps = a.KH * a.KW;
   for (int e = tid; e < ntaps * 256; e += 512) {
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
     tapt[e] = off;
   }
   __syncthreads();
+  stamp(1);
 
   // ---- DMA roles: per half-tile this wavefront deposits rows (wave*2 + j)*8 + lrow, j = 0,1 (of 128) ----------------
   // LDS row r of X half h  <->  tile pixel (r>>6)*128 + h*64 + (r&63);  W half h: channel (r>>5)*64 + h*32 + (r&31)
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   for (int w = 0; w < 4; ++w) issue(w, 0);
   wait_vm<0>();
   wg_barrier();
+  stamp(2);
 
   for (int t = 0; t < KT; ++t) {
     const unsigned char* bufp = smem + (t & 1) * BUF;
@@ -242,7 +252,13 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   }
 
   // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
+  stamp(3);
   conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane);
+  if (a.stamps) {
+    stamp(4);
+    wait_vm<0>();
+    stamp(5);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -703,6 +719,7 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   if (persist < 0) { const char* e = getenv("RCGAN_P8_PERSIST"); persist = e ? atoi(e) : 0; }
   if (wide) {
     MfmaConvArgs b = a;
+    b.stamps = (unsigned long long*)ctx->dbg_stamps;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
     if (persist && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)

@@ -176,6 +176,194 @@ __global__ void softmax_rows_bwd_kernel(int rows, int cols, const float* p, cons
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused projection head: everything between the discriminator's pooled features and the loss, forward AND backward,
+// as two (forward + data gradient) or four (+ parameter gradients) short launches -- it replaces ~16 launches of a few
+// microseconds each per step: D.Output linear, embedding gather, D.Embedding_y linear, projection logit, the loss terms and
+// all their gradient kernels.
+//   psi[s]      = <feat[s], w_out> / sigma_out + b_out                       (gan_resnet.py:408-411, Linear SN 128 -> 1)
+//   E[l]        = table[l] @ W_e / sigma_e + b_e                             (:414-421 for every label l: only V = 10 distinct rows exist)
+//   logit[s,l]  = psi[s] + <feat[s], E[l]>                                   (:588, :654-660)
+//   part p of the rows (e.g. real | fake) contributes  weight/rows_p * sum_s sum_l w[s,l] * loss_kind_p(logit[s,l]),
+//   w = onehot(labels[s]) or an explicit [rows_p, V] weight matrix (confusion rows :682-684 / C^-1 rows :647).
+// Gradients: dfeat written; dw_out / db_out / dtable / dW_e / db_e ACCUMULATED (+=) into the caller's buffers (the SN
+// weights' d/dW_bar scratch or the gradient slab, zeroed at the start of the step); dwts written.  Because only V rows of
+// E exist, the embedding gradients collapse to V x d problems: dE[l] = sum_s dlogit[s,l] feat[s], dW_e = table^T dE,
+// dtable = dE W_e^T / sigma_e.
+// ---------------------------------------------------------------------------------------------------------
+#define HEAD_MAX_V 16
+#define HEAD_MAX_D 256
+#define HEAD_MAX_N 1024
+struct HeadPart { int rows, kind; const int32_t* labels; const float* wts; float* dwts; };
+struct HeadArgs {
+  int n, d, v, e_dim;
+  HeadPart part[2];
+  float weight;
+  const float *feat, *w_out, *sigma_out, *b_out, *table, *w_e, *sigma_e, *b_e;
+  float *loss_acc, *logits, *dfeat, *dw_out, *db_out, *dtable, *dw_e, *db_e;
+};
+
+// Four short multi-workgroup launches (a single workgroup would be latency-bound: hundreds of dependent L2 round trips):
+//   embed : E[l][j]                      grid (v, d/64)      256 threads = 64 columns x 4 k-lanes
+//   logit : per sample psi, logits, loss, dlogit, dfeat       grid n/8           4 wavefronts x 2 samples; the last
+//           workgroup to arrive adds the loss partials in workgroup order
+//   dE    : dE[l][j] = sum_s dlogit[s,l] feat[s][j]  (row v: the psi column)     grid (v+1, d/64)
+//   wgrad : dW_e += table^T dE,  dtable += dE W_e^T / sigma_e,  dw_out, db_out, db_e   grid (e_dim*d + ...)/256
+__global__ __launch_bounds__(256) void head_embed_kernel(HeadArgs a, float* Eg) {
+  __shared__ float red[4][64];
+  const int l = blockIdx.x, jj = threadIdx.x & 63, kl = threadIdx.x >> 6, j = blockIdx.y * 64 + jj;
+  const int d = a.d, ed = a.e_dim;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < d) {
+    int k = kl;
+    for (; k + 4 < ed; k += 8) { s0 += a.table[l * ed + k] * a.w_e[(long)k * d + j]; s1 += a.table[l * ed + k + 4] * a.w_e[(long)(k + 4) * d + j]; }
+    if (k < ed) s0 += a.table[l * ed + k] * a.w_e[(long)k * d + j];
+  }
+  red[kl][jj] = s0 + s1;
+  __syncthreads();
+  if (kl == 0 && j < d) {
+    const float inv_se = a.sigma_e ? 1.f / a.sigma_e[0] : 1.f;
+    Eg[l * d + j] = ((red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj])) * inv_se + (a.b_e ? a.b_e[j] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float* Eg, float* dlg, float* losspart, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];
+  const int n = a.n, d = a.d, v = a.v, vp = v + 1;
+  float* E = hs;                    // [v][d]
+  float* red = E + v * d;           // [4]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < v * d; i += 256) E[i] = Eg[i];
+  __syncthreads();
+  const float inv_so = a.sigma_out ? 1.f / a.sigma_out[0] : 1.f;
+  const float bo = a.b_out ? a.b_out[0] : 0.f;
+  float lacc = 0.f;
+  for (int s = blockIdx.x * 8 + wave; s < n && s < (int)blockIdx.x * 8 + 8; s += 4) {
+    const int p = s < a.part[0].rows ? 0 : 1;
+    const HeadPart& P = a.part[p];
+    const int sr = p ? s - a.part[0].rows : s;
+    const float inv_rows = 1.f / (float)P.rows;
+    float f[HEAD_MAX_D / 64], wo[HEAD_MAX_D / 64], df[HEAD_MAX_D / 64];
+    float ps = 0.f;
+#pragma unroll
+    for (int q = 0; q < HEAD_MAX_D / 64; ++q) {
+      const int j = lane + q * 64;
+      f[q] = j < d ? a.feat[(long)s * d + j] : 0.f;
+      wo[q] = j < d ? a.w_out[j] * inv_so : 0.f;
+      ps += f[q] * wo[q];
+      df[q] = 0.f;
+    }
+    ps = wave_sum(ps) + bo;
+    const int lab = P.labels ? P.labels[sr] : -1;
+    float dsum = 0.f;
+    for (int l = 0; l < v; ++l) {
+      float g = 0.f;
+      if (lab < 0 || lab == l) {                           // wave-uniform
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; dot += j < d ? f[q] * E[l * d + j] : 0.f; }
+        const float x = wave_sum(dot) + ps;
+        float tt, dd;
+        loss_term(P.kind, x, &tt, &dd);
+        const float wf = (P.wts ? P.wts[(long)sr * v + l] : 1.f) * inv_rows;
+        lacc += tt * wf;
+        g = a.weight * dd * wf;
+#pragma unroll
+        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; df[q] += j < d ? g * E[l * d + j] : 0.f; }
+        if (lane == 0) {
+          if (P.dwts) P.dwts[(long)sr * v + l] = a.weight * tt * inv_rows;
+          if (a.logits) a.logits[(long)s * v + l] = x;
+        }
+      } else if (lane == 0 && a.logits) {
+        a.logits[(long)s * v + l] = 0.f;
+      }
+      if (lane == 0) dlg[s * vp + l] = g;
+      dsum += g;
+    }
+    if (lane == 0) dlg[s * vp + v] = dsum;
+    if (a.dfeat) {
+#pragma unroll
+      for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; if (j < d) a.dfeat[(long)s * d + j] = df[q] + dsum * wo[q]; }
+    }
+  }
+  // ---- loss: per-workgroup partial, summed in workgroup order by the last arrival (deterministic) -------------------
+  if (lane == 0) red[wave] = lacc;
+  __syncthreads();
+  if (t == 0) {
+    __hip_atomic_store(losspart + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1u) {
+      float tot = 0.f;
+      for (unsigned w = 0; w < gridDim.x; ++w) tot += __hip_atomic_load(losspart + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.loss_acc) *a.loss_acc += a.weight * tot;
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_dE_kernel(HeadArgs a, const float* dlg, float* dEg) {
+  __shared__ float red[4][64];
+  const int l = blockIdx.x, jj = threadIdx.x & 63, sl = threadIdx.x >> 6, j = blockIdx.y * 64 + jj;
+  const int n = a.n, d = a.d, vp = a.v + 1;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < d) {
+    int s = sl;
+    for (; s + 4 < n; s += 8) { s0 += dlg[s * vp + l] * a.feat[(long)s * d + j]; s1 += dlg[(s + 4) * vp + l] * a.feat[(long)(s + 4) * d + j]; }
+    if (s < n) s0 += dlg[s * vp + l] * a.feat[(long)s * d + j];
+  }
+  red[sl][jj] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && j < d) dEg[l * d + j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
+  if (l == a.v && blockIdx.y == 0 && threadIdx.x == 0 && a.db_out) {
+    float tot = 0.f;
+    for (int s = 0; s < n; ++s) tot += dlg[s * vp + a.v];
+    a.db_out[0] += tot;
+  }
+}
+
+// items: [0, ed*d) dW_e;  then ed wavefront-items for dtable (one k each);  then d items for dw_out and d for db_e
+__global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, const float* dEg) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];
+  const int d = a.d, v = a.v, ed = a.e_dim;
+  float* dE = hs;                   // [v+1][d]
+  for (int i = threadIdx.x; i < (v + 1) * d; i += 256) dE[i] = dEg[i];
+  __syncthreads();
+  const int nb_w = (ed * d + 255) / 256;                  // blocks of the dW_e range
+  const int nb_t = (ed + 3) / 4;                          // blocks of the dtable range (4 wavefronts = 4 k per block)
+  const int b = blockIdx.x;
+  if (b < nb_w) {
+    const int o = b * 256 + threadIdx.x;
+    if (o < ed * d && a.dw_e) {
+      const int k = o / d, j = o - k * d;
+      float acc = 0.f;
+      for (int l = 0; l < v; ++l) acc += a.table[l * ed + k] * dE[l * d + j];
+      a.dw_e[o] += acc;
+    }
+  } else if (b < nb_w + nb_t) {
+    const int k = (b - nb_w) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k < ed && a.dtable) {
+      const float inv_se = a.sigma_e ? 1.f / a.sigma_e[0] : 1.f;
+      float w[HEAD_MAX_D / 64];
+#pragma unroll
+      for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; w[q] = j < d ? a.w_e[(long)k * d + j] : 0.f; }
+      for (int l = 0; l < v; ++l) {
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; dot += j < d ? w[q] * dE[l * d + j] : 0.f; }
+        dot = wave_sum(dot);
+        if (lane == 0) a.dtable[(long)l * ed + k] += dot * inv_se;
+      }
+    }
+  } else {
+    for (int j = threadIdx.x; j < d; j += 256) {
+      if (a.dw_out) a.dw_out[j] += dE[v * d + j];
+      if (a.db_e) { float tot = 0.f; for (int l = 0; l < v; ++l) tot += dE[l * d + j]; a.db_e[j] += tot; }
+    }
+  }
+}
+
 static inline int g1(long total) {
   long b = (total + 255) / 256;
   if (b > 4096) b = 4096;
@@ -278,6 +466,50 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
   RC_REQUIRE(ctx, kind >= 0 && kind <= RCGAN_LOSS_CE_ZEROS, "kind %d", kind);
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, ctx->stream, kind, rows, cols, x, wts, weight, loss_acc, dlogit, dwts);
   RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
+                            const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,
+                            float* loss_acc, float* logits, float* dfeat, float* dw_out, float* db_out, float* dtable, float* dw_e,
+                            float* db_e, void* ws, size_t ws_bytes) {
+  RC_REQUIRE(ctx, hd && feat && w_out && table && w_e, "null argument");
+  RC_REQUIRE(ctx, hd->n >= 1 && hd->n <= HEAD_MAX_N && hd->d >= 1 && hd->d <= HEAD_MAX_D && hd->v >= 1 && hd->v <= HEAD_MAX_V && hd->e_dim >= 1,
+             "head shape n %d d %d v %d e %d", hd->n, hd->d, hd->v, hd->e_dim);
+  RC_REQUIRE(ctx, hd->rows_a >= 1 && hd->rows_a <= hd->n, "rows_a %d of %d", hd->rows_a, hd->n);
+  HeadArgs a;
+  a.n = hd->n; a.d = hd->d; a.v = hd->v; a.e_dim = hd->e_dim; a.weight = hd->weight;
+  a.part[0] = {hd->rows_a, hd->kind_a, hd->labels_a, hd->wts_a, hd->dwts_a};
+  a.part[1] = {hd->n - hd->rows_a, hd->kind_b, hd->labels_b, hd->wts_b, hd->dwts_b};
+  for (int p = 0; p < 2; ++p) {
+    if (a.part[p].rows == 0) continue;
+    RC_REQUIRE(ctx, a.part[p].kind >= 0 && a.part[p].kind <= RCGAN_LOSS_CE_ZEROS, "kind %d", a.part[p].kind);
+    RC_REQUIRE(ctx, (a.part[p].labels != nullptr) != (a.part[p].wts != nullptr), "part %d needs labels or weights (exactly one)", p);
+  }
+  a.feat = feat; a.w_out = w_out; a.sigma_out = sigma_out; a.b_out = b_out; a.table = table; a.w_e = w_e; a.sigma_e = sigma_e; a.b_e = b_e;
+  a.loss_acc = loss_acc; a.logits = logits; a.dfeat = dfeat; a.dw_out = dw_out; a.db_out = db_out; a.dtable = dtable; a.dw_e = dw_e; a.db_e = db_e;
+  const int vp = a.v + 1;
+  const size_t need = ((size_t)a.v * a.d + (size_t)a.n * vp + (size_t)vp * a.d + 256) * sizeof(float);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  float* Eg = (float*)ws;
+  float* dlg = Eg + (size_t)a.v * a.d;
+  float* dEg = dlg + (size_t)a.n * vp;
+  float* losspart = dEg + (size_t)vp * a.d;
+  const int dblk = cdiv(a.d, 64);
+  hipLaunchKernelGGL(head_embed_kernel, dim3(a.v, dblk), dim3(256), 0, ctx->stream, a, Eg);
+  RC_LAUNCH_CHECK(ctx);
+  const int nwg = cdiv(a.n, 8);
+  RC_REQUIRE(ctx, nwg <= 256, "too many rows for the loss partials");
+  hipLaunchKernelGGL(head_logit_kernel, dim3(nwg), dim3(256), ((size_t)a.v * a.d + 4) * sizeof(float), ctx->stream, a, (const float*)Eg, dlg,
+                     losspart, ctx->counters() + RC_COUNTER_HEAD);
+  RC_LAUNCH_CHECK(ctx);
+  if (dw_out || db_out || dtable || dw_e || db_e) {
+    hipLaunchKernelGGL(head_dE_kernel, dim3(vp, dblk), dim3(256), 0, ctx->stream, a, (const float*)dlg, dEg);
+    RC_LAUNCH_CHECK(ctx);
+    const int blocks = cdiv(a.e_dim * a.d, 256) + cdiv(a.e_dim, 4) + 1;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), (size_t)vp * a.d * sizeof(float), ctx->stream, a, (const float*)dEg);
+    RC_LAUNCH_CHECK(ctx);
+  }
   return RCGAN_OK;
 }
 

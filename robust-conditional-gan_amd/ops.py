@@ -629,6 +629,44 @@ def proj_logit_all(ctx, feat, psi, E):
     return y
 
 
+HEAD_MAX_N = 1024
+
+
+def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=None):
+    """The whole projection head in one launch (rcgan_proj_head_fwd_bwd): psi = Linear_SN(feat) (gan_resnet.py:408-411),
+    E = Linear_SN(embed_y(l)) for every label l (:414-421), logit[s,l] = psi[s] + <feat[s], E[l]> (:588, :654-660), the loss terms
+    and every gradient.  w_out / w_e: Weight handles (sigma fused); table: the embedding_map parameter.
+    parts: one or two (rows, kind, labels, wts) tuples covering feat's rows in order -- labels: int32 DT [rows] (one-hot
+    weighting) or wts: fp32 DT [rows, v] (may require a gradient).  Adds weight * (mean over each part's rows) to loss_acc.
+    Like loss_term this computes its gradients in the forward launch: feat (and a wts that requires one) get their .grad
+    here, the parameter gradients are accumulated into the step's zeroed buffers."""
+    n, d = feat.shape
+    v, e_dim = table.shape
+    assert 1 <= len(parts) <= 2 and sum(p[0] for p in parts) == n, (parts, n)
+    rec = ctx.recording
+    hd = L.HeadDesc(n, d, v, e_dim, parts[0][0], parts[0][1], parts[1][1] if len(parts) > 1 else 0, float(weight))
+    for (rows, kind, labels, wts), sfx in zip(parts, ("a", "b")):
+        assert (labels is None) != (wts is None)
+        setattr(hd, "labels_" + sfx, labels.ptr if labels is not None else None)
+        setattr(hd, "wts_" + sfx, wts.ptr if wts is not None else None)
+        if wts is not None and wts.req and rec:
+            dw, _ = grad_of(ctx, wts)
+            setattr(hd, "dwts_" + sfx, dw.ptr)
+    dfeat = None
+    if feat.req and rec:
+        assert feat.grad is None, "the projection head is its features' only consumer"
+        dfeat, _ = grad_of(ctx, feat)
+    pg = lambda t: _p(t) if (rec and t is not None) else None
+    dw_out = w_out.grad_target() if (rec and w_out.req) else None
+    dw_e = w_e.grad_target() if (rec and w_e.req) else None
+    db_out = b_out.grad if (b_out is not None and b_out.req) else None
+    db_e = b_e.grad if (b_e is not None and b_e.req) else None
+    dtable = table.grad if table.req else None
+    ctx.check(ctx.lib.rcgan_proj_head_fwd_bwd(
+        ctx.h, C.byref(hd), _p(feat), _p(w_out.param), _p(w_out.sigma), _p(b_out), _p(table), _p(w_e.param), _p(w_e.sigma), _p(b_e),
+        _p(loss_acc), _p(logits), _p(dfeat), pg(dw_out), pg(db_out), pg(dtable), pg(dw_e), pg(db_e), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+
+
 def loss_term(ctx, kind, x, weight, loss_acc, wts=None):
     """Adds weight * L(x) to the device scalar loss_acc; the gradient weight*dL/dx is computed in the
     same launch (the total cost is a weighted sum of such terms, so no upstream gradient is needed)."""
