@@ -528,6 +528,230 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
   if (t == 0) __hip_atomic_store(a.counter + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tree variant of the fused reduction for LARGE tensors (>= a few MB).  The kernel above gives every workgroup a 64-channel
+// column block: 128 bytes out of every 512-byte (c = 256) row, with the other three quarters of the row read by workgroups
+// on other XCDs at other times -- measured 2.5-2.9 TB/s where the contiguous apply kernels reach 5-6.  Here a workgroup
+// streams WHOLE rows (rows_per_group x c contiguous bytes), and because every workgroup then holds partial sums of every
+// channel, the combination is a two-level arrival tree instead of "last workgroup of the column":
+//   level 1: groups are dealt to clusters (16 consecutive groups; backward with labels: the groups of one sample).  The
+//            last group of a cluster to arrive adds the cluster's partials in group order -> cpart[cluster][2][c] (fp64).
+//   level 2: the last cluster to finish adds the cluster partials in cluster order (per label for the conditional
+//            backward) and writes mean / rstd (or dgamma / dbeta / P,Q).
+// Every sum has a fixed order: results are bit-reproducible.  Partials travel with agent-scope (write-through) stores and
+// loads; counters reset themselves (graph replay).
+// ------------------------------------------------------------------------------------------------
+struct BnTreeArgs {
+  BnFusedArgs f;             // partial = [ngroups][2c] fp32
+  float* cpart;              // [nclusters][2c]
+  unsigned* counters;        // [nclusters] + [1]   (per segment)
+  int cs, nclusters;         // groups per cluster
+};
+
+typedef unsigned int v4u32 __attribute__((__vector_size__(16)));
+// 16-byte agent-scope (sc1) accesses: served by / written through to the memory side, never a stale or dirty line of an XCD's L2
+__device__ __forceinline__ float4 ld_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+  const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];     // (named scalars: __builtin_bit_cast of a vector ELEMENT reads element 0)
+  return make_float4(__builtin_bit_cast(float, e0), __builtin_bit_cast(float, e1), __builtin_bit_cast(float, e2), __builtin_bit_cast(float, e3));
+}
+__device__ __forceinline__ void st_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 f) {
+  const v4u32 v = {__builtin_bit_cast(unsigned, f.x), __builtin_bit_cast(unsigned, f.y), __builtin_bit_cast(unsigned, f.z), __builtin_bit_cast(unsigned, f.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  __shared__ int flag;
+  BnFusedArgs& a = ta.f;
+  const int t = threadIdx.x;
+  const int c = a.c, c2 = 2 * c;
+  const int cpr = c >> 3, lcpr = __ffs(cpr) - 1;
+  const int chunk = t & (cpr - 1), rl = t >> lcpr, RL = 256 >> lcpr;
+  const int g = blockIdx.x;
+  const long rb = (long)g * a.rows_per_group;
+  long re = rb + a.rows_per_group;
+  if (re > a.rows) re = a.rows;
+  if (MODE == 0 && a.nseg > 1) {
+    const long sg = blockIdx.y;
+    a.x = (const T*)a.x + sg * a.rows * c;
+    a.partial += sg * (long)a.ngroups * c2;
+    ta.cpart += sg * (long)ta.nclusters * c2;
+    ta.counters += sg * (ta.nclusters + 1);
+    a.mean += sg * c; a.rstd += sg * c;
+  }
+  const T* x = (const T*)a.x; const T* y = (const T*)a.y; const T* dy = (const T*)a.dy;
+  float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  if (MODE == 1) { ld8(a.mean_in + chunk * 8, mu); ld8(a.rstd_in + chunk * 8, rs); }
+#pragma unroll 4
+  for (long r = rb + rl; r < re; r += RL) {
+    const long off = r * c + chunk * 8;
+    float xv[8];
+    ld8(x + off, xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += xv[j]; s2[j] += xv[j] * xv[j]; }
+    } else {
+      float gv[8];
+      ld8(dy + off, gv);
+      if (a.act != RCGAN_ACT_NONE) {
+        float yv[8];
+        ld8(y + off, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] *= act_grad(a.act, yv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += gv[j]; s2[j] += gv[j] * (xv[j] - mu[j]) * rs[j]; }
+    }
+  }
+  // ---- workgroup partial: sum over the row lanes through LDS ([2][RL][c] floats), written through as [2c] ----------
+  float* red = tsm;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[(0 * RL + rl) * c + chunk * 8 + j] = s1[j]; red[(1 * RL + rl) * c + chunk * 8 + j] = s2[j]; }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(a.partial, 0, (int)((long)a.ngroups * c2 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cp = __builtin_amdgcn_make_buffer_rsrc(ta.cpart, 0, (int)((long)ta.nclusters * c2 * 4), 0x00020000);
+  const int Q = c2 >> 2;                                     // 16-byte quads of one partial row
+  for (int qd = t; qd < Q; qd += 256) {
+    const int q = qd * 4 >= c ? 1 : 0, ch = qd * 4 - q * c;
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RL; ++k) {
+      const float4 v = *(const float4*)(red + (q * RL + k) * c + ch);
+      sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+    }
+    st_sc1_f4(rs_part, (unsigned)(((long)g * c2 + qd * 4) * 4), sm);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wavefront drains its write-through stores ...
+  __syncthreads();                                           // ... before one lane signals
+  const int cl = g / ta.cs;
+  const int cl_groups = min(ta.cs, a.ngroups - cl * ta.cs);
+  if (t == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(ta.counters + cl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag = (prev == (unsigned)cl_groups - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!flag) return;
+  // ---- level 1: this workgroup closes its cluster: cpart[cl] = sum of its groups' partials, in group order ------------
+  for (int qd = t; qd < Q; qd += 256) {
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned base = (unsigned)(((long)cl * ta.cs * c2 + qd * 4) * 4);
+#pragma unroll 16
+    for (int k = 0; k < cl_groups; ++k) {
+      const float4 v = ld_sc1_f4(rs_part, base + (unsigned)k * (unsigned)c2 * 4u);
+      sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+    }
+    st_sc1_f4(rs_cp, (unsigned)(((long)cl * c2 + qd * 4) * 4), sm);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __hip_atomic_store(ta.counters + cl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(ta.counters + ta.nclusters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag = (prev == (unsigned)ta.nclusters - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!flag) return;
+  // ---- level 2: the last cluster to finish closes the reduction --------------------------------------------------------
+  const bool cond = MODE == 1 && a.labels != nullptr;
+  const int ncl = ta.nclusters;
+  if (!cond) {
+    double* fin = (double*)tsm;                              // [2c]
+    for (int qd = t; qd < Q; qd += 256) {
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll 16
+      for (int k = 0; k < ncl; ++k) {
+        const float4 v = ld_sc1_f4(rs_cp, (unsigned)(((long)k * c2 + qd * 4) * 4));
+        d0 += (double)v.x; d1 += (double)v.y; d2 += (double)v.z; d3 += (double)v.w;
+      }
+      fin[qd * 4 + 0] = d0; fin[qd * 4 + 1] = d1; fin[qd * 4 + 2] = d2; fin[qd * 4 + 3] = d3;
+    }
+    __syncthreads();
+    for (int ch = t; ch < c; ch += 256) {
+      const double d1 = fin[ch], d2 = fin[c + ch];
+      if (MODE == 0) {
+        const double mean = d1 / (double)a.rows;
+        double var = d2 / (double)a.rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.mean[ch] = (float)mean;
+        a.rstd[ch] = (float)(1.0 / sqrt(var + (double)a.eps));
+        if (a.mm) {
+          const double uvar = a.rows > 1 ? var * ((double)a.rows / (double)(a.rows - 1)) : var;
+          const float om = 1.f - a.decay;
+          a.mm[ch] = a.mm[ch] - (a.mm[ch] - (float)mean) * om;
+          a.mv[ch] = a.mv[ch] - (a.mv[ch] - (float)uvar) * om;
+        }
+      } else {
+        float og = (float)d2, ob = (float)d1;
+        if (a.accumulate) { og += a.dgamma[ch]; ob += a.dbeta[ch]; }
+        a.dgamma[ch] = og; a.dbeta[ch] = ob;
+        const double gmm = (double)a.gamma[ch];
+        const float invM = 1.f / (float)a.rows;
+        const float r = a.rstd_in[ch];
+        const float p = -r * r * (float)(gmm * d2) * invM;
+        a.PQ[ch] = p;
+        a.PQ[c + ch] = -p * a.mean_in[ch] - r * (float)(gmm * d1) * invM;
+      }
+    }
+  } else {
+    // conditional backward: cluster = sample.  Thread (quad, sample lane) bins its samples' partial rows by label into
+    // lacc[SL][n_labels][2c] (LDS; every (lane, quad) column is private to one thread), then a thread per channel adds the
+    // lanes in order.
+    const int nl = a.n_labels;
+    const int SL = Q >= 256 ? 1 : 256 / Q;
+    float* lacc = tsm;
+    for (int i = t; i < SL * nl * c2; i += 256) lacc[i] = 0.f;
+    __syncthreads();
+    const int sl = Q >= 256 ? 0 : t / Q;
+    for (int qd = Q >= 256 ? t : t - sl * Q; qd < Q; qd += 256) {
+      for (int s0 = sl; s0 < ncl; s0 += SL * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int s = s0 + k * SL;
+          v[k] = s < ncl ? ld_sc1_f4(rs_cp, (unsigned)(((long)s * c2 + qd * 4) * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int s = s0 + k * SL;
+          if (s < ncl) {
+            const int l = a.labels[s];
+            if (l >= 0 && l < nl) {
+              float4* dst = (float4*)(lacc + ((long)sl * nl + l) * c2 + qd * 4);
+              float4 o = *dst;
+              o.x += v[k].x; o.y += v[k].y; o.z += v[k].z; o.w += v[k].w;
+              *dst = o;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int ch = t; ch < c; ch += 256) {
+      double q1 = 0.0, q2 = 0.0;
+      for (int l = 0; l < nl; ++l) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < SL; ++k) { a1 += lacc[((long)k * nl + l) * c2 + ch]; a2 += lacc[((long)k * nl + l) * c2 + c + ch]; }
+        const long o = (long)l * c + ch;
+        float og = a2, ob = a1;
+        if (a.accumulate) { og += a.dgamma[o]; ob += a.dbeta[o]; }
+        a.dgamma[o] = og; a.dbeta[o] = ob;
+        const double gm = (double)a.gamma[o];
+        q1 += gm * (double)a1;
+        q2 += gm * (double)a2;
+      }
+      const float invM = 1.f / (float)a.rows;
+      const float r = a.rstd_in[ch];
+      const float p = -r * r * (float)q2 * invM;
+      a.PQ[ch] = p;
+      a.PQ[c + ch] = -p * a.mean_in[ch] - r * (float)q1 * invM;
+    }
+  }
+  if (t == 0) __hip_atomic_store(ta.counters + ta.nclusters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // y = act(x*A + B), A = rstd*gamma[label], B = beta[label] - mean*A, computed in-line: the thread's 8 channels are fixed
 // (grid stride is a multiple of the chunks per row), so mean/rstd live in registers.
 template <typename T>
@@ -630,12 +854,79 @@ static inline int ew_grid2(long total) {
   return (int)b;
 }
 
+// tree path: VERY big tensors with a power-of-two channel count (full rows per workgroup need c/8 <= 256 chunk lanes).
+// Measured (scripts/bench_bn.py, MI355X): the reductions are bound by their serial arrival chain (write-through partials,
+// drain, counter, finisher loads), not by the access pattern -- the tree has one hop more than the column kernel and only
+// wins once the streaming part dominates: [320,32,32,256] bf16 (168 MB) statistics 37 us vs 55 us, backward 278 vs 317 us;
+// [128,32,32,256] (67 MB) 24.7 vs 25.9 us; [320,16,16,256] (42 MB) 21.8 vs 16.9 us (slower).  More than ~512 groups make
+// it slower (1024: 35 us, 4096: 89 us on the 67 MB case).  Threshold: 48M elements (RCGAN_BN_TREE_MIN; the tests lower it).
+static inline bool bn_tree_ok(long rows, int c) {
+  static long min_elems = -1;
+  if (min_elems < 0) {
+    const char* e = getenv("RCGAN_BN_TREE");
+    const char* m = getenv("RCGAN_BN_TREE_MIN");
+    min_elems = (e && atoi(e) == 0) ? (1L << 62) : (m ? atol(m) : (48L << 20));
+  }
+  return bn_fused_ok(c) && rows * (long)c >= min_elems;
+}
+
+// launch of the tree reduction.  ws layout: partial [nseg][ng][2c] | cpart [nseg][ncl][2c] | (backward) PQ [2c]
+template <int MODE>
+static int launch_bn_tree(rcgan_ctx* ctx, int dtype, BnFusedArgs& a, int nseg, int cs, void* ws, size_t ws_bytes, float** pq_out) {
+  const int c = a.c, ng = a.ngroups;
+  const int ncl = cdiv(ng, cs);
+  const size_t n_part = (size_t)nseg * ng * 2 * c, n_cp = (size_t)nseg * ncl * 2 * c;
+  const size_t need = (n_part + n_cp + 2 * (size_t)c) * sizeof(float);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  RC_REQUIRE(ctx, (size_t)nseg * (ncl + 1) <= 8192, "too many clusters (%d x %d)", nseg, ncl);
+  RC_REQUIRE(ctx, (size_t)ng * 2 * c * 4 < (1ull << 31) && (size_t)ncl * 2 * c * 4 < (1ull << 31), "partials exceed a buffer descriptor");
+  BnTreeArgs ta;
+  a.partial = (float*)ws;
+  a.nseg = nseg;
+  ta.cpart = a.partial + n_part;
+  if (pq_out) { *pq_out = ta.cpart + n_cp; a.PQ = *pq_out; }
+  ta.counters = ctx->tree_counters();
+  ta.cs = cs; ta.nclusters = ncl;
+  ta.f = a;
+  const int Q = 2 * c / 4, SL = Q >= 256 ? 1 : 256 / Q;
+  size_t lds = 16384;                                             // [2][RL][c] floats = 4096 floats
+  if ((size_t)4 * c * sizeof(float) > lds) lds = (size_t)4 * c * sizeof(float);
+  if (MODE == 1 && a.labels) { const size_t l2 = (size_t)SL * a.n_labels * 2 * c * sizeof(float); if (l2 > lds) lds = l2; }
+  RC_REQUIRE(ctx, lds <= 128 * 1024, "tree reduction needs %zu bytes of LDS", lds);
+  if (dtype == RCGAN_F32) {
+    static size_t set = 0;
+    if (lds > set) { RC_HIP(ctx, hipFuncSetAttribute((const void*)bn_tree_reduce_kernel<float, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = lds; }
+    hipLaunchKernelGGL((bn_tree_reduce_kernel<float, MODE>), dim3(ng, nseg), dim3(256), lds, ctx->stream, ta);
+  } else if (dtype == RCGAN_H16) {
+    static size_t set = 0;
+    if (lds > set) { RC_HIP(ctx, hipFuncSetAttribute((const void*)bn_tree_reduce_kernel<bf16_t, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = lds; }
+    hipLaunchKernelGGL((bn_tree_reduce_kernel<bf16_t, MODE>), dim3(ng, nseg), dim3(256), lds, ctx->stream, ta);
+  } else {
+    RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtype %d", dtype);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// rows per group of the tree path: ~512 workgroups, a multiple of the row lanes, at least 16 rows
+static inline long tree_group_rows(long rows, int c) {
+  const int RL = 256 / (c / 8) > 0 ? 256 / (c / 8) : 1;
+  static long target = -1;
+  if (target < 0) { const char* e = getenv("RCGAN_BN_TREE_GROUPS"); target = e ? atol(e) : 512; }
+  long rpg = cdiv(rows, target);
+  if (rpg < 16) rpg = 16;
+  rpg = (rpg + RL - 1) / RL * RL;
+  return rpg;
+}
+
 extern "C" {
 
 size_t rcgan_bn_workspace_bytes(int rows, int c) {
-  // stats: ngroups*2*c ; bwd: ngroups*2*c + 2*c, with ngroups <= max(rows/512, n) <= rows
+  // stats: ngroups*2*c ; bwd: ngroups*2*c + 2*c, with ngroups <= max(rows/512, n) <= rows; the tree path adds its cluster
+  // partials (<= one per group)
   long ng = (rows + 511) / 512 + 1;
   if (ng < 4096) ng = 4096;   // per-sample grouping (n <= 4096 samples)
+  ng *= 2;
   return (size_t)(ng * 2 * (long)c + 4 * (long)c + 2 * MAX_LABELS * (long)c) * sizeof(float) + 256;
 }
 
@@ -646,6 +937,12 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
   size_t need = (size_t)ng * 2 * c * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   float* partial = (float*)ws;
+  if (bn_tree_ok(rows, c)) {
+    BnFusedArgs a = {};
+    a.rows = rows; a.c = c; a.rows_per_group = tree_group_rows(rows, c); a.ngroups = (int)cdiv((long)rows, a.rows_per_group); a.x = x;
+    a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = mm; a.mv = mv; a.decay = decay;
+    return launch_bn_tree<0>(ctx, dtype, a, 1, 16, ws, ws_bytes, nullptr);
+  }
   if (bn_fused_ok(c)) {
     BnFusedArgs a = {};
     a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.partial = partial;
@@ -722,16 +1019,24 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
     }
     return RCGAN_OK;
   }
-  const long rpg = stats_group_rows(rows);
-  const int ng = cdiv(rows, rpg);
-  const size_t need = (size_t)nseg * ng * 2 * c * sizeof(float);
-  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
-  BnFusedArgs a = {};
-  a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.nseg = nseg; a.x = x; a.partial = (float*)ws;
-  a.counter = ctx->counters() + RC_COUNTER_BNSEG;
-  a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = nullptr; a.mv = nullptr; a.decay = 0.f;
-  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), 0, ctx->stream, a));
-  RC_LAUNCH_CHECK(ctx);
+  if (bn_tree_ok(rows, c)) {
+    BnFusedArgs a = {};
+    a.rows = rows; a.c = c; a.rows_per_group = tree_group_rows(rows, c); a.ngroups = (int)cdiv(rows, a.rows_per_group); a.x = x;
+    a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = nullptr; a.mv = nullptr; a.decay = 0.f;
+    int rc = launch_bn_tree<0>(ctx, dtype, a, nseg, 16, ws, ws_bytes, nullptr);
+    if (rc) return rc;
+  } else {
+    const long rpg = stats_group_rows(rows);
+    const int ng = cdiv(rows, rpg);
+    const size_t need = (size_t)nseg * ng * 2 * c * sizeof(float);
+    if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+    BnFusedArgs a = {};
+    a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.nseg = nseg; a.x = x; a.partial = (float*)ws;
+    a.counter = ctx->counters() + RC_COUNTER_BNSEG;
+    a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = nullptr; a.mv = nullptr; a.decay = 0.f;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), 0, ctx->stream, a));
+    RC_LAUNCH_CHECK(ctx);
+  }
   const long nchunks = rows * c / 8;
   int gx = apply_grid_fused(nchunks, c);
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(gx, nseg), dim3(256), 0, ctx->stream,
@@ -749,6 +1054,35 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
   long rows = (long)n * rows_per_sample;
   long rpg;
   int ng;
+  if (bn_tree_ok(rows, c) && !(labels && (size_t)n_labels * 2 * c * sizeof(float) > 96 * 1024) && (!labels || n <= 8000)) {
+    // tree path: full rows per workgroup; with labels a cluster is exactly one sample (gps groups)
+    BnFusedArgs a = {};
+    int cs = 16;
+    if (labels) {
+      const int RL = 256 / (c / 8) > 0 ? 256 / (c / 8) : 1;
+      int gps = 1;
+      rpg = rows_per_sample;
+      static long target = -1;
+      if (target < 0) { const char* e = getenv("RCGAN_BN_TREE_GROUPS"); target = e ? atol(e) : 512; }
+      while ((long)n * gps < target && rpg % 2 == 0 && rpg / 2 >= 16 && (rpg / 2) % RL == 0 && gps < 16) { gps *= 2; rpg /= 2; }
+      ng = n * gps; cs = gps;
+    } else {
+      rpg = tree_group_rows(rows, c); ng = (int)cdiv(rows, rpg);
+    }
+    a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.y = y; a.dy = dy;
+    a.mean_in = mean; a.rstd_in = rstd; a.act = act;
+    a.n_labels = n_labels; a.groups_per_sample = cs; a.labels = labels; a.n_samples = n;
+    a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    float* PQ = nullptr;
+    int rc = launch_bn_tree<1>(ctx, dtype, a, 1, cs, ws, ws_bytes, &PQ);
+    if (rc) return rc;
+    long nchunks = rows * c / 8;
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
+                                                     nchunks, rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, rstd,
+                                                     (const float*)PQ, act, (T*)dx, accumulate_dx));
+    RC_LAUNCH_CHECK(ctx);
+    return RCGAN_OK;
+  }
   if (bn_fused_ok(c)) {
     int gps = 1;
     if (labels) {

@@ -31,9 +31,11 @@ struct rcgan_ctx {
   bool on_side;
   void* dbg_stamps;    // rcgan_debug_stamps
   int num_cus;         // compute units of the device (grid size of the persistent kernels)
-  void* zero_page;     // 4 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
+  void* zero_page;     // 36 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
                        // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels
   unsigned* counters() const { return (unsigned*)((char*)zero_page + 1024); }
+  // bytes [4096, 4096+32768): 8192 more self-resetting arrival counters (two-level reductions: one per cluster + one per launch)
+  unsigned* tree_counters() const { return (unsigned*)((char*)zero_page + 4096); }
 };
 #define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
 #define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish

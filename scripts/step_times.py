@@ -19,7 +19,21 @@ def main():
     for it in range(3):
         bench.iteration(m, pool, it, dc)
     torch.cuda.synchronize()
-    for name, fn, reps in (("d_step", lambda i: (bench.feed_d(m, pool, i), m.d_step(iteration=5)), 50),
+    def d5(i):
+        m.set_feed("gf", pool["feed_gf"][i % bench.POOL])
+        m.prepare_critic_fakes()
+        for k in range(5):
+            bench.feed_d(m, pool, i + k)
+            m.d_step(iteration=5)
+
+    def gf(i):
+        m.set_feed("gf", pool["feed_gf"][i % bench.POOL])
+        m.prepare_critic_fakes()
+        m._fakes_left = 0
+
+    for name, fn, reps in (("prepare_critic_fakes (G forward, 5B samples)", gf, 20),
+                           ("prepare_critic_fakes + 5 d_steps", d5, 20),
+                           ("d_step incl. its own G forward", lambda i: (bench.feed_d(m, pool, i), m.d_step(iteration=5)), 50),
                            ("g_step", lambda i: (bench.feed_g(m, pool, i), m.g_step(iteration=5)), 20)):
         torch.cuda.synchronize()
         t0 = time.time()

@@ -323,7 +323,11 @@ def test_linear(dev, m, k, n):
 
 
 @pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False),
-                                        ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True)] + _random_cases("bn", 10, 13))
+                                        ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True),
+                                        # >= 4M elements: the tree reduction (whole rows per workgroup, two-level arrival tree)
+                                        ((32, 32, 32, 128), True), ((128, 8, 8, 512), True), ((64, 16, 16, 256), False),
+                                        ((40, 16, 16, 1024), True), ((70, 32, 32, 64), False), ((33, 16, 16, 512), True)]
+                         + _random_cases("bn", 10, 13))
 def test_batch_norm(dev, shape, cond):
     from rcgan_amd import _lib as L
     from rcgan_amd import ops as O
@@ -368,6 +372,32 @@ def test_batch_norm(dev, shape, cond):
     assert_close(ctx.download(xd.grad).reshape(x4.shape), dx, TOL[mode] * 2, "bn dx")
     assert_close(gp.grad(ctx), dg, 2e-4, "bn dgamma")
     assert_close(bp.grad(ctx), db, 2e-4, "bn dbeta")
+
+
+def test_batch_norm_segments_large(dev):
+    """Segmented forward (several Generator() batches in one pass, statistics per segment) on the tree reduction path:
+    3 segments of [32, 32, 32, 128] against the oracle applied to each segment on its own."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(77)
+    K, n, c = 3, 32, 128
+    x = _prep(rs.randn(K * n, 32, 32, c) * 1.3 + rs.randn(K, 1, 1, 1, 1).repeat(n, 1).reshape(K * n, 1, 1, 1), mode)
+    gamma = (1 + 0.3 * rs.randn(10, c)).astype(np.float32)
+    beta = (0.2 * rs.randn(10, c)).astype(np.float32)
+    labels = rs.randint(10, size=K * n).astype(np.int32)
+    ctx.new_step()
+    rec, ctx.recording = ctx.recording, False
+    try:
+        y = O.batch_norm_act(ctx, ctx.upload(x), ctx.upload(gamma, L.F32), ctx.upload(beta, L.F32), act=L.ACT_RELU, labels=ctx.upload(labels),
+                             n_labels=10, segments=K)
+    finally:
+        ctx.recording = rec
+    got = ctx.download(y)
+    for k in range(K):
+        sl = slice(k * n, (k + 1) * n)
+        pre, _ = nn.cond_batchnorm_fwd(x[sl].astype(np.float64), labels[sl], gamma.astype(np.float64), beta.astype(np.float64))
+        assert_close(got[sl], np.maximum(pre, 0), TOL[mode], "segment %d" % k)
 
 
 def test_batch_norm_infer(dev):
