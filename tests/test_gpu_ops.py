@@ -252,6 +252,89 @@ def test_conv_persistent_tiles(dev, case):
         assert_close(ctx.download(xd.grad), dx, TOL[mode], "persistent conv dgrad %s" % (case,))
 
 
+HEAD_CASES = [
+    # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
+    (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
+    (16, 16, "NEG_MEAN", "lab", None, None),                   # generator step (:763-773)
+    (24, 12, "HINGE_REAL", "lab", "HINGE_FAKE", "wts"),       # rcgan-u critic step: fake logits of every label x confusion rows (:654-684)
+    (12, 12, "NEG_MEAN", "wts", None, None),                   # rcgan-u generator step (:751-760)
+    (20, 10, "HINGE_REAL", "wts", "HINGE_FAKE", "lab"),       # unbiased: real logits of every label x C^-1 rows (:613-648)
+    (1024, 512, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),    # the largest supported batch (B = 512 per GPU)
+]
+
+
+@pytest.mark.parametrize("case", HEAD_CASES)
+def test_proj_head(dev, case):
+    """The fused projection head (D.Output, label embedding + D.Embedding_y, projection logits, loss terms and every
+    gradient in 2-4 launches) against a float64 autograd restatement of the same formulas."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode != "f32":
+        pytest.skip("the head is fp32 regardless of the activation dtype")
+    n, rows_a, kind_a, mode_a, kind_b, mode_b = case
+    d, v, ed = 128, 10, 300
+    rs = np.random.RandomState(n + rows_a)
+    feat = rs.rand(n, d).astype(np.float32)
+    w_out = (rs.randn(d, 1) * 0.3).astype(np.float32); b_out = rs.randn(1).astype(np.float32)
+    table = (rs.randn(v, ed) * 0.1).astype(np.float32)
+    w_e = (rs.randn(ed, d) * 0.2).astype(np.float32); b_e = (rs.randn(d) * 0.1).astype(np.float32)
+    s_out, s_e, weight = np.float32(1.3), np.float32(0.7), 3.0
+    kinds = {"HINGE_REAL": L.LOSS_HINGE_REAL, "HINGE_FAKE": L.LOSS_HINGE_FAKE, "NEG_MEAN": L.LOSS_NEG_MEAN}
+    ctx.new_step()
+    fd = ctx.upload(feat, L.F32); fd.req = True
+    pw_out, pb_out, ptab, pw_e, pb_e = (FakeParam(ctx, a) for a in (w_out, b_out, table, w_e, b_e))
+    W_out = O.Weight(ctx, pw_out.t, ctx.upload(np.array([s_out]), L.F32))
+    W_e = O.Weight(ctx, pw_e.t, ctx.upload(np.array([s_e]), L.F32))
+    parts, host = [], []
+    for rows, kind, md in ((rows_a, kind_a, mode_a), (n - rows_a, kind_b, mode_b)):
+        if rows == 0:
+            continue
+        if md == "lab":
+            lab = rs.randint(v, size=rows).astype(np.int32)
+            parts.append((rows, kinds[kind], ctx.upload(lab), None)); host.append((rows, kind, lab, None, None))
+        else:
+            w = rs.rand(rows, v).astype(np.float32)
+            wd = ctx.upload(w, L.F32); wd.req = True
+            parts.append((rows, kinds[kind], None, wd)); host.append((rows, kind, None, w, wd))
+    loss = ctx.persistent((1,), L.F32, fill=0.0)
+    logits = ctx.empty((n, v), L.F32)
+    O.proj_head(ctx, fd, W_out, pb_out.t, ptab.t, W_e, pb_e.t, parts, weight, loss, logits=logits)
+    # float64 autograd restatement
+    T = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    tf, two, tbo, tt, twe, tbe = T(feat), T(w_out), T(b_out), T(table), T(w_e), T(b_e)
+    E = tt @ (twe / float(s_e)) + tbe
+    psi = (tf @ (two / float(s_out))).reshape(-1) + tbo
+    lg = psi[:, None] + tf @ E.t()
+    total, r0, twts = 0.0, 0, []
+    for rows, kind, lab, w, _ in host:
+        x = lg[r0:r0 + rows]
+        term = {"HINGE_REAL": torch.relu(1 - x), "HINGE_FAKE": torch.relu(1 + x), "NEG_MEAN": -x}[kind]
+        if lab is not None:
+            wt = torch.nn.functional.one_hot(torch.as_tensor(lab, dtype=torch.long), v).double()
+        else:
+            wt = T(w); twts.append(wt)
+        total = total + (term * wt).sum(1).mean()
+        r0 += rows
+    total = weight * total
+    total.backward()
+    assert_close(ctx.download(loss), np.array([float(total.detach())]), 1e-5, "head loss")
+    got_l, ref_l = ctx.download(logits), lg.detach().numpy()
+    r0 = 0
+    for rows, kind, lab, w, _ in host:          # logits are reported where they enter the loss
+        m = np.ones((rows, v), bool) if lab is None else (np.arange(v)[None] == lab[:, None])
+        assert_close(got_l[r0:r0 + rows][m], ref_l[r0:r0 + rows][m], 2e-5, "head logits")
+        r0 += rows
+    assert_close(ctx.download(fd.grad), tf.grad.numpy(), 2e-5, "head dfeat")
+    assert_close(ctx.download(W_out.dwbar), two.grad.numpy() * float(s_out), 2e-5, "head d(w_out / sigma)")
+    assert_close(pb_out.grad(ctx), tbo.grad.numpy(), 2e-5, "head db_out")
+    assert_close(ptab.grad(ctx), tt.grad.numpy(), 2e-5, "head dtable")
+    assert_close(ctx.download(W_e.dwbar), twe.grad.numpy() * float(s_e), 2e-5, "head d(W_e / sigma)")
+    assert_close(pb_e.grad(ctx), tbe.grad.numpy(), 2e-5, "head db_e")
+    for (_, _, _, _, wd), wt in zip([h for h in host if h[3] is not None], twts):
+        assert_close(ctx.download(wd.grad), wt.grad.numpy(), 2e-5, "head dwts")
+
+
 def _random_cases(kind, count, seed):
     """Seeded shape sweeps for the dense / transposed-conv / batch-norm tests (sizes the fixed lists do not pin down)."""
     rs = np.random.RandomState(seed)
