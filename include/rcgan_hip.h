@@ -301,6 +301,17 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
                        float weight, float* loss_acc, float* dlogit, float* dwts);
 /* weight * mean over all rows*cols of sigmoid_cross_entropy_with_logits(x, onehot(labels))
  * (perm regulariser: gan_resnet.py:693-694,782-783; mnist/model.py:218-221). */
+/* The 8x8 stage of the CIFAR discriminator -- D.Block.3 .. D.Block.6, four identity-shortcut residual blocks of two 3x3
+ * convolutions 128 -> 128 each (gan_resnet.py:275-328, 398-404) -- as ONE launch: a workgroup carries one image through all
+ * eight layers with the activations in LDS.  16-bit activations only; x0 / outs / masks are [n][8][8][128].
+ *   forward  (backward = 0): layer 2b = h_b = conv1(relu(x_b)) + bias, layer 2b+1 = x_{b+1} = x_b + conv2(relu(h_b)) + bias;
+ *            outs[i] receives layer i's output (outs[7] is the stage's output, the others are what the backward pass needs).
+ *   backward (backward = 1): x0 = gradient of the stage's output; layers run last to first: prepared[0] / masks[0] belong to
+ *            block 6's conv2 (mask = h_6), prepared[1] / masks[1] to its conv1 (mask = x_6), ...; outs[2j] = dh (gradient at
+ *            conv1's output), outs[2j+1] = dx (gradient at the block's input; outs[7] is the gradient of the stage's input).
+ * prepared[i]: rcgan_conv_prepare layout of a 3x3 128 -> 128 filter (forward rows, then data-gradient rows). */
+int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* const* prepared, const float* const* bias,
+                 const void* const* masks, void* const* outs);
 /* Fused projection head: pooled features -> psi (D.Output, SN linear d -> 1), label embeddings E = table @ W_e / sigma_e + b_e
  * (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421), logits psi + <feat, E[l]> (:588, :654-660), loss terms and ALL
  * gradients in one launch.  Rows [0, rows_a) form part a, rows [rows_a, n) part b (real | fake of the critic step, :604-606);

@@ -29,6 +29,12 @@ OUTPUT_DIM = 3072
 N_CRITIC = 5
 GEN_BS_MULTIPLE = 2
 ALGORITHMS = ("rcgan", "rcgan-u", "biased", "unbiased")
+# The 8x8 discriminator stage as one launch each way (ops.d_trunk / conv_trunk.hip).  Parity-tested, but NOT faster on MI355X
+# (scripts/bench_trunk.py, n = 128: 78 us fused vs 73 us for the eight launches; n = 1024: 327 vs 218 us): a workgroup's
+# filter stream (295 KB per layer) arrives by LDS-DMA at ~74 GB/s per CU with at most three taps (24 KiB per wavefront) in
+# flight next to the activations in LDS -- 4 us per layer against 2.1 us of MFMA work; without the DMA the four one-per-SIMD
+# wavefronts still take 5.6 us per layer (LDS read -> MFMA latency with nothing else to issue).  Off unless RCGAN_FUSED_TRUNK=1.
+FUSED_TRUNK = os.environ.get("RCGAN_FUSED_TRUNK", "0") == "1"
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -201,9 +207,23 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
         h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
         t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
         x = O.meanpool2(ctx, t)
-        for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
-            h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
-            x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv2' % blk, _in_relu=True, _residual=x, **kw)   # shortcut + output
+        if FUSED_TRUNK and O.d_trunk_ok(ctx, x):
+            # D.Block.3 .. D.Block.6 (identity shortcuts, 8 x 8 pixels): one launch for the eight convolutions (ops.d_trunk)
+            g, blocks = Graph.current, []
+            for blk in (3, 4, 5, 6):
+                ws = []
+                for cv in ('Conv1', 'Conv2'):
+                    with variable_scope('D.Block.%d.%s' % (blk, cv)):
+                        fname = scoped('Filters')
+                        with variable_scope('filters'):
+                            ws.append(spectral_normed_weight(fname, update_collection=update_collection))
+                        ws.append(g.param(scoped('Biases')))
+                blocks.append(tuple(ws))
+            x = O.d_trunk(ctx, x, blocks)
+        else:
+            for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
+                h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
+                x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv2' % blk, _in_relu=True, _residual=x, **kw)   # shortcut + output
         output = O.act_meanhw(ctx, x, L.ACT_RELU)                       # relu + reduce_mean over (1,2)
         if not _head:
             return output

@@ -250,6 +250,62 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     return y
 
 
+def d_trunk_ok(ctx, x):
+    """The fused 8x8 discriminator stage takes 16-bit [n, 8, 8, 128] activations."""
+    return x.dtype != L.F32 and tuple(x.shape[1:]) == (8, 8, 128)
+
+
+def d_trunk(ctx, x, blocks):
+    """D.Block.3 .. D.Block.6 of the CIFAR discriminator -- four identity-shortcut residual blocks
+    x' = x + Conv2(relu(Conv1(relu(x)))) (gan_resnet.py:275-328 with resample=None, :398-404) -- as ONE launch each way
+    (rcgan_dtrunk): a workgroup carries one image through all eight 3x3 convolutions with the activations in LDS.
+    blocks: [(Weight conv1, bias1, Weight conv2, bias2)] x 4.  Same values as eight conv2d calls up to the summation order
+    inside a convolution (the rounding points -- 16-bit activations between layers, fp32 residual adds -- are the same)."""
+    n = x.shape[0]
+    assert d_trunk_ok(ctx, x) and len(blocks) == 4
+    desc = L.ConvDesc(n, 8, 8, 128, 128, 3, 3, 1, x.dtype, L.CONV_IN_RELU)
+    arr = lambda ts: (C.c_void_p * 8)(*[(t.ptr if t is not None else None) for t in ts])
+    flat = []                                                  # (Weight, bias) of the eight layers in execution order
+    for w1, b1, w2, b2 in blocks:
+        flat += [(w1, b1), (w2, b2)]
+    preps = [w.prepared(desc) for w, _ in flat]
+    outs = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
+    ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 0, _p(x), arr(preps), arr([b for _, b in flat]), None, arr(outs)))
+    y = outs[7]
+    params = [t for w, b in flat for t in (w.param, b)]
+    if _track(ctx, y, x, *params):
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            # layers last to first: block 6 conv2 (mask h_6), block 6 conv1 (mask x_6), block 5 conv2, ...
+            hs = [outs[0], outs[2], outs[4], outs[6]]                    # h_3 .. h_6
+            xs = [x, outs[1], outs[3], outs[5]]                          # x_3 .. x_6 (block inputs)
+            order = [(3, 1), (3, 0), (2, 1), (2, 0), (1, 1), (1, 0), (0, 1), (0, 0)]      # (block index, conv index)
+            preps_b = [flat[2 * bi + ci][0].prepared(desc) for bi, ci in order]
+            masks = [hs[bi] if ci == 1 else xs[bi] for bi, ci in order]
+            gouts = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
+            ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 1, _p(dy), arr(preps_b), None, arr(masks), arr(gouts)))
+            for j, bi in enumerate((3, 2, 1, 0)):
+                dh, dy_k = gouts[2 * j], (dy if j == 0 else gouts[2 * j - 1])
+                for (w, b), xin, g in ((flat[2 * bi + 1], hs[bi], dy_k), (flat[2 * bi], xs[bi], dh)):
+                    if not w.req:
+                        continue
+                    db = b.grad if (b is not None and b.req) else None
+                    if ctx.group_wgrads:
+                        ctx.defer_wgrad(desc, xin, g, w.grad_target(), db)      # read again at flush_wgrads: never written below
+                    else:
+                        ctx.check(ctx.lib.rcgan_conv2d_bwd_weight(ctx.h, C.byref(desc), _p(xin), _p(g), _p(w.grad_target()), _p(db), 1,
+                                                                  C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            if x.req:
+                if x.grad is None:
+                    x.grad = gouts[7]
+                else:
+                    ctx.check(ctx.lib.rcgan_axpby(ctx.h, x.size, x.dtype, 1.0, _p(gouts[7]), 1.0, _p(x.grad)))
+        ctx.record(bw)
+    return y
+
+
 def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
     """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], out_shape, strides) + bias (mnist/ops.py:78-86)."""
     n, oh, ow, cout = out_shape

@@ -252,6 +252,59 @@ def test_conv_persistent_tiles(dev, case):
         assert_close(ctx.download(xd.grad), dx, TOL[mode], "persistent conv dgrad %s" % (case,))
 
 
+@pytest.mark.parametrize("n", [3, 128])
+def test_d_trunk_equals_layerwise_blocks(dev, n):
+    """The fused 8x8 discriminator stage (four residual blocks, eight 3x3 convolutions in one launch each way, activations
+    in LDS) against the same blocks built from eight conv2d calls: stage output, every saved activation's effect through the
+    gradient of the input, and all filter / bias gradients.  Same rounding points, so only the fp32 summation order inside
+    a convolution differs; both sides are also checked against the float64 oracle for the forward values."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the fused stage runs on 16-bit activations")
+    rs = np.random.RandomState(n)
+    x = _prep(rs.randn(n, 8, 8, 128), mode)
+    ws = [(rs.randn(3, 3, 128, 128) / np.sqrt(9 * 128) * 1.2).astype(np.float32) for _ in range(8)]
+    bs = [(0.1 * rs.randn(128)).astype(np.float32) for _ in range(8)]
+    dy = _prep(rs.randn(n, 8, 8, 128), mode)
+    res = {}
+    for fused in (True, False):
+        ctx.new_step()
+        xd = ctx.upload(x)
+        xd.req = True
+        pw, pb = [FakeParam(ctx, w) for w in ws], [FakeParam(ctx, b) for b in bs]
+        W = [O.Weight(ctx, p.t, ctx.upload(np.array([1.3], np.float32), L.F32)) for p in pw]
+        if fused:
+            y = O.d_trunk(ctx, xd, [(W[2 * k], pb[2 * k].t, W[2 * k + 1], pb[2 * k + 1].t) for k in range(4)])
+        else:
+            t = xd
+            for k in range(4):
+                h = O.conv2d(ctx, t, W[2 * k], pb[2 * k].t, 3, in_relu=True)
+                t = O.conv2d(ctx, h, W[2 * k + 1], pb[2 * k + 1].t, 3, in_relu=True, residual=t)
+            y = t
+        out = ctx.download(y)
+        y.grad = ctx.upload(dy)
+        ctx.backward()
+        res[fused] = dict(y=out, dx=ctx.download(xd.grad), dw=[ctx.download(w.dwbar) for w in W], db=[p.grad(ctx) for p in pb])
+    a, b = res[True], res[False]
+    assert_close(a["y"], b["y"], TOL[mode], "trunk output vs layerwise")
+    # gradients: the two forwards differ by summation-order noise, so a pre-activation within that noise of zero gets a
+    # different ReLU mask -- isolated elements differ by their whole value; compare in the norm
+    from tests.gpu_util import rel_err
+    assert rel_err(a["dx"], b["dx"]) < 2e-2, rel_err(a["dx"], b["dx"])
+    for i in range(8):
+        assert rel_err(a["dw"][i], b["dw"][i]) < 2e-2, (i, rel_err(a["dw"][i], b["dw"][i]))
+        assert rel_err(a["db"][i], b["db"][i]) < 2e-2, (i, rel_err(a["db"][i], b["db"][i]))
+    if n <= 8:       # float64 oracle of the forward values (16-bit rounding between layers restated)
+        t = x.astype(np.float64)
+        q = lambda v: half_round(mode, v).astype(np.float64)
+        for k in range(4):
+            h = q(nn.conv2d_fwd(np.maximum(t, 0), q(ws[2 * k] / np.float32(1.3))) + bs[2 * k])
+            t = q(t + nn.conv2d_fwd(np.maximum(h, 0), q(ws[2 * k + 1] / np.float32(1.3))) + bs[2 * k + 1])
+        assert_close(a["y"], t, TOL[mode] * 3, "trunk output vs oracle")
+
+
 HEAD_CASES = [
     # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
     (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
