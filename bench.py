@@ -115,9 +115,10 @@ def kernel_roofline(m, pool, default_workload=True):
     # HBM bytes per launch of this kernel: measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass; corrections as MI355X_MICROARCH.md prescribes) and committed with the profile
     traffic = None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv_p8.json")
-    if default_workload and os.path.exists(tf):          # the counters were collected on the default workload only
-        with open(tf) as f:
+    import glob
+    tfs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_conv_p8.json")))
+    if default_workload and tfs:                         # the counters were collected on the default workload only; newest round
+        with open(tfs[-1]) as f:
             traffic = float(json.load(f)["traffic_bytes_per_launch"])
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -126,10 +127,24 @@ def kernel_roofline(m, pool, default_workload=True):
             "flops_per_launch_avg": fl.value / n.value}
 
 
+def effective_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs under a 16-CPU quota; 256 threads on 16 CPUs ran the same step 180x slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(alpha, batch):
     """The same iteration on the host cores (kind "port": TensorFlow 1.5, the reference's CPU path, is not installable):
     oracle/torch_port.py -- the PyTorch-CPU restatement of the reference graph (autograd + TF-form Adam, fp32) -- on all
-    cores at the benchmark's own per-GPU batch.  Bounded sample: one warm-up and one timed D step + G step; the iteration is
+    usable cores (scheduler affinity capped by the cgroup CPU quota) at the benchmark's own per-GPU batch.  Bounded sample: one warm-up and one timed D step + G step; the iteration is
     5 D steps + 1 G step, so images/sec = 5*B / (5*t_D + t_G).  (The single-process numpy oracle, the parity checker, runs
     the same step at B=16 in ~2.1 s / ~4.1 s: ~5.4 images/sec.)"""
     from oracle import cifar as oc
@@ -138,7 +153,7 @@ def cpu_baseline(alpha, batch):
     rs = np.random.RandomState(0)
     P, U = oc.init_params(0, "rcgan")
     Cm = oc.c_alpha(alpha)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     torch.set_num_threads(cores)
 
     def batches():

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   bash scripts/make_profiles.sh r02
+# Writes text / csv / json summaries under gpurun_out/<tag>/ (the rocpd databases themselves are deleted); the ones to be judged
+# are then copied into profiles/.
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py"
+
+python3 "$B" > "$OUT/bench_n1_default.json" 2> "$OUT/bench_n1_default.err"
+
+rocprofv3 --kernel-trace -d "$OUT/prof_kt" -o kt -- python3 "$B" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_n1_under_rocprof.json" 2> "$OUT/prof_kt.err"
+DB=$(find "$OUT/prof_kt" -name "*.db" | head -1)
+python3 "$ROOT/scripts/prof_summary.py" "$DB" 24 --csv "$OUT/bench_n1_kernel_stats.csv" > "$OUT/bench_n1_kernel_stats.txt"
+python3 "$ROOT/scripts/prof_timeline.py" "$DB" > "$OUT/bench_n1_timeline_groups.txt"
+rm -rf "$OUT/prof_kt"
+
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CTR --kernel-trace -d "$OUT/pmc_$CTR" -o pmc -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$CTR.err"
+  DB=$(find "$OUT/pmc_$CTR" -name "*.db" | head -1)
+  python3 "$ROOT/scripts/pmc_summary.py" conv_mfma_p8_kernel "$DB" > "$OUT/pmc_${CTR}_conv_p8.txt"
+  rm -rf "$OUT/pmc_$CTR"
+done
+
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS \
+  --kernel-trace -d "$OUT/pmc_mfma" -o pmc -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_mfma.err"
+DB=$(find "$OUT/pmc_mfma" -name "*.db" | head -1)
+python3 "$ROOT/scripts/pmc_summary.py" conv_ "$DB" > "$OUT/pmc_mfma_busy_raw.txt"
+rm -rf "$OUT/pmc_mfma"
+
+cd "$ROOT"
+python3 scripts/bench_conv.py > "$OUT/microbench_conv.txt" 2>&1
+python3 scripts/bench_bn.py 128 > "$OUT/microbench_bn.txt" 2>&1
+python3 scripts/bench_trunk.py 128 > "$OUT/microbench_trunk.txt" 2>&1
+python3 scripts/exp_p8_fixed_cost.py > "$OUT/exp_p8_fixed_cost.txt" 2>&1
+python3 scripts/exp_p8_timeline.py 320 256 3 > "$OUT/exp_p8_timeline.txt" 2>&1
+python3 scripts/step_times.py > "$OUT/step_times.txt" 2>&1
+python3 scripts/bench_mnist.py 256 f32 > "$OUT/bench_mnist.txt" 2>&1
+[ -x scripts/probes/_bin/epilogue_store ] && ./scripts/probes/_bin/epilogue_store > "$OUT/probe_epilogue_store.txt" 2>&1
+ls -la "$OUT"

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the dominant kernel from the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+summarised by scripts/pmc_summary.py  ->  the JSON that bench.py reports as roofline.traffic.
+
+usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_p8.txt> <pmc_WRITE_SIZE_conv_p8.txt> <out.json>
+
+Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KB and counts the 128-byte requests of a wide
+coalesced stream at 64 bytes on gfx950 -> x2; WRITE_SIZE (KB) as reported."""
+import json
+import re
+import sys
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"(\S.*) grid \((\d+), (\d+), (\d+)\) \((\d+) dispatches\)", line)
+        if m:
+            cur = (int(m.group(2)), int(m.group(5)))
+            continue
+        m = re.match(r"\s+(\w+)\s+([\d.]+)", line)
+        if m and cur:
+            out[cur[0]] = (cur[1], float(m.group(2)))
+    return out
+
+
+def main():
+    fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
+    n = sum(v[0] for v in fetch.values())
+    f_avg = sum(v[0] * v[1] for v in fetch.values()) / n
+    w_avg = sum(v[0] * v[1] for v in write.values()) / n
+    # algorithmic bytes of the launch mix: 512 workgroups = G step, n = 128 at 32x32 (3 forward: Conv1 and Shortcut read the
+    # 16x16 input, Conv2 the 32x32 one; 3 data gradients read 32x32); 1280 workgroups = G.Block.3 of the 5 critic batches, n = 320
+    px = {512: 128 * 1024, 1280: 320 * 1024}
+    alg = {}
+    for g, (cnt, _) in fetch.items():
+        full = px[g] * 256 * 2
+        reads = ((full / 4 + full / 4 + full) / 3 if g == 1280 else ((full / 4 + full / 4 + full) + 3 * full) / 6) + 1.2e6
+        alg[g] = reads + full
+    alg_avg = sum(fetch[g][0] * alg[g] for g in fetch) / n
+    out = {
+        "kernel": "conv_mfma_p8_kernel<false, true> (channel-major K order, shared epilogue with paired 16-byte stores)",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes; scripts/make_profiles.sh)",
+        "fetch_size_kb_avg": f_avg, "write_size_kb_avg": w_avg, "launches": n,
+        "per_grid": {str(g): {"launches": fetch[g][0], "fetch_kb": fetch[g][1], "write_kb": write[g][1], "algorithmic_bytes": alg[g]} for g in sorted(fetch)},
+        "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+        "traffic_bytes_per_launch": (2 * f_avg + w_avg) * 1024,
+        "algorithmic_bytes_per_launch": alg_avg,
+        "algorithmic_note": "reads = the conv input at its STORED resolution (the nearest-2x upsample is folded into the load) + 1.2 MB of filters; writes = the output",
+    }
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
