@@ -205,6 +205,11 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
                  const void* x, const void* y, const void* dy, const int32_t* labels,
                  const float* gamma, const float* mean, const float* rstd, int act,
                  void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
+/* rcgan_bn_bwd with the forward's beta (offset) table: for ReLU / leaky-ReLU the activation mask is then recomputed from x with
+ * the forward's exact arithmetic (the fused power-of-two-channel kernels), so y is not read: 2 instead of 3 tensor reads per pass. */
+int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x, const void* y,
+                  const void* dy, const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                  int act, void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes);
 /* Inference-mode batch norm with moving statistics (gen_sampler, mnist/model.py:745-754). */
 int rcgan_bn_infer(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, const float* gamma,
                    const float* beta, const float* moving_mean, const float* moving_var, float eps,

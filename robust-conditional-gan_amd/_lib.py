@@ -101,6 +101,7 @@ SIGNATURES = {
     "rcgan_bn_apply_fwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, I, P, P, SZ]),
     "rcgan_bn_fwd_segments": (I, [P, I, I, I, I, I, I, P, P, P, P, F, I, P, P, P, P, SZ]),
     "rcgan_bn_bwd": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, I, P, I, P, P, I, P, SZ]),
+    "rcgan_bn_bwd2": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, I, P, P, I, P, SZ]),
     "rcgan_bn_infer": (I, [P, I, I, I, P, P, P, P, P, F, I, P]),
     "rcgan_bn_infer_bwd": (I, [P, I, I, I, P, P, P, P, F, I, P, I]),
     "rcgan_sn_save_floats": (SZ, [I, I]),

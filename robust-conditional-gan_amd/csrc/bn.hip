@@ -322,6 +322,18 @@ __global__ void bn_bwd_apply_vec_kernel(long nchunks, int rows_per_sample, int c
 //     order (deterministic, fp64) and resets the counter for the next launch / graph replay.  Agent-scope
 //     accesses go to the memory side, so no workgroup pays an L2 write-back/invalidate (8 XCDs = 8 L2s).
 // ------------------------------------------------------------------------------------------------
+// The affine part of batch norm as ONE fixed sequence of fp32 operations -- inv = rstd*gamma, c0 = fma(-mean, inv, beta),
+// pre = fma(x, inv, c0) -- shared by the forward apply kernel and the backward kernels: the backward pass can then recompute
+// the sign of the pre-activation (the ReLU / leaky-ReLU mask) from x bit-exactly instead of reading y a second and third time
+// (y = act(pre) rounded to 16 bits has the sign of pre: bf16 / fp16 rounding keeps it, underflow to zero aside).
+__device__ __forceinline__ float bn_pre(float x, float inv, float c0) { return __fmaf_rn(x, inv, c0); }
+// ... rounded the way the forward stored act(pre): the recomputed mask is then bit-identical to one read from y, including the
+// pre-activations that underflow to zero in fp16 (0 < pre < 2^-25; seen once in 4M elements in the parity tests)
+template <typename T> __device__ __forceinline__ float bn_stored(float v);
+template <> __device__ __forceinline__ float bn_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float bn_stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float bn_c0(float mean, float inv, float beta) { return __fmaf_rn(-mean, inv, beta); }
+
 struct BnFusedArgs {
   long rows; int c; long rows_per_group; int ngroups;
   int nseg;                             // forward only: blockIdx.z = segment; x, partial, counter, mean, rstd advance per segment
@@ -335,6 +347,7 @@ struct BnFusedArgs {
   // backward finish
   int n_labels; int groups_per_sample; const int32_t* labels; int n_samples;
   const float* gamma; float *dgamma, *dbeta; int accumulate; float* PQ;
+  const float* beta;                    // backward, optional: with it the activation mask is recomputed from x (no read of y)
 };
 
 template <typename T, int MODE>
@@ -363,7 +376,16 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
   float s1[8], s2[8], mu[8], rs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  float ainv[8], ac0[8];
+  const bool mask_x = MODE == 1 && a.beta != nullptr;
   if (MODE == 1) { ld8(a.mean_in + c0 + chunk * 8, mu); ld8(a.rstd_in + c0 + chunk * 8, rs); }
+  if (mask_x) {                           // the group's rows belong to one sample: one label
+    const long lo = (long)(a.labels ? a.labels[blockIdx.y / a.groups_per_sample] : 0) * c + c0 + chunk * 8;
+    float gm8[8], bt8[8];
+    ld8(a.gamma + lo, gm8); ld8(a.beta + lo, bt8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ainv[j] = rs[j] * gm8[j]; ac0[j] = bn_c0(mu[j], ainv[j], bt8[j]); }
+  }
 #pragma unroll 2
   for (long r = rb + rl; r < re; r += 32) {
     const long off = r * c + c0 + chunk * 8;
@@ -375,7 +397,10 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
     } else {
       float gv[8];
       ld8(dy + off, gv);
-      if (a.act != RCGAN_ACT_NONE) {
+      if (mask_x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] *= act_grad(a.act, bn_stored<T>(bn_pre(xv[j], ainv[j], ac0[j])));
+      } else if (a.act != RCGAN_ACT_NONE) {
         float yv[8];
         ld8(y + off, yv);
 #pragma unroll
@@ -585,7 +610,16 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
   float s1[8], s2[8], mu[8], rs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  float ainv[8], ac0[8];
+  const bool mask_x = MODE == 1 && a.beta != nullptr;
   if (MODE == 1) { ld8(a.mean_in + chunk * 8, mu); ld8(a.rstd_in + chunk * 8, rs); }
+  if (mask_x) {
+    const long lo = (long)(a.labels ? a.labels[g / a.groups_per_sample] : 0) * c + chunk * 8;
+    float gm8[8], bt8[8];
+    ld8(a.gamma + lo, gm8); ld8(a.beta + lo, bt8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ainv[j] = rs[j] * gm8[j]; ac0[j] = bn_c0(mu[j], ainv[j], bt8[j]); }
+  }
 #pragma unroll 4
   for (long r = rb + rl; r < re; r += RL) {
     const long off = r * c + chunk * 8;
@@ -597,7 +631,10 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
     } else {
       float gv[8];
       ld8(dy + off, gv);
-      if (a.act != RCGAN_ACT_NONE) {
+      if (mask_x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] *= act_grad(a.act, bn_stored<T>(bn_pre(xv[j], ainv[j], ac0[j])));
+      } else if (a.act != RCGAN_ACT_NONE) {
         float yv[8];
         ld8(y + off, yv);
 #pragma unroll
@@ -782,7 +819,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(long nchunks, int r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float inv = rs[j] * g[j];
-      xv[j] = act_apply(act, xv[j] * inv + (b[j] - mu[j] * inv));
+      xv[j] = act_apply(act, bn_pre(xv[j], inv, bn_c0(mu[j], inv, b[j])));
     }
     st8(y + (long)row * c + ch, xv);
   }
@@ -791,15 +828,18 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(long nchunks, int r
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long nchunks, int rows_per_sample, int c, const T* x, const T* y, const T* dy,
                                                                  const int32_t* labels, const float* gamma, const float* rstd,
-                                                                 const float* PQ, int act, T* dx, int accumulate_dx) {
+                                                                 const float* PQ, int act, T* dx, int accumulate_dx,
+                                                                 const float* beta, const float* mean) {
   const unsigned cpr = (unsigned)c / 8u;              // a power of two on this path
   const int lcpr = __ffs((int)cpr) - 1;
   const int lrps = (rows_per_sample & (rows_per_sample - 1)) == 0 ? __ffs(rows_per_sample) - 1 : -1;
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
   const unsigned stride = gridDim.x * 256u;
   const int ch = (int)(i0 & (cpr - 1u)) * 8;
-  float rs[8], p[8], q[8];
+  float rs[8], p[8], q[8], mu[8];
   ld8(rstd + ch, rs); ld8(PQ + ch, p); ld8(PQ + c + ch, q);
+  const bool mask_x = beta != nullptr;      // activation mask from x (bn_pre) instead of a read of y
+  if (mask_x) ld8(mean + ch, mu);
   for (unsigned i = i0; i < (unsigned)nchunks; i += stride) {
     const unsigned row = i >> lcpr;
     const int l = labels ? labels[lrps >= 0 ? (row >> lrps) : (row / (unsigned)rows_per_sample)] : 0;
@@ -807,13 +847,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long nchunks, i
     float xv[8], gv[8], gm[8];
     ld8(x + off, xv);
     ld8(dy + off, gv);
-    if (act != RCGAN_ACT_NONE) {
+    ld8(gamma + (long)l * c + ch, gm);
+    if (mask_x) {
+      float bt[8];
+      ld8(beta + (long)l * c + ch, bt);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float inv = rs[j] * gm[j];
+        gv[j] *= act_grad(act, bn_stored<T>(bn_pre(xv[j], inv, bn_c0(mu[j], inv, bt[j]))));
+      }
+    } else if (act != RCGAN_ACT_NONE) {
       float yv[8];
       ld8(y + off, yv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) gv[j] *= act_grad(act, yv[j]);
     }
-    ld8(gamma + (long)l * c + ch, gm);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = rs[j] * gm[j] * gv[j] + p[j] * xv[j] + q[j];
@@ -1049,6 +1097,15 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
 int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x, const void* y,
                  const void* dy, const int32_t* labels, const float* gamma, const float* mean, const float* rstd, int act,
                  void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+  return rcgan_bn_bwd2(ctx, n, rows_per_sample, c, n_labels, dtype, x, y, dy, labels, gamma, nullptr, mean, rstd, act, dx, accumulate_dx,
+                       dgamma, dbeta, accumulate, ws, ws_bytes);
+}
+
+int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels, int dtype, const void* x, const void* y,
+                  const void* dy, const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                  int act, void* dx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes) {
+  // with beta, ReLU / leaky ReLU masks are recomputed from x on the fused paths (two instead of three tensor reads per pass)
+  const float* beta_m = (beta && (act == RCGAN_ACT_RELU || act == RCGAN_ACT_LRELU)) ? beta : nullptr;
   RC_REQUIRE(ctx, n_labels >= 1 && n_labels <= MAX_LABELS, "n_labels %d", n_labels);
   RC_REQUIRE(ctx, labels != nullptr || n_labels == 1, "labels required for n_labels > 1");
   long rows = (long)n * rows_per_sample;
@@ -1072,14 +1129,14 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
     a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.y = y; a.dy = dy;
     a.mean_in = mean; a.rstd_in = rstd; a.act = act;
     a.n_labels = n_labels; a.groups_per_sample = cs; a.labels = labels; a.n_samples = n;
-    a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate; a.beta = beta_m;
     float* PQ = nullptr;
     int rc = launch_bn_tree<1>(ctx, dtype, a, 1, cs, ws, ws_bytes, &PQ);
     if (rc) return rc;
     long nchunks = rows * c / 8;
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
                                                      nchunks, rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, rstd,
-                                                     (const float*)PQ, act, (T*)dx, accumulate_dx));
+                                                     (const float*)PQ, act, (T*)dx, accumulate_dx, beta_m, mean));
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
   }
@@ -1100,13 +1157,15 @@ int rcgan_bn_bwd(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_labels
     a.mean_in = mean; a.rstd_in = rstd; a.act = act; a.partial = (float*)ws; a.counter = ctx->counters() + RC_COUNTER_BN;
     a.n_labels = n_labels; a.groups_per_sample = gps; a.labels = labels; a.n_samples = n;
     a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    // mask from x needs a group's rows to belong to one sample (conditional grouping) or no labels at all
+    a.beta = beta_m;
     a.PQ = a.partial + (size_t)ng * 2 * c;
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 1>), dim3(c / 64, ng), dim3(256), 0, ctx->stream, a));
     RC_LAUNCH_CHECK(ctx);
     long nchunks = rows * c / 8;
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,
                                                      nchunks, rows_per_sample, c, (const T*)x, (const T*)y, (const T*)dy, labels, gamma, rstd,
-                                                     (const float*)a.PQ, act, (T*)dx, accumulate_dx));
+                                                     (const float*)a.PQ, act, (T*)dx, accumulate_dx, beta_m, mean));
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
   }

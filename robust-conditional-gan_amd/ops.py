@@ -407,9 +407,10 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
             else:
                 dg = zeros_like_grad(ctx, gamma)
                 db = zeros_like_grad(ctx, beta)
-            ctx.check(ctx.lib.rcgan_bn_bwd(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(y), _p(dy), _p(labels), _p(gamma),
-                                           _p(mean), _p(rstd), act, _p(dx), acc_dx, _p(dg), _p(db), 1,
-                                           C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            # beta lets the fused kernels recompute the ReLU mask from x (the forward's exact arithmetic) instead of reading y
+            ctx.check(ctx.lib.rcgan_bn_bwd2(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(y), _p(dy), _p(labels), _p(gamma), _p(beta),
+                                            _p(mean), _p(rstd), act, _p(dx), acc_dx, _p(dg), _p(db), 1,
+                                            C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         ctx.record(bw)
     return y
 

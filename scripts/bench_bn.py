@@ -42,7 +42,7 @@ def main():
                                              P(rstd.ptr), L.ACT_RELU, P(y.ptr), P(ws), wsb))
 
         def bwd():
-            ctx.check(lib.rcgan_bn_bwd(h, n, rps, c, 10, L.BF16, P(x.ptr), P(y.ptr), P(dy.ptr), P(labels.ptr), P(gamma.ptr), P(mean.ptr),
+            ctx.check(lib.rcgan_bn_bwd2(h, n, rps, c, 10, L.BF16, P(x.ptr), P(y.ptr), P(dy.ptr), P(labels.ptr), P(gamma.ptr), P(beta.ptr), P(mean.ptr),
                                        P(rstd.ptr), L.ACT_RELU, P(dx.ptr), 0, P(dg.ptr), P(db.ptr), 0, P(ws), wsb))
         res = []
         for fn in (stats, apply, bwd):
