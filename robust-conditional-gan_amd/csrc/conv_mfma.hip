@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int lrow = lane >> 3, pos = lane & 7;
 
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   int p_n[AI], p_oh[AI], p_ow[AI], a_coff[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
   for (int t = 0; t < NS - 1; ++t)
     if (t < KT) issue(t);
   int buf = 0;
+  stamp(1);
   for (int kt = 0; kt < KT_max; ++kt) {
     // tile kt landed (this wave's part), then rendezvous: everyone's part landed and everyone left tile kt-1
     if (kt + NS - 2 < KT) wait_vmcnt<INFLIGHT>(); else wait_vmcnt<0>();
@@ -299,7 +304,9 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
       }
     }
     if (++buf == NS) buf = 0;
+    if (kt == 0) stamp(2);
   }
+  stamp(3);
 
   if (KS > 1) {
     // sum the groups' partial tiles in group order: groups 1.. park their accumulators in LDS (the pipelines are idle)
@@ -325,7 +332,211 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
     }
   }
 
+  stamp(4);
   conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+  if (a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
+    if (tid == 0) {
+      a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Halo-staged variant of the small-tile kernel (3x3 filters, tiles = whole image rows).
+//
+// Measured on the kernel above (rcgan_debug_stamps, scripts/exp_p8_timeline.py 128 128 3 8 128): a workgroup's K loop
+// moves 294 KB through the LDS-DMA path -- 147 KB of filters and 147 KB of pixels, the SAME 16 KB of pixels once per
+// tap -- at the 60-75 GB/s a CU ingests by LDS-DMA however many tiles are in flight (2 x 4 stages: 58 GB/s, 4 x 2: 72)
+// and however few workgroups run (32 or 256: the same 7.65 us per workgroup).  The 8x8 layers (one workgroup per CU) and
+// the 16x16 layers (four per CU: 1.18 MB per CU = 16 us of their 19) are bound by that rate, not by latency or L2.
+// Here the tile's pixels are fetched ONCE, as a zero-padded patch of (rows + 2) x (W + 2) pixels per 64-channel chunk
+// (all chunks resident: <= 70 KB at 256 channels), and the nine taps are row offsets into it, so the K loop streams only
+// the filter tiles (8 KB per K-tile): 163 KB instead of 294 KB per 64 x 64 tile.
+//   patch pixel pp = pr * (W + 2) + pc  <->  input (oh0 + pr - 1, pc - 1); 128-byte rows, 16-byte slots XOR-swizzled with
+//   (pp >> 1) & 7 on the DMA's source side and in the fragment reads, exactly like the tile rows of the kernel above.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS, int KS>
+__global__ __launch_bounds__(256 * KS) void conv_mfma_halo_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  constexpr int BBYTES = BN * 128;
+  constexpr int BI = BN / 32;
+  constexpr int TM = BM / 2, TN = BN / 2;
+  constexpr int NI = TN / 16, NJ = TM / 16;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KS > 1 ? wave_all >> 2 : 0;
+  const int wave = wave_all & 3;
+  const int wm = wave & 1, wn = wave >> 1;
+  const long m0 = (long)blockIdx.x * BM;
+  const int co0 = blockIdx.y * BN;
+  const int K = 9 * a.Cin;
+  const int KT_all = K / 64;
+  const int KT = KS > 1 ? (KT_all - grp + KS - 1) / KS : KT_all;
+  const int KT_max = (KT_all + KS - 1) / KS;
+  const int nchunk = a.Cin >> 6;
+  const int W = a.W, PW = W + 2;
+  const int TR = BM >> a.lw;                       // image rows of the tile
+  const int PP = (TR + 2) * PW;                    // patch pixels
+  const int PD = (PP + 7) >> 3;                    // 1-KiB deposits (8 patch pixels x 128 B) per chunk
+  const int a_chunk = PD * 1024;
+  const int lrow = lane >> 3, pos = lane & 7;
+  unsigned char* const Abase = smem_all;
+  unsigned char* const Bbase = smem_all + nchunk * a_chunk + grp * (NS * BBYTES);
+  const unsigned lds_all = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_all;
+  const unsigned ldsB = lds_all + nchunk * a_chunk + grp * (NS * BBYTES);
+
+  // ---- the patch, one 64-channel chunk at a time: every wavefront of the workgroup deposits its share.  The K loop runs
+  //      chunk-major (the nine taps of chunk 0, then chunk 1, ...), so only chunk 0 has to land before the first MFMA; chunk
+  //      c + 1 is requested when chunk c's first K-tile starts and is older than every filter tile waited for after that
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  const unsigned mm0 = (unsigned)m0;
+  const int n_img = (int)(mm0 >> (a.lw + a.lh));
+  const int oh0 = (int)((mm0 >> a.lw) & (unsigned)(a.H - 1));
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  auto load_patch = [&](int chunk) __attribute__((always_inline)) {
+    for (int d = wave_all; d < PD; d += 4 * KS) {
+      const int pp = d * 8 + lrow;
+      const int pr = pp / PW, pc = pp - pr * PW;
+      int ih = oh0 + pr - 1, iw = pc - 1;
+      const bool ok = pp < PP && ih >= 0 && ih < a.H && iw >= 0 && iw < W;
+      if (a.up) { ih >>= 1; iw >>= 1; }
+      const bf16_t* src = ok ? a.in + (unsigned)((((unsigned)n_img * Hs + ih) * Ws + iw) * a.Cin + chunk * 64 + ((pos ^ ((pp >> 1) & 7)) * 8))
+                             : a.zero;
+      glds16_asm(src, lds_all + chunk * a_chunk + d * 1024);
+    }
+  };
+  load_patch(0);
+
+  // ---- filter tiles: as in the kernel above ------------------------------------------------------------------------------
+  const bf16_t* wsrc[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = (wave * BI + i) * 8 + lrow;
+    wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ ((row >> 1) & 7)) * 8;
+  }
+  // K-tile kg of the chunk-major order = (chunk kg / 9, tap kg % 9); its filter columns start at tap * Cin + chunk * 64
+  int i_kg = grp;
+  auto issue = [&](int buf) __attribute__((always_inline)) {
+    const int chunk = i_kg / 9, tap = i_kg - chunk * 9;
+    const int k0 = tap * a.Cin + chunk * 64;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) glds16_asm(wsrc[i] + k0, ldsB + buf * BBYTES + (wave * BI + i) * 1024);
+    i_kg += KS;
+  };
+
+  f32x4_t acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  const int foff0 = frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  const int foff1 = frow * 128 + (((4 + kc) ^ ((frow >> 1) & 7)) * 16);
+  // patch index of this lane's pixel of fragment j for tap (0, 0)
+  int pp00[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int p = wm * TM + j * 16 + frow;
+    pp00[j] = (p >> a.lw) * PW + (p & (W - 1));
+  }
+
+  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;
+  constexpr int INFLIGHT = (NS - 2) * BI;
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < KT) issue(t);
+  int buf = 0;
+  bool drain = false;                    // the previous iteration requested a patch chunk: wait for everything once
+  stamp(1);
+  for (int kt = 0; kt < KT_max; ++kt) {
+    // (chunk 0 of the patch is older than every filter tile; later chunks are covered by the full wait that follows them)
+    if (!drain && kt + NS - 2 < KT) wait_vmcnt<INFLIGHT>(); else wait_vmcnt<0>();
+    drain = false;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + NS - 1 < KT) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      issue(nb);
+    }
+    {
+      // the next chunk's patch: requested by every wavefront once, when the workgroup's first K-group enters the chunk before
+      const int kg0 = kt * KS;                       // K-tile of group 0 in this iteration
+      const int c0 = kg0 / 9;
+      if (kg0 - c0 * 9 < KS && c0 + 1 < nchunk) { load_patch(c0 + 1); drain = true; }
+    }
+    if (KS == 1 || kt < KT) {
+      const int kg = grp + kt * KS;                  // global K-tile, chunk-major
+      const int chunk = kg / 9, tap = kg - chunk * 9;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const unsigned char* Ac = Abase + chunk * a_chunk;
+      const unsigned char* Bb = Bbase + buf * BBYTES + (wn * TN) * 128;
+      int prow[NJ], psw[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { const int pp = pp00[j] + kh * PW + kw; prow[j] = pp * 128; psw[j] = (pp >> 1) & 7; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int fo = ks ? foff1 : foff0;
+        bf16x8_t wf[NI], xf[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8_t*)(Bb + i * 16 * 128 + fo);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          uint4 v = *(const uint4*)(Ac + prow[j] + (((ks * 4 + kc) ^ psw[j]) << 4));
+          v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
+          xf[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+      }
+    }
+    if (++buf == NS) buf = 0;
+    if (kt == 0) stamp(2);
+  }
+  stamp(3);
+
+  if (KS > 1) {
+    __syncthreads();
+    float* part = (float*)smem_all;
+    constexpr int PER = NI * NJ * 4;
+    if (grp > 0) {
+      float* dst = part + ((grp - 1) * 256 + (tid & 255)) * PER;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *(f32x4_t*)(dst + (i * NJ + j) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* src = part + ((g - 1) * 256 + tid) * PER;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] += *(const f32x4_t*)(src + (i * NJ + j) * 4);
+    }
+  }
+  stamp(4);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+  if (a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
+    if (tid == 0) {
+      a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1014,6 +1225,35 @@ static int launch_conv_glds(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return RCGAN_OK;
 }
 
+// halo-staged kernel: 3x3 filters on power-of-two images whose rows fit the tile (tile = whole rows of one image), at most 256
+// input channels (all 64-channel patches resident in LDS)
+template <int BM>
+static bool halo_ok(const MfmaConvArgs& a) {
+  static const int on = env_int("RCGAN_CONV_HALO", 1);
+  return on && a.KH == 3 && a.KW == 3 && a.lw >= 0 && a.lh >= 0 && a.W <= BM && (a.H * a.W) % BM == 0 && a.Cin <= 256 && a.zero != nullptr &&
+         (long)a.N * a.H * a.W * a.Cin < (1L << 32);
+}
+
+template <int BM, int BN, int NS, int KS>
+static int launch_conv_halo(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  const int TR = BM / a.W, PD = ((TR + 2) * (a.W + 2) + 7) / 8;
+  size_t lds = (size_t)(a.Cin / 64) * PD * 1024 + (size_t)KS * NS * BN * 128;
+  const size_t part = (size_t)(KS - 1) * 256 * (BM / 32) * (BN / 32) * 4 * sizeof(float);       // K-group partial sums
+  if (part > lds) lds = part;
+  static size_t attr = 0;
+  if (lds > attr) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_halo_kernel<BM, BN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  dim3 grid(cdiv(a.M, BM), a.Cout / BN);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_64, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_halo_kernel<BM, BN, NS, KS>), grid, dim3(256 * KS), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 template <int BM, int BN>
 static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   if (conv_impl() == 1 && a.zero != nullptr) {
@@ -1025,6 +1265,17 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
     const long blocks = (long)cdiv(a.M, BM) * (a.Cout / BN);
     const int ktiles = a.KH * a.KW * a.Cin / 64;
     if constexpr (BM == 64) {
+      if (halo_ok<64>(a)) {
+        // Measured (scripts/bench_conv.py): the halo form pays where ONE workgroup per CU runs a short K loop -- the 8x8
+        // 128-channel layers, 9.7 -> 8.4 us.  On the 16x16 layers (four resident workgroups per CU hide each other's DMA
+        // round trips; the patch costs LDS = residency) and at 256 input channels (53 KB of patches: one workgroup per CU
+        // instead of two) it is 5-30 % slower, with 64- or 128-pixel tiles, two or four filter stages alike: those keep the
+        // tile-per-tap kernel.
+        if (blocks <= ks4_max && ktiles >= 8 && a.Cin <= 128) return launch_conv_halo<64, 64, 2, 4>(ctx, a);
+      }
+      static const int deep = env_int("RCGAN_KS_DEEP", 0);      // experiment: 1 = 2 K-groups x 4 stages, 2 = 3 K-groups x 3 stages
+      if (deep == 1 && blocks <= ks4_max && ktiles >= 8) return launch_conv_glds<BM, BN, 4, 2>(ctx, a);
+      if (deep == 2 && blocks <= ks4_max && ktiles >= 9) return launch_conv_glds<BM, BN, 3, 3>(ctx, a);
       if (blocks <= ks4_max && ktiles >= 8) return launch_conv_glds<BM, BN, 2, 4>(ctx, a);
       if (blocks <= ks2_max && ktiles >= 4) return launch_conv_glds<BM, BN, 2, 2>(ctx, a);
     }
@@ -1047,7 +1298,9 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return RCGAN_OK;
 }
 
-int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
+  MfmaConvArgs a = a_in;
+  a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
   long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
   static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);

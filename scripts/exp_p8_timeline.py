@@ -2,7 +2,9 @@
 """Where a workgroup of the 256 x 256 convolution kernel spends its time (s_memtime stamps, rcgan_debug_stamps):
 per workgroup  start -> table -> first K-tile landed -> K loop done -> stores issued -> stores complete,
 and per CU the gap between one workgroup's last stamp and the next workgroup's first (dispatch + wave launch).
-usage: python scripts/exp_p8_timeline.py [n] [cin] [k]"""
+usage: python scripts/exp_p8_timeline.py [n] [cin] [k] [hw] [cout]     (defaults 320 256 3 32 256: the 256 x 256 kernel;
+       e.g. 128 128 3 8 128 = a D.Block.3-6 convolution on the 64 x 64 K-split kernel, whose stamps are start, set-up done, first
+       K-tile multiplied, K loop done, partial sums combined, stores complete)"""
 import ctypes as C
 import os
 import sys
@@ -20,18 +22,20 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 320
     cin = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    hw = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    cout = int(sys.argv[5]) if len(sys.argv) > 5 else 256
     ctx = Context(0, "bf16", arena_bytes=8 << 30, ws_bytes=1 << 30)
     lib, h = ctx.lib, ctx.h
-    x = ctx.empty((n, 32, 32, cin))
-    y = ctx.empty((n, 32, 32, 256))
-    w = ctx.empty((k, k, cin, 256), L.F32)
+    x = ctx.empty((n, hw, hw, cin))
+    y = ctx.empty((n, hw, hw, cout))
+    w = ctx.empty((k, k, cin, cout), L.F32)
     ctx.check(lib.rcgan_rng_fill(h, x.size, x.dtype, 1, 0.0, 1.0, 7, None, C.c_void_p(x.ptr)))
     ctx.check(lib.rcgan_rng_fill(h, w.size, L.F32, 1, 0.0, 0.05, 9, None, C.c_void_p(w.ptr)))
-    desc = L.ConvDesc(n, 32, 32, cin, 256, k, k, 1, L.BF16, 0)
+    desc = L.ConvDesc(n, hw, hw, cin, cout, k, k, 1, L.BF16, 0)
     prep = ctx.arena.alloc(lib.rcgan_conv_prepared_bytes(C.byref(desc)))
     ctx.check(lib.rcgan_conv_prepare(h, C.byref(desc), C.c_void_p(w.ptr), None, C.c_void_p(prep)))
     call = lambda: ctx.check(lib.rcgan_conv2d_fwd(h, C.byref(desc), C.c_void_p(x.ptr), C.c_void_p(prep), None, C.c_void_p(y.ptr)))
-    tiles = n * 1024 // 256
+    tiles = int(os.environ.get("TILES", n * hw * hw // 256 * (cout // 256) if cout % 256 == 0 and n * hw * hw >= 51200 else (n * hw * hw + 63) // 64 * (cout // 64)))
     stamps = torch.zeros(tiles * 8, dtype=torch.int64, device=ctx.device)
     for _ in range(3):
         call()

@@ -292,10 +292,11 @@ def test_d_trunk_equals_layerwise_blocks(dev, n):
     # gradients: the two forwards differ by summation-order noise, so a pre-activation within that noise of zero gets a
     # different ReLU mask -- isolated elements differ by their whole value; compare in the norm
     from tests.gpu_util import rel_err
-    assert rel_err(a["dx"], b["dx"]) < 2e-2, rel_err(a["dx"], b["dx"])
+    tol = 6e-2 if n < 16 else 2e-2            # a few hundred pixels: one flipped mask is a visible fraction of a filter gradient
+    assert rel_err(a["dx"], b["dx"]) < tol, rel_err(a["dx"], b["dx"])
     for i in range(8):
-        assert rel_err(a["dw"][i], b["dw"][i]) < 2e-2, (i, rel_err(a["dw"][i], b["dw"][i]))
-        assert rel_err(a["db"][i], b["db"][i]) < 2e-2, (i, rel_err(a["db"][i], b["db"][i]))
+        assert rel_err(a["dw"][i], b["dw"][i]) < tol, (i, rel_err(a["dw"][i], b["dw"][i]))
+        assert rel_err(a["db"][i], b["db"][i]) < tol, (i, rel_err(a["db"][i], b["db"][i]))
     if n <= 8:       # float64 oracle of the forward values (16-bit rounding between layers restated)
         t = x.astype(np.float64)
         q = lambda v: half_round(mode, v).astype(np.float64)
