@@ -116,7 +116,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   }
   c->dbg_stamps = nullptr;
   c->zero_page = nullptr;
-  if (hipMalloc(&c->zero_page, 4096 + 32768) != hipSuccess || hipMemset(c->zero_page, 0, 4096 + 32768) != hipSuccess) {
+  if (hipMalloc(&c->zero_page, RC_ZERO_PAGE_BYTES) != hipSuccess || hipMemset(c->zero_page, 0, RC_ZERO_PAGE_BYTES) != hipSuccess) {
     delete c;
     return RCGAN_EHIP;
   }

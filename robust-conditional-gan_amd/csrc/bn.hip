@@ -334,6 +334,10 @@ template <> __device__ __forceinline__ float bn_stored<float>(float v) { return 
 template <> __device__ __forceinline__ float bn_stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 __device__ __forceinline__ float bn_c0(float mean, float inv, float beta) { return __fmaf_rn(-mean, inv, beta); }
 
+__device__ __forceinline__ float ld_sc1_f1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, soff, 16));
+}
+
 struct BnFusedArgs {
   long rows; int c; long rows_per_group; int ngroups;
   int nseg;                             // forward only: blockIdx.z = segment; x, partial, counter, mean, rstd advance per segment
@@ -348,16 +352,24 @@ struct BnFusedArgs {
   int n_labels; int groups_per_sample; const int32_t* labels; int n_samples;
   const float* gamma; float *dgamma, *dbeta; int accumulate; float* PQ;
   const float* beta;                    // backward, optional: with it the activation mask is recomputed from x (no read of y)
+  int nsub;                             // conditional backward, samples of < 32 rows: a workgroup takes 32 rows = nsub samples (0, 1: off)
 };
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
-  __shared__ float red[2][32][64];
+  // dynamic LDS: the row buffer red[2][32][64] of the streaming phase; the finisher of the conditional backward reuses it as
+  // lacc[2][n_labels][4][64] (per-label sums, private per (lane4, column)).  Sharing the storage (16 KiB, 20 KiB with ten labels,
+  // instead of 60 KiB of static arrays) is what lets six workgroups instead of two stay on a CU: this kernel is a latency chain
+  // (load -> LDS -> write-through store -> arrival), so its time is rounds x chain.
+  extern __shared__ float uni[];
   __shared__ double fin[2][4][64];
-  __shared__ float lab_s[2][MAX_LABELS][64];
+  __shared__ float lab_s[2][64];
   __shared__ int is_last;
-  __shared__ int lab_ids[32];
-  __shared__ float lacc[MODE == 1 ? 2 : 1][MODE == 1 ? MAX_LABELS : 1][4][64];   // backward: per-label sums, private per (lane4, column)
+  __shared__ int lab_ids[128];
+#define RED(k, q, col) uni[((k) * 32 + (q)) * 64 + (col)]
+#define LACC(k, l, ln, col) uni[(((k) * NL + (l)) * 4 + (ln)) * 64 + (col)]
+  const int NL = a.n_labels;
+  const int nsub = a.nsub > 1 ? a.nsub : 1;     // samples per workgroup when a sample has fewer than 32 rows
   const int t = threadIdx.x;
   const int c = a.c;
   const int c0 = blockIdx.x * 64;
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
     const long sg = blockIdx.z;
     a.x = (const T*)a.x + sg * a.rows * c;
     a.partial += sg * (long)a.ngroups * 2 * c;
-    a.counter += sg * (c / 64);
+    a.counter += sg * (c / 64) * RC_LINE_STRIDE;
     a.mean += sg * c; a.rstd += sg * c;
   }
   const T* x = (const T*)a.x; const T* y = (const T*)a.y; const T* dy = (const T*)a.dy;
@@ -378,15 +390,17 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
   float ainv[8], ac0[8];
   const bool mask_x = MODE == 1 && a.beta != nullptr;
+  constexpr int UNR = MODE == 0 ? 4 : 2;
   if (MODE == 1) { ld8(a.mean_in + c0 + chunk * 8, mu); ld8(a.rstd_in + c0 + chunk * 8, rs); }
   if (mask_x) {                           // the group's rows belong to one sample: one label
-    const long lo = (long)(a.labels ? a.labels[blockIdx.y / a.groups_per_sample] : 0) * c + c0 + chunk * 8;
+    const int smp = nsub > 1 ? (int)blockIdx.y * nsub + rl / (32 / nsub) : (int)blockIdx.y / a.groups_per_sample;
+    const long lo = (long)(a.labels ? a.labels[smp] : 0) * c + c0 + chunk * 8;
     float gm8[8], bt8[8];
     ld8(a.gamma + lo, gm8); ld8(a.beta + lo, bt8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ainv[j] = rs[j] * gm8[j]; ac0[j] = bn_c0(mu[j], ainv[j], bt8[j]); }
   }
-#pragma unroll 2
+#pragma unroll UNR
   for (long r = rb + rl; r < re; r += 32) {
     const long off = r * c + c0 + chunk * 8;
     float xv[8];
@@ -411,22 +425,26 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { red[0][rl][chunk * 8 + j] = s1[j]; red[1][rl][chunk * 8 + j] = s2[j]; }
+  for (int j = 0; j < 8; ++j) { RED(0, rl, chunk * 8 + j) = s1[j]; RED(1, rl, chunk * 8 + j) = s2[j]; }
   __syncthreads();
   // wavefront 0 writes both partial rows and then signals: the agent-scope release of thread 0 orders the
   // stores of its OWN wavefront, so no other wavefront has to fence
   if (t < 64) {
-    float sa = 0.f, sb = 0.f;
+    const int qn = 32 / nsub;
+    for (int sub = 0; sub < nsub; ++sub) {
+      float sa = 0.f, sb = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) { sa += red[0][q][t]; sb += red[1][q][t]; }
-    // agent-scope stores (write through to the memory side: visible to every XCD without an L2 write-back)
-    __hip_atomic_store(a.partial + ((long)blockIdx.y * 2 + 0) * c + c0 + t, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(a.partial + ((long)blockIdx.y * 2 + 1) * c + c0 + t, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = sub * qn; q < (sub + 1) * qn; ++q) { sa += RED(0, q, t); sb += RED(1, q, t); }
+      // agent-scope stores (write through to the memory side: visible to every XCD without an L2 write-back)
+      const long pr = (long)blockIdx.y * nsub + sub;
+      __hip_atomic_store(a.partial + (pr * 2 + 0) * c + c0 + t, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.partial + (pr * 2 + 1) * c + c0 + t, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores are performed before it signals
   }
   // ---- arrival: the last workgroup of this column block finishes ------------------------------------------
   if (t == 0) {
-    unsigned prev = __hip_atomic_fetch_add(a.counter + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned prev = __hip_atomic_fetch_add(a.counter + blockIdx.x * RC_LINE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (prev == (unsigned)a.ngroups - 1u) ? 1 : 0;
   }
   __syncthreads();
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
         float og = (float)d2, ob = (float)d1;
         if (a.accumulate) { og += a.dgamma[ch]; ob += a.dbeta[ch]; }
         a.dgamma[ch] = og; a.dbeta[ch] = ob;
-        lab_s[0][0][t] = (float)d1; lab_s[1][0][t] = (float)d2;
+        lab_s[0][t] = (float)d1; lab_s[1][t] = (float)d2;
       }
     }
   } else {
@@ -474,57 +492,60 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
     // every batch of 32: it sums their groups (independent loads) and adds the result to its PRIVATE per-label
     // slot in LDS; afterwards the four lanes of a (label, column) are summed in a fixed order.
     const int gps = a.groups_per_sample;
-#pragma unroll
-    for (int l = 0; l < MAX_LABELS; ++l) { lacc[0][l][lane4][col] = 0.f; lacc[1][l][lane4][col] = 0.f; }
-    for (int s0 = 0; s0 < a.n_samples; s0 += 32) {
+    for (int l = 0; l < NL; ++l) { LACC(0, l, lane4, col) = 0.f; LACC(1, l, lane4, col) = 0.f; }
+    // FB*32 samples per round: FB*16 independent loads per thread and group; buffer loads (one 32-bit offset per sample, the
+    // second row through the scalar offset; samples past the end read zero).  Measured: 64 samples per round 3 us faster than
+    // 128 (142 VGPRs), and than 32 with 64-bit addresses
+    constexpr int FB = 2;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, (int)((long)a.n_samples * gps * gstride * 4), 0x00020000);
+    const unsigned sstride = (unsigned)(gps * gstride * 4);
+    for (int s0 = 0; s0 < a.n_samples; s0 += FB * 32) {
       __syncthreads();
-      if (t < 32) lab_ids[t] = (s0 + t < a.n_samples) ? a.labels[s0 + t] : -1;
-      float d1[8], d2[8];
+      int lab = -1;
+      if (t < FB * 32 && s0 + t < a.n_samples) lab = a.labels[s0 + t];
+      float d1[FB][8], d2[FB][8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { d1[k] = 0.f; d2[k] = 0.f; }
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { d1[b][k] = 0.f; d2[b][k] = 0.f; }
       for (int q = 0; q < gps; ++q) {
+        const unsigned o0 = (unsigned)(c0 + col) * 4u + (unsigned)q * (unsigned)(gstride * 4);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {           // 16 independent loads per round
-          const int sidx = s0 + lane4 * 8 + k;
-          if (sidx < a.n_samples) {
-            const float* pp = part + ((long)sidx * gps + q) * gstride;
-            d1[k] += __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d2[k] += __hip_atomic_load(pp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = 0; b < FB; ++b) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned o = o0 + (unsigned)(s0 + b * 32 + lane4 * 8 + k) * sstride;
+            d1[b][k] += ld_sc1_f1(rs_p, o, 0);
+            d2[b][k] += ld_sc1_f1(rs_p, o, c * 4);
           }
         }
       }
+      if (t < FB * 32) lab_ids[t] = lab;
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int l = lab_ids[lane4 * 8 + k];
-        if (l >= 0 && l < MAX_LABELS) { lacc[0][l][lane4][col] += d1[k]; lacc[1][l][lane4][col] += d2[k]; }
+      for (int b = 0; b < FB; ++b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int l = lab_ids[b * 32 + lane4 * 8 + k];
+          if (l >= 0 && l < NL) { LACC(0, l, lane4, col) += d1[b][k]; LACC(1, l, lane4, col) += d2[b][k]; }
+        }
       }
     }
     __syncthreads();
-    float acc1[MAX_LABELS / 4], acc2[MAX_LABELS / 4];
-#pragma unroll
-    for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
-      const int l = lane4 + 4 * slot;
-      acc1[slot] = (lacc[0][l][0][col] + lacc[0][l][1][col]) + (lacc[0][l][2][col] + lacc[0][l][3][col]);
-      acc2[slot] = (lacc[1][l][0][col] + lacc[1][l][1][col]) + (lacc[1][l][2][col] + lacc[1][l][3][col]);
-    }
-    float gm[MAX_LABELS / 4];
-#pragma unroll
-    for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
-      const int l = lane4 + 4 * slot;
-      gm[slot] = l < a.n_labels ? a.gamma[(long)l * c + c0 + col] : 0.f;
-    }
     double q1 = 0.0, q2 = 0.0;
 #pragma unroll
     for (int slot = 0; slot < MAX_LABELS / 4; ++slot) {
       const int l = lane4 + 4 * slot;
-      if (l < a.n_labels) {
+      if (l < NL) {
+        const float acc1 = (LACC(0, l, 0, col) + LACC(0, l, 1, col)) + (LACC(0, l, 2, col) + LACC(0, l, 3, col));
+        const float acc2 = (LACC(1, l, 0, col) + LACC(1, l, 1, col)) + (LACC(1, l, 2, col) + LACC(1, l, 3, col));
         const long o = (long)l * c + c0 + col;
-        float og = acc2[slot], ob = acc1[slot];
+        const float gm = a.gamma[o];
+        float og = acc2, ob = acc1;
         if (a.accumulate) { og += a.dgamma[o]; ob += a.dbeta[o]; }
         a.dgamma[o] = og; a.dbeta[o] = ob;
-        q1 += (double)gm[slot] * (double)acc1[slot];
-        q2 += (double)gm[slot] * (double)acc2[slot];
+        q1 += (double)gm * (double)acc1;
+        q2 += (double)gm * (double)acc2;
       }
     }
     fin[0][lane4][col] = q1; fin[1][lane4][col] = q2;
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
       double q1, q2;
       if (a.labels == nullptr) {
         const double gmm = (double)a.gamma[ch];
-        q1 = gmm * (double)lab_s[0][0][t]; q2 = gmm * (double)lab_s[1][0][t];
+        q1 = gmm * (double)lab_s[0][t]; q2 = gmm * (double)lab_s[1][t];
       } else {
         q1 = fin[0][0][t] + fin[0][1][t] + fin[0][2][t] + fin[0][3][t];
         q2 = fin[1][0][t] + fin[1][1][t] + fin[1][2][t] + fin[1][3][t];
@@ -550,7 +571,15 @@ __global__ __launch_bounds__(256) void bn_fused_reduce_kernel(BnFusedArgs a) {
       a.PQ[c + ch] = -p * a.mean_in[ch] - r * (float)q1 * invM;
     }
   }
-  if (t == 0) __hip_atomic_store(a.counter + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0) __hip_atomic_store(a.counter + blockIdx.x * RC_LINE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef RED
+#undef LACC
+}
+
+// dynamic LDS of the kernel above
+static inline size_t bn_fused_lds(int mode, int n_labels) {
+  size_t red = 2 * 32 * 64 * sizeof(float), lacc = mode == 1 ? (size_t)n_labels * 2 * 4 * 64 * sizeof(float) : 0;
+  return red > lacc ? red : lacc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,7 +632,7 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
     a.x = (const T*)a.x + sg * a.rows * c;
     a.partial += sg * (long)a.ngroups * c2;
     ta.cpart += sg * (long)ta.nclusters * c2;
-    ta.counters += sg * (ta.nclusters + 1);
+    ta.counters += sg * (ta.nclusters + 1) * RC_LINE_STRIDE;
     a.mean += sg * c; a.rstd += sg * c;
   }
   const T* x = (const T*)a.x; const T* y = (const T*)a.y; const T* dy = (const T*)a.dy;
@@ -666,7 +695,7 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
   const int cl = g / ta.cs;
   const int cl_groups = min(ta.cs, a.ngroups - cl * ta.cs);
   if (t == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(ta.counters + cl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(ta.counters + cl * RC_LINE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flag = (prev == (unsigned)cl_groups - 1u) ? 1 : 0;
   }
   __syncthreads();
@@ -685,8 +714,8 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
-    __hip_atomic_store(ta.counters + cl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned prev = __hip_atomic_fetch_add(ta.counters + ta.nclusters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ta.counters + cl * RC_LINE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(ta.counters + ta.nclusters * RC_LINE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flag = (prev == (unsigned)ta.nclusters - 1u) ? 1 : 0;
   }
   __syncthreads();
@@ -786,7 +815,7 @@ __global__ __launch_bounds__(256) void bn_tree_reduce_kernel(BnTreeArgs ta) {
       a.PQ[c + ch] = -p * a.mean_in[ch] - r * (float)q1 * invM;
     }
   }
-  if (t == 0) __hip_atomic_store(ta.counters + ta.nclusters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0) __hip_atomic_store(ta.counters + ta.nclusters * RC_LINE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // y = act(x*A + B), A = rstd*gamma[label], B = beta[label] - mean*A, computed in-line: the thread's 8 channels are fixed
@@ -902,18 +931,19 @@ static inline int ew_grid2(long total) {
   return (int)b;
 }
 
-// tree path: VERY big tensors with a power-of-two channel count (full rows per workgroup need c/8 <= 256 chunk lanes).
-// Measured (scripts/bench_bn.py, MI355X): the reductions are bound by their serial arrival chain (write-through partials,
-// drain, counter, finisher loads), not by the access pattern -- the tree has one hop more than the column kernel and only
-// wins once the streaming part dominates: [320,32,32,256] bf16 (168 MB) statistics 37 us vs 55 us, backward 278 vs 317 us;
-// [128,32,32,256] (67 MB) 24.7 vs 25.9 us; [320,16,16,256] (42 MB) 21.8 vs 16.9 us (slower).  More than ~512 groups make
-// it slower (1024: 35 us, 4096: 89 us on the 67 MB case).  Threshold: 48M elements (RCGAN_BN_TREE_MIN; the tests lower it).
+// tree path (power-of-two channel counts; full rows per workgroup need c/8 <= 256 chunk lanes): OFF unless RCGAN_BN_TREE_MIN gives
+// an element threshold.  Measured (scripts/bench_bn.py, MI355X): the reductions are bound by their serial arrival chain
+// (write-through partials, drain, counter, finisher loads), not by the access pattern, and the tree has one hop more than the column
+// kernel.  While the column kernel's arrival counters shared one 128-byte line the tree won on the biggest tensor ([320,32,32,256]
+// bf16, 168 MB: statistics 37 vs 55 us); with one counter per line (RC_LINE_STRIDE) the column kernel is faster at every size
+// (that tensor: 36.2 vs 36.7 us, backward 202 vs 226 us; [128,16,16,256]: 6.6 vs 16 us).  The tests lower the threshold so the
+// path stays covered.
 static inline bool bn_tree_ok(long rows, int c) {
   static long min_elems = -1;
   if (min_elems < 0) {
     const char* e = getenv("RCGAN_BN_TREE");
     const char* m = getenv("RCGAN_BN_TREE_MIN");
-    min_elems = (e && atoi(e) == 0) ? (1L << 62) : (m ? atol(m) : (48L << 20));
+    min_elems = (e && atoi(e) == 0) ? (1L << 62) : (m ? atol(m) : (1L << 62));
   }
   return bn_fused_ok(c) && rows * (long)c >= min_elems;
 }
@@ -933,7 +963,7 @@ static int launch_bn_tree(rcgan_ctx* ctx, int dtype, BnFusedArgs& a, int nseg, i
   a.nseg = nseg;
   ta.cpart = a.partial + n_part;
   if (pq_out) { *pq_out = ta.cpart + n_cp; a.PQ = *pq_out; }
-  ta.counters = ctx->tree_counters();
+  ta.counters = ctx->tree_line_counters();
   ta.cs = cs; ta.nclusters = ncl;
   ta.f = a;
   const int Q = 2 * c / 4, SL = Q >= 256 ? 1 : 256 / Q;
@@ -994,9 +1024,9 @@ int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, fl
   if (bn_fused_ok(c)) {
     BnFusedArgs a = {};
     a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.partial = partial;
-    a.counter = ctx->counters() + RC_COUNTER_BN;
+    a.counter = ctx->line_counters() + RC_LCOUNTER_BN * RC_LINE_STRIDE;
     a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = mm; a.mv = mv; a.decay = decay;
-    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng), dim3(256), 0, ctx->stream, a));
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng), dim3(256), bn_fused_lds(0, 0), ctx->stream, a));
     RC_LAUNCH_CHECK(ctx);
     return RCGAN_OK;
   }
@@ -1080,9 +1110,9 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     BnFusedArgs a = {};
     a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.nseg = nseg; a.x = x; a.partial = (float*)ws;
-    a.counter = ctx->counters() + RC_COUNTER_BNSEG;
+    a.counter = ctx->line_counters() + RC_LCOUNTER_BNSEG * RC_LINE_STRIDE;
     a.eps = eps; a.mean = mean; a.rstd = rstd; a.mm = nullptr; a.mv = nullptr; a.decay = 0.f;
-    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), 0, ctx->stream, a));
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), bn_fused_lds(0, 0), ctx->stream, a));
     RC_LAUNCH_CHECK(ctx);
   }
   const long nchunks = rows * c / 8;
@@ -1141,26 +1171,35 @@ int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_label
     return RCGAN_OK;
   }
   if (bn_fused_ok(c)) {
-    int gps = 1;
+    int gps = 1, nsub = 1;
     if (labels) {
-      // groups never straddle samples; split each sample until the grid has a few hundred workgroups
+      // groups never straddle samples; split each sample until the grid has enough workgroups (six fit on a CU); samples of
+      // fewer than 32 rows (the 4x4 stage) go nsub to a workgroup, which still writes one partial row per sample
+      static long target = -1, maxg = -1;
+      if (target < 0) {
+        const char* e = getenv("RCGAN_BN_BWD_WGS"); target = e ? atol(e) : 512;
+        const char* m = getenv("RCGAN_BN_BWD_MAXG"); maxg = m ? atol(m) : 512;
+      }
       rpg = rows_per_sample;
-      while ((long)n * gps * (c / 64) < 512 && rpg % 2 == 0 && rpg / 2 >= 32 && (long)n * gps * 2 <= 1024) { gps *= 2; rpg /= 2; }
+      if (rows_per_sample < 32 && 32 % rows_per_sample == 0 && n % (32 / rows_per_sample) == 0) { nsub = 32 / rows_per_sample; rpg = 32; }
+      else while ((long)n * gps * (c / 64) < target && rpg % 2 == 0 && rpg / 2 >= 32 && (long)n * gps * 2 <= maxg) { gps *= 2; rpg /= 2; }
       ng = n * gps;
     } else {
       rpg = stats_group_rows(rows); ng = cdiv(rows, rpg);
     }
+    const int nwg = ng / nsub;
     size_t need = ((size_t)ng * 2 * c + 2 * (size_t)c) * sizeof(float);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     BnFusedArgs a = {};
     a.rows = rows; a.c = c; a.rows_per_group = rpg; a.ngroups = ng; a.x = x; a.y = y; a.dy = dy;
-    a.mean_in = mean; a.rstd_in = rstd; a.act = act; a.partial = (float*)ws; a.counter = ctx->counters() + RC_COUNTER_BN;
+    a.mean_in = mean; a.rstd_in = rstd; a.act = act; a.partial = (float*)ws; a.counter = ctx->line_counters() + RC_LCOUNTER_BN * RC_LINE_STRIDE;
+    a.ngroups = nwg; a.nsub = nsub;
     a.n_labels = n_labels; a.groups_per_sample = gps; a.labels = labels; a.n_samples = n;
     a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
     // mask from x needs a group's rows to belong to one sample (conditional grouping) or no labels at all
     a.beta = beta_m;
     a.PQ = a.partial + (size_t)ng * 2 * c;
-    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 1>), dim3(c / 64, ng), dim3(256), 0, ctx->stream, a));
+    RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 1>), dim3(c / 64, nwg), dim3(256), bn_fused_lds(1, labels ? n_labels : 0), ctx->stream, a));
     RC_LAUNCH_CHECK(ctx);
     long nchunks = rows * c / 8;
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T>, dim3(apply_grid_fused(nchunks, c)), dim3(256), 0, ctx->stream,

@@ -36,7 +36,16 @@ struct rcgan_ctx {
   unsigned* counters() const { return (unsigned*)((char*)zero_page + 1024); }
   // bytes [4096, 4096+32768): 8192 more self-resetting arrival counters (two-level reductions: one per cluster + one per launch)
   unsigned* tree_counters() const { return (unsigned*)((char*)zero_page + 4096); }
+  // bytes [36864, 36864+65536): arrival counters of the batch-norm column reductions, ONE PER 128-BYTE LINE (RC_LINE_STRIDE words
+  // apart): counters that share a line are served one after the other by the memory-side atomic unit
+  unsigned* line_counters() const { return (unsigned*)((char*)zero_page + 36864); }
+  // bytes [102400, 102400 + 1 MiB): 8192 line counters of the two-level (tree) reductions, one per cluster + one per launch
+  unsigned* tree_line_counters() const { return (unsigned*)((char*)zero_page + 102400); }
 };
+#define RC_ZERO_PAGE_BYTES (102400 + 8192 * 128)
+#define RC_LINE_STRIDE 32      // words between two line counters
+#define RC_LCOUNTER_BN 0       // lines [0,32)
+#define RC_LCOUNTER_BNSEG 32   // lines [32,288)
 #define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
 #define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish
 #define RC_COUNTER_HEAD 500    // loss partials of the fused projection head
