@@ -1,5 +1,6 @@
 // extern "C" entry points: context, conv / dense dispatch (MFMA vs direct), optimiser, graphs.
 #include "conv_mfma.h"
+#include "conv_image.h"
 
 // ---- provided by the other translation units ------------------------------------------------------
 
@@ -34,19 +35,34 @@ __global__ void slab_reduce2_kernel(const float* slab, long stride, float* out, 
   *o = s;
 }
 
-// the same reduction for several filter gradients in one launch (blockIdx.y = problem)
-#define REDUCE_GROUP_MAX 12
+// the same reduction for several filter gradients in one launch (blockIdx.y = problem).  Slabs of the image-end kernels
+// (conv_image.h: [32][Cb] + 32 floats per workgroup) are described by bias_off / orient: the bias sums sit at bias_off instead of
+// behind the filter elements, and with orient 1 (the small side is dy) slab element k*Cb + n goes to dW[(t*Cb + n)*Cs + c],
+// k = t*Cs + c.
+#define REDUCE_GROUP_MAX 16
 struct SlabReduceGroup {
-  struct Item { const float* slab; long stride; float* out; long count; float* bias_out; int nbias, nz, accumulate; } it[REDUCE_GROUP_MAX];
+  struct Item {
+    const float* slab; long stride; float* out; long count; float* bias_out; int nbias, nz, accumulate;
+    long bias_off;          // slab index of the first bias sum (= count for the three-tap / per-tap slabs)
+    int orient, Cb, Cs;     // orient 1: transposed image-end mapping
+  } it[REDUCE_GROUP_MAX];
 };
 __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
   const SlabReduceGroup::Item& r = g.it[blockIdx.y];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= r.count + r.nbias) return;
+  const long si = i < r.count ? i : r.bias_off + (i - r.count);
   float s = 0.f;
 #pragma unroll 4
-  for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + i];
-  float* o = i < r.count ? r.out + i : r.bias_out + (i - r.count);
+  for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
+  float* o;
+  if (i >= r.count) o = r.bias_out + (i - r.count);
+  else if (r.orient == 0) o = r.out + i;
+  else {
+    const int k = (int)(i / r.Cb), n = (int)(i - (long)k * r.Cb);
+    const int t = k / r.Cs, c = k - t * r.Cs;
+    o = r.out + ((long)t * r.Cb + n) * r.Cs + c;
+  }
   if (r.accumulate) s += *o;
   *o = s;
 }
@@ -574,10 +590,44 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   std::vector<unsigned> gxs[3], gys[3];
   std::vector<SlabReduceGroup::Item> red;
   size_t used = 0;
+  // image-end layers ride in the first grouped launch (if there is one) and in the grouped reduction
+  ImgWGroup img;
+  img.n = 0;
+  for (int q = 0; q <= IMG_GROUP_MAX; ++q) img.first[q] = 0;
+  static const int img_group = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_IMG"); return e ? atoi(e) : 1; }();
+  bool any_group = false;
+  for (int i = 0; i < n && img_group; ++i) any_group = any_group || takes[i];
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
     bool grouped = false;
-    if (mfma_wgrad_eligible(d)) {
+    if (any_group && img.n < IMG_GROUP_MAX && img_side(d) && (d->cin <= 3 ? d->cout : d->cin) == 128) {
+      ImgWArgs ia;
+      int cb = 0, nwg = 0;
+      static const int img_wgs = [] { const char* e = getenv("RCGAN_WGRAD_IMG_WGS"); return e ? atoi(e) : 128; }();
+      int rc = img_wgrad_plan(ctx, d, xs[i], dys[i], img_wgs, &ia, &cb, &nwg);
+      if (rc) return rc;
+      const long per = 32L * cb + 32;
+      const size_t need = ((size_t)nwg * per * sizeof(float) + 255) / 256 * 256;
+      if (used + need <= ws_bytes / 2) {
+        ia.slab = (float*)((char*)ws + used);
+        used += need;
+        const int q = img.n++;
+        img.a[q] = ia;
+        for (int r = q + 1; r <= IMG_GROUP_MAX; ++r) img.first[r] = img.first[q] + (unsigned)nwg;
+        const int side = img_side(d), cs = side == 1 ? d->cin : d->cout, T = d->kh * d->kw;
+        SlabReduceGroup::Item it = {};
+        it.slab = ia.slab; it.stride = per; it.out = dws[i]; it.count = (long)T * cs * cb; it.nz = nwg; it.accumulate = accumulate;
+        it.Cb = cb; it.Cs = cs;
+        if (side == 1) {           // small = conv input: slab order is dW order; bias gradient = the ones row (31)
+          it.orient = 0; it.bias_out = dbiases[i]; it.nbias = dbiases[i] ? cb : 0; it.bias_off = 31L * cb;
+        } else {                   // small = dy: transposed; bias gradient = column sums of the centre tap
+          it.orient = 1; it.bias_out = dbiases[i]; it.nbias = dbiases[i] ? cs : 0; it.bias_off = 32L * cb + (T == 9 ? 4 : 0) * cs;
+        }
+        red.push_back(it);
+        grouped = true;
+      }
+    }
+    if (!grouped && mfma_wgrad_eligible(d)) {
       MfmaWgradArgs a = cand[i];
       const int nz = mfma_wgrad_splits(d, a.M);
       unsigned gx = 0, gy = 0;
@@ -590,7 +640,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
           const int f = three ? (a.relu_in ? 1 : 0) : 2;
           args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
           const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-          SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate};
+          SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate, cnt, 0, 0, 0};
           red.push_back(it);
           grouped = true;
         }
@@ -601,9 +651,21 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       if (rc) return rc;
     }
   }
+  // the image-end workgroups go with the launch that has the most workgroups to hide under
+  int img_f = -1;
+  if (img.n) {
+    unsigned best = 0;
+    for (int f = 0; f < 3; ++f) {
+      unsigned tot = 0;
+      for (size_t q = 0; q < args[f].size() && q < WGRAD_GROUP_MAX_HOST; ++q) tot += gxs[f][q] * gys[f][q];
+      if (!args[f].empty() && tot >= best) { best = tot; img_f = f; }
+    }
+    RC_REQUIRE(ctx, img_f >= 0, "image-end filter gradients planned without a grouped launch");
+  }
   for (int f = 0; f < 3; ++f)
     if (!args[f].empty()) {
-      int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data(), f == 2 ? 1 : 0);
+      int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data(), f == 2 ? 1 : 0,
+                                        f == img_f ? &img : nullptr);
       if (rc) return rc;
     }
   for (size_t i0 = 0; i0 < red.size(); i0 += REDUCE_GROUP_MAX) {

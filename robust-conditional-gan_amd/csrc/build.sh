@@ -14,7 +14,7 @@ build_one() {   # $1 = object dir, $2 = output, $3 = extra flags
   pids=()
   for s in $SRCS; do
     o=$1/${s%.hip}.o
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_mfma.h -nt "$o" ] || [ mfma_util.h -nt "$o" ] || [ ../../include/rcgan_hip.h -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_mfma.h -nt "$o" ] || [ conv_image.h -nt "$o" ] || [ mfma_util.h -nt "$o" ] || [ ../../include/rcgan_hip.h -nt "$o" ]; then
       $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC $3 -c "$s" -o "$o" &
       pids+=($!)
     fi

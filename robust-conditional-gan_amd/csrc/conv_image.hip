@@ -11,6 +11,7 @@
 // The fp32 path and the shapes these kernels do not take (non power-of-two images, Cs = 4) stay on conv_small.hip.
 #include "conv_mfma.h"
 #include "mfma_util.h"
+#include "conv_image.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // eligibility + prepared-filter layouts
@@ -53,35 +54,6 @@ int img_prepare_launch(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w,
                      (bf16_t*)((char*)prepared + img_extra_offset(d)));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// im2col geometry of the small tensor
-// ---------------------------------------------------------------------------------------------------------
-struct ColGeom {
-  const bf16_t* s;       // [N][H][W][Cs]
-  int H, W, lw, lh, Cs, TT, PT, PL, sign;   // sign +1: (oh + kh - PT, ow + kw - PL);  -1: (oh - kh + PT, ow - kw + PL)
-  long M;
-};
-
-// (row offset, column offset, channel) of im2col column k; dh = 1 << 20 marks a padding column (k >= TT*Cs)
-__device__ __forceinline__ void col_tap(const ColGeom& g, int k, int& dh, int& dw, int& c) {
-  if (k >= g.TT * g.Cs) { dh = 1 << 20; dw = 0; c = 0; return; }
-  const int t = k / g.Cs;
-  c = k - t * g.Cs;
-  const int kh = g.TT == 9 ? t / 3 : 0, kw = g.TT == 9 ? t - 3 * (t / 3) : 0;
-  dh = g.sign > 0 ? kh - g.PT : g.PT - kh;
-  dw = g.sign > 0 ? kw - g.PL : g.PL - kw;
-}
-
-__device__ __forceinline__ uint32_t col_load(const ColGeom& g, long m, int dh, int dw, int c) {
-  if (m >= g.M) return 0u;
-  const unsigned mm = (unsigned)m;
-  const int ow = (int)(mm & (unsigned)(g.W - 1)) + dw;
-  const int oh = (int)((mm >> g.lw) & (unsigned)(g.H - 1)) + dh;
-  if (oh < 0 || oh >= g.H || ow < 0 || ow >= g.W) return 0u;
-  const unsigned n = mm >> (g.lw + g.lh);
-  return (uint32_t)g.s[(((n << g.lh) + oh) << g.lw | (unsigned)ow) * (unsigned)g.Cs + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -266,114 +238,6 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// small-side filter gradient: slab[blk][k<32][n<Cb] = sum over the block's pixels of col[m][k] * big[m][n].
-// A workgroup takes PB = 32768/Cb pixels: the big rows arrive by LDS-DMA ([pixel][128 channels] per half, read back
-// transposed), the im2col columns are gathered to LDS as [k][pixel].  Column 31 can be forced to ones: row 31 of
-// the result is then the column sum of the big tensor (bias gradient when the big tensor is dy); an extra MFMA
-// against an all-ones A operand gives the column sums of col (bias gradient when the small tensor is dy).
-// ---------------------------------------------------------------------------------------------------------
-struct ImgWArgs {
-  ColGeom g;
-  const bf16_t* big;     // [M][Cb]
-  const bf16_t* zero;
-  float* slab;           // [nblk][32*Cb + 32]
-  int ones_col, relu_big;
-};
-
-template <int CB>
-__global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int PB = 32768 / CB;                  // pixels per workgroup: 256 (Cb = 128) or 128 (Cb = 256)
-  constexpr int NH = CB / 128;                    // 128-channel halves
-  constexpr int CPITCH = PB * 2 + 16;             // bytes per im2col row (+16: the 16 rows of a fragment read hit 16 bank groups)
-  constexpr int NFW = CB / 64;                    // 16-channel fragments per wavefront
-  unsigned char* bigs = smem;                     // [NH][PB][256 B]
-  unsigned char* cols = smem + NH * PB * 256;     // [32][CPITCH]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long m0 = (long)blockIdx.x * PB;
-
-  // big rows: deposits of 4 rows x 256 B; NH*PB/4 deposits, split over the 4 wavefronts
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  constexpr int NDEP = NH * PB / 16;              // per wavefront
-#pragma unroll 4
-  for (int i = 0; i < NDEP; ++i) {
-    const int dep = i * 4 + wave;                 // 0 .. NH*PB/4
-    const int half = dep / (PB / 4), row = (dep - half * (PB / 4)) * 4 + (lane >> 4);
-    const long m = m0 + row;
-    const int slot = (lane & 15) ^ ((row & 7) << 1);
-    const bf16_t* p = m < a.g.M ? a.big + (unsigned)((unsigned)m * CB + half * 128 + slot * 8) : a.zero;
-    glds16_asm(p, lds0 + dep * 1024);
-  }
-  // im2col columns: thread -> column k = tid/8, pixels (tid%8)*(PB/8) .. +PB/8
-  {
-    const int k = tid >> 3, pg = tid & 7;
-    int dh, dw, c;
-    col_tap(a.g, k, dh, dw, c);
-    const bool ones = a.ones_col && k == 31;
-#pragma unroll
-    for (int j = 0; j < PB / 64; ++j) {
-      uint32_t v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const long m = m0 + pg * (PB / 8) + j * 8 + e;
-        v[e] = ones ? (m < a.g.M ? H16_ONE : 0u) : col_load(a.g, m, dh, dw, c);
-      }
-      *(uint4*)(cols + k * CPITCH + (pg * (PB / 8) + j * 8) * 2) =
-          make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // wavefront w: channels w*(CB/4) .. +CB/4 (inside one half); both 16-column groups of the 32 im2col columns
-  const int g4 = lane >> 4, li = lane & 15;
-  const int chw = wave * (CB / 4);
-  const unsigned char* bh = bigs + (chw / 128) * PB * 256;
-  const int slotw = (chw % 128) / 8;
-  const uint32_t relu_lb = a.relu_big ? 0u : 0x80008000u;
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(H16_ONE_X2, H16_ONE_X2, H16_ONE_X2, H16_ONE_X2));
-  f32x4_t acc[NFW][2], accs[2];
-#pragma unroll
-  for (int i = 0; i < NFW; ++i) { acc[i][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-  accs[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; accs[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int ks = 0; ks < PB / 32; ++ks) {
-    bf16x8_t cf[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      // the transposing read hands lane group g4 the pixels {4*g4..+3} U {16+4*g4..+3} of the 32-pixel step: same order here
-      const unsigned char* cp = cols + (j * 16 + li) * CPITCH + (ks * 32 + g4 * 4) * 2;
-      const uint2 lo = *(const uint2*)cp, hi = *(const uint2*)(cp + 32);
-      cf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-    }
-    if (wave == 0) {
-      accs[0] = mfma16(ones, cf[0], accs[0]);
-      accs[1] = mfma16(ones, cf[1], accs[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) {
-      const int row = ks * 32 + g4 * 4 + (li >> 2);
-      const int slot0 = slotw + i * 2;
-      const unsigned char* p = bh + row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
-      uint4 v = __builtin_bit_cast(uint4, tr_pair(p, 16 * 256));
-      v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
-      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, v);
-      acc[i][0] = mfma16(bf, cf[0], acc[i][0]);
-      acc[i][1] = mfma16(bf, cf[1], acc[i][1]);
-    }
-  }
-  // D[row = channel (4*g4 + r)][col = im2col column li (+16 j)]
-  float* slab = a.slab + (long)blockIdx.x * (32 * CB + 32);
-#pragma unroll
-  for (int i = 0; i < NFW; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      *(float4*)(slab + (j * 16 + li) * CB + chw + i * 16 + g4 * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-  if (wave == 0 && g4 == 0) { slab[32 * CB + li] = accs[0][0]; slab[32 * CB + 16 + li] = accs[1][0]; }
-}
-
 // dW (HWIO) and the bias gradient from the workgroup slabs.  thread block = 16 outputs x 16 slab lanes.
 //   orient 0 (small = conv input):   dW[k*Cb + n],  k = t*Cs + c;  dbias[n<Cb] = row 31 (ones column)
 //   orient 1 (small = dy):           dW[(t*Cb + n)*Cs + c];        dbias[c<Cs] = column sums of the centre tap
@@ -492,44 +356,70 @@ int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const vo
   return launch_small_out(ctx, d, a);
 }
 
+// standalone launch of the filter-gradient body (conv_image.h); in a backward pass the same body rides in the grouped launches
+template <int CB>
+__global__ __launch_bounds__(256) void conv_img_wgrad_kernel(ImgWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  img_wgrad_body<CB>(a, blockIdx.x, smem);
+}
+
+// pixel blocks per workgroup for about `target` workgroups; workgroups = slabs
+static void img_wgrad_split(const rcgan_conv_desc* d, int target, int* nsub, int* nwg) {
+  const int cb = d->cin <= 3 ? d->cout : d->cin;
+  const long M = (long)d->n * d->h * d->w, pb = 16384 / cb, blocks = (M + pb - 1) / pb;
+  long ns = (blocks + target - 1) / target;
+  if (ns < 1) ns = 1;
+  *nsub = (int)ns;
+  *nwg = (int)((blocks + ns - 1) / ns);
+}
+
+#define IMG_WGRAD_ALONE_WGS 512
 size_t img_wgrad_ws_bytes(const rcgan_conv_desc* d) {
   const int cb = d->cin <= 3 ? d->cout : d->cin;
-  const long M = (long)d->n * d->h * d->w, pb = 32768 / cb;
-  return (size_t)((M + pb - 1) / pb) * (32 * (size_t)cb + 32) * sizeof(float) + 256;
+  int nsub, nwg;
+  img_wgrad_split(d, IMG_WGRAD_ALONE_WGS, &nsub, &nwg);
+  return (size_t)nwg * (32 * (size_t)cb + 32) * sizeof(float) + 256;
+}
+
+// Kernel arguments of one image-end filter gradient cut into about target_wgs workgroups (a->slab is left to the caller:
+// *nwg slabs of 32*cb + 32 floats)
+int img_wgrad_plan(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int target_wgs, ImgWArgs* a, int* cb_out, int* nwg) {
+  int pt, pl, oh, ow;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  const int side = img_side(d);
+  RC_REQUIRE(ctx, side != 0, "not an image-end convolution");
+  const int cb = side == 1 ? d->cout : d->cin, cs = side == 1 ? d->cin : d->cout;
+  // side 1: col = im2col(x) (+), big = dy;  side 2: col = dy gathered at (oh - kh + PT), big = x
+  a->g = side == 1 ? col_geom(d, (const bf16_t*)x, cs, +1, pt, pl) : col_geom(d, (const bf16_t*)dy, cs, -1, pt, pl);
+  a->big = side == 1 ? (const bf16_t*)dy : (const bf16_t*)x;
+  a->zero = (const bf16_t*)ctx->zero_page;
+  a->slab = nullptr;
+  a->ones_col = side == 1 ? 1 : 0;
+  a->relu_big = (side == 2 && (d->flags & RCGAN_CONV_IN_RELU)) ? 1 : 0;
+  img_wgrad_split(d, target_wgs, &a->nsub, nwg);
+  *cb_out = cb;
+  return RCGAN_OK;
 }
 
 int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
               void* ws, size_t ws_bytes) {
-  int pt, pl, oh, ow;
-  same_pad(d->h, d->kh, 1, &oh, &pt);
-  same_pad(d->w, d->kw, 1, &ow, &pl);
   const size_t need = img_wgrad_ws_bytes(d);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
-  const int side = img_side(d);
-  const int cb = side == 1 ? d->cout : d->cin, cs = side == 1 ? d->cin : d->cout;
   ImgWArgs a;
-  // side 1: col = im2col(x) (+), big = dy;  side 2: col = dy gathered at (oh - kh + PT), big = x
-  a.g = side == 1 ? col_geom(d, (const bf16_t*)x, cs, +1, pt, pl) : col_geom(d, (const bf16_t*)dy, cs, -1, pt, pl);
-  a.big = side == 1 ? (const bf16_t*)dy : (const bf16_t*)x;
-  a.zero = (const bf16_t*)ctx->zero_page;
+  int cb, nwg;
+  int rc = img_wgrad_plan(ctx, d, x, dy, IMG_WGRAD_ALONE_WGS, &a, &cb, &nwg);
+  if (rc) return rc;
   a.slab = (float*)ws;
-  a.ones_col = side == 1 ? 1 : 0;
-  a.relu_big = (side == 2 && (d->flags & RCGAN_CONV_IN_RELU)) ? 1 : 0;
-  const long pb = 32768 / cb;
-  const int nblk = (int)((a.g.M + pb - 1) / pb);
-  const size_t lds = (size_t)65536 + 32 * (pb * 2 + 16);
+  const int side = img_side(d), cs = side == 1 ? d->cin : d->cout;
   if (cb == 128) {
-    static bool attr = false;
-    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(conv_img_wgrad_kernel<128>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(conv_img_wgrad_kernel<128>, dim3(nwg), dim3(256), ImgWGeom<128>::LDS, ctx->stream, a);
   } else {
-    static bool attr = false;
-    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_wgrad_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(conv_img_wgrad_kernel<256>, dim3(nblk), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(conv_img_wgrad_kernel<256>, dim3(nwg), dim3(256), ImgWGeom<256>::LDS, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   const int per = 32 * cb + 32;
-  hipLaunchKernelGGL(conv_img_wgrad_reduce_kernel, dim3(cdiv(per, 16)), dim3(256), 0, ctx->stream, (const float*)a.slab, nblk, cb, cs,
+  hipLaunchKernelGGL(conv_img_wgrad_reduce_kernel, dim3(cdiv(per, 16)), dim3(256), 0, ctx->stream, (const float*)a.slab, nwg, cb, cs,
                      d->kh * d->kw, side == 1 ? 0 : 1, dw, dbias, accumulate);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;

@@ -2,6 +2,9 @@
 #pragma once
 #include "common.h"
 
+struct ImgWArgs;    // conv_image.h
+struct ImgWGroup;
+
 struct MfmaConvArgs {
   const bf16_t* in;       // [N][H(/2)][W(/2)][Cin]
   const bf16_t* wt;       // [Cout][T*Cin]
@@ -43,13 +46,15 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
 bool mfma_wgrad3_takes(const MfmaWgradArgs& a);
-int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family);
+int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
+                             const ImgWGroup* img);
 bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);
 int mfma_selftest(rcgan_ctx* ctx, int* host_result);
 // image-end kernels (conv_image.hip): bf16 convs with a <= 3-channel side
+#define WGRAD_GROUP_MAX_HOST 12   /* = WGRAD_GROUP_MAX of conv_mfma.hip */
 int img_side(const rcgan_conv_desc* d);          // 0: not taken; 1: cin small; 2: cout small
 size_t img_extra_offset(const rcgan_conv_desc* d);
 size_t img_extra_bytes(const rcgan_conv_desc* d);
@@ -57,6 +62,7 @@ size_t img_wgrad_ws_bytes(const rcgan_conv_desc* d);
 int img_prepare_launch(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w, const float* sigma, void* prepared);
 int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y);
 int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, void* dx, int accumulate);
+int img_wgrad_plan(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int target_wgs, ImgWArgs* a, int* cb, int* nwg);
 int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
               void* ws, size_t ws_bytes);
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts

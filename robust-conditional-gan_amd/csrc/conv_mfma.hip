@@ -23,6 +23,7 @@
 //   blocks into fp32 slabs that a second kernel reduces (deterministic, no atomics).
 #include "conv_mfma.h"
 #include "mfma_util.h"
+#include "conv_image.h"
 
 #define LDS_PITCH 72          // elements per LDS row in the fwd kernel (64 + 8 pad)
 #define WG_PITCH 144          // elements per LDS row in the wgrad kernel (128 + 16 pad = 288 B)
@@ -1052,16 +1053,31 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) 
 // and plays (b - first[p]) % gx[p], (b - first[p]) / gx[p] of that problem's own grid.  The 8x8 / 16x16 discriminator layers
 // launch 224..602 workgroups each and are latency-bound alone; together their workgroups share the CUs (3 fit per CU).
 #define WGRAD_GROUP_MAX 12
+static_assert(WGRAD_GROUP_MAX == WGRAD_GROUP_MAX_HOST, "group size");
+// The image-end layers' filter gradients (conv_image.h: D.Block.1.Conv1 / Shortcut) ride in the same launch as its LAST
+// img.first[IMG_GROUP_MAX] workgroups.  Alone they are two launches of a few hundred short workgroups plus two slab reductions
+// (59 us per critic step, 4 % of the iteration); here ~128 workgroups per layer walk their pixel blocks in the CU slots the
+// three-tap workgroups leave free and finish under them: 8.41 -> 8.19 ms per iteration.  Measured: leading instead of trailing
+// workgroups +0.11 ms, 512 / 1024 instead of 128 per layer +0.19 / +0.46 ms (slots taken from the three-tap workgroups,
+// more slabs), 32 per layer +0.38 ms (they outlast the launch).
 struct WgradGroup {
   int n;
   unsigned first[WGRAD_GROUP_MAX + 1];
   unsigned gx[WGRAD_GROUP_MAX];
   MfmaWgradArgs a[WGRAD_GROUP_MAX];
+  ImgWGroup img;
 };
 
 template <int NS, bool RELU>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup g) {
+  // (the branch is marked unlikely so that its code is laid out BEHIND the three-tap body: with the image-end code in front the
+  // same, instruction-for-instruction identical hot loop ran 40 % slower -- 198 vs 141 us for the critic step's eleven layers)
   const unsigned b = blockIdx.x;
+  if (__builtin_expect(b >= g.first[g.n], 0)) {         // the image-end workgroups trail the grid
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_img[];
+    img_wgrad_group_body(g.img, b - g.first[g.n], smem_img);
+    return;
+  }
   int p = 0;
 #pragma unroll
   for (int q = 1; q < WGRAD_GROUP_MAX; ++q)
@@ -1075,6 +1091,11 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup 
 template <int NS>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_glds_group_kernel(WgradGroup g) {
   const unsigned b = blockIdx.x;
+  if (__builtin_expect(b >= g.first[g.n], 0)) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_img[];
+    img_wgrad_group_body(g.img, b - g.first[g.n], smem_img);
+    return;
+  }
   int p = 0;
 #pragma unroll
   for (int q = 1; q < WGRAD_GROUP_MAX; ++q)
@@ -1444,7 +1465,7 @@ static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
   for (int p = 0; p < g.n; ++p) fl += 2.0 * (double)g.a[p].M * g.a[p].KH * g.a[p].KW * g.a[p].Cin * g.a[p].Cout;
   {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl);
-    hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.first[g.n]), dim3(256), lds, ctx->stream, g);
+    hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.img.first[IMG_GROUP_MAX] + g.first[g.n]), dim3(256), lds, ctx->stream, g);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -1462,7 +1483,7 @@ static int launch_wgrad_glds_group(rcgan_ctx* ctx, const WgradGroup& g) {
   for (int p = 0; p < g.n; ++p) fl += 2.0 * (double)g.a[p].M * g.a[p].KH * g.a[p].KW * g.a[p].Cin * g.a[p].Cout;
   {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl);
-    hipLaunchKernelGGL(conv_mfma_wgrad_glds_group_kernel<NS>, dim3(g.first[g.n]), dim3(256), lds, ctx->stream, g);
+    hipLaunchKernelGGL(conv_mfma_wgrad_glds_group_kernel<NS>, dim3(g.img.first[IMG_GROUP_MAX] + g.first[g.n]), dim3(256), lds, ctx->stream, g);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -1480,9 +1501,14 @@ bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy) {
 }
 
 // args[i] planned by mfma_wgrad3_plan (family 0; all with the same relu_in) or mfma_wgrad_tap_plan (family 1)
-int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family) {
+// img (optional): image-end problems that ride in the FIRST launch
+int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
+                             const ImgWGroup* img) {
+  static_assert(ImgWGeom<128>::LDS <= 4 * (40 * 128 + 32 * 256), "image-end body needs more LDS than the three-tap kernel");
   for (int i0 = 0; i0 < n; i0 += WGRAD_GROUP_MAX) {
     WgradGroup g;
+    if (img && i0 == 0) g.img = *img;
+    else { g.img.n = 0; for (int q = 0; q <= IMG_GROUP_MAX; ++q) g.img.first[q] = 0; }
     g.n = (n - i0 < WGRAD_GROUP_MAX) ? n - i0 : WGRAD_GROUP_MAX;
     unsigned tot = 0;
     for (int p = 0; p < g.n; ++p) {

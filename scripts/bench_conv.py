@@ -35,7 +35,14 @@ def main():
         ("G3.Conv2   32x32 256>256", 2 * B, 32, 32, 256, 256, 3, 0),
         ("G3.Short   32x32 256>256 1x1 up", 2 * B, 32, 32, 256, 256, 1, L.CONV_IN_UPSAMPLE2X),
         ("G3.Conv2   32x32 256>256 (n=B)", B, 32, 32, 256, 256, 3, 0),
+        # image-end layers (conv_image.hip): bound by streaming the big-channel tensor, the TFLOP/s columns mean nothing
+        ("D1.Conv1   32x32   3>128", 2 * B, 32, 32, 3, 128, 3, 0),
+        ("D1.Short   16x16   3>128 1x1", 2 * B, 16, 16, 3, 128, 1, 0),
+        ("G.Output   32x32 256>3", 2 * B, 32, 32, 256, 3, 3, L.CONV_IN_RELU),
     ]
+    only = os.environ.get("BENCH_CONV_ONLY")
+    if only:
+        shapes = [s for s in shapes if only in s[0]]
     reps = 20
     print("%-36s %10s %10s %10s   (TFLOP/s: fwd dgrad wgrad)" % ("layer", "fwd us", "dgrad us", "wgrad us"))
     tot = [0.0, 0.0, 0.0]
