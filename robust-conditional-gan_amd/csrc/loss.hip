@@ -205,26 +205,79 @@ struct HeadArgs {
 };
 
 // Four short multi-workgroup launches (a single workgroup would be latency-bound: hundreds of dependent L2 round trips):
-//   embed : E[l][j]                      grid (v, d/64)      256 threads = 64 columns x 4 k-lanes
-//   logit : per sample psi, logits, loss, dlogit, dfeat       grid n/8           4 wavefronts x 2 samples; the last
+//   embed : E[l][j]                      small-left GEMM, grid d/16: 16 columns x 16 k-lanes, all rows l
+//   logit : per sample psi, logits, loss, dlogit, dfeat       grid n/4           one sample per wavefront; the last
 //           workgroup to arrive adds the loss partials in workgroup order
-//   dE    : dE[l][j] = sum_s dlogit[s,l] feat[s][j]  (row v: the psi column)     grid (v+1, d/64)
+//   dE    : dE[l][j] = sum_s dlogit[s,l] feat[s][j]  (row v: the psi column)     the same small-left GEMM
 //   wgrad : dW_e += table^T dE,  dtable += dE W_e^T / sigma_e,  dw_out, db_out, db_e   grid (e_dim*d + ...)/256
-__global__ __launch_bounds__(256) void head_embed_kernel(HeadArgs a, float* Eg) {
-  __shared__ float red[4][64];
-  const int l = blockIdx.x, jj = threadIdx.x & 63, kl = threadIdx.x >> 6, j = blockIdx.y * 64 + jj;
-  const int d = a.d, ed = a.e_dim;
-  float s0 = 0.f, s1 = 0.f;
-  if (j < d) {
-    int k = kl;
-    for (; k + 4 < ed; k += 8) { s0 += a.table[l * ed + k] * a.w_e[(long)k * d + j]; s1 += a.table[l * ed + k + 4] * a.w_e[(long)(k + 4) * d + j]; }
-    if (k < ed) s0 += a.table[l * ed + k] * a.w_e[(long)k * d + j];
+// out[l][j] = scale * sum_k A(l,k) * B[k][j] + bias[j] for a FEW rows l (L <= HEAD_MAX_V + 1): the embedding of every label
+// (A = table, B = W_e) and dE = dlogit^T feat (A = dlogit transposed, B = feat).  The reduction index is what is long, so a
+// workgroup owns 16 columns and splits k over 16 lanes per column; per chunk of SG_KC = 320 reduction indices every thread
+// requests its <= 20 B elements AND its share of the A chunk (-> LDS) before it waits: ONE memory round trip per chunk
+// (the 64-columns x 4-lanes form these two kernels had walked k in 38 dependent steps: 13 us for 0.4 MFLOP).
+// rowsum_out (optional): += the sum over k of row rowsum_row of A (the bias gradient of D.Output).
+#define SG_KC 320
+#define SG_UB (SG_KC / 16)
+struct SmallGemmArgs {
+  int L, K, d;
+  const float* A; int lda_l, lda_k;
+  const float* B;
+  const float* sigma;      // scale = 1 / sigma[0], or 1 if null
+  const float* bias;       // [d] or null
+  float* out;              // [L][d]
+  float* rowsum_out; int rowsum_row;
+};
+__global__ __launch_bounds__(256) void head_smallgemm_kernel(SmallGemmArgs g) {
+  __shared__ float As[(HEAD_MAX_V + 1) * SG_KC];
+  __shared__ float red[16][HEAD_MAX_V + 1][16];
+  const int t = threadIdx.x, jj = t & 15, kl = t >> 4, j = blockIdx.x * 16 + jj;
+  const int L = g.L, d = g.d;
+  float acc[HEAD_MAX_V + 1];
+#pragma unroll
+  for (int l = 0; l <= HEAD_MAX_V; ++l) acc[l] = 0.f;
+  float rs = 0.f;
+  const float scale = g.sigma ? 1.f / g.sigma[0] : 1.f;
+  const float bj = (g.bias && j < d) ? g.bias[j] : 0.f;
+  for (int kc0 = 0; kc0 < g.K; kc0 += SG_KC) {
+    const int kc = min(SG_KC, g.K - kc0);
+    float w[SG_UB];
+#pragma unroll
+    for (int u = 0; u < SG_UB; ++u) {
+      const int k = kl + 16 * u;
+      w[u] = (k < kc && j < d) ? g.B[(long)(kc0 + k) * d + j] : 0.f;
+    }
+    if (kc0) __syncthreads();                   // the previous chunk of A has been consumed
+    for (int i = t; i < L * kc; i += 256) {
+      const int l = i / kc, k = i - l * kc;
+      As[l * SG_KC + k] = g.A[(long)l * g.lda_l + (long)(kc0 + k) * g.lda_k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SG_UB; ++u) {
+      const int k = kl + 16 * u;
+      if (k < kc) {
+#pragma unroll
+        for (int l = 0; l <= HEAD_MAX_V; ++l)
+          if (l < L) acc[l] += As[l * SG_KC + k] * w[u];
+      }
+    }
+    if (g.rowsum_out && blockIdx.x == 0 && t < 64)
+      for (int k = t; k < kc; k += 64) rs += As[g.rowsum_row * SG_KC + k];
   }
-  red[kl][jj] = s0 + s1;
+#pragma unroll
+  for (int l = 0; l <= HEAD_MAX_V; ++l)
+    if (l < L) red[kl][l][jj] = acc[l];
   __syncthreads();
-  if (kl == 0 && j < d) {
-    const float inv_se = a.sigma_e ? 1.f / a.sigma_e[0] : 1.f;
-    Eg[l * d + j] = ((red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj])) * inv_se + (a.b_e ? a.b_e[j] : 0.f);
+  if (t < L * 16) {
+    const int l = t >> 4;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) { s0 += red[q][l][jj]; s1 += red[q + 1][l][jj]; }
+    if (j < d) g.out[l * d + j] = (s0 + s1) * scale + bj;
+  }
+  if (g.rowsum_out && blockIdx.x == 0 && t < 64) {
+    rs = wave_sum(rs);
+    if (t == 0) g.rowsum_out[0] += rs;
   }
 }
 
@@ -234,28 +287,40 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
   float* E = hs;                    // [v][d]
   float* red = E + v * d;           // [4]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < v * d; i += 256) E[i] = Eg[i];
-  __syncthreads();
-  const float inv_so = a.sigma_out ? 1.f / a.sigma_out[0] : 1.f;
-  const float bo = a.b_out ? a.b_out[0] : 0.f;
-  float lacc = 0.f;
-  for (int s = blockIdx.x * 8 + wave; s < n && s < (int)blockIdx.x * 8 + 8; s += 4) {
-    const int p = s < a.part[0].rows ? 0 : 1;
-    const HeadPart& P = a.part[p];
-    const int sr = p ? s - a.part[0].rows : s;
-    const float inv_rows = 1.f / (float)P.rows;
-    float f[HEAD_MAX_D / 64], wo[HEAD_MAX_D / 64], df[HEAD_MAX_D / 64];
-    float ps = 0.f;
+  // one sample per wavefront; everything the sample needs from memory is requested before the first wait
+  const int s = blockIdx.x * 4 + wave;
+  const int p = s < a.part[0].rows ? 0 : 1;
+  const HeadPart& P = a.part[p];
+  const int sr = p ? s - a.part[0].rows : s;
+  const float inv_rows = 1.f / (float)P.rows;
+  float f[HEAD_MAX_D / 64], wo[HEAD_MAX_D / 64], df[HEAD_MAX_D / 64];
+  int lab_pre = -1;
+  float wt_pre = 0.f;
+  if (s < n) {
 #pragma unroll
     for (int q = 0; q < HEAD_MAX_D / 64; ++q) {
       const int j = lane + q * 64;
       f[q] = j < d ? a.feat[(long)s * d + j] : 0.f;
-      wo[q] = j < d ? a.w_out[j] * inv_so : 0.f;
+      wo[q] = j < d ? a.w_out[j] : 0.f;
+    }
+    if (P.labels) lab_pre = P.labels[sr];
+    if (P.wts && lane < v) wt_pre = P.wts[(long)sr * v + lane];
+  }
+  const float inv_so = a.sigma_out ? 1.f / a.sigma_out[0] : 1.f;
+  const float bo = a.b_out ? a.b_out[0] : 0.f;
+  for (int i = t; i < v * d; i += 256) E[i] = Eg[i];
+  __syncthreads();
+  float lacc = 0.f;
+  if (s < n) {
+    const int lab = P.labels ? lab_pre : -1;
+    float ps = 0.f;
+#pragma unroll
+    for (int q = 0; q < HEAD_MAX_D / 64; ++q) {
+      wo[q] *= inv_so;
       ps += f[q] * wo[q];
       df[q] = 0.f;
     }
     ps = wave_sum(ps) + bo;
-    const int lab = P.labels ? P.labels[sr] : -1;
     float dsum = 0.f;
     for (int l = 0; l < v; ++l) {
       float g = 0.f;
@@ -266,7 +331,7 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
         const float x = wave_sum(dot) + ps;
         float tt, dd;
         loss_term(P.kind, x, &tt, &dd);
-        const float wf = (P.wts ? P.wts[(long)sr * v + l] : 1.f) * inv_rows;
+        const float wf = (P.wts ? __shfl(wt_pre, l) : 1.f) * inv_rows;
         lacc += tt * wf;
         g = a.weight * dd * wf;
 #pragma unroll
@@ -300,26 +365,6 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
       if (a.loss_acc) *a.loss_acc += a.weight * tot;
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-}
-
-__global__ __launch_bounds__(256) void head_dE_kernel(HeadArgs a, const float* dlg, float* dEg) {
-  __shared__ float red[4][64];
-  const int l = blockIdx.x, jj = threadIdx.x & 63, sl = threadIdx.x >> 6, j = blockIdx.y * 64 + jj;
-  const int n = a.n, d = a.d, vp = a.v + 1;
-  float s0 = 0.f, s1 = 0.f;
-  if (j < d) {
-    int s = sl;
-    for (; s + 4 < n; s += 8) { s0 += dlg[s * vp + l] * a.feat[(long)s * d + j]; s1 += dlg[(s + 4) * vp + l] * a.feat[(long)(s + 4) * d + j]; }
-    if (s < n) s0 += dlg[s * vp + l] * a.feat[(long)s * d + j];
-  }
-  red[sl][jj] = s0 + s1;
-  __syncthreads();
-  if (sl == 0 && j < d) dEg[l * d + j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
-  if (l == a.v && blockIdx.y == 0 && threadIdx.x == 0 && a.db_out) {
-    float tot = 0.f;
-    for (int s = 0; s < n; ++s) tot += dlg[s * vp + a.v];
-    a.db_out[0] += tot;
   }
 }
 
@@ -469,6 +514,19 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
   return RCGAN_OK;
 }
 
+// dE (small-left GEMM over the samples) and the parameter gradients from the dlogit rows the logit kernel left in the scratch
+static int head_param_grads(rcgan_ctx* ctx, const HeadArgs& a, const float* dlg, float* dEg) {
+  const int vp = a.v + 1;
+  // dE[l] = sum_s dlogit[s,l] feat[s]  (row v: the psi column -> dw_out; its sum over the samples -> db_out)
+  SmallGemmArgs gd = {vp, a.n, a.d, dlg, 1, vp, a.feat, nullptr, nullptr, dEg, a.db_out, a.v};
+  hipLaunchKernelGGL(head_smallgemm_kernel, dim3(cdiv(a.d, 16)), dim3(256), 0, ctx->stream, gd);
+  RC_LAUNCH_CHECK(ctx);
+  const int blocks = cdiv(a.e_dim * a.d, 256) + cdiv(a.e_dim, 4) + 1;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), (size_t)vp * a.d * sizeof(float), ctx->stream, a, (const float*)dEg);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
                             const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,
                             float* loss_acc, float* logits, float* dfeat, float* dw_out, float* db_out, float* dtable, float* dw_e,
@@ -495,21 +553,16 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   float* dlg = Eg + (size_t)a.v * a.d;
   float* dEg = dlg + (size_t)a.n * vp;
   float* losspart = dEg + (size_t)vp * a.d;
-  const int dblk = cdiv(a.d, 64);
-  hipLaunchKernelGGL(head_embed_kernel, dim3(a.v, dblk), dim3(256), 0, ctx->stream, a, Eg);
+  const int dblk = cdiv(a.d, 16);
+  SmallGemmArgs ge = {a.v, a.e_dim, a.d, a.table, a.e_dim, 1, a.w_e, a.sigma_e, a.b_e, Eg, nullptr, 0};
+  hipLaunchKernelGGL(head_smallgemm_kernel, dim3(dblk), dim3(256), 0, ctx->stream, ge);
   RC_LAUNCH_CHECK(ctx);
-  const int nwg = cdiv(a.n, 8);
+  const int nwg = cdiv(a.n, 4);
   RC_REQUIRE(ctx, nwg <= 256, "too many rows for the loss partials");
   hipLaunchKernelGGL(head_logit_kernel, dim3(nwg), dim3(256), ((size_t)a.v * a.d + 4) * sizeof(float), ctx->stream, a, (const float*)Eg, dlg,
                      losspart, ctx->counters() + RC_COUNTER_HEAD);
   RC_LAUNCH_CHECK(ctx);
-  if (dw_out || db_out || dtable || dw_e || db_e) {
-    hipLaunchKernelGGL(head_dE_kernel, dim3(vp, dblk), dim3(256), 0, ctx->stream, a, (const float*)dlg, dEg);
-    RC_LAUNCH_CHECK(ctx);
-    const int blocks = cdiv(a.e_dim * a.d, 256) + cdiv(a.e_dim, 4) + 1;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), (size_t)vp * a.d * sizeof(float), ctx->stream, a, (const float*)dEg);
-    RC_LAUNCH_CHECK(ctx);
-  }
+  if (dw_out || db_out || dtable || dw_e || db_e) return head_param_grads(ctx, a, dlg, dEg);
   return RCGAN_OK;
 }
 
