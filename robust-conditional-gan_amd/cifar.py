@@ -302,7 +302,7 @@ class CifarRCGAN:
         if variables is None:
             variables = create_variables(seed, algorithm, perm_classifier, perm_type, confuse_init, confuse_init_diag)
         gs, ds, cs, U = variables
-        self.PG, self.PD = ParamGroup(ctx, gs), ParamGroup(ctx, ds)
+        self.PG, self.PD = ParamGroup(ctx, gs), ParamGroup(ctx, ds, sn_scratch=True)
         self.PC = ParamGroup(ctx, cs) if cs else None
         self.groups = [self.PG, self.PD] + ([self.PC] if self.PC else [])
         self.state = {}
@@ -343,8 +343,9 @@ class CifarRCGAN:
         self.fakes_all = P((N_CRITIC * B, OUTPUT_DIM), act)
         self.x_all = P((2 * B, OUTPUT_DIM), act)
         self._fakes_left = 0
-        self.loss_d = P((1,), f32, fill=0.0)
-        self.loss_g = P((1,), f32, fill=0.0)
+        # loss accumulators: scalars behind the gradient slabs, cleared by the step's zero_grad()
+        self.loss_d = self.PD.scalar(0)
+        self.loss_g = self.PG.scalar(0)
         self.rng_state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
         self.seed = seed
         self._graphs = {}
@@ -465,7 +466,6 @@ class CifarRCGAN:
         ctx.new_step()
         g.begin_step({1})
         self.PD.zero_grad()
-        ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss_d.ptr, 0.0))
         if self.device_rng:
             self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
             if not fakes_ready:
@@ -537,7 +537,6 @@ class CifarRCGAN:
         self.PG.zero_grad()
         if self.PC is not None:
             self.PC.zero_grad()
-        ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss_g.ptr, 0.0))
         if self.device_rng:
             self._rng(inp["z_G"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(False, True))        # D convs + D.Output: NO_OPS; projection / perm: update

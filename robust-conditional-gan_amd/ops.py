@@ -140,7 +140,11 @@ def spectral_norm_batch(ctx, entries):
     if ctx.recording:
         req = [w for w in weights if w.param.req]
         total = sum((w.param.size + 63) // 64 * 64 for w in req)
-        if total:
+        if total and all(w.param.group is not None and w.param.group.sn_scratch and w.param.group.zero_epoch == ctx.epoch for w in req):
+            # the group's zero_grad() of this step already cleared its d/dW_bar slab (runtime.ParamGroup): no fill
+            for w in req:
+                w.dwbar = w.param.group.dwbar(w.param.name)
+        elif total:
             base = ctx.arena.alloc(total * 4)
             ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, total, base, 0.0))
             off = 0

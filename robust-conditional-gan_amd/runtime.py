@@ -31,7 +31,7 @@ def _np_dtype(code):
 
 class DT:
     """A device tensor: raw pointer + shape + dtype code.  ``base`` keeps the owning torch storage alive."""
-    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen")
+    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen", "group")
 
     def __init__(self, ptr, shape, dtype, base=None, name=None):
         self.ptr = int(ptr)
@@ -42,6 +42,7 @@ class DT:
         self.req = False
         self.name = name
         self.frozen = False        # a gradient buffer that must not be written any more (ops.grad_of copies on write)
+        self.group = None          # the ParamGroup a parameter lives in
 
     @property
     def size(self):
@@ -125,6 +126,7 @@ class Context:
         # opt-in (RCGAN_OVERLAP=1): filter gradients launched on a side stream next to their data gradient, with their own
         # workspace.  Measured on MI355X: 12.1 ms/iteration with the fork/join in the captured graph vs 11.4 without --
         # the graph's cross-stream dependencies cost more than the idle CUs they fill -- so it stays off.
+        self.epoch = 0             # bumped by new_step(): ParamGroup.zero_grad stamps it (ops.spectral_norm_batch)
         self.overlap = os.environ.get("RCGAN_OVERLAP", "0") == "1"
         self.ws2 = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device) if self.overlap else None
         self.ws2_ptr = self.ws2.data_ptr() if self.overlap else 0
@@ -239,6 +241,7 @@ class Context:
         self.tape = []
         self.pending_wgrads = []
         self.arena.reset()
+        self.epoch += 1
 
     # ------------------------------------------------------------------ graphs
     def graph_begin(self):
@@ -264,8 +267,10 @@ class Context:
 class ParamGroup:
     """Flat fp32 slabs (value, grad, Adam m, Adam v) for one optimiser group."""
 
-    def __init__(self, ctx, specs):
-        """specs: list of (name, shape, init ndarray)."""
+    def __init__(self, ctx, specs, sn_scratch=False):
+        """specs: list of (name, shape, init ndarray).  sn_scratch: the gradient buffer carries a second slab for the
+        d/dW_bar scratch of spectrally normalised weights (same offsets), so that ONE fill zeroes the gradients, that scratch
+        and the group's loss scalars at the start of a step."""
         self.ctx = ctx
         self.names, self.offsets, self.shapes = [], {}, {}
         off = 0
@@ -281,7 +286,12 @@ class ParamGroup:
         self.count = max((off + 63) // 64 * 64, 64)
         dev = ctx.device
         self.value = torch.zeros(self.count, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(self.count, dtype=torch.float32, device=dev)
+        self.sn_scratch = bool(sn_scratch)
+        self._extra = self.count if sn_scratch else 0
+        # [gradients (count) | d/dW_bar scratch (count, optional) | 64 scalars]: zero_grad() clears all of it in one launch
+        self.gradbuf = torch.zeros(self.count + self._extra + 64, dtype=torch.float32, device=dev)
+        self.grad = self.gradbuf[:self.count]
+        self.zero_epoch = -1       # Context.epoch of the last zero_grad()
         self.m = torch.zeros(self.count, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.count, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)      # {lr, t} read by the Adam kernel
@@ -304,8 +314,20 @@ class ParamGroup:
     def param(self, name):
         o = self.offsets[name] * 4
         p = DT(self.value.data_ptr() + o, self.shapes[name], L.F32, self.value, name)
-        p.grad = DT(self.grad.data_ptr() + o, self.shapes[name], L.F32, self.grad, name + ":grad")
+        p.grad = DT(self.grad.data_ptr() + o, self.shapes[name], L.F32, self.gradbuf, name + ":grad")
+        p.group = self
         return p
+
+    def dwbar(self, name):
+        """The d/dW_bar scratch of a spectrally normalised parameter (zeroed by zero_grad)."""
+        assert self.sn_scratch
+        o = (self.count + self.offsets[name]) * 4
+        return DT(self.gradbuf.data_ptr() + o, self.shapes[name], L.F32, self.gradbuf, name + ":dwbar")
+
+    def scalar(self, i):
+        """One of 64 fp32 scalars behind the gradients (loss accumulators): zeroed by zero_grad with everything else."""
+        assert 0 <= i < 64
+        return DT(self.gradbuf.data_ptr() + (self.count + self._extra + i) * 4, (1,), L.F32, self.gradbuf, "scalar%d" % i)
 
     def get(self, name, which="value"):
         o = self.offsets[name]
@@ -325,7 +347,8 @@ class ParamGroup:
 
     def zero_grad(self):
         c = self.ctx
-        c.check(c.lib.rcgan_fill_f32(c.h, self.count, self.grad.data_ptr(), 0.0))
+        c.check(c.lib.rcgan_fill_f32(c.h, self.gradbuf.numel(), self.gradbuf.data_ptr(), 0.0))
+        self.zero_epoch = c.epoch
 
     def set_hyper(self, lr, t):
         """{lr, t} for the next Adam launch: written into a pinned ring slot and copied asynchronously.  A slot is reused
