@@ -461,6 +461,9 @@ def test_linear(dev, m, k, n):
 
 @pytest.mark.parametrize("shape,cond", [((6, 4, 4, 64), True), ((5, 8, 8, 256), True), ((16, 1024), False), ((7, 14, 14, 128), False), ((4, 2, 2, 64), False),
                                         ((32, 16, 16, 256), True), ((48, 32, 32, 64), False), ((3, 5, 5, 24), True),
+                                        # conditional backward finisher: 4x4 samples two to a workgroup (even n) / one each (odd n), more than
+                                        # one 64-sample round with a ragged tail, split samples (groups per sample > 1)
+                                        ((5, 4, 4, 128), True), ((130, 4, 4, 64), True), ((200, 8, 8, 64), True), ((3, 32, 32, 64), True),
                                         # >= 4M elements: the tree reduction (whole rows per workgroup, two-level arrival tree)
                                         ((32, 32, 32, 128), True), ((128, 8, 8, 512), True), ((64, 16, 16, 256), False),
                                         ((40, 16, 16, 1024), True), ((70, 32, 32, 64), False), ((33, 16, 16, 512), True)]
