@@ -85,6 +85,9 @@ int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* 
 #define RCGAN_PROF_CONV_P8N 5        /* conv_mfma_p8n_kernel: 256 x 128 tile */
 int rcgan_prof_begin(rcgan_ctx* ctx, int which);
 int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);
+/* Flops the kernels of the last rcgan_prof_begin .. rcgan_prof_end section EXECUTED: equal to the algorithmic count except for
+ * the sub-pixel form of the upsample-3x3 convolutions (four 2x2 convolutions with summed filters: 4/9 of the multiply-adds). */
+int rcgan_prof_executed_flops(rcgan_ctx* ctx, double* executed_flops);
 /* Diagnostics: while `stamps` is non-null, every workgroup of the 256 x 256 convolution kernel writes 8 x uint64 to
  * stamps[workgroup * 8 ..]: s_memtime at {start, tap table built, first K-tile landed, K loop done, stores issued,
  * stores complete}, HW_ID, XCC_ID (scripts/exp_p8_timeline.py).  Pass null to switch it off. */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "rcgan_debug_stamps": (I, [P, P]),
     "rcgan_prof_begin": (I, [P, I]),
     "rcgan_prof_end": (I, [P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rcgan_prof_executed_flops": (I, [P, C.POINTER(C.c_double)]),
     "rcgan_graph_begin": (I, [P]),
     "rcgan_graph_end": (I, [P, C.POINTER(I)]),
     "rcgan_graph_launch": (I, [P, I]),

@@ -433,7 +433,10 @@ class CifarRCGAN:
             if n.endswith("/Filters"):
                 shp = grp.shapes[n]
                 # the 3-channel image-end convs (D.Block.1.*, G.Output) run at the image resolution
-                names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8))
+                # the up blocks' first convolutions read their input through the nearest 2x upsample (UpsampleConv, gan_resnet.py:259-272):
+                # their prepared buffers also carry the summed filters of the sub-pixel form
+                up = L.CONV_IN_UPSAMPLE2X if (n.startswith("Generator/G.Block.") and n.endswith(".Conv1/Filters")) else 0
+                names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8, up))
         return names
 
     def _prepare_all(self, which):

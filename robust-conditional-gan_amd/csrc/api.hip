@@ -117,7 +117,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->devtmp = nullptr;
   c->devtmp_bytes = 0;
   c->prof_which = 0;
-  c->prof_flops = 0.0;
+  c->prof_flops = 0.0; c->prof_flops_exec = 0.0;
   c->main_stream = c->stream; c->side_stream = nullptr; c->fork_ev = nullptr; c->join_ev = nullptr; c->on_side = false;
   if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
@@ -284,6 +284,7 @@ int rcgan_prof_begin(rcgan_ctx* ctx, int which) {
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
   ctx->prof_ev.clear();
   ctx->prof_flops = 0.0;
+  ctx->prof_flops_exec = 0.0;
   ctx->prof_which = which;
   return RCGAN_OK;
 }
@@ -303,6 +304,12 @@ int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* tota
   if (launches) *launches = (int)n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = ctx->prof_flops;
+  return RCGAN_OK;
+}
+
+int rcgan_prof_executed_flops(rcgan_ctx* ctx, double* executed_flops) {
+  RC_REQUIRE(ctx, executed_flops != nullptr, "null argument");
+  *executed_flops = ctx->prof_flops_exec;
   return RCGAN_OK;
 }
 
@@ -331,7 +338,7 @@ static int check_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d) {
 
 size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d) {
   size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
-  if (mfma_eligible(d)) return 2 * elems * sizeof(bf16_t) + 256;
+  if (mfma_eligible(d)) return 2 * elems * sizeof(bf16_t) + (mfma_phase_filters(d) ? 32 * (size_t)d->cin * d->cout * sizeof(bf16_t) : 0) + 256;
   if (img_side(d)) return img_extra_offset(d) + img_extra_bytes(d);
   return elems * sizeof(float) + 256;
 }
@@ -343,7 +350,10 @@ int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w,
   size_t elems = (size_t)T * d->cin * d->cout;
   if (mfma_eligible(d)) {
     bf16_t* wt = (bf16_t*)prepared;
-    return mfma_prepare_launch(ctx, w, sigma, wt, wt + elems, T, d->cin, d->cout);
+    rc = mfma_prepare_launch(ctx, w, sigma, wt, wt + elems, T, d->cin, d->cout);
+    if (rc || !mfma_phase_filters(d)) return rc;
+    bf16_t* wph = wt + 2 * elems;
+    return conv_prepare_phase_launch(ctx, 1, &w, &sigma, &wph, &d->cin, &d->cout);
   }
   rc = direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
   if (rc) return rc;
@@ -394,6 +404,7 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
   a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
   if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
   a.stamps = nullptr;
+  a.wph = nullptr; a.phase = 0;
 }
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
@@ -419,6 +430,7 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
     MfmaConvArgs a;
     fill_mfma_args(d, a);
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+    if (mfma_phase_filters(d)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
     a.resid = (const bf16_t*)residual;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cin; a.Cout = d->cout;
@@ -461,6 +473,22 @@ int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, con
     size_t need = (size_t)d->n * d->h * d->w * d->cin * dtype_size(d->dtype);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     target = ws;
+  }
+  if (up && mfma_phase_dgrad_ok(d)) {
+    // sub-pixel form: dx over the low-resolution grid straight from dy (16 taps at stride 2, transposed summed filters), the
+    // ReLU mask and the accumulation in the epilogue -- no full-resolution scratch, no 2x2 sum pass
+    MfmaConvArgs a;
+    fill_mfma_args(d, a);
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared + elems; a.bias = nullptr; a.mask = relu ? (const bf16_t*)x : nullptr;
+    a.resid = nullptr; a.out = (bf16_t*)dx;
+    a.zero = (const bf16_t*)ctx->zero_page;
+    a.Cin = d->cout; a.Cout = d->cin;
+    a.up = 0; a.relu_in = 0; a.accumulate = acc;
+    a.M = (long)d->n * (d->h / 2) * (d->w / 2);
+    a.wph = (const bf16_t*)prepared + 2 * elems + 16 * (size_t)d->cin * d->cout;
+    a.phase = 2;
+    return mfma_conv_launch(ctx, a);
   }
   const void* mask = (relu && !up) ? x : nullptr;
   const int acc_now = up ? 0 : acc;

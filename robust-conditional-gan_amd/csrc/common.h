@@ -23,7 +23,7 @@ struct rcgan_ctx {
   // per-kernel HIP-event profiling (bench.py roofline leg): every launch of kernel `prof_which` is bracketed
   int prof_which;
   std::vector<hipEvent_t> prof_ev;
-  double prof_flops;
+  double prof_flops, prof_flops_exec;      // algorithmic (the reference's formulation) / executed by the kernels
   // fork/join onto a second stream (rcgan_side_begin/end/join): lets an independent kernel pair -- a layer's filter
   // gradient and its data gradient -- share the chip when neither fills it.  Capturable (event fork/join).
   hipStream_t main_stream, side_stream;
@@ -54,13 +54,14 @@ struct rcgan_ctx {
 // brackets one launch with events when profiling is armed for kernel id `which`
 struct ProfScope {
   rcgan_ctx* c; bool on;
-  ProfScope(rcgan_ctx* ctx, int which, double flops) : c(ctx), on(ctx->prof_which == which) {
+  ProfScope(rcgan_ctx* ctx, int which, double flops, double executed = -1.0) : c(ctx), on(ctx->prof_which == which) {
     if (!on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
     (void)hipEventRecord(e, c->stream);
     c->prof_ev.push_back(e);
     c->prof_flops += flops;
+    c->prof_flops_exec += executed < 0.0 ? flops : executed;
   }
   ~ProfScope() {
     if (!on) return;

@@ -19,6 +19,13 @@ struct MfmaConvArgs {
   int lw, lh;             // log2(W), log2(H) when both are powers of two (pixel decode by shifts), else -1
   long M;
   unsigned long long* stamps;   // diagnostics (rcgan_debug_stamps), normally null
+  // Sub-pixel form of a 3x3 convolution behind the nearest 2x upsample (eight-wave kernels): output pixel (2i + ph, 2j + pw)
+  // only sees the 2x2 source pixels (i + a - 1 + ph, j + b - 1 + pw), a, b in {0, 1}, each with the SUM of the filter taps that
+  // fall on it -- four 2x2 convolutions over the low-resolution grid, 4/9 of the multiply-adds.  wph: the four summed filters
+  // [phase = ph*2 + pw][Cout][(a*2 + b)*Cin + ci] (conv_prepare_phase_kernel), phase = 1: use them.  phase = 2: the data
+  // gradient of that form, wph = [Cin][(u*4 + v)*Cout + co] (16 taps at source stride 2 over the full-resolution dy).
+  const bf16_t* wph;
+  int phase;
 };
 
 struct MfmaWgradArgs {
@@ -42,6 +49,9 @@ static inline int ilog2_exact(int v) {
 
 bool mfma_eligible(const rcgan_conv_desc* d);
 bool mfma_wgrad_eligible(const rcgan_conv_desc* d);
+bool mfma_phase_filters(const rcgan_conv_desc* d);
+bool mfma_phase_dgrad_ok(const rcgan_conv_desc* d);
+int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts);
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);

@@ -21,6 +21,7 @@
 //   them pixel(k)-contiguous per lane; tiles are staged as [pixel][channel] and the fragments are
 //   read with ds_read_b64_tr_b16 (the gfx950 LDS transpose read).  Pixel ranges are split across
 //   blocks into fp32 slabs that a second kernel reduces (deterministic, no atomics).
+#include <vector>
 #include "conv_mfma.h"
 #include "mfma_util.h"
 #include "conv_image.h"
@@ -167,7 +168,11 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 // SIMD's wave slots empty.  KS groups of 4 wavefronts then take K-tiles g, g+KS, g+2KS, ... of the SAME output tile,
 // each group with its own LDS pipeline (the barriers stay workgroup-wide: all groups run the same iteration count),
 // and the partial accumulators are summed through LDS in a fixed order before the epilogue.
-template <int BM, int BN, int NS, int KS>
+// PHASE 1: the sub-pixel form of an upsample-3x3 convolution (MfmaConvArgs::wph; conv_mfma8.hip has the description) -- the tile's
+// pixel index runs over (phase, n, i, j) of the low-resolution grid, four taps with the phase's summed filters.  PHASE 2: its data
+// gradient (16 taps at source stride 2 over the full-resolution dy).  A template flag: the ordinary instantiations stay
+// instruction-for-instruction what they were.
+template <int BM, int BN, int NS, int KS, int PHASE = 0>
 __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
@@ -183,11 +188,22 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
   const int wm = wave & 1, wn = wave >> 1;
   const long m0 = (long)blockIdx.x * BM;
   const int co0 = blockIdx.y * BN;
-  const int K = a.KH * a.KW * a.Cin;
+  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  constexpr bool PHM = PHASE == 1, DGM = PHASE == 2;
+  const long Mph = a.M >> 2;
+  const int tph = PHM ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;      // a tile lies inside one phase (launcher)
+  const long mbase = PHM ? (long)tph * Mph : 0;
+  const int glw = PHASE ? a.lw - 1 : a.lw, glh = PHASE ? a.lh - 1 : a.lh;
+  const int GH = PHM ? Hs : (DGM ? (a.H >> 1) : a.H), GW = PHM ? Ws : (DGM ? (a.W >> 1) : a.W);
+  const int BH = PHM ? Hs : a.H, BW = PHM ? Ws : a.W;
+  constexpr int sstr = DGM ? 2 : 1;
+  const int kwn = PHM ? 2 : (DGM ? 4 : a.KW);
+  const int pt = PHM ? 1 - ph : (DGM ? 1 : a.PT), pl = PHM ? 1 - pw : (DGM ? 1 : a.PL);
+  const bool up = PHASE ? false : (a.up != 0);
+  const int K = (PHM ? 4 : (DGM ? 16 : a.KH * a.KW)) * a.Cin;
   const int KT_all = K / 64;
   const int KT = KS > 1 ? (KT_all - grp + KS - 1) / KS : KT_all;      // K-tiles of this group
   const int KT_max = (KT_all + KS - 1) / KS;                          // iterations every group runs (barrier count)
-  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int lrow = lane >> 3, pos = lane & 7;
 
   auto stamp = [&](int k) __attribute__((always_inline)) {
@@ -201,16 +217,17 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
     const long m = m0 + row;
     a_coff[i] = (pos ^ ((row >> 1) & 7)) * 8;
     if (m < a.M) {
-      decode_pix(m, a.H, a.W, a.lh, a.lw, p_n[i], p_oh[i], p_ow[i]);
+      decode_pix(m - mbase, GH, GW, glh, glw, p_n[i], p_oh[i], p_ow[i]);
     } else {
       p_n[i] = 0; p_oh[i] = -100000; p_ow[i] = 0;
     }
   }
+  const bf16_t* const wbase = PHM ? a.wph + (long)tph * a.Cout * K : (DGM ? a.wph : a.wt);
   const bf16_t* wsrc[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int row = (wave * BI + i) * 8 + lrow;
-    wsrc[i] = a.wt + (long)(co0 + row) * K + (pos ^ ((row >> 1) & 7)) * 8;
+    wsrc[i] = wbase + (long)(co0 + row) * K + (pos ^ ((row >> 1) & 7)) * 8;
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -223,9 +240,9 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
   auto set_tap = [&](int kh, int kw) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
-      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      if (a.up) { ih >>= 1; iw >>= 1; }
+      int ih = p_oh[i] * sstr + kh - pt, iw = p_ow[i] * sstr + kw - pl;
+      const bool ok = ih >= 0 && ih < BH && iw >= 0 && iw < BW;
+      if (up) { ih >>= 1; iw >>= 1; }
       rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
       rstep[i] = ok ? 1 : 0;
     }
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
     i_c0 += 64 * steps;
     while (i_c0 >= a.Cin) {
       i_c0 -= a.Cin;
-      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+      if (++i_kw == kwn) { i_kw = 0; ++i_kh; }
       moved = true;
     }
     if (moved) set_tap(i_kh, i_kw);
@@ -334,7 +351,10 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
   }
 
   stamp(4);
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+  if constexpr (PHASE == 1)
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowPhase{1, glw, glh, ph, pw, mbase});
+  else
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
   if (a.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
@@ -1123,6 +1143,67 @@ __global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf1
   wd[(long)ci * T * Cout + (long)(T - 1 - t) * Cout + co] = v;
 }
 
+// Summed filters of the sub-pixel form of an upsample-3x3 convolution (MfmaConvArgs::wph):
+//   wph[phase = ph*2 + pw][co][(a*2 + b)*Cin + ci] = sum of W[kh][kw][ci][co] over the taps (kh, kw) that read source pixel
+//   (i + a - 1 + ph, j + b - 1 + pw) for output pixel (2i + ph, 2j + pw): row sets {0},{1,2} for ph = 0 and {0,1},{2} for ph = 1.
+// Summed in fp32, rounded to 16 bits once.
+struct PhasePrepBatch { struct It { const float* w; const float* sigma; bf16_t* wph; int Cin, Cout; } it[8]; };
+__global__ __launch_bounds__(256) void conv_prepare_phase_kernel(PhasePrepBatch b) {
+  const PhasePrepBatch::It it = b.it[blockIdx.y];
+  const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
+  const long per = (long)it.Cout * 4 * it.Cin, total = 4 * per;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int phase = (int)(e / per);
+    long r = e - phase * per;
+    const int co = (int)(r / (4 * it.Cin));
+    r -= (long)co * 4 * it.Cin;
+    const int ab = (int)(r / it.Cin), ci = (int)(r - (long)ab * it.Cin);
+    const int ph = phase >> 1, pw = phase & 1, ta = ab >> 1, tb = ab & 1;
+    // taps of row-class ta for phase ph: ph = 0: {0} | {1,2};  ph = 1: {0,1} | {2}
+    const int kh0 = ph == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), kh1 = ph == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+    const int kw0 = pw == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = pw == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+    float s = 0.f;
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
+    it.wph[e] = f32_to_bf16(s * inv);
+  }
+  // data-gradient layout  wdp[ci][(u*4 + v)*Cout + co]: dy position (2p + u - 1, 2q + v - 1) reaches dx (p, q) through the taps
+  // u = 0: {kh = 2}, 1: {1, 2}, 2: {0, 1}, 3: {0}  (the transposed row classes), likewise v
+  bf16_t* wdp = it.wph + total;
+  const long total2 = 16L * it.Cin * it.Cout;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total2; e += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(e / (16L * it.Cout));
+    long r = e - (long)ci * 16 * it.Cout;
+    const int uv = (int)(r / it.Cout), co = (int)(r - (long)uv * it.Cout);
+    const int u = uv >> 2, v = uv & 3;
+    const int kh0 = u == 0 ? 2 : (u == 1 ? 1 : 0), kh1 = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
+    const int kw0 = v == 0 ? 2 : (v == 1 ? 1 : 0), kw1 = v == 0 ? 2 : (v == 1 ? 2 : (v == 2 ? 1 : 0));
+    float s = 0.f;
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
+    wdp[e] = f32_to_bf16(s * inv);
+  }
+}
+
+// phase filters of every upsample-3x3 convolution among the items (at most 8 per launch)
+int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts) {
+  for (int base = 0; base < n; base += 8) {
+    PhasePrepBatch b;
+    const int m = n - base < 8 ? n - base : 8;
+    long maxel = 0;
+    for (int i = 0; i < m; ++i) {
+      b.it[i] = {ws[base + i], sigmas[base + i], outs[base + i], cins[base + i], couts[base + i]};
+      const long el = 16L * cins[base + i] * couts[base + i];
+      if (el > maxel) maxel = el;
+    }
+    int bx = (int)cdiv(maxel, 256 * 8);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(conv_prepare_phase_kernel, dim3(bx, m), dim3(256), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  return RCGAN_OK;
+}
+
 // batched preparation: every filter of a network in ONE launch (blockIdx.y = filter)
 struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
 struct PrepBatch { PrepItem it[48]; };
@@ -1191,6 +1272,18 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
     hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(bx, m), dim3(256), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
   }
+  // the summed phase filters of the upsample-3x3 convolutions
+  std::vector<const float*> pw_, ps_;
+  std::vector<bf16_t*> po_;
+  std::vector<int> pci, pco;
+  for (int i = 0; i < n; ++i) {
+    const rcgan_conv_desc& d = items[i].desc;
+    if (!mfma_phase_filters(&d)) continue;
+    pw_.push_back(items[i].w); ps_.push_back(items[i].sigma);
+    po_.push_back((bf16_t*)items[i].prepared + 2 * (size_t)d.kh * d.kw * d.cin * d.cout);
+    pci.push_back(d.cin); pco.push_back(d.cout);
+  }
+  if (!pw_.empty()) return conv_prepare_phase_launch(ctx, (int)pw_.size(), pw_.data(), ps_.data(), po_.data(), pci.data(), pco.data());
   return RCGAN_OK;
 }
 
@@ -1204,6 +1297,11 @@ __global__ void conv_prepare_direct_kernel(const float* w, const float* sigma, f
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 bool mfma_eligible(const rcgan_conv_desc* d) {
   if (d->dtype != RCGAN_H16) return false;
   if (d->flags & RCGAN_CONV_FORCE_DIRECT) return false;
@@ -1211,6 +1309,20 @@ bool mfma_eligible(const rcgan_conv_desc* d) {
   if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return false;
   if (d->cin % 64 || d->cout % 64) return false;
   return true;
+}
+
+// an upsample-3x3 convolution on the matrix-core path: its prepared buffer carries the four summed phase filters behind the two
+// ordinary layouts (16 * cin * cout elements)
+bool mfma_phase_filters(const rcgan_conv_desc* d) {
+  return mfma_eligible(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) && d->kh == 3 && d->kw == 3;
+}
+
+// the data gradient of such a layer in the sub-pixel form: power-of-two images, whole 64-pixel tiles of low-resolution pixels
+bool mfma_phase_dgrad_ok(const rcgan_conv_desc* d) {
+  static const int on = env_int("RCGAN_UP_PHASE_DGRAD", 1), on1 = env_int("RCGAN_UP_PHASE", 1);
+  if (!on || !on1 || !mfma_phase_filters(d)) return false;
+  const int lw = ilog2_exact(d->w), lh = ilog2_exact(d->h);
+  return lw >= 1 && lh >= 1 && ((long)d->n * (d->h / 2) * (d->w / 2)) % 64 == 0;
 }
 
 bool mfma_wgrad_eligible(const rcgan_conv_desc* d) {
@@ -1223,9 +1335,27 @@ static int conv_impl() {      // 1 = direct-to-LDS (default), 0 = register-stage
   return v;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
+
+// the sub-pixel instantiation of the 64 x 64 kernel (G.Block.1.Conv1: 8x8 from 4x4, 1024 -> 256): whole tiles per phase
+template <int BM, int BN, int NS, int KS, int PHASE = 1>
+static int launch_conv_glds_phase(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
+  MfmaConvArgs a = a_in;
+  a.phase = PHASE;
+  static bool attr_set = false;
+  size_t lds = (size_t)KS * NS * (BM + BN) * 128;
+  const size_t part = (size_t)(KS - 1) * 256 * (BM / 32) * (BN / 32) * 4 * sizeof(float);
+  if (part > lds) lds = part;
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<BM, BN, NS, KS, PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM), a.Cout / BN);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_MFMA_64, 2.0 * (double)a.M * (PHASE == 2 ? 36 : 9) * a.Cin * a.Cout, 2.0 * (double)a.M * (PHASE == 2 ? 16 : 4) * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_glds_kernel<BM, BN, NS, KS, PHASE>), grid, dim3(256 * KS), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
 }
 
 template <int BM, int BN, int NS, int KS = 1>
@@ -1297,6 +1427,13 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
       static const int deep = env_int("RCGAN_KS_DEEP", 0);      // experiment: 1 = 2 K-groups x 4 stages, 2 = 3 K-groups x 3 stages
       if (deep == 1 && blocks <= ks4_max && ktiles >= 8) return launch_conv_glds<BM, BN, 4, 2>(ctx, a);
       if (deep == 2 && blocks <= ks4_max && ktiles >= 9) return launch_conv_glds<BM, BN, 3, 3>(ctx, a);
+      {
+        static const int up_phase = env_int("RCGAN_UP_PHASE", 1);
+        if (up_phase && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % BM) == 0) {
+          if (blocks <= ks2_max) return launch_conv_glds_phase<BM, BN, 2, 2>(ctx, a);
+          return launch_conv_glds_phase<BM, BN, 2, 1>(ctx, a);
+        }
+      }
       if (blocks <= ks4_max && ktiles >= 8) return launch_conv_glds<BM, BN, 2, 4>(ctx, a);
       if (blocks <= ks2_max && ktiles >= 4) return launch_conv_glds<BM, BN, 2, 2>(ctx, a);
     }
@@ -1323,6 +1460,16 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
   MfmaConvArgs a = a_in;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
+  if (a.phase == 2) {
+    // data gradient of the sub-pixel form (the caller checked mfma_phase_dgrad_ok): 256-pixel tiles where the grid fills
+    // the chip, else the 64 x 64 kernel
+    static const int p8_min2 = env_int("RCGAN_P8_MINBLK", 200), p8n_min2 = env_int("RCGAN_P8N_MINBLK", 190), ks2_max2 = env_int("RCGAN_KS2_MAXBLK", 576);
+    const long b8 = (a.M / 256) * (a.Cout / 256);
+    if (a.M % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min2 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);
+    if (a.M % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= p8n_min2) return mfma_conv8_launch(ctx, a, false);
+    if ((a.M / 64) * (a.Cout / 64) <= ks2_max2) return launch_conv_glds_phase<64, 64, 2, 2, 2>(ctx, a);
+    return launch_conv_glds_phase<64, 64, 2, 1, 2>(ctx, a);
+  }
   long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
   static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
   static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);         // 256 x 256 four-phase kernel (conv_mfma8.hip)

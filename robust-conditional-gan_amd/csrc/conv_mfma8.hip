@@ -49,9 +49,26 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   if (XCDSWZ && (gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const long m0 = (long)mt * 256;
   const int co0 = blockIdx.y * 256;
-  const int K = a.KH * a.KW * a.Cin;
-  const int KT = K / 64;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  // sub-pixel form (a.phase): the tile's pixel index runs over (phase, n, i, j) of the low-resolution grid; all 256 pixels of a
+  // tile share the phase (pixels per phase % 256 == 0, checked by the launcher)
+  // a.phase == 2: the data gradient of that form -- dx over the low-resolution grid gathers the 4 x 4 neighbourhood
+  // (2p + u - 1, 2q + v - 1) of the full-resolution dy, each position with the transposed summed filter that reaches it
+  // (16 taps, source stride 2; a.H, a.W = the dy grid, a.M = low-resolution pixels)
+  const bool phm = a.phase == 1, dgm = a.phase == 2;
+  const long Mph = a.M >> 2;
+  const int tph = phm ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;
+  const long mbase = phm ? (long)tph * Mph : 0;
+  const int glw = (phm || dgm) ? a.lw - 1 : a.lw, glh = (phm || dgm) ? a.lh - 1 : a.lh;
+  const int GH = phm ? Hs : (dgm ? (a.H >> 1) : a.H), GW = phm ? Ws : (dgm ? (a.W >> 1) : a.W);     // grid of the tile's pixel index
+  const int BH = phm ? Hs : a.H, BW = phm ? Ws : a.W;                                              // grid of the source pixels
+  const int sstr = dgm ? 2 : 1;
+  const int kwn = phm ? 2 : (dgm ? 4 : a.KW), ntaps = phm ? 4 : (dgm ? 16 : a.KH * a.KW);
+  const int pt = phm ? 1 - ph : (dgm ? 1 : a.PT), pl = phm ? 1 - pw : (dgm ? 1 : a.PL);
+  const bool up = a.up && !phm && !dgm;
+  const int K = ntaps * a.Cin;
+  const int KT = K / 64;
+  const bf16_t* const wbase = phm ? a.wph + (long)tph * a.Cout * K : (dgm ? a.wph : a.wt);
   const int lrow = lane >> 3, pos = lane & 7;
 
   // ---- tap-source table: T[tap][p] = element offset (into a.in) of the pixel that tile pixel p reads for that tap, or
@@ -67,27 +84,26 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
     a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
   }
   unsigned* const tapt = (unsigned*)(smem + 2 * BUF);
-  const int ntaps = a.KH * a.KW;
   for (int e = tid; e < ntaps * 256; e += 512) {
     const int tap = e >> 8;
     const long m = m0 + (e & 255);
     unsigned off = ~0u;
     if (m < a.M) {
       int n, oh, ow;
-      const unsigned mm = (unsigned)m;
+      const unsigned mm = (unsigned)(m - mbase);
       if (a.lw >= 0) {
-        ow = (int)(mm & (unsigned)(a.W - 1));
-        oh = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
-        n = (int)(mm >> (a.lw + a.lh));
+        ow = (int)(mm & (unsigned)(GW - 1));
+        oh = (int)((mm >> glw) & (unsigned)(GH - 1));
+        n = (int)(mm >> (glw + glh));
       } else {
         ow = (int)(m % a.W);
         oh = (int)((m / a.W) % a.H);
         n = (int)(m / ((long)a.W * a.H));
       }
-      const int kh = tap / a.KW, kw = tap - kh * a.KW;
-      int ih = oh + kh - a.PT, iw = ow + kw - a.PL;
-      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-        if (a.up) { ih >>= 1; iw >>= 1; }
+      const int kh = tap / kwn, kw = tap - kh * kwn;
+      int ih = oh * sstr + kh - pt, iw = ow * sstr + kw - pl;
+      if (ih >= 0 && ih < BH && iw >= 0 && iw < BW) {
+        if (up) { ih >>= 1; iw >>= 1; }
         off = (((unsigned)n * Hs + ih) * Ws + iw) * a.Cin;
       }
     }
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       pix[h * 2 + j] = (r >> 6) * 128 + h * 64 + (r & 63);
       a_coff[h * 2 + j] = swz;
       const int co = co0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      wsrc[h * 2 + j] = a.wt + (long)co * K + swz;
+      wsrc[h * 2 + j] = wbase + (long)co * K + swz;
     }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -253,7 +269,8 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 
   // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
   stamp(3);
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
+                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase});
   if (a.stamps) {
     stamp(4);
     wait_vm<0>();
@@ -515,9 +532,25 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
   const int wm = wave & 3, wn = wave >> 2;        // pixel quarter / channel half of this wavefront
   const long m0 = (long)blockIdx.x * 256;
   const int co0 = blockIdx.y * 128;
-  const int K = a.KH * a.KW * a.Cin;
-  const int KT = K / 64;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  // sub-pixel form (a.phase), as in the 256 x 256 kernel above
+  // a.phase == 2: the data gradient of that form -- dx over the low-resolution grid gathers the 4 x 4 neighbourhood
+  // (2p + u - 1, 2q + v - 1) of the full-resolution dy, each position with the transposed summed filter that reaches it
+  // (16 taps, source stride 2; a.H, a.W = the dy grid, a.M = low-resolution pixels)
+  const bool phm = a.phase == 1, dgm = a.phase == 2;
+  const long Mph = a.M >> 2;
+  const int tph = phm ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;
+  const long mbase = phm ? (long)tph * Mph : 0;
+  const int glw = (phm || dgm) ? a.lw - 1 : a.lw, glh = (phm || dgm) ? a.lh - 1 : a.lh;
+  const int GH = phm ? Hs : (dgm ? (a.H >> 1) : a.H), GW = phm ? Ws : (dgm ? (a.W >> 1) : a.W);     // grid of the tile's pixel index
+  const int BH = phm ? Hs : a.H, BW = phm ? Ws : a.W;                                              // grid of the source pixels
+  const int sstr = dgm ? 2 : 1;
+  const int kwn = phm ? 2 : (dgm ? 4 : a.KW), ntaps = phm ? 4 : (dgm ? 16 : a.KH * a.KW);
+  const int pt = phm ? 1 - ph : (dgm ? 1 : a.PT), pl = phm ? 1 - pw : (dgm ? 1 : a.PL);
+  const bool up = a.up && !phm && !dgm;
+  const int K = ntaps * a.Cin;
+  const int KT = K / 64;
+  const bf16_t* const wbase = phm ? a.wph + (long)tph * a.Cout * K : (dgm ? a.wph : a.wt);
   const int lrow = lane >> 3, pos = lane & 7;
 
   // X half h, LDS row r <-> tile pixel (r>>5)*64 + h*32 + (r&31);  W row r <-> channel r
@@ -527,17 +560,17 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int r = (wave * 2 + j) * 8 + lrow;
     const int swz = (pos ^ ((r >> 1) & 7)) * 8;
-    wsrc[j] = a.wt + (long)(co0 + r) * K + swz;
+    wsrc[j] = wbase + (long)(co0 + r) * K + swz;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const long m = m0 + (r >> 5) * 64 + h * 32 + (r & 31);
       a_coff[h * 2 + j] = swz;
       if (m < a.M) {
-        const unsigned mm = (unsigned)m;
+        const unsigned mm = (unsigned)(m - mbase);
         if (a.lw >= 0) {
-          p_ow[h * 2 + j] = (int)(mm & (unsigned)(a.W - 1));
-          p_oh[h * 2 + j] = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
-          p_n[h * 2 + j] = (int)(mm >> (a.lw + a.lh));
+          p_ow[h * 2 + j] = (int)(mm & (unsigned)(GW - 1));
+          p_oh[h * 2 + j] = (int)((mm >> glw) & (unsigned)(GH - 1));
+          p_n[h * 2 + j] = (int)(mm >> (glw + glh));
         } else {
           p_ow[h * 2 + j] = (int)(m % a.W);
           p_oh[h * 2 + j] = (int)((m / a.W) % a.H);
@@ -556,9 +589,9 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
   auto set_tap = [&](int kh, int kw) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int ih = p_oh[i] + kh - a.PT, iw = p_ow[i] + kw - a.PL;
-      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      if (a.up) { ih >>= 1; iw >>= 1; }
+      int ih = p_oh[i] * sstr + kh - pt, iw = p_ow[i] * sstr + kw - pl;
+      const bool ok = ih >= 0 && ih < BH && iw >= 0 && iw < BW;
+      if (up) { ih >>= 1; iw >>= 1; }
       rp[i] = ok ? a.in + (unsigned)((((unsigned)p_n[i] * Hs + ih) * Ws + iw) * a.Cin + a_coff[i]) : a.zero;
       rstep[i] = ok ? 1 : 0;
     }
@@ -578,7 +611,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
     i_c0 += 64;
     if (i_c0 == a.Cin) {
       i_c0 = 0;
-      if (++i_kw == a.KW) { i_kw = 0; ++i_kh; }
+      if (++i_kw == kwn) { i_kw = 0; ++i_kh; }
       set_tap(i_kh, i_kw);
     }
   };
@@ -649,20 +682,22 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
     wg_barrier();
   }
 
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane,
+                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase});
 }
 
 template <bool RELU, bool XCDSWZ>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  const size_t lds = (size_t)2 * 4 * 128 * 128 + 9 * 256 * sizeof(unsigned);      // tile buffers + tap-source table
+  const size_t lds = (size_t)2 * 4 * 128 * 128 + 16 * 256 * sizeof(unsigned);     // tile buffers + tap-source table (<= 16 taps)
   if (!attr_set) {
     RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * (a.phase == 2 ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
+                 2.0 * (double)a.M * (a.phase == 2 ? 16 : a.phase == 1 ? 4 : a.KH * a.KW) * a.Cin * a.Cout);
     hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -703,7 +738,8 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 128);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * (a.phase == 2 ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
+                 2.0 * (double)a.M * (a.phase == 2 ? 16 : a.phase == 1 ? 4 : a.KH * a.KW) * a.Cin * a.Cout);
     hipLaunchKernelGGL(conv_mfma_p8n_kernel<RELU>, grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -717,15 +753,21 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 1; }
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("RCGAN_P8_PERSIST"); persist = e ? atoi(e) : 0; }
+  // sub-pixel form of an upsample-3x3 convolution (MfmaConvArgs::wph): power-of-two images, whole tiles per phase
+  static const int up_phase = [] { const char* e = getenv("RCGAN_UP_PHASE"); return e ? atoi(e) : 1; }();
+  const bool phase = up_phase && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % 256) == 0;
   if (wide) {
     MfmaConvArgs b = a;
+    b.phase = a.phase == 2 ? 2 : (phase ? 1 : 0);
     b.stamps = (unsigned long long*)ctx->dbg_stamps;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
-    if (persist && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
+    if (persist && !b.phase && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
       return b.relu_in ? launch8p<true>(ctx, b, swz) : launch8p<false>(ctx, b, swz);
     if (swz) return b.relu_in ? launch8<true, true>(ctx, b) : launch8<false, true>(ctx, b);
     return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }
-  return a.relu_in ? launch8n<true>(ctx, a) : launch8n<false>(ctx, a);
+  MfmaConvArgs b = a;
+  b.phase = a.phase == 2 ? 2 : (phase ? 1 : 0);
+  return b.relu_in ? launch8n<true>(ctx, b) : launch8n<false>(ctx, b);
 }

@@ -103,11 +103,25 @@ __device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
 __device__ __forceinline__ float h16_lo(uint32_t w) { return bf16_to_f32((bf16_t)(w & 0xffffu)); }
 __device__ __forceinline__ float h16_hi(uint32_t w) { return bf16_to_f32((bf16_t)(w >> 16)); }
 
-template <int NI, int NJ>
+// Row maps: the pixel index a tile row stands for -> the row of the output tensor.  RowIdent for every ordinary convolution;
+// RowPhase for the sub-pixel form of a 3x3 convolution behind a nearest 2x upsample (conv_mfma8.hip): there the tile rows
+// enumerate (phase, n, i, j) over the LOW-resolution grid and land at output pixel (n, 2i + ph, 2j + pw).
+struct RowIdent { __device__ __forceinline__ long operator()(long m) const { return m; } };
+struct RowPhase {
+  int on, lws, lhs, ph, pw; long base;          // base = phase * (pixels per phase); on = 0: identity
+  __device__ __forceinline__ long operator()(long m) const {
+    if (!on) return m;
+    const unsigned ms = (unsigned)(m - base);
+    const unsigned j = ms & ((1u << lws) - 1u), i = (ms >> lws) & ((1u << lhs) - 1u), n = ms >> (lws + lhs);
+    return (long)(((((n << lhs) + i) * 2u + (unsigned)ph) << (lws + 1)) + 2u * j + (unsigned)pw);
+  }
+};
+
+template <int NI, int NJ, typename Map = RowIdent>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const float* __restrict__ bias, const bf16_t* mask,
                                               const bf16_t* resid, bf16_t* out, int accumulate, long M, int Cout,
                                               long m_wave /* first pixel of the wavefront's rows */,
-                                              int co_wave /* first channel of the wavefront's columns */, int lane) {
+                                              int co_wave /* first channel of the wavefront's columns */, int lane, Map rowmap = Map()) {
   static_assert(NI % 2 == 0, "channel fragments are stored in pairs");
   constexpr int NP = NI / 2;
   const int row = lane >> 4;
@@ -117,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const floa
     b4[i] = bias ? *(const float4*)(bias + co_wave + i * 16 + row * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   // element offset of this lane's 8-channel run of pair p in pixel row j
   auto offs = [&](int j, int p) __attribute__((always_inline)) -> long {
-    return (m_wave + j * 16 + (lane & 15)) * Cout + co_wave + (2 * p + (row & 1)) * 16 + (row >> 1) * 8;
+    return rowmap(m_wave + j * 16 + (lane & 15)) * Cout + co_wave + (2 * p + (row & 1)) * 16 + (row >> 1) * 8;
   };
   auto valid = [&](int j) __attribute__((always_inline)) -> bool { return m_wave + j * 16 + (lane & 15) < M; };
   const bool extras = mask != nullptr || resid != nullptr || accumulate != 0;

@@ -94,9 +94,10 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None):
                 dict {param name: {key: DT}} -> (re)fill buffers that survive the step (filters that only change
                 with their optimiser step)."""
     todo = []
-    for w, k, stride, hw in weights_and_shapes:
+    for w, k, stride, hw, *rest in weights_and_shapes:
         kk, _, cin, cout = w.param.shape
-        desc = L.ConvDesc(1, hw, hw, cin, cout, k, k, stride, dtype, 0)
+        # flags that change the prepared layout (CONV_IN_UPSAMPLE2X: the summed phase filters of the sub-pixel form ride along)
+        desc = L.ConvDesc(1, hw, hw, cin, cout, k, k, stride, dtype, rest[0] if rest else 0)
         nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
         key = Weight._key(desc, nbytes)
         if persistent is None:

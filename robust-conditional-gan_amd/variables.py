@@ -82,15 +82,15 @@ class Graph:
     def prepare_convs(self, names, dtype):
         """Batch-prepare the conv filters named in ``names`` ([(param name, k, stride, input hw)]): one launch."""
         ws = []
-        for pn, k, stride, hw in names:
+        for pn, k, stride, hw, *rest in names:
             w = self.sn[pn][0] if pn in self.sn else self.weight(pn)
-            ws.append((w, k, stride, hw))
+            ws.append((w, k, stride, hw, *rest))
         O.prepare_batch(self.ctx, ws, dtype)
 
     def refresh_persistent(self, names, dtype):
         """(Re)prepare the un-normalised filters in ``names`` into buffers that survive the step: called after their
         optimiser step (or any other write to the parameters), NOT once per step."""
-        ws = [(O.Weight(self.ctx, self.groups[self.index[pn]].param(pn), None), k, stride, hw) for pn, k, stride, hw in names]
+        ws = [(O.Weight(self.ctx, self.groups[self.index[pn]].param(pn), None), k, stride, hw, *rest) for pn, k, stride, hw, *rest in names]
         O.prepare_batch(self.ctx, ws, dtype, persistent=self.persist)
 
     def weight(self, pname):

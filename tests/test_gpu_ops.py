@@ -44,6 +44,8 @@ CONV_CASES = [
     (3, 5, 5, 64, 128, 3, 1, False, True),      # MFMA, M tail (75 pixels)
     (2, 16, 16, 128, 128, 3, 1, False, True),   # MFMA + MFMA filter gradient
     (1, 8, 8, 128, 256, 3, 1, True, False),     # MFMA with folded upsample
+    (32, 8, 8, 256, 128, 3, 1, True, True),     # ... in its sub-pixel form (four summed 2x2 filters), 64 x 64 tiles with K-split 2
+    (200, 8, 8, 64, 256, 3, 1, True, False),    # ... 64 x 64 tiles, 800 workgroups (no K-split)
     (2, 8, 8, 256, 128, 1, 1, False, False),    # MFMA 1x1
     (5, 32, 32, 128, 128, 3, 1, False, True),   # MFMA 128x128 tile (M = 5120 -> 40 blocks < 384 -> 64 tile) ...
     (48, 32, 32, 128, 128, 3, 1, False, False), # ... and M = 49152 -> 384 blocks of 128x128
@@ -197,6 +199,15 @@ PERSISTENT_CASES = [
     (400, 16, 16, 256, 256, 1, False, False, "acc"),    # accumulate into an existing tensor (shortcut + conv, gan_resnet.py:328)
     (400, 16, 16, 256, 256, 1, False, True, "res"),     # residual added in the epilogue
     (1280, 8, 8, 256, 256, 3, False, False, ""),        # 320 -> the 256 x 128 kernel (1.25 rounds of 256 x 256 tiles)
+    # sub-pixel form of the upsample-3x3 convolution (four 2x2 convolutions with summed filters over the low-resolution grid):
+    # taken when a phase holds whole 256-pixel tiles (the case with n = 393 above does not and keeps the folded upsample)
+    (400, 16, 16, 64, 256, 3, True, False, ""),         # 256 x 256 kernel, 100 tiles per phase
+    (52, 32, 32, 128, 256, 3, True, True, "res"),       # ... with input ReLU and a residual operand (rows remapped to 2i+ph, 2j+pw)
+    (400, 16, 16, 64, 128, 3, True, False, "acc"),      # 256 x 128 kernel, accumulating
+    # ... and its data gradient: dx over the low-resolution grid from the 4 x 4 neighbourhood of dy (16 taps, stride 2)
+    (100, 32, 32, 256, 64, 3, True, True, "dgrad"),     # 256 x 128 kernel (200 workgroups), ReLU mask in the epilogue
+    (100, 32, 32, 512, 64, 3, True, False, "dgrad"),    # 256 x 256 kernel (200 workgroups)
+    (40, 16, 16, 128, 64, 3, True, True, "dgrad"),      # 64 x 64 kernel with K-split 2
 ]
 
 
@@ -239,7 +250,7 @@ def test_conv_persistent_tiles(dev, case):
     pad = ntile * 256 - gt.shape[0]
     e = np.abs(np.pad(gt - rt, ((0, pad), (0, 0)))).reshape(ntile, -1).max(1)
     assert e.max() <= TOL[mode] * np.abs(rt).max(), "tile %d off by %.3e" % (int(e.argmax()), float(e.max()))
-    if cin % 256 == 0 and not up:
+    if (cin % 256 == 0 and not up) or (up and extra == "dgrad"):
         dy = _prep(rs.randn(*ref.shape).astype(np.float32), mode)
         y.grad = ctx.upload(dy)
         ctx.group_wgrads, keep = True, ctx.group_wgrads
@@ -247,9 +258,12 @@ def test_conv_persistent_tiles(dev, case):
         ctx.group_wgrads = keep
         wf = np.ascontiguousarray(wgt[::-1, ::-1].transpose(0, 1, 3, 2))            # adjoint: 180-degree rotation, in/out swapped
         dx = _torch_conv_ref(dy, wf)
+        if up:                              # adjoint of the nearest upsample: 2x2 sum
+            dx = dx.reshape(n, hs, 2, ws, 2, cin).sum(axis=(2, 4))
         if relu:
             dx = dx * (x > 0)
-        assert_close(ctx.download(xd.grad), dx, TOL[mode], "persistent conv dgrad %s" % (case,))
+        tol = TOL[mode] * (2 if up else 1)  # the sub-pixel form rounds SUMS of up to four filter taps to 16 bits
+        assert_close(ctx.download(xd.grad), dx, tol, "persistent conv dgrad %s" % (case,))
 
 
 @pytest.mark.parametrize("n", [3, 128])
