@@ -104,6 +104,9 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
 #define RCGAN_CONV_IN_RELU 2        /* relu applied to the input on load (gan_resnet.py:305,317,347) */
 #define RCGAN_CONV_ACCUMULATE 4     /* out += result (residual add, gan_resnet.py:328,353) */
 #define RCGAN_CONV_FORCE_DIRECT 8   /* testing: bypass the MFMA path */
+#define RCGAN_CONV_OUT_MEANPOOL2 16 /* ConvMeanPool (gan_resnet.py:241-247): the 2x2 mean pool folded into the convolution -- y [n,h/2,w/2,cout] =
+                                      * meanpool2(conv(x)) + bias, computed as ONE 4x4 stride-2 convolution with summed filters (4/9 of the
+                                      * multiply-adds); forward and data gradient only, and only where rcgan_conv_fused_pool_ok says so */
 
 typedef struct rcgan_conv_desc {
   int n, h, w, cin;   /* logical conv input: after the 2x upsample when IN_UPSAMPLE2X is set */
@@ -131,6 +134,8 @@ int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, in
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
 /* y = conv2d_SAME(x, w) (+bias).  Replaces tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
  * cifar10/common/ops/conv2d.py:181-216.  x: [n, h(/2), w(/2), cin]; y: [n, oh, ow, cout]. */
+/* 1 if the matrix-core kernels take d (3x3, stride 1, 16-bit, power-of-two image, channels % 64 == 0) with RCGAN_CONV_OUT_MEANPOOL2 */
+int rcgan_conv_fused_pool_ok(const rcgan_conv_desc* d);
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
                      const float* bias /* or NULL */, void* y);
 /* y = conv2d_SAME(x, w) (+bias) + residual: the pre-activation residual sum `shortcut + output` of

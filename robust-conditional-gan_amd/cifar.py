@@ -189,6 +189,16 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         return O.reshape(ctx, output, (-1, OUTPUT_DIM))
 
 
+def fused_pool_d(ctx, n):
+    """The down blocks' ConvMeanPool layers run with the pool folded into the convolution: 16-bit activations and a batch that
+    gives whole 64-pixel tiles of pooled pixels on both layers (n * 64 % 64 == 0 always; n * 256 for D.Block.1)."""
+    if ctx.act_dtype == L.F32 or os.environ.get("RCGAN_FUSED_POOL", "1") != "1":
+        return False
+    d1 = L.ConvDesc(n, IMG_SIZE, IMG_SIZE, DIM_D, DIM_D, 3, 3, 1, ctx.act_dtype, L.CONV_OUT_MEANPOOL2)
+    d2 = L.ConvDesc(n, IMG_SIZE // 2, IMG_SIZE // 2, DIM_D, DIM_D, 3, 3, 1, ctx.act_dtype, L.CONV_OUT_MEANPOOL2)
+    return bool(ctx.lib.rcgan_conv_fused_pool_ok(C.byref(d1))) and bool(ctx.lib.rcgan_conv_fused_pool_ok(C.byref(d2)))
+
+
 def Discriminator(inputs, labels, update_collection=None, _head=True):
     """gan_resnet.py:374-412 (+ OptimizedResBlockDisc1 :331-353, ResidualBlock :275-328).  No norm in D
     (NORMALIZATION_D=False), so ``labels`` is unused exactly as in the reference.  _head=False: return the pooled features
@@ -197,16 +207,26 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
     kw = dict(spectral_normed=True, update_collection=update_collection)
     with variable_scope("Discriminator"):
         x = O.reshape(ctx, inputs, (-1, IMG_SIZE, IMG_SIZE, IMG_DIM))
-        # D.Block.1: shortcut = conv1x1(meanpool(x)) == meanpool(conv1x1(x)); pooled together with Conv2
-        t = Conv2D(x, IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
-        h = Conv2D(x, IMG_DIM, DIM_D, 3, 1, 'D.Block.1.Conv1', **kw)
-        t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.1.Conv2', _in_relu=True, _accumulate_into=t, **kw)
-        x = O.meanpool2(ctx, t)
-        # D.Block.2 (down)
-        t = Conv2D(x, DIM_D, DIM_D, 1, 1, 'D.Block.2.Shortcut', he_init=False, **kw)
-        h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
-        t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
-        x = O.meanpool2(ctx, t)
+        if fused_pool_d(ctx, x.shape[0]):
+            # ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution, ops.conv2d_meanpool); the
+            # shortcuts as the reference writes them, MeanPoolConv: 1x1 convolution of the pooled input (gan_resnet.py:249-257, 346)
+            t = Conv2D(O.meanpool2(ctx, x), IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
+            h = Conv2D(x, IMG_DIM, DIM_D, 3, 1, 'D.Block.1.Conv1', **kw)
+            x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.1.Conv2', _in_relu=True, _accumulate_into=t, _out_meanpool=True, **kw)
+            t = Conv2D(O.meanpool2(ctx, x), DIM_D, DIM_D, 1, 1, 'D.Block.2.Shortcut', he_init=False, **kw)
+            h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
+            x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, _out_meanpool=True, **kw)
+        else:
+            # D.Block.1: shortcut = conv1x1(meanpool(x)) == meanpool(conv1x1(x)); pooled together with Conv2
+            t = Conv2D(x, IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
+            h = Conv2D(x, IMG_DIM, DIM_D, 3, 1, 'D.Block.1.Conv1', **kw)
+            t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.1.Conv2', _in_relu=True, _accumulate_into=t, **kw)
+            x = O.meanpool2(ctx, t)
+            # D.Block.2 (down)
+            t = Conv2D(x, DIM_D, DIM_D, 1, 1, 'D.Block.2.Shortcut', he_init=False, **kw)
+            h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
+            t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
+            x = O.meanpool2(ctx, t)
         if FUSED_TRUNK and O.d_trunk_ok(ctx, x):
             # D.Block.3 .. D.Block.6 (identity shortcuts, 8 x 8 pixels): one launch for the eight convolutions (ops.d_trunk)
             g, blocks = Graph.current, []
@@ -426,9 +446,9 @@ class CifarRCGAN:
                 ents.append((name, base + "/spectral_norm/u", upd))
         return ents
 
-    @staticmethod
-    def _filter_names(grp):
+    def _filter_names(self, grp):
         names = []
+        pool = fused_pool_d(self.ctx, GEN_BS_MULTIPLE * self.B)      # D always sees 2B images (real + fake, or 2B fakes)
         for n in grp.names:
             if n.endswith("/Filters"):
                 shp = grp.shapes[n]
@@ -436,6 +456,9 @@ class CifarRCGAN:
                 # the up blocks' first convolutions read their input through the nearest 2x upsample (UpsampleConv, gan_resnet.py:259-272):
                 # their prepared buffers also carry the summed filters of the sub-pixel form
                 up = L.CONV_IN_UPSAMPLE2X if (n.startswith("Generator/G.Block.") and n.endswith(".Conv1/Filters")) else 0
+                # ... and the down blocks' second convolutions those of the folded mean pool (ops.conv2d_meanpool)
+                if pool and n in ("Discriminator/D.Block.1.Conv2/Filters", "Discriminator/D.Block.2.Conv2/Filters"):
+                    up = L.CONV_OUT_MEANPOOL2
                 names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8, up))
         return names
 

@@ -333,8 +333,12 @@ static int check_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d) {
   RC_REQUIRE(ctx, d->kh > 0 && d->kw > 0 && d->stride > 0, "bad kernel/stride");
   RC_REQUIRE(ctx, d->dtype == RCGAN_F32 || d->dtype == RCGAN_H16, "bad dtype");
   if (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) RC_REQUIRE(ctx, d->h % 2 == 0 && d->w % 2 == 0, "upsampled size must be even");
+  if (d->flags & RCGAN_CONV_OUT_MEANPOOL2)
+    RC_REQUIRE(ctx, !(d->flags & RCGAN_CONV_IN_UPSAMPLE2X) && d->h % 2 == 0 && d->w % 2 == 0, "fused mean pool: even size, no upsampled input");
   return RCGAN_OK;
 }
+
+int rcgan_conv_fused_pool_ok(const rcgan_conv_desc* d) { return d && mfma_pool_ok(d) ? 1 : 0; }
 
 size_t rcgan_conv_prepared_bytes(const rcgan_conv_desc* d) {
   size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
@@ -353,7 +357,8 @@ int rcgan_conv_prepare(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w,
     rc = mfma_prepare_launch(ctx, w, sigma, wt, wt + elems, T, d->cin, d->cout);
     if (rc || !mfma_phase_filters(d)) return rc;
     bf16_t* wph = wt + 2 * elems;
-    return conv_prepare_phase_launch(ctx, 1, &w, &sigma, &wph, &d->cin, &d->cout);
+    const int kind = (d->flags & RCGAN_CONV_OUT_MEANPOOL2) ? 1 : 0;
+    return conv_prepare_phase_launch(ctx, 1, &w, &sigma, &wph, &d->cin, &d->cout, &kind);
   }
   rc = direct_prepare_launch(ctx, w, sigma, (float*)prepared, (long)elems);
   if (rc) return rc;
@@ -424,13 +429,32 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
     same_pad(d->w, d->kw, d->stride, &ow, &p);
     return rcgan_axpby(ctx, (size_t)d->n * oh * ow * d->cout, d->dtype, 1.f, residual, 1.f, y);
   }
+  if (d->flags & RCGAN_CONV_OUT_MEANPOOL2) {
+    // ConvMeanPool as one 4x4 stride-2 convolution over x (16 taps, summed filters x 1/4): y over the pooled grid
+    RC_REQUIRE(ctx, mfma_pool_ok(d) && residual == nullptr, "fused mean pool not available for this convolution (rcgan_conv_fused_pool_ok)");
+    if ((long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31))
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tensor exceeds the 32-bit element offsets of the MFMA kernels");
+    MfmaConvArgs a;
+    fill_mfma_args(d, a);
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y; a.resid = nullptr;
+    a.zero = (const bf16_t*)ctx->zero_page;
+    a.Cin = d->cin; a.Cout = d->cout;
+    a.up = 0;
+    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+    a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+    a.M = (long)d->n * (d->h / 2) * (d->w / 2);
+    a.wph = (const bf16_t*)prepared + 2 * elems;        // gather layout [Cout][16 * Cin]
+    a.phase = 2;
+    return mfma_conv_launch(ctx, a);
+  }
   if (mfma_eligible(d)) {
     if ((long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31))
       RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tensor exceeds the 32-bit element offsets of the MFMA kernels");
     MfmaConvArgs a;
     fill_mfma_args(d, a);
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
-    if (mfma_phase_filters(d)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
+    if (mfma_phase_filters(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
     a.resid = (const bf16_t*)residual;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cin; a.Cout = d->cout;
@@ -468,6 +492,23 @@ int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, con
   const bool relu = d->flags & RCGAN_CONV_IN_RELU;
   const int acc = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
   RC_REQUIRE(ctx, !relu || x != nullptr, "IN_RELU needs x for the mask");
+  if (d->flags & RCGAN_CONV_OUT_MEANPOOL2) {
+    // dy lives on the pooled grid: dx (full resolution) in the sub-pixel form -- pixel (2i + ph, 2j + pw) gathers the 2x2 pooled
+    // pixels around it with the transposed summed filters of its phase
+    RC_REQUIRE(ctx, mfma_pool_ok(d) && residual == nullptr, "fused mean pool not available for this convolution (rcgan_conv_fused_pool_ok)");
+    MfmaConvArgs a;
+    fill_mfma_args(d, a);
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    a.in = (const bf16_t*)dy; a.wt = (const bf16_t*)prepared; a.bias = nullptr; a.mask = relu ? (const bf16_t*)x : nullptr;
+    a.resid = nullptr; a.out = (bf16_t*)dx;
+    a.zero = (const bf16_t*)ctx->zero_page;
+    a.Cin = d->cout; a.Cout = d->cin;
+    a.up = 1;                                             // source grid = the pooled one (h/2 x w/2)
+    a.relu_in = 0; a.accumulate = acc;
+    a.wph = (const bf16_t*)prepared + 2 * elems + 16 * (size_t)d->cin * d->cout;        // phase layout [4][Cin][4 * Cout]
+    a.phase = 1;
+    return mfma_conv_launch(ctx, a);
+  }
   void* target = dx;
   if (up) {
     size_t need = (size_t)d->n * d->h * d->w * d->cin * dtype_size(d->dtype);

@@ -51,7 +51,9 @@ bool mfma_eligible(const rcgan_conv_desc* d);
 bool mfma_wgrad_eligible(const rcgan_conv_desc* d);
 bool mfma_phase_filters(const rcgan_conv_desc* d);
 bool mfma_phase_dgrad_ok(const rcgan_conv_desc* d);
-int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts);
+int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts,
+                              const int* kinds);
+bool mfma_pool_ok(const rcgan_conv_desc* d);
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);

@@ -1147,52 +1147,79 @@ __global__ void conv_prepare_mfma_kernel(const float* w, const float* sigma, bf1
 //   wph[phase = ph*2 + pw][co][(a*2 + b)*Cin + ci] = sum of W[kh][kw][ci][co] over the taps (kh, kw) that read source pixel
 //   (i + a - 1 + ph, j + b - 1 + pw) for output pixel (2i + ph, 2j + pw): row sets {0},{1,2} for ph = 0 and {0,1},{2} for ph = 1.
 // Summed in fp32, rounded to 16 bits once.
-struct PhasePrepBatch { struct It { const float* w; const float* sigma; bf16_t* wph; int Cin, Cout; } it[8]; };
+struct PhasePrepBatch { struct It { const float* w; const float* sigma; bf16_t* wph; int Cin, Cout, kind; } it[8]; };
+// Tap classes of the summed filters.  Upsample family (kind 0): row class a of phase ph covers kh in U(ph, a) = {0},{1,2} (ph = 0) /
+// {0,1},{2} (ph = 1); the data gradient's 4 taps u cover {2},{1,2},{0,1},{0}.  Mean-pool family (kind 1, ConvMeanPool): the
+// forward's 4 taps u cover P(u) = {0},{0,1},{1,2},{2} (x 1/4), and the data gradient's phase classes are P(u(ph, a)) with
+// u(0,0) = 3, u(0,1) = 1, u(1,0) = 2, u(1,1) = 0.
+__device__ __forceinline__ void phase_taps2(int kind, int ph, int a, int& k0, int& k1) {       // 2 classes per phase
+  if (kind == 0) { k0 = ph == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); k1 = ph == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); }
+  else {
+    const int u = ph == 0 ? (a == 0 ? 3 : 1) : (a == 0 ? 2 : 0);
+    k0 = u == 0 ? 0 : (u == 1 ? 0 : (u == 2 ? 1 : 2)); k1 = u == 0 ? 0 : (u == 1 ? 1 : 2);
+  }
+}
+__device__ __forceinline__ void phase_taps4(int kind, int u, int& k0, int& k1) {               // 4 classes of the stride-2 form
+  if (kind == 0) { k0 = u == 0 ? 2 : (u == 1 ? 1 : 0); k1 = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0)); }
+  else { k0 = u == 0 ? 0 : (u == 1 ? 0 : (u == 2 ? 1 : 2)); k1 = u == 0 ? 0 : (u == 1 ? 1 : 2); }
+}
+
+// Layouts (16 * Cin * Cout elements each):
+//   "phase" layout  [phase = ph*2 + pw][O][(a*2 + b)*R + r]   -- four 2x2 convolutions over the low-resolution grid
+//   "gather" layout [O][(u*4 + v)*R + r]                      -- one 4x4 stride-2 convolution over the full-resolution grid
+// kind 0 (upsample -> conv): forward = phase layout (O = Cout, R = Cin), data gradient = gather layout (O = Cin, R = Cout)
+// kind 1 (conv -> mean pool): forward = gather layout (O = Cout, R = Cin, x 1/4), data gradient = phase layout (O = Cin, R = Cout, x 1/4)
 __global__ __launch_bounds__(256) void conv_prepare_phase_kernel(PhasePrepBatch b) {
   const PhasePrepBatch::It it = b.it[blockIdx.y];
-  const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
-  const long per = (long)it.Cout * 4 * it.Cin, total = 4 * per;
+  const float inv = (it.sigma ? 1.f / *it.sigma : 1.f) * (it.kind == 1 ? 0.25f : 1.f);
+  const long total = 16L * it.Cin * it.Cout;
+  bf16_t* const phase_l = it.kind == 0 ? it.wph : it.wph + total;
+  bf16_t* const gather_l = it.kind == 0 ? it.wph + total : it.wph;
+  const bool fwd_is_phase = it.kind == 0;
+  const int Op = fwd_is_phase ? it.Cout : it.Cin, Rp = fwd_is_phase ? it.Cin : it.Cout;     // phase layout: output / reduction channels
+  const int Og = fwd_is_phase ? it.Cin : it.Cout, Rg = fwd_is_phase ? it.Cout : it.Cin;     // gather layout
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int phase = (int)(e / per);
-    long r = e - phase * per;
-    const int co = (int)(r / (4 * it.Cin));
-    r -= (long)co * 4 * it.Cin;
-    const int ab = (int)(r / it.Cin), ci = (int)(r - (long)ab * it.Cin);
-    const int ph = phase >> 1, pw = phase & 1, ta = ab >> 1, tb = ab & 1;
-    // taps of row-class ta for phase ph: ph = 0: {0} | {1,2};  ph = 1: {0,1} | {2}
-    const int kh0 = ph == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), kh1 = ph == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
-    const int kw0 = pw == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kw1 = pw == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
-    float s = 0.f;
-    for (int kh = kh0; kh <= kh1; ++kh)
-      for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
-    it.wph[e] = f32_to_bf16(s * inv);
-  }
-  // data-gradient layout  wdp[ci][(u*4 + v)*Cout + co]: dy position (2p + u - 1, 2q + v - 1) reaches dx (p, q) through the taps
-  // u = 0: {kh = 2}, 1: {1, 2}, 2: {0, 1}, 3: {0}  (the transposed row classes), likewise v
-  bf16_t* wdp = it.wph + total;
-  const long total2 = 16L * it.Cin * it.Cout;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total2; e += (long)gridDim.x * blockDim.x) {
-    const int ci = (int)(e / (16L * it.Cout));
-    long r = e - (long)ci * 16 * it.Cout;
-    const int uv = (int)(r / it.Cout), co = (int)(r - (long)uv * it.Cout);
-    const int u = uv >> 2, v = uv & 3;
-    const int kh0 = u == 0 ? 2 : (u == 1 ? 1 : 0), kh1 = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
-    const int kw0 = v == 0 ? 2 : (v == 1 ? 1 : 0), kw1 = v == 0 ? 2 : (v == 1 ? 2 : (v == 2 ? 1 : 0));
-    float s = 0.f;
-    for (int kh = kh0; kh <= kh1; ++kh)
-      for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
-    wdp[e] = f32_to_bf16(s * inv);
+    {   // phase layout element e
+      const long per = (long)Op * 4 * Rp;
+      const int phase = (int)(e / per);
+      long r = e - phase * per;
+      const int o = (int)(r / (4 * Rp));
+      r -= (long)o * 4 * Rp;
+      const int ab = (int)(r / Rp), rr = (int)(r - (long)ab * Rp);
+      int kh0, kh1, kw0, kw1;
+      phase_taps2(it.kind, phase >> 1, ab >> 1, kh0, kh1);
+      phase_taps2(it.kind, phase & 1, ab & 1, kw0, kw1);
+      const int ci = fwd_is_phase ? rr : o, co = fwd_is_phase ? o : rr;
+      float s = 0.f;
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
+      phase_l[e] = f32_to_bf16(s * inv);
+    }
+    {   // gather layout element e
+      const int o = (int)(e / (16L * Rg));
+      long r = e - (long)o * 16 * Rg;
+      const int uv = (int)(r / Rg), rr = (int)(r - (long)uv * Rg);
+      int kh0, kh1, kw0, kw1;
+      phase_taps4(it.kind, uv >> 2, kh0, kh1);
+      phase_taps4(it.kind, uv & 3, kw0, kw1);
+      const int ci = fwd_is_phase ? o : rr, co = fwd_is_phase ? rr : o;
+      float s = 0.f;
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) s += it.w[(((long)kh * 3 + kw) * it.Cin + ci) * it.Cout + co];
+      gather_l[e] = f32_to_bf16(s * inv);
+    }
   }
 }
 
 // phase filters of every upsample-3x3 convolution among the items (at most 8 per launch)
-int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts) {
+int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, const float* const* sigmas, bf16_t* const* outs, const int* cins, const int* couts,
+                              const int* kinds) {
   for (int base = 0; base < n; base += 8) {
     PhasePrepBatch b;
     const int m = n - base < 8 ? n - base : 8;
     long maxel = 0;
     for (int i = 0; i < m; ++i) {
-      b.it[i] = {ws[base + i], sigmas[base + i], outs[base + i], cins[base + i], couts[base + i]};
+      b.it[i] = {ws[base + i], sigmas[base + i], outs[base + i], cins[base + i], couts[base + i], kinds[base + i]};
       const long el = 16L * cins[base + i] * couts[base + i];
       if (el > maxel) maxel = el;
     }
@@ -1275,15 +1302,15 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
   // the summed phase filters of the upsample-3x3 convolutions
   std::vector<const float*> pw_, ps_;
   std::vector<bf16_t*> po_;
-  std::vector<int> pci, pco;
+  std::vector<int> pci, pco, pk;
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc& d = items[i].desc;
     if (!mfma_phase_filters(&d)) continue;
     pw_.push_back(items[i].w); ps_.push_back(items[i].sigma);
     po_.push_back((bf16_t*)items[i].prepared + 2 * (size_t)d.kh * d.kw * d.cin * d.cout);
-    pci.push_back(d.cin); pco.push_back(d.cout);
+    pci.push_back(d.cin); pco.push_back(d.cout); pk.push_back((d.flags & RCGAN_CONV_OUT_MEANPOOL2) ? 1 : 0);
   }
-  if (!pw_.empty()) return conv_prepare_phase_launch(ctx, (int)pw_.size(), pw_.data(), ps_.data(), po_.data(), pci.data(), pco.data());
+  if (!pw_.empty()) return conv_prepare_phase_launch(ctx, (int)pw_.size(), pw_.data(), ps_.data(), po_.data(), pci.data(), pco.data(), pk.data());
   return RCGAN_OK;
 }
 
@@ -1314,7 +1341,15 @@ bool mfma_eligible(const rcgan_conv_desc* d) {
 // an upsample-3x3 convolution on the matrix-core path: its prepared buffer carries the four summed phase filters behind the two
 // ordinary layouts (16 * cin * cout elements)
 bool mfma_phase_filters(const rcgan_conv_desc* d) {
-  return mfma_eligible(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) && d->kh == 3 && d->kw == 3;
+  return mfma_eligible(d) && (d->flags & (RCGAN_CONV_IN_UPSAMPLE2X | RCGAN_CONV_OUT_MEANPOOL2)) && d->kh == 3 && d->kw == 3;
+}
+
+// ConvMeanPool with the pool folded in (RCGAN_CONV_OUT_MEANPOOL2): power-of-two images, whole 64-pixel tiles of pooled pixels
+bool mfma_pool_ok(const rcgan_conv_desc* d) {
+  static const int on = env_int("RCGAN_FUSED_POOL", 1);
+  if (!on || !mfma_phase_filters(d) || !(d->flags & RCGAN_CONV_OUT_MEANPOOL2) || (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) return false;
+  const int lw = ilog2_exact(d->w), lh = ilog2_exact(d->h);
+  return lw >= 1 && lh >= 1 && ((long)d->n * (d->h / 2) * (d->w / 2)) % 64 == 0;
 }
 
 // the data gradient of such a layer in the sub-pixel form: power-of-two images, whole 64-pixel tiles of low-resolution pixels
@@ -1460,6 +1495,15 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
   MfmaConvArgs a = a_in;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
+  if (a.phase == 1) {
+    // forced sub-pixel form (the data gradient of a ConvMeanPool: a.wt is not a usable fallback): same routing as below
+    static const int p8_min1 = env_int("RCGAN_P8_MINBLK", 200), p8n_min1 = env_int("RCGAN_P8N_MINBLK", 190), ks2_max1 = env_int("RCGAN_KS2_MAXBLK", 576);
+    const long b8 = (a.M / 256) * (a.Cout / 256);
+    if ((a.M >> 2) % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min1 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);
+    if ((a.M >> 2) % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= p8n_min1) return mfma_conv8_launch(ctx, a, false);
+    if ((a.M / 64) * (a.Cout / 64) <= ks2_max1) return launch_conv_glds_phase<64, 64, 2, 2, 1>(ctx, a);
+    return launch_conv_glds_phase<64, 64, 2, 1, 1>(ctx, a);
+  }
   if (a.phase == 2) {
     // data gradient of the sub-pixel form (the caller checked mfma_phase_dgrad_ok): 256-pixel tiles where the grid fills
     // the chip, else the 64 x 64 kernel

@@ -758,7 +758,7 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   const bool phase = up_phase && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % 256) == 0;
   if (wide) {
     MfmaConvArgs b = a;
-    b.phase = a.phase == 2 ? 2 : (phase ? 1 : 0);
+    b.phase = a.phase ? a.phase : (phase ? 1 : 0);
     b.stamps = (unsigned long long*)ctx->dbg_stamps;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
@@ -768,6 +768,6 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
     return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }
   MfmaConvArgs b = a;
-  b.phase = a.phase == 2 ? 2 : (phase ? 1 : 0);
+  b.phase = a.phase ? a.phase : (phase ? 1 : 0);
   return b.relu_in ? launch8n<true>(ctx, b) : launch8n<false>(ctx, b);
 }

@@ -255,6 +255,63 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     return y
 
 
+def conv_meanpool_ok(ctx, x, weight, k=3):
+    """conv2d_meanpool takes this layer (16-bit activations, 3x3, power-of-two image, channels % 64 == 0, whole tiles)."""
+    if x.dtype == L.F32 or k != 3:
+        return False
+    n, h, w, cin = x.shape
+    desc = L.ConvDesc(n, h, w, cin, weight.param.shape[-1], 3, 3, 1, x.dtype, L.CONV_OUT_MEANPOOL2)
+    return bool(ctx.lib.rcgan_conv_fused_pool_ok(C.byref(desc)))
+
+
+def conv2d_meanpool(ctx, x, weight, bias, in_relu=False, accumulate_into=None):
+    """ConvMeanPool (gan_resnet.py:241-247): meanpool2(conv3x3(x) + bias) as ONE 4x4 stride-2 convolution with summed filters
+    (RCGAN_CONV_OUT_MEANPOOL2: 4/9 of the multiply-adds, no full-resolution conv output, no pooling pass).  accumulate_into: a
+    pooled-resolution tensor the result is added to (the block's shortcut).  Backward: the data gradient in the sub-pixel form
+    straight from the pooled dy; the filter gradient goes through the ordinary grouped path on dy spread back to the
+    conv resolution (d meanpool)."""
+    n, h, w, cin = x.shape
+    cout = weight.param.shape[-1]
+    assert weight.param.shape == (3, 3, cin, cout)
+    flags = L.CONV_OUT_MEANPOOL2 | (L.CONV_IN_RELU if in_relu else 0)
+    desc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, flags)
+    prep = weight.prepared(desc)
+    if accumulate_into is not None:
+        y = accumulate_into
+        assert y.shape == (n, h // 2, w // 2, cout)
+        fdesc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, flags | L.CONV_ACCUMULATE)
+    else:
+        y = ctx.empty((n, h // 2, w // 2, cout), x.dtype)
+        fdesc = desc
+    ctx.check(ctx.lib.rcgan_conv2d_fwd(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(y)))
+    prev_req = y.req if accumulate_into is not None else False
+    if _track(ctx, y, x, weight.param, bias) or prev_req:
+        y.req = True
+        xr, wr, br = x.req, weight.req, (bias is not None and bias.req)
+
+        def bw():
+            dy = y.grad
+            if dy is None:
+                return
+            if wr:
+                # dL/d(conv output) = dy spread over each 2x2 block / 4: the filter (and bias) gradient of the plain convolution
+                dyf = ctx.empty((n, h, w, cout), x.dtype)
+                ctx.check(ctx.lib.rcgan_meanpool2_bwd(ctx.h, n, h, w, cout, x.dtype, _p(dy), _p(dyf), 0))
+                wdesc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, L.CONV_IN_RELU if in_relu else 0)
+                if ctx.group_wgrads:
+                    ctx.defer_wgrad(wdesc, x, dyf, weight.grad_target(), bias.grad if br else None)
+                else:
+                    ctx.check(ctx.lib.rcgan_conv2d_bwd_weight(ctx.h, C.byref(wdesc), _p(x), _p(dyf), _p(weight.grad_target()),
+                                                              _p(bias.grad) if br else None, 1, C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            if xr:
+                dx, acc = grad_of(ctx, x)
+                d2 = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, flags | (L.CONV_ACCUMULATE if acc else 0))
+                ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
+                                                        _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        ctx.record(bw)
+    return y
+
+
 def d_trunk_ok(ctx, x):
     """The fused 8x8 discriminator stage takes 16-bit [n, 8, 8, 128] activations."""
     return x.dtype != L.F32 and tuple(x.shape[1:]) == (8, 8, 128)

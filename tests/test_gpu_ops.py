@@ -266,6 +266,56 @@ def test_conv_persistent_tiles(dev, case):
         assert_close(ctx.download(xd.grad), dx, tol, "persistent conv dgrad %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(4, 32, 32, 128, 128, True, True),      # 64 x 64 kernel both ways, accumulating into a shortcut
+                                  (8, 16, 16, 64, 64, False, False),
+                                  (128, 32, 32, 128, 128, True, False),    # D.Block.1.Conv2 at the bench batch: 256 x 128 kernel for dx
+                                  (128, 16, 16, 128, 128, True, True)])    # D.Block.2.Conv2
+def test_conv2d_meanpool(dev, case):
+    """ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution with summed filters forward, the
+    sub-pixel form for the data gradient, the ordinary grouped filter gradient on the spread dy) against conv -> mean pool."""
+    import torch.nn.functional as F
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the folded pool runs on the 16-bit matrix-core path")
+    n, h, w, cin, cout, relu, acc = case
+    rs = np.random.RandomState(n * 7 + cin)
+    x = _prep(rs.randn(n, h, w, cin).astype(np.float32), mode)
+    wgt = half_round(mode, (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32))
+    b = rs.randn(cout).astype(np.float32)
+    ctx.new_step()
+    xd = ctx.upload(x)
+    xd.req = True
+    wp, bp = FakeParam(ctx, wgt), FakeParam(ctx, b)
+    W = O.Weight(ctx, wp.t)
+    assert O.conv_meanpool_ok(ctx, xd, W)
+    full = _torch_conv_ref(x, wgt, False, relu) + b
+    ref = full.reshape(n, h // 2, 2, w // 2, 2, cout).mean(axis=(2, 4))
+    t0 = None
+    if acc:
+        t0 = _prep(rs.randn(n, h // 2, w // 2, cout).astype(np.float32), mode)
+        ref = ref + t0
+    y = O.conv2d_meanpool(ctx, xd, W, bp.t, in_relu=relu, accumulate_into=ctx.upload(t0) if acc else None)
+    assert_close(ctx.download(y), ref, 2 * TOL[mode], "conv+meanpool fwd %s" % (case,))       # sums of up to four taps rounded once
+    dy = _prep(rs.randn(*ref.shape).astype(np.float32), mode)
+    y.grad = ctx.upload(dy)
+    ctx.group_wgrads, keep = True, ctx.group_wgrads
+    ctx.backward()
+    ctx.group_wgrads = keep
+    dyf = np.repeat(np.repeat(dy, 2, axis=1), 2, axis=2) * 0.25
+    wf = np.ascontiguousarray(wgt[::-1, ::-1].transpose(0, 1, 3, 2))
+    dx = _torch_conv_ref(dyf, wf)
+    if relu:
+        dx = dx * (x > 0)
+    assert_close(ctx.download(xd.grad), dx, 2 * TOL[mode], "conv+meanpool dgrad %s" % (case,))
+    xin = np.maximum(x, 0) if relu else x
+    xt = torch.from_numpy(np.ascontiguousarray(xin)).permute(0, 3, 1, 2).double()
+    gt = torch.from_numpy(np.ascontiguousarray(half_round(mode, dyf))).permute(0, 3, 1, 2).double()
+    dw = torch.nn.grad.conv2d_weight(xt, (cout, cin, 3, 3), gt, padding=1).permute(2, 3, 1, 0).numpy()
+    assert_close(wp.grad(ctx), dw, 2e-2 if mode in HALF else 2e-4, "conv+meanpool wgrad %s" % (case,))
+    assert_close(bp.grad(ctx), dyf.astype(np.float64).sum((0, 1, 2)), 2e-2, "conv+meanpool bias grad %s" % (case,))
+
+
 @pytest.mark.parametrize("n", [3, 128])
 def test_d_trunk_equals_layerwise_blocks(dev, n):
     """The fused 8x8 discriminator stage (four residual blocks, eight 3x3 convolutions in one launch each way, activations
