@@ -1233,11 +1233,80 @@ int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, con
 
 // batched preparation: every filter of a network in ONE launch (blockIdx.y = filter)
 struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
-struct PrepBatch { PrepItem it[48]; };
+// rows = the n filters, then the phase filters; row r owns workgroups [start[r], start[r+1]) of the one-dimensional grid
+struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[58]; int n, rows; };
+
+// One (64 ci x 64 co tile, tap class) unit of the summed filters of the sub-pixel forms (layouts and tap classes: see
+// conv_prepare_phase_kernel, whose values these are bit for bit -- same fp32 summation order).  The filter is read along co;
+// the layout whose reduction index is co is written straight from registers, the one whose reduction index is ci goes through
+// an LDS transpose, so all three streams are coalesced (the element-per-thread kernel read one of its two layouts with a stride
+// of Cout floats per lane: 20 us for two 128 x 128 filters).
+__device__ __forceinline__ void prepare_phase_units(const PhasePrepBatch::It& p, bf16_t (*tile)[66], int bid, int nb) {
+  const float inv = (p.sigma ? 1.f / *p.sigma : 1.f) * (p.kind == 1 ? 0.25f : 1.f);
+  const long total = 16L * p.Cin * p.Cout;
+  bf16_t* const phase_l = p.kind == 0 ? p.wph : p.wph + total;
+  bf16_t* const gather_l = p.kind == 0 ? p.wph + total : p.wph;
+  const bool fwd_is_phase = p.kind == 0;
+  const int nco = p.Cout / 64, units = (p.Cin / 64) * nco * 32;
+  const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int unit = bid; unit < units; unit += nb) {
+    const int cls = unit & 31, tl = unit >> 5, c = cls & 15;
+    const int co0 = (tl % nco) * 64, ci0 = (tl / nco) * 64;
+    const bool is_phase = cls < 16;
+    int kh0, kh1, kw0, kw1;
+    if (is_phase) { phase_taps2(p.kind, c >> 3, (c >> 1) & 1, kh0, kh1); phase_taps2(p.kind, (c >> 2) & 1, c & 1, kw0, kw1); }
+    else { phase_taps4(p.kind, c >> 2, kh0, kh1); phase_taps4(p.kind, c & 3, kw0, kw1); }
+    const bool o_is_co = is_phase ? fwd_is_phase : !fwd_is_phase;
+    const int O = o_is_co ? p.Cout : p.Cin, R = o_is_co ? p.Cin : p.Cout;
+    bf16_t* const dst = is_phase ? phase_l + (long)(c >> 2) * O * 4 * R + (long)(c & 3) * R : gather_l + (long)c * R;
+    const long ostride = is_phase ? 4L * R : 16L * R;
+    __syncthreads();
+    // all 16 rows x (up to) 4 taps requested before the first sum: one memory round trip per unit instead of a chain of 64
+    const float* src[4];
+    bool on[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kh = kh0 + (j >> 1), kw = kw0 + (j & 1);
+      on[j] = kh <= kh1 && kw <= kw1;
+      src[j] = p.w + (((long)(on[j] ? kh * 3 + kw : 0)) * p.Cin + ci0 + grp) * p.Cout + co0 + lane64;
+    }
+    float v[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = on[j] ? src[j][(long)i * 4 * p.Cout] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = i * 4 + grp;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += v[i][j];        // (kh, kw) ascending, absent taps add +0: the sum of the nested tap loops
+      const bf16_t h = f32_to_bf16(s * inv);
+      if (o_is_co) tile[ci][lane64] = h;
+      else dst[(long)(ci0 + ci) * ostride + co0 + lane64] = h;
+    }
+    if (o_is_co) {
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int co = i * 4 + grp;
+        dst[(long)(co0 + co) * ostride + ci0 + lane64] = tile[lane64][co];
+      }
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
   __shared__ bf16_t tile[64][66];
-  const PrepItem it = b.it[blockIdx.y];
+  int row = 0;                                   // largest r with start[r] <= blockIdx.x (six dependent scalar loads, not 57)
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {
+    const int r = row + step;
+    if (r < b.rows && (int)blockIdx.x >= b.start[r]) row = r;
+  }
+  const int bid = (int)blockIdx.x - b.start[row], nb = b.start[row + 1] - b.start[row];
+  if (row >= b.n) { prepare_phase_units(b.ph[row - b.n], tile, bid, nb); return; }
+  const PrepItem it = b.it[row];
   const long total = (long)it.T * it.Cin * it.Cout;
   const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
   if (it.mfma) {
@@ -1248,14 +1317,17 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
     const int nci = it.Cin / 64, nco = it.Cout / 64;
     const int ntiles = it.T * nci * nco;
     const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    for (int tl = bid; tl < ntiles; tl += nb) {
       const int cot = tl % nco, cit = (tl / nco) % nci, t = tl / (nco * nci);
       const int ci0 = cit * 64, co0 = cot * 64;
       __syncthreads();
-#pragma unroll 4
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = it.w[((long)t * it.Cin + ci0 + i * 4 + grp) * it.Cout + co0 + lane64];     // one round trip
+#pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ci = i * 4 + grp;
-        const bf16_t h = f32_to_bf16(it.w[((long)t * it.Cin + ci0 + ci) * it.Cout + co0 + lane64] * inv);
+        const bf16_t h = f32_to_bf16(v[i] * inv);
         wd[(long)(ci0 + ci) * it.T * it.Cout + (long)(it.T - 1 - t) * it.Cout + co0 + lane64] = h;
         tile[ci][lane64] = h;
       }
@@ -1268,38 +1340,21 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
     }
     return;
   }
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+  for (long idx = (long)bid * blockDim.x + threadIdx.x; idx < total; idx += (long)nb * blockDim.x)
     ((float*)it.out)[idx] = it.w[idx] * inv;
   if (it.img) {      // bf16 layouts of the image-end kernels (conv_image.hip)
     const int cb = it.img == 1 ? it.Cout : it.Cin;
     const long extra = (long)cb * 32 + (long)it.T * 16 * cb;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < extra; e += (long)gridDim.x * blockDim.x)
+    for (long e = (long)bid * blockDim.x + threadIdx.x; e < extra; e += (long)nb * blockDim.x)
       ((bf16_t*)it.extra)[e] = img_prepare_elem(e, it.img, it.T, it.Cin, it.Cout, it.w, inv);
   }
 }
 
+static int env_int(const char* name, int dflt);
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n) {
-  for (int base = 0; base < n; base += 48) {
-    PrepBatch b;
-    int m = n - base < 48 ? n - base : 48;
-    long maxel = 0;
-    for (int i = 0; i < m; ++i) {
-      const rcgan_prepare_item& s = items[base + i];
-      rcgan_conv_desc d = s.desc;
-      b.it[i].w = s.w; b.it[i].sigma = s.sigma; b.it[i].out = s.prepared;
-      b.it[i].T = d.kh * d.kw; b.it[i].Cin = d.cin; b.it[i].Cout = d.cout; b.it[i].mfma = mfma_eligible(&d) ? 1 : 0;
-      b.it[i].img = b.it[i].mfma ? 0 : img_side(&d);
-      b.it[i].extra = b.it[i].img ? (char*)s.prepared + img_extra_offset(&d) : nullptr;
-      long el = (long)d.kh * d.kw * d.cin * d.cout;
-      if (el > maxel) maxel = el;
-    }
-    int bx = cdiv(maxel, 4096 * 2);      // two 64x64 tiles per workgroup for the largest filter
-    if (bx < 1) bx = 1;
-    if (bx > 288) bx = 288;
-    hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(bx, m), dim3(256), 0, ctx->stream, b);
-    RC_LAUNCH_CHECK(ctx);
-  }
-  // the summed phase filters of the upsample-3x3 convolutions
+  // the summed phase filters of the sub-pixel forms (upsample-3x3, ConvMeanPool): up to 8 of them ride as extra rows of the
+  // first launch's grid, the rest (none in these networks) take the stand-alone kernel
+  static const int ride = env_int("RCGAN_PREP_PHASE_RIDE", 1);
   std::vector<const float*> pw_, ps_;
   std::vector<bf16_t*> po_;
   std::vector<int> pci, pco, pk;
@@ -1310,7 +1365,47 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
     po_.push_back((bf16_t*)items[i].prepared + 2 * (size_t)d.kh * d.kw * d.cin * d.cout);
     pci.push_back(d.cin); pco.push_back(d.cout); pk.push_back((d.flags & RCGAN_CONV_OUT_MEANPOOL2) ? 1 : 0);
   }
-  if (!pw_.empty()) return conv_prepare_phase_launch(ctx, (int)pw_.size(), pw_.data(), ps_.data(), po_.data(), pci.data(), pco.data(), pk.data());
+  int nride = ride ? (int)pw_.size() : 0;
+  if (nride > 8) nride = 8;
+  for (int base = 0; base < n; base += 48) {
+    PrepBatch b;
+    int m = n - base < 48 ? n - base : 48;
+    b.n = m;
+    const int np = base == 0 ? nride : 0;
+    for (int i = 0; i < np; ++i) b.ph[i] = {pw_[i], ps_[i], po_[i], pci[i], pco[i], pk[i]};
+    // workgroups per row: one 64 x 64 tile (MFMA layouts) or 256 elements each, at most 512 per filter; a phase filter has
+    // (Cin/64)(Cout/64) * 32 units (tile x tap class), one per workgroup up to 1024
+    int at = 0;
+    for (int i = 0; i < m; ++i) {
+      const rcgan_prepare_item& s = items[base + i];
+      rcgan_conv_desc d = s.desc;
+      b.it[i].w = s.w; b.it[i].sigma = s.sigma; b.it[i].out = s.prepared;
+      b.it[i].T = d.kh * d.kw; b.it[i].Cin = d.cin; b.it[i].Cout = d.cout; b.it[i].mfma = mfma_eligible(&d) ? 1 : 0;
+      b.it[i].img = b.it[i].mfma ? 0 : img_side(&d);
+      b.it[i].extra = b.it[i].img ? (char*)s.prepared + img_extra_offset(&d) : nullptr;
+      const long el = (long)d.kh * d.kw * d.cin * d.cout;
+      // (the image-end layouts gather up to 27 taps per element: one element per thread)
+      const long img_el = b.it[i].img ? (long)(b.it[i].img == 1 ? d.cout : d.cin) * (32 + b.it[i].T * 16) : 0;
+      long want = b.it[i].mfma ? el / 4096 : cdiv(el > img_el ? el : img_el, 256);
+      if (want < 1) want = 1;
+      if (want > 512) want = 512;
+      b.start[i] = at;
+      at += (int)want;
+    }
+    for (int i = 0; i < np; ++i) {
+      const long units = (long)(pci[i] / 64) * (pco[i] / 64) * 32;
+      b.start[m + i] = at;
+      at += units > 1024 ? 1024 : (int)units;
+    }
+    b.rows = m + np;
+    b.start[m + np] = at;
+    hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(at), dim3(256), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  const int rest = (int)pw_.size() - nride;
+  if (rest > 0)
+    return conv_prepare_phase_launch(ctx, rest, pw_.data() + nride, ps_.data() + nride, po_.data() + nride, pci.data() + nride, pco.data() + nride,
+                                     pk.data() + nride);
   return RCGAN_OK;
 }
 

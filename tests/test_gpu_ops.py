@@ -3,6 +3,8 @@ seeded inputs.  fp32 activations: tolerance 2e-5 of the reference's scale (fp32 
 noise only).  bf16 activations: inputs are rounded to bf16 on the host first, so what remains is fp32
 accumulation order + one bf16 rounding of the stored result: tolerance 1e-2 (bf16 has 8 mantissa bits,
 half-ulp 2^-9 = 0.2 %; sums of a few roundings stay well under 1 %)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -314,6 +316,40 @@ def test_conv2d_meanpool(dev, case):
     dw = torch.nn.grad.conv2d_weight(xt, (cout, cin, 3, 3), gt, padding=1).permute(2, 3, 1, 0).numpy()
     assert_close(wp.grad(ctx), dw, 2e-2 if mode in HALF else 2e-4, "conv+meanpool wgrad %s" % (case,))
     assert_close(bp.grad(ctx), dyf.astype(np.float64).sum((0, 1, 2)), 2e-2, "conv+meanpool bias grad %s" % (case,))
+
+
+def test_batched_phase_filters_equal_single_calls(dev):
+    """The summed sub-pixel filters written by the batched preparation (tile x tap-class units riding in the grid of
+    conv_prepare_batch_kernel, LDS transpose) against the one-filter entry point (one element per thread): every byte of the
+    prepared buffers -- both ordinary layouts and both summed layouts, upsample and mean-pool families, with and without sigma."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the sub-pixel forms run on the 16-bit matrix-core path")
+    rs = np.random.RandomState(5)
+    ctx.new_step()
+    shapes = [(1024, 256, L.CONV_IN_UPSAMPLE2X, False), (256, 256, L.CONV_IN_UPSAMPLE2X, False), (128, 128, L.CONV_OUT_MEANPOOL2, True),
+              (128, 128, L.CONV_OUT_MEANPOOL2, True), (64, 192, L.CONV_IN_UPSAMPLE2X, True), (192, 64, L.CONV_OUT_MEANPOOL2, False),
+              (128, 128, 0, True)]
+    ws, items = [], []
+    for cin, cout, flags, sn in shapes:
+        wp = FakeParam(ctx, (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32))
+        sigma = ctx.upload(np.array([1.7], np.float32)) if sn else None
+        ws.append((O.Weight(ctx, wp.t, sigma), flags))
+        items.append((ws[-1][0], 3, 1, 8, flags))
+    O.prepare_batch(ctx, items, ctx.act_dtype)
+    for (w, flags), (cin, cout, _, _) in zip(ws, shapes):
+        desc = L.ConvDesc(1, 8, 8, cin, cout, 3, 3, 1, ctx.act_dtype, flags)
+        nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
+        (batched,) = w._prepared.values()
+        assert batched.shape == (nbytes,)
+        w._prepared.clear()
+        single = w.prepared(desc)
+        raw = lambda t: t.base.view(torch.uint8).reshape(-1)[t.ptr - t.base.data_ptr():][:nbytes - 256].cpu().numpy()
+        a, b = raw(batched), raw(single)
+        assert a.size == (18 + (32 if flags else 0)) * cin * cout * 2
+        assert np.array_equal(a, b), "prepared bytes differ for %s: first at %d" % ((cin, cout, flags), int(np.flatnonzero(a != b)[0]))
 
 
 @pytest.mark.parametrize("n", [3, 128])
