@@ -106,7 +106,9 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
 #define RCGAN_CONV_FORCE_DIRECT 8   /* testing: bypass the MFMA path */
 #define RCGAN_CONV_OUT_MEANPOOL2 16 /* ConvMeanPool (gan_resnet.py:241-247): the 2x2 mean pool folded into the convolution -- y [n,h/2,w/2,cout] =
                                       * meanpool2(conv(x)) + bias, computed as ONE 4x4 stride-2 convolution with summed filters (4/9 of the
-                                      * multiply-adds); forward and data gradient only, and only where rcgan_conv_fused_pool_ok says so */
+                                      * multiply-adds), only where rcgan_conv_fused_pool_ok says so.  In rcgan_conv2d_bwd_weight[_group] the
+                                      * flag means "dy is the POOLED gradient [n,h/2,w/2,cout]" (sub-pixel filter gradient, 4/9 of the
+                                      * multiply-adds, no spread dy), only where rcgan_conv_wgrad_pool_ok says so */
 
 typedef struct rcgan_conv_desc {
   int n, h, w, cin;   /* logical conv input: after the 2x upsample when IN_UPSAMPLE2X is set */
@@ -153,7 +155,11 @@ int rcgan_conv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
 int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared,
                                    const void* x /* IN_RELU mask or NULL */, const void* residual, void* dx, void* ws, size_t ws_bytes);
 /* dw (fp32 HWIO) = d(conv)/dw (dw = or += by accumulate), dbias = sum dy (if non-NULL).
- * Replaces tf.nn.conv2d_backprop_filter + BiasAddGrad. */
+ * Replaces tf.nn.conv2d_backprop_filter + BiasAddGrad.  Upsample-3x3 (IN_UPSAMPLE2X: x stored at [n,h/2,w/2,cin]) and
+ * ConvMeanPool (OUT_MEANPOOL2: dy pooled) layers on the matrix cores are computed in their sub-pixel form: 16 Cin x Cout
+ * products over the low-resolution grid folded into the 9 taps by the slab reduction, instead of 9 over the full one. */
+/* 1 if rcgan_conv2d_bwd_weight takes d with RCGAN_CONV_OUT_MEANPOOL2 (dy = the pooled gradient) */
+int rcgan_conv_wgrad_pool_ok(const rcgan_conv_desc* d);
 int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
                             float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
 /* The filter gradients of `n` layers in one call (all x / dy available: the end of a backward pass).  Same results as n

@@ -86,6 +86,7 @@ SIGNATURES = {
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),
+    "rcgan_conv_wgrad_pool_ok": (I, [DP]),
     "rcgan_conv2d_fwd_residual": (I, [P, DP, P, P, P, P, P]),
     "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),
     "rcgan_conv2d_bwd_data_residual": (I, [P, DP, P, P, P, P, P, P, SZ]),

@@ -45,6 +45,8 @@ struct SlabReduceGroup {
     const float* slab; long stride; float* out; long count; float* bias_out; int nbias, nz, accumulate;
     long bias_off;          // slab index of the first bias sum (= count for the three-tap / per-tap slabs)
     int orient, Cb, Cs;     // orient 1: transposed image-end mapping
+    int sub;                // 1 / 2: the slab holds the 16 cells of the sub-pixel form (MfmaWgradArgs::sub), folded into the 9 taps here
+    long cc;                // Cin * Cout (sub only)
   } it[REDUCE_GROUP_MAX];
 };
 __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
@@ -53,8 +55,29 @@ __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
   if (i >= r.count + r.nbias) return;
   const long si = i < r.count ? i : r.bias_off + (i - r.count);
   float s = 0.f;
+  if (r.sub && i < r.count) {
+    // dW[kh][kw] = scale * sum over the parities (pa, pb) of G[pa][pb][S(pa, kh)][S(pb, kw)]
+    const int tap = (int)(i / r.cc), kh = tap / 3, kw = tap - kh * 3;
+    const long rem = i - (long)tap * r.cc;
+    long c4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pa = q >> 1, pb = q & 1;
+      // S(sub 1): parity 0 -> 0,1,1; parity 1 -> 0,0,1.  S(sub 2): the other way round
+      const int sa = ((r.sub == 1) == (pa == 0)) ? (kh >= 1) : (kh >= 2);
+      const int sb = ((r.sub == 1) == (pb == 0)) ? (kw >= 1) : (kw >= 2);
+      c4[q] = (long)(q * 4 + sa * 2 + sb) * r.cc + rem;
+    }
+#pragma unroll 2
+    for (int z = 0; z < r.nz; ++z) {
+      const float* sl = r.slab + (long)z * r.stride;
+      s += (sl[c4[0]] + sl[c4[1]]) + (sl[c4[2]] + sl[c4[3]]);
+    }
+    if (r.sub == 2) s *= 0.25f;
+  } else {
 #pragma unroll 4
-  for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
+    for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
+  }
   float* o;
   if (i >= r.count) o = r.bias_out + (i - r.count);
   else if (r.orient == 0) o = r.out + i;
@@ -563,6 +586,43 @@ int rcgan_conv2d_bwd_data_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, con
   return RCGAN_OK;
 }
 
+// The matrix-core filter-gradient problem of a layer (everything but the slab).  Upsample-3x3 and ConvMeanPool layers the
+// three-tap kernel takes are posed in their sub-pixel form (MfmaWgradArgs::sub): reduction over the low-resolution grid.
+static void wgrad_args_from_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, bool want_bias, MfmaWgradArgs& a) {
+  int oh, ow, pt, pl;
+  same_pad(d->h, d->kh, 1, &oh, &pt);
+  same_pad(d->w, d->kw, 1, &ow, &pl);
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = nullptr;
+  a.zero = (const bf16_t*)ctx->zero_page;
+  a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
+  a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+  a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+  a.use_tr = g_use_tr;
+  a.sub = mfma_wgrad_sub_kind(d, g_use_tr);
+  if (a.sub) { a.H >>= 1; a.W >>= 1; a.up = 0; }
+  a.cells = a.sub ? 16 : d->kh * d->kw;
+  a.M = (long)d->n * a.H * a.W;
+  a.lw = ilog2_exact(a.W); a.lh = ilog2_exact(a.H);
+  if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
+  a.slab_stride = (long)a.cells * d->cin * d->cout + d->cout;
+  a.want_bias = want_bias ? 1 : 0;
+  a.m_chunk = 0;
+}
+
+static SlabReduceGroup::Item wgrad_reduce_item(const rcgan_conv_desc* d, const MfmaWgradArgs& a, float* dw, float* dbias, int nbias, int nz, int accumulate) {
+  SlabReduceGroup::Item it = {};
+  it.slab = a.slab; it.stride = a.slab_stride; it.out = dw; it.count = (long)d->kh * d->kw * d->cin * d->cout;
+  it.bias_out = dbias; it.nbias = nbias; it.nz = nz; it.accumulate = accumulate;
+  it.bias_off = (long)a.cells * d->cin * d->cout;
+  it.sub = a.sub; it.cc = (long)d->cin * d->cout;
+  return it;
+}
+
+int rcgan_conv_wgrad_pool_ok(const rcgan_conv_desc* d) {
+  // (before the self test has run the transposing LDS read counts as available; rcgan_conv2d_bwd_weight re-checks)
+  return d && (d->flags & RCGAN_CONV_OUT_MEANPOOL2) && mfma_wgrad_sub_kind(d, g_use_tr < 0 ? 1 : g_use_tr) == 2 ? 1 : 0;
+}
+
 int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                             int accumulate, void* ws, size_t ws_bytes) {
   int rc = check_desc(ctx, d);
@@ -571,30 +631,26 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     rc = ensure_selftest(ctx);
     if (rc) return rc;
     MfmaWgradArgs a;
-    int oh, ow, pt, pl;
-    same_pad(d->h, d->kh, 1, &oh, &pt);
-    same_pad(d->w, d->kw, 1, &ow, &pl);
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
-    a.zero = (const bf16_t*)ctx->zero_page;
-    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
-    a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
-    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
-    a.use_tr = g_use_tr;
-    a.M = (long)d->n * d->h * d->w;
-    a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
-    if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
-    int nz = mfma_wgrad_splits(d, a.M);
+    wgrad_args_from_desc(ctx, d, x, dy, dbias != nullptr, a);
+    if ((d->flags & RCGAN_CONV_OUT_MEANPOOL2) && a.sub != 2)
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "filter gradient from the pooled dy needs the sub-pixel three-tap kernel (rcgan_conv_wgrad_pool_ok)");
+    a.slab = (float*)ws;
+    int nz = a.sub ? mfma_wgrad_sub_splits(d, a.M) : mfma_wgrad_splits(d, a.M);
     long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-    a.slab_stride = cnt + d->cout;
-    a.want_bias = dbias ? 1 : 0;
     size_t need = (size_t)nz * a.slab_stride * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     bool bias_done = false;
     int nzz = mfma_wgrad_launch(ctx, a, nz, &bias_done);
     if (nzz < 0) return nzz;
     const int nb = bias_done ? d->cout : 0;
-    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(cnt + nb, 256)), dim3(256), 0, ctx->stream, (const float*)a.slab, a.slab_stride, dw, cnt,
-                       dbias, nb, nzz, accumulate);
+    if (a.sub) {
+      SlabReduceGroup g;
+      for (int q = 0; q < REDUCE_GROUP_MAX; ++q) g.it[q] = wgrad_reduce_item(d, a, dw, dbias, nb, nzz, accumulate);
+      hipLaunchKernelGGL(slab_reduce2_group_kernel, dim3(cdiv(cnt + nb, 256), 1), dim3(256), 0, ctx->stream, g);
+    } else {
+      hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(cnt + nb, 256)), dim3(256), 0, ctx->stream, (const float*)a.slab, a.slab_stride, dw, cnt,
+                         dbias, nb, nzz, accumulate);
+    }
     RC_LAUNCH_CHECK(ctx);
     if (dbias && !bias_done) {
       float* part = (float*)((char*)ws + (size_t)nz * a.slab_stride * sizeof(float));
@@ -630,23 +686,13 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     rc = ensure_selftest(ctx);
     if (rc) return rc;
     MfmaWgradArgs& a = cand[i];
-    int oh, ow, pt, pl;
-    same_pad(d->h, d->kh, 1, &oh, &pt);
-    same_pad(d->w, d->kw, 1, &ow, &pl);
-    a.x = (const bf16_t*)xs[i]; a.dy = (const bf16_t*)dys[i]; a.slab = nullptr;
-    a.zero = (const bf16_t*)ctx->zero_page;
-    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw; a.PT = pt; a.PL = pl;
-    a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
-    a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
-    a.use_tr = g_use_tr;
-    a.M = (long)d->n * d->h * d->w;
-    a.lw = ilog2_exact(d->w); a.lh = ilog2_exact(d->h);
-    if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
-    a.slab_stride = (long)d->kh * d->kw * d->cin * d->cout + d->cout;
-    a.want_bias = dbiases[i] ? 1 : 0;
+    wgrad_args_from_desc(ctx, d, xs[i], dys[i], dbiases[i] != nullptr, a);
+    if ((d->flags & RCGAN_CONV_OUT_MEANPOOL2) && a.sub != 2)
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "filter gradient from the pooled dy needs the sub-pixel three-tap kernel (rcgan_conv_wgrad_pool_ok)");
     if (mfma_wgrad3_takes(a)) {
       takes[i] = 1;
-      work += (double)a.M * a.KH * (a.Cin / 64) * (a.Cout / 128);
+      // workgroup-passes over a pixel: 3 filter rows of three taps, or 8 (parity, row shift) tiles of two taps
+      work += (double)a.M * (a.sub ? 8 * 2.0 / 3.0 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
     }
   }
   static const int px_max = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_PXMAX"); return e ? atoi(e) : 6144; }();
@@ -698,9 +744,10 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     }
     if (!grouped && mfma_wgrad_eligible(d)) {
       MfmaWgradArgs a = cand[i];
-      const int nz = mfma_wgrad_splits(d, a.M);
+      const int nz = a.sub ? mfma_wgrad_sub_splits(d, a.M) : mfma_wgrad_splits(d, a.M);
       unsigned gx = 0, gy = 0;
       const bool three = takes[i] && mfma_wgrad3_plan(a, nz, &gx, &gy, px);
+      if (a.sub && !three) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
       if (three || mfma_wgrad_tap_plan(a, nz, &gx, &gy)) {
         const size_t need = ((size_t)gy * a.slab_stride * sizeof(float) + 255) / 256 * 256;
         if (used + need <= ws_bytes / 2) {
@@ -708,9 +755,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
           used += need;
           const int f = three ? (a.relu_in ? 1 : 0) : 2;
           args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
-          const long cnt = (long)d->kh * d->kw * d->cin * d->cout;
-          SlabReduceGroup::Item it = {a.slab, a.slab_stride, dws[i], cnt, dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate, cnt, 0, 0, 0};
-          red.push_back(it);
+          red.push_back(wgrad_reduce_item(d, a, dws[i], dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate));
           grouped = true;
         }
       }

@@ -39,6 +39,18 @@ struct MfmaWgradArgs {
   int up, relu_in, use_tr;
   int lw, lh;
   long M, m_chunk;
+  // Sub-pixel form of the filter gradient of an upsample-3x3 (sub = 1) or ConvMeanPool (sub = 2) layer, three-tap kernel only.
+  // The reduction index runs over the LOW-resolution grid (N, H, W, lw, lh, M describe it; up = 0) and one operand is gathered
+  // with stride 2 at a parity (pa, pb):
+  //   sub 1: G[pa][pb][s][d] = sum_m x[n, i + dh, j + dw] * dy[n, 2i + pa, 2j + pb],   dh = s - 1 + pa, dw = d - 1 + pb
+  //          (x = the stored low-resolution input, dy on the full-resolution grid)
+  //   sub 2: G[pa][pb][s][d] = sum_m x[n, 2(i + dh) + pa, 2(j + dw) + pb] * dy[n, i, j],   dh = s - pa, dw = d - pb
+  //          (x on the full-resolution grid, dy = the POOLED gradient; dW carries the pool's 1/4)
+  // 16 matrices of Cin x Cout over M pixels instead of 9 over 4M: 4/9 of the multiply-adds.  The slab holds the 16 cells
+  // [(pa*2 + pb)*4 + s*2 + d]; the slab reduction folds them into the 9 taps: dW[kh][kw] = scale * sum over the four parities of
+  // G[pa][pb][S(pa, kh)][S(pb, kw)], S(sub 1) = {0: 0,1,1; 1: 0,0,1}, S(sub 2) = {0: 0,0,1; 1: 0,1,1}.
+  int sub;
+  int cells;              // filter cells per slab in front of the bias tail: KH*KW, or 16 in the sub-pixel form
 };
 
 static inline int ilog2_exact(int v) {
@@ -58,6 +70,8 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
 bool mfma_wgrad3_takes(const MfmaWgradArgs& a);
+int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr);
+int mfma_wgrad_sub_splits(const rcgan_conv_desc* d, long M);
 int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
                              const ImgWGroup* img);
 bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);

@@ -821,7 +821,7 @@ __device__ __forceinline__ void wgrad_glds_body(const MfmaWgradArgs& a, const un
       *(float4*)(slab + ((long)tap * a.Cin + ci) * a.Cout + co) = v;
     }
   if (do_bias && (lane & 15) == 0) {
-    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
+    float* bs = slab + (long)a.cells * a.Cin * a.Cout;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *(float4*)(bs + co0 + wo * 64 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
@@ -897,17 +897,20 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
     }
   }
   if ((lane & 15) == 0) {
-    float* bs = slab + (long)a.KH * a.KW * a.Cin * a.Cout;
+    float* bs = slab + (long)a.cells * a.Cin * a.Cout;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       *(float4*)(bs + co0 + wave * 32 + i * 16 + (lane >> 4) * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
   }
 }
 
-template <int NS, bool RELU>
+// SUB: the sub-pixel form (MfmaWgradArgs::sub != 0, checked by the caller): two column taps per workgroup (dw = tb, tb + 1 with
+// tb = -1 or 0 by the column parity) instead of three -- 16 accumulators, the tap rows and the edge mask chosen once per workgroup
+template <int NS, bool RELU, bool SUB>
 __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsigned bx, const unsigned by) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int XT = 40 * 128, YT = 32 * 256, STAGE = XT + YT;
+  constexpr int NT = SUB ? 2 : 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wo = wave >> 1;
@@ -915,8 +918,12 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const long mb = (long)by * a.m_chunk;
   long me = mb + a.m_chunk;
   if (me > a.M) me = a.M;
-  if ((int)bx >= a.KH * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
-    wgrad_bias_block<NS>(a, smem, (int)bx - a.KH * nci * nco, mb, me, a.slab + (long)by * a.slab_stride);
+  const int sub = SUB ? a.sub : 0;
+  const int trows = SUB ? 8 : a.KH;        // tile rows: filter rows kh, or (pa, pb, s) of the sub-pixel form
+  if ((int)bx >= trows * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
+    // (sub 1: dy lives on the full-resolution grid, whose pixels [4 mb, 4 me) are as good a quarter-share as any)
+    wgrad_bias_block<NS>(a, smem, (int)bx - trows * nci * nco, sub == 1 ? 4 * mb : mb, sub == 1 ? 4 * me : me,
+                         a.slab + (long)by * a.slab_stride);
     return;
   }
   int b = (int)bx;
@@ -925,7 +932,10 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const int kh = b;
   const int ci0 = cit * 64, co0 = cot * 128;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
-  const int dh = kh - a.PT;
+  const int pa = kh >> 2, pb = (kh >> 1) & 1, srow = kh & 1;                 // sub-pixel form only
+  const int dh = !SUB ? kh - a.PT : (sub == 1 ? srow - 1 + pa : srow - pa);
+  // first column tap: dw = tap - 1 for the three taps, or dw in {-1, 0} / {0, +1} by the column parity
+  const int tb = !SUB ? -1 : ((sub == 1 ? pb == 0 : pb == 1) ? -1 : 0);
   const int g = lane >> 4, li = lane & 15;
 
   // ---- DMA roles -------------------------------------------------------------------------------
@@ -949,17 +959,25 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
       int ih = oh + dh, iw = ow;
       if (ih >= 0 && ih < a.H) {
         if (a.up) { ih >>= 1; iw >>= 1; }
-        p = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + coff);
+        if (sub == 2) p = a.x + (unsigned)((((unsigned)n * 2 * a.H + 2 * ih + pa) * 2 * a.W + 2 * iw + pb) * a.Cin + coff);
+        else p = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + coff);
       }
     }
     return p;
+  };
+  // dy row of reduction pixel m: itself, or (sub 1) pixel (2i + pa, 2j + pb) of the full-resolution grid
+  auto y_pix = [&](long m) -> unsigned {
+    const unsigned mm = (unsigned)m;
+    if (sub != 1) return mm;
+    const unsigned ow = mm & (unsigned)(a.W - 1), oh = (mm >> a.lw) & (unsigned)(a.H - 1), n = mm >> (a.lw + a.lh);
+    return ((n * 2 * a.H + 2 * oh + pa) * 2 * a.W + 2 * ow + pb);
   };
   long i_p0 = mb;
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * STAGE;
     const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
-    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)((unsigned)m0 * a.Cout + y_c0) : a.zero;
-    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)((unsigned)m1 * a.Cout + y_c1) : a.zero;
+    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)(y_pix(m0) * a.Cout + y_c0) : a.zero;
+    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)(y_pix(m1) * a.Cout + y_c1) : a.zero;
     glds16_asm(py0, stage + XT + (wave * 2) * 1024);
     glds16_asm(py1, stage + XT + (wave * 2 + 1) * 1024);
     glds16_asm(x_src(i_p0 - 4 + x_rowa, x_ca), stage + wave * 1024);
@@ -969,12 +987,12 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
 
   // ---- fragment addresses (per lane, stage-relative) and the left/right column masks -----------------
   // lane (g, li): channel = subtile*16 + li... transposing read: row = k-group g*4 + li/4, columns 4*(li%4)..+3
-  int offx[3][2], offy[4];
+  int offx[NT][2], offy[4];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = 4 + (t - 1) + g * 4 + (li >> 2);
+      const int row = 4 + (t + tb) + g * 4 + (li >> 2);
       const int slot0 = wi * 4 + j * 2;
       offx[t][j] = row * 128 + (((slot0 + ((li & 3) >> 1)) ^ (((row >> 1) & 3) << 1)) << 4) + (li & 1) * 8;
     }
@@ -984,7 +1002,10 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
     const int slot0 = wo * 8 + i * 2;
     offy[i] = XT + row * 256 + (((slot0 + ((li & 3) >> 1)) ^ ((row & 7) << 1)) << 4) + (li & 1) * 8;
   }
-  uint32_t maskl[4], maskr[4];     // fragment element e <-> pixel k = (e<4 ? g*4+e : 16+g*4+e-4)
+  // fragment element e <-> pixel k = (e<4 ? g*4+e : 16+g*4+e-4); maskl clears the pixels of image column 0 (tap dw = -1),
+  // maskr those of column W-1 (dw = +1).  SUB: only one of the two taps needs a mask -- mask1 belongs to tap 0 when tb = -1
+  // (dw = -1: left) and to tap 1 when tb = 0 (dw = +1: right)
+  uint32_t maskl[4], maskr[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     uint32_t ml = 0, mr = 0;
@@ -997,11 +1018,12 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
       if (ow != a.W - 1) mr |= 0xFFFFu << (16 * h);
     }
     maskl[d] = ml; maskr[d] = mr;
+    if (SUB) { maskl[d] = tb < 0 ? ml : 0xFFFFFFFFu; maskr[d] = tb < 0 ? 0xFFFFFFFFu : mr; }     // = the masks of tap 0 / tap 1
   }
 
-  f32x4_t acc[3][4][2];   // [kw][co subtile][ci subtile]
+  f32x4_t acc[NT][4][2];   // [kw][co subtile][ci subtile]
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1029,14 +1051,14 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
 #pragma unroll
         for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NT; ++t) {
           bf16x8_t xf[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             uint4 v = __builtin_bit_cast(uint4, tr_pair(sb + offx[t][j], 16 * 128));
             if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
             if (t == 0) { v.x &= maskl[0]; v.y &= maskl[1]; v.z &= maskl[2]; v.w &= maskl[3]; }
-            if (t == 2) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
+            if (t == NT - 1) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
             xf[j] = __builtin_bit_cast(bf16x8_t, v);
           }
 #pragma unroll
@@ -1051,7 +1073,9 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   // D[row = co (4*(lane>>4)+r)][col = ci (lane&15)]
   float* slab = a.slab + (long)by * a.slab_stride;
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NT; ++t) {
+    // slab cell: tap (kh, t), or [(pa*2 + pb)*4 + s*2 + d] with d = t, the rank among this parity's two taps
+    const int cell = !SUB ? kh * 3 + t : (kh >> 1) * 4 + srow * 2 + t;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1059,14 +1083,16 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
         const int co = co0 + wo * 64 + i * 16 + (lane >> 4) * 4;
         const int ci = ci0 + wi * 32 + j * 16 + (lane & 15);
         float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
-        *(float4*)(slab + ((long)(kh * 3 + t) * a.Cin + ci) * a.Cout + co) = v;
+        *(float4*)(slab + ((long)cell * a.Cin + ci) * a.Cout + co) = v;
       }
+  }
 }
 
 
 template <int NS, bool RELU>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad3_kernel(MfmaWgradArgs a) {
-  wgrad3_body<NS, RELU>(a, blockIdx.x, blockIdx.y);
+  if (__builtin_expect(a.sub != 0, 0)) wgrad3_body<NS, RELU, true>(a, blockIdx.x, blockIdx.y);
+  else wgrad3_body<NS, RELU, false>(a, blockIdx.x, blockIdx.y);
 }
 
 // Several layers' filter gradients in ONE launch: workgroup b belongs to the problem p with first[p] <= b < first[p+1]
@@ -1104,7 +1130,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup 
     if (q < g.n && b >= g.first[q]) p = q;
   const unsigned l = b - g.first[p];
   const unsigned gxp = g.gx[p];
-  wgrad3_body<NS, RELU>(g.a[p], l % gxp, l / gxp);
+  // (the sub-pixel body behind the three-tap one, as the image-end body: see the note on code placement above)
+  if (__builtin_expect(g.a[p].sub != 0, 0)) wgrad3_body<NS, RELU, true>(g.a[p], l % gxp, l / gxp);
+  else wgrad3_body<NS, RELU, false>(g.a[p], l % gxp, l / gxp);
 }
 
 // the same grouping for the per-tap kernel (1x1 shortcuts and the shapes the three-tap kernel does not take)
@@ -1658,6 +1686,22 @@ int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
   return (int)want;
 }
 
+// Sub-pixel filter gradient (MfmaWgradArgs::sub) of an upsample-3x3 (1) or ConvMeanPool (2) layer: 0 where the layer is posed
+// as an ordinary 3x3 filter gradient (shape the three-tap kernel does not take, RCGAN_WGRAD_SUBPIXEL=0)
+int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr) {
+  static const int on = env_int("RCGAN_WGRAD_SUBPIXEL", 1);
+  if (!on || !use_tr || !wgrad3_enabled() || !mfma_wgrad_eligible(d) || d->kh != 3 || d->kw != 3) return 0;
+  const bool up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) != 0, pool = (d->flags & RCGAN_CONV_OUT_MEANPOOL2) != 0;
+  if (up == pool || (d->h & 1) || (d->w & 1)) return 0;
+  if (!wgrad3_shape(3, 3, d->h / 2, d->w / 2)) return 0;
+  return up ? 1 : 2;
+}
+
+int mfma_wgrad_sub_splits(const rcgan_conv_desc* d, long M) {
+  const long tiles3 = 8L * (d->cin / 64) * (d->cout / 128);
+  return (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, M);
+}
+
 template <bool RELU>
 static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
   constexpr int NS = 4;
@@ -1668,7 +1712,8 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
     attr = true;
   }
   {
-    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * a.KH * a.KW * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * (a.sub ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
+                 2.0 * (double)a.M * (a.sub ? 16 : a.KH * a.KW) * a.Cin * a.Cout);
     hipLaunchKernelGGL((conv_mfma_wgrad3_kernel<NS, RELU>), grid, dim3(256), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -1677,8 +1722,9 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
 
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done) {
   *bias_done = false;
+  if (a.sub && !mfma_wgrad3_takes(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
   if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1) {
-    long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
+    long tiles3 = (long)(a.sub ? 8 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
     int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
     if (want > nz) want = nz;
     a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
@@ -1725,7 +1771,7 @@ bool mfma_wgrad3_takes(const MfmaWgradArgs& a) {
 
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block) {
   if (!(wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1)) return false;
-  long tiles3 = (long)a.KH * (a.Cin / 64) * (a.Cout / 128);
+  long tiles3 = (long)(a.sub ? 8 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
   // pixel chunks: alone, enough of them for ~512 workgroups; in a group the caller fixes the pixels per workgroup for all
   // layers (equal workgroup run times, and far fewer fp32 slabs to write and reduce than 512 workgroups per layer)
   int want = px_per_block > 0 ? (int)wgrad_clamp_splits(cdiv(a.M, px_per_block), a.M)
@@ -1747,10 +1793,13 @@ static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
     RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_wgrad3_group_kernel<NS, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  double fl = 0;
-  for (int p = 0; p < g.n; ++p) fl += 2.0 * (double)g.a[p].M * g.a[p].KH * g.a[p].KW * g.a[p].Cin * g.a[p].Cout;
+  double fl = 0, fx = 0;
+  for (int p = 0; p < g.n; ++p) {
+    fl += 2.0 * (double)g.a[p].M * (g.a[p].sub ? 36 : g.a[p].KH * g.a[p].KW) * g.a[p].Cin * g.a[p].Cout;
+    fx += 2.0 * (double)g.a[p].M * (g.a[p].sub ? 16 : g.a[p].KH * g.a[p].KW) * g.a[p].Cin * g.a[p].Cout;
+  }
   {
-    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl);
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl, fx);
     hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.img.first[IMG_GROUP_MAX] + g.first[g.n]), dim3(256), lds, ctx->stream, g);
   }
   RC_LAUNCH_CHECK(ctx);

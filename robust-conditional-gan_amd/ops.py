@@ -267,9 +267,9 @@ def conv_meanpool_ok(ctx, x, weight, k=3):
 def conv2d_meanpool(ctx, x, weight, bias, in_relu=False, accumulate_into=None):
     """ConvMeanPool (gan_resnet.py:241-247): meanpool2(conv3x3(x) + bias) as ONE 4x4 stride-2 convolution with summed filters
     (RCGAN_CONV_OUT_MEANPOOL2: 4/9 of the multiply-adds, no full-resolution conv output, no pooling pass).  accumulate_into: a
-    pooled-resolution tensor the result is added to (the block's shortcut).  Backward: the data gradient in the sub-pixel form
-    straight from the pooled dy; the filter gradient goes through the ordinary grouped path on dy spread back to the
-    conv resolution (d meanpool)."""
+    pooled-resolution tensor the result is added to (the block's shortcut).  Backward: data and filter gradient in their
+    sub-pixel forms straight from the pooled dy (the filter gradient in the grouped launch; where the three-tap kernel does
+    not take the shape, through the ordinary path on dy spread back to the conv resolution)."""
     n, h, w, cin = x.shape
     cout = weight.param.shape[-1]
     assert weight.param.shape == (3, 3, cin, cout)
@@ -294,10 +294,16 @@ def conv2d_meanpool(ctx, x, weight, bias, in_relu=False, accumulate_into=None):
             if dy is None:
                 return
             if wr:
-                # dL/d(conv output) = dy spread over each 2x2 block / 4: the filter (and bias) gradient of the plain convolution
-                dyf = ctx.empty((n, h, w, cout), x.dtype)
-                ctx.check(ctx.lib.rcgan_meanpool2_bwd(ctx.h, n, h, w, cout, x.dtype, _p(dy), _p(dyf), 0))
-                wdesc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, L.CONV_IN_RELU if in_relu else 0)
+                wdesc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, flags)
+                if ctx.lib.rcgan_conv_wgrad_pool_ok(C.byref(wdesc)):
+                    # the sub-pixel filter gradient straight from the pooled dy (16 products over the pooled grid instead of 9
+                    # over the full one; dy is final here and nothing below writes into it)
+                    dyf = dy
+                else:
+                    # dL/d(conv output) = dy spread over each 2x2 block / 4: the filter (and bias) gradient of the plain convolution
+                    dyf = ctx.empty((n, h, w, cout), x.dtype)
+                    ctx.check(ctx.lib.rcgan_meanpool2_bwd(ctx.h, n, h, w, cout, x.dtype, _p(dy), _p(dyf), 0))
+                    wdesc = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, x.dtype, L.CONV_IN_RELU if in_relu else 0)
                 if ctx.group_wgrads:
                     ctx.defer_wgrad(wdesc, x, dyf, weight.grad_target(), bias.grad if br else None)
                 else:

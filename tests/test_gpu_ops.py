@@ -48,6 +48,8 @@ CONV_CASES = [
     (1, 8, 8, 128, 256, 3, 1, True, False),     # MFMA with folded upsample
     (32, 8, 8, 256, 128, 3, 1, True, True),     # ... in its sub-pixel form (four summed 2x2 filters), 64 x 64 tiles with K-split 2
     (200, 8, 8, 64, 256, 3, 1, True, False),    # ... 64 x 64 tiles, 800 workgroups (no K-split)
+    (8, 32, 32, 128, 128, 3, 1, True, True),    # ... and the sub-pixel filter gradient over a 16 x 16 low-resolution grid, input ReLU
+    (6, 16, 16, 256, 256, 3, 1, True, False),   # ... 8 x 8 grid, 4 x 2 channel tiles, a ragged last pixel chunk
     (2, 8, 8, 256, 128, 1, 1, False, False),    # MFMA 1x1
     (5, 32, 32, 128, 128, 3, 1, False, True),   # MFMA 128x128 tile (M = 5120 -> 40 blocks < 384 -> 64 tile) ...
     (48, 32, 32, 128, 128, 3, 1, False, False), # ... and M = 49152 -> 384 blocks of 128x128
@@ -301,7 +303,8 @@ def test_conv2d_meanpool(dev, case):
     assert_close(ctx.download(y), ref, 2 * TOL[mode], "conv+meanpool fwd %s" % (case,))       # sums of up to four taps rounded once
     dy = _prep(rs.randn(*ref.shape).astype(np.float32), mode)
     y.grad = ctx.upload(dy)
-    ctx.group_wgrads, keep = True, ctx.group_wgrads
+    # (the small case takes the one-layer entry point, the others the grouped launch)
+    ctx.group_wgrads, keep = n > 4, ctx.group_wgrads
     ctx.backward()
     ctx.group_wgrads = keep
     dyf = np.repeat(np.repeat(dy, 2, axis=1), 2, axis=2) * 0.25
