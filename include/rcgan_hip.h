@@ -368,6 +368,10 @@ int rcgan_softmax_rows_bwd(rcgan_ctx* ctx, int rows, int cols, const float* p, c
  * so a captured graph can be replayed with new values.  grad_scale multiplies g first (1/world_size). */
 int rcgan_adam_tf(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v,
                   const float* hyper, float beta1, float beta2, float eps, float clip, float grad_scale);
+/* The same with {lr, t} as launch arguments: an eagerly launched step (every optimiser step of both training loops: the
+ * all-reduce sits between the captured graph and Adam) needs no host-to-device copy of two floats in front of it. */
+int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v,
+                       float lr, float t, float beta1, float beta2, float eps, float clip, float grad_scale);
 int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float value);
 
 /* ---- self test ---------------------------------------------------------------------------------------- */

@@ -140,6 +140,7 @@ SIGNATURES = {
     "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),
     "rcgan_softmax_rows_bwd": (I, [P, I, I, P, P, P, I]),
     "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),
+    "rcgan_adam_tf_host": (I, [P, SZ, P, P, P, P, F, F, F, F, F, F, F]),
     "rcgan_fill_f32": (I, [P, SZ, P, F]),
     "rcgan_selftest": (I, [P]),
     "rcgan_query": (I, [P, I]),

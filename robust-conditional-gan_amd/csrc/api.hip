@@ -90,11 +90,12 @@ __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
   *o = s;
 }
 
-__global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float beta1,
-                               float beta2, float eps, float clip, float grad_scale) {
+__global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float lr_v, float t_v,
+                               float beta1, float beta2, float eps, float clip, float grad_scale) {
   // the arithmetic form of TF's ApplyAdam kernel: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
   // m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); w -= (m*alpha)/(sqrt(v)+eps), all in fp32
-  const float lr = hyper[0], t = hyper[1];
+  // {lr, t}: device memory (a captured launch replayed with new values) or kernel arguments (hyper == nullptr)
+  const float lr = hyper ? hyper[0] : lr_v, t = hyper ? hyper[1] : t_v;
   const float alpha = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -874,7 +875,19 @@ int rcgan_adam_tf(rcgan_ctx* ctx, size_t count, float* w, const float* g, float*
   if (count == 0) return RCGAN_OK;
   size_t blocks = (count + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, w, g, m, v, hyper, beta1, beta2, eps, clip, grad_scale);
+  RC_REQUIRE(ctx, hyper != nullptr, "null hyper (rcgan_adam_tf_host takes {lr, t} by value)");
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, w, g, m, v, hyper, 0.f, 0.f, beta1, beta2, eps, clip, grad_scale);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v, float lr, float t, float beta1,
+                       float beta2, float eps, float clip, float grad_scale) {
+  if (count == 0) return RCGAN_OK;
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, w, g, m, v, (const float*)nullptr, lr, t, beta1, beta2, eps,
+                     clip, grad_scale);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

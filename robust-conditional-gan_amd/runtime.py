@@ -294,10 +294,7 @@ class ParamGroup:
         self.zero_epoch = -1       # Context.epoch of the last zero_grad()
         self.m = torch.zeros(self.count, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.count, dtype=torch.float32, device=dev)
-        self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)      # {lr, t} read by the Adam kernel
-        self.hyper_host = torch.zeros(256, 2, dtype=torch.float32).pin_memory()   # ring: async H2D sources
-        self._hslot = 0
-        self._hevents = [None] * 4   # one event per quarter of the ring: its copies of the previous lap have executed
+        self._lr, self._t = 0.0, 0.0      # {lr, t} of the next Adam launch (set_hyper)
         self.t = 0
         self.version = 0        # bumped by every write to the values (set / adam): keys caches of derived layouts
         host = np.zeros(self.count, np.float32)
@@ -351,29 +348,15 @@ class ParamGroup:
         self.zero_epoch = c.epoch
 
     def set_hyper(self, lr, t):
-        """{lr, t} for the next Adam launch: written into a pinned ring slot and copied asynchronously.  A slot is reused
-        256 calls later; an event per quarter of the ring (recorded behind the quarter's last copy, waited for before the
-        quarter is written again) keeps a host that runs ahead of the GPU from overwriting a slot whose copy has not run
-        yet -- which also bounds how far ahead the host can get (192-256 optimiser steps)."""
-        self._hslot = (self._hslot + 1) % 256
-        q, r = divmod(self._hslot, 64)
-        if r == 0 and self._hevents[q] is not None:
-            self._hevents[q].synchronize()
-        src = self.hyper_host[self._hslot]
-        src[0] = float(lr)
-        src[1] = float(t)
-        with torch.cuda.stream(self.ctx.stream):
-            self.hyper.copy_(src, non_blocking=True)
-            if r == 63:
-                ev = torch.cuda.Event()
-                ev.record(self.ctx.stream)
-                self._hevents[q] = ev
+        """{lr, t} of the next Adam launch.  Adam is launched eagerly behind the step's captured graph and the all-reduce, so the
+        two values travel as kernel arguments (rcgan_adam_tf_host): no host-to-device copy per optimiser step."""
+        self._lr, self._t = float(lr), float(t)
 
     def adam(self, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0, lo=0, hi=None):
         c = self.ctx
         hi = self.count if hi is None else hi
         o = lo * 4
-        c.check(c.lib.rcgan_adam_tf(c.h, hi - lo, self.value.data_ptr() + o, self.grad.data_ptr() + o,
-                                    self.m.data_ptr() + o, self.v.data_ptr() + o, self.hyper.data_ptr(),
-                                    beta1, beta2, eps, clip, grad_scale))
+        c.check(c.lib.rcgan_adam_tf_host(c.h, hi - lo, self.value.data_ptr() + o, self.grad.data_ptr() + o,
+                                         self.m.data_ptr() + o, self.v.data_ptr() + o, self._lr, self._t,
+                                         beta1, beta2, eps, clip, grad_scale))
         self.version += 1

@@ -881,6 +881,14 @@ def test_adam_tf(dev):
         pg.set_hyper(2e-4, t)
         pg.adam(0.5, 0.999, clip=1.0, grad_scale=0.5)
         w, m, v = nn.adam_tf(w, g * np.float32(0.5), m, v, t, 2e-4, 0.5, 0.999, clip=1.0)
+    # one more step through the entry point that reads {lr, t} from device memory (a captured launch replayed with new values)
+    from rcgan_amd import _lib as L
+    g = rs.randn(1000).astype(np.float32)
+    pg.set("w", g, "grad")
+    hyper = ctx.upload(np.array([2e-4, 4.0], np.float32), L.F32)
+    ctx.check(ctx.lib.rcgan_adam_tf(ctx.h, 1000, pg.value.data_ptr(), pg.grad.data_ptr(), pg.m.data_ptr(), pg.v.data_ptr(), hyper.ptr,
+                                    0.5, 0.999, 1e-8, 1.0, 0.5))
+    w, m, v = nn.adam_tf(w, g * np.float32(0.5), m, v, 4, 2e-4, 0.5, 0.999, clip=1.0)
     ctx.sync()
     assert_close(pg.get("w"), w, 2e-6, "adam w")
     assert_close(pg.get("w", "m"), m, 2e-6, "adam m")
