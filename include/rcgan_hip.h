@@ -110,6 +110,11 @@ int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
                                       * flag means "dy is the POOLED gradient [n,h/2,w/2,cout]" (sub-pixel filter gradient, 4/9 of the
                                       * multiply-adds, no spread dy), only where rcgan_conv_wgrad_pool_ok says so */
 
+#define RCGAN_CONV_RESID_UPSAMPLE2X 32 /* rcgan_conv2d_fwd_residual: the residual is [n,h/2,w/2,cout] and is added nearest-upsampled -- the
+                                      * shortcut of an up block evaluated BEFORE the upsample (a 1x1 convolution commutes with it:
+                                      * gan_resnet.py:258-272, 295-328), a quarter of its multiply-adds and of its bytes; only where
+                                      * rcgan_conv_resid_up_ok says so */
+
 typedef struct rcgan_conv_desc {
   int n, h, w, cin;   /* logical conv input: after the 2x upsample when IN_UPSAMPLE2X is set */
   int cout, kh, kw, stride;
@@ -138,6 +143,8 @@ size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
  * cifar10/common/ops/conv2d.py:181-216.  x: [n, h(/2), w(/2), cin]; y: [n, oh, ow, cout]. */
 /* 1 if the matrix-core kernels take d (3x3, stride 1, 16-bit, power-of-two image, channels % 64 == 0) with RCGAN_CONV_OUT_MEANPOOL2 */
 int rcgan_conv_fused_pool_ok(const rcgan_conv_desc* d);
+/* 1 if rcgan_conv2d_fwd_residual takes d with RCGAN_CONV_RESID_UPSAMPLE2X */
+int rcgan_conv_resid_up_ok(const rcgan_conv_desc* d);
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
                      const float* bias /* or NULL */, void* y);
 /* y = conv2d_SAME(x, w) (+bias) + residual: the pre-activation residual sum `shortcut + output` of

@@ -13,7 +13,7 @@ LIB_PATH_F16 = os.environ.get("RCGAN_LIB_PATH_F16") or os.path.join(_HERE, "libr
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-CONV_IN_UPSAMPLE2X, CONV_IN_RELU, CONV_ACCUMULATE, CONV_FORCE_DIRECT, CONV_OUT_MEANPOOL2 = 1, 2, 4, 8, 16
+CONV_IN_UPSAMPLE2X, CONV_IN_RELU, CONV_ACCUMULATE, CONV_FORCE_DIRECT, CONV_OUT_MEANPOOL2, CONV_RESID_UPSAMPLE2X = 1, 2, 4, 8, 16, 32
 LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_CE_ONES, LOSS_CE_ZEROS = 0, 1, 2, 3, 4
 QUERY_TR_READ = 0
 
@@ -86,6 +86,7 @@ SIGNATURES = {
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),
+    "rcgan_conv_resid_up_ok": (I, [DP]),
     "rcgan_conv_wgrad_pool_ok": (I, [DP]),
     "rcgan_conv2d_fwd_residual": (I, [P, DP, P, P, P, P, P]),
     "rcgan_conv2d_bwd_data": (I, [P, DP, P, P, P, P, P, SZ]),

@@ -153,6 +153,9 @@ def _ctx():
     return Graph.current.ctx
 
 
+SHORTCUT_BEFORE_UPSAMPLE = os.environ.get("RCGAN_SHORTCUT_LOW", "1") == "1"
+
+
 def UpsampleConv(inputs, output_dim, filter_size=3, name=None, spectral_normed=False, update_collection=None,
                  he_init=True, biases=True, _in_relu=False, _accumulate_into=None):
     return Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, 1, name, spectral_normed=spectral_normed,
@@ -162,12 +165,20 @@ def UpsampleConv(inputs, output_dim, filter_size=3, name=None, spectral_normed=F
 
 def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels, segments=1):
     """ResidualBlock(resample='up') with conditional batch norm (gan_resnet.py:275-328)."""
-    shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
+    # the 1x1 shortcut commutes with the nearest upsample in front of it (gan_resnet.py:258-272): evaluated on the block's
+    # low-resolution input (a quarter of the multiply-adds and bytes) and added upsampled by Conv2's epilogue
+    low = SHORTCUT_BEFORE_UPSAMPLE
+    if low:
+        shortcut = Conv2D(inputs, input_dim, output_dim, 1, 1, name + '.Shortcut', he_init=False)
+    else:
+        shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
     with variable_scope(name + '.N1'):
         out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
     out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1')
     with variable_scope(name + '.N2'):
         out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
+    if low:
+        return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _residual=shortcut, _residual_up=True)
     return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _accumulate_into=shortcut)
 
 

@@ -434,6 +434,12 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
   if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
   a.stamps = nullptr;
   a.wph = nullptr; a.phase = 0;
+  a.resid_up = 0;
+}
+
+// RCGAN_CONV_RESID_UPSAMPLE2X: the matrix-core epilogue reads the half-resolution residual in place (power-of-two output grid)
+int rcgan_conv_resid_up_ok(const rcgan_conv_desc* d) {
+  return d && mfma_eligible(d) && !(d->flags & RCGAN_CONV_OUT_MEANPOOL2) && d->stride == 1 && ilog2_exact(d->w) >= 1 && ilog2_exact(d->h) >= 1 ? 1 : 0;
 }
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
@@ -444,6 +450,8 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
                               const void* residual, void* y) {
   int rc = check_desc(ctx, d);
   if (rc) return rc;
+  if (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X))
+    RC_REQUIRE(ctx, rcgan_conv_resid_up_ok(d), "half-resolution residual not available for this convolution (rcgan_conv_resid_up_ok)");
   if (residual != nullptr && !mfma_eligible(d)) {      // other kernels: plain forward, then y += residual
     RC_REQUIRE(ctx, residual != y, "residual must not alias the output");
     rc = rcgan_conv2d_fwd_residual(ctx, d, x, prepared, bias, nullptr, y);
@@ -480,6 +488,7 @@ int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
     a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
     if (mfma_phase_filters(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
     a.resid = (const bf16_t*)residual;
+    a.resid_up = (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X)) ? 1 : 0;
     a.zero = (const bf16_t*)ctx->zero_page;
     a.Cin = d->cin; a.Cout = d->cout;
     a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;

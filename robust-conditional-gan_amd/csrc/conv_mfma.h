@@ -11,6 +11,7 @@ struct MfmaConvArgs {
   const float* bias;      // [Cout] or null
   const bf16_t* mask;     // [M][Cout] or null: output zeroed where mask <= 0 (ReLU backward)
   const bf16_t* resid;    // [M][Cout] or null: added to the output (residual connection, gan_resnet.py:328)
+  int resid_up;           // the residual lives on the HALF-resolution grid [N][H/2][W/2][Cout] and is added nearest-upsampled (lw, lh >= 1)
   bf16_t* out;            // [M][Cout]
   const bf16_t* zero;     // >= 16 zero bytes (halo source of the direct-to-LDS loader)
   int N, H, W, Cin, Cout, KH, KW, PT, PL;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaConvArgs a) {
   }
 
   // epilogue: lane holds out[m][co..co+3], m = pixel (lane&15), co = 4*(lane>>4)
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowIdent(), a.resid_up ? a.lw : -1, a.lh);
 }
 
 
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_glds_kernel(MfmaConvArgs a
 
   stamp(4);
   if constexpr (PHASE == 1)
-    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowPhase{1, glw, glh, ph, pw, mbase});
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowPhase{1, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
   else
-    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowIdent(), a.resid_up ? a.lw : -1, a.lh);
   if (a.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256 * KS) void conv_mfma_halo_kernel(MfmaConvArgs a
     }
   }
   stamp(4);
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * TM, co0 + wn * TN, lane, RowIdent(), a.resid_up ? a.lw : -1, a.lh);
   if (a.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
   stamp(3);
   conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
-                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase});
+                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
   if (a.stamps) {
     stamp(4);
     wait_vm<0>();
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8p_kernel(MfmaConvArgs a, int 
     //      build the table of the tile after next in the slot this tile's table occupied (dead since its last K-tile
     //      was issued, one K-tile ago; first read a whole tile from now, with >= 4 barriers in between)
     const long m0 = (long)tile_of(ti) * 256;
-    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane);
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane, RowIdent(), a.resid_up ? a.lw : -1, a.lh);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
   }
 
   conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane,
-                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase});
+                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
 }
 
 template <bool RELU, bool XCDSWZ>

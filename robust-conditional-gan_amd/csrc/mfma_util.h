@@ -121,7 +121,9 @@ template <int NI, int NJ, typename Map = RowIdent>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const float* __restrict__ bias, const bf16_t* mask,
                                               const bf16_t* resid, bf16_t* out, int accumulate, long M, int Cout,
                                               long m_wave /* first pixel of the wavefront's rows */,
-                                              int co_wave /* first channel of the wavefront's columns */, int lane, Map rowmap = Map()) {
+                                              int co_wave /* first channel of the wavefront's columns */, int lane, Map rowmap = Map(),
+                                              int res_lw = -1 /* >= 1: resid lives on the half-resolution grid of a 2^res_lh x 2^res_lw image */,
+                                              int res_lh = 0) {
   static_assert(NI % 2 == 0, "channel fragments are stored in pairs");
   constexpr int NP = NI / 2;
   const int row = lane >> 4;
@@ -143,7 +145,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const floa
       const long o = offs(j, p);
       if (mask) e_mask[p] = *(const uint4*)(mask + o);
       if (accumulate) e_acc[p] = *(const uint4*)(out + o);
-      if (resid) e_res[p] = *(const uint4*)(resid + o);
+      if (resid) {
+        long ro = o;
+        if (res_lw >= 1) {      // output pixel (n, oh, ow) reads the residual's pixel (n, oh/2, ow/2)
+          const unsigned r = (unsigned)rowmap(m_wave + j * 16 + (lane & 15));
+          const unsigned ow = r & ((1u << res_lw) - 1u), oh = (r >> res_lw) & ((1u << res_lh) - 1u), n = r >> (res_lw + res_lh);
+          const unsigned rl = (((n << (res_lh - 1)) + (oh >> 1)) << (res_lw - 1)) + (ow >> 1);
+          ro = o + ((long)rl - (long)r) * Cout;
+        }
+        e_res[p] = *(const uint4*)(resid + ro);
+      }
     }
   };
   if (extras) fetch(0);

@@ -171,12 +171,14 @@ def spectral_norm_batch(ctx, entries):
 # convolution / dense
 # ----------------------------------------------------------------------------------------------------
 def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumulate_into=None, force_direct=False,
-           residual=None):
+           residual=None, residual_up=False):
     """SAME conv on NHWC x with HWIO weight [k,k,cin,cout] (tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
     cifar10/common/ops/conv2d.py:181-216).  in_up / in_relu fold the preceding nearest-2x upsample
     (gan_resnet.py:263-264) and ReLU into the operand load; accumulate_into adds the result into an
     existing tensor (the residual sum of gan_resnet.py:328); residual adds another tensor in the epilogue
-    (y = conv + residual: the identity-shortcut blocks, where the shortcut is the block input itself)."""
+    (y = conv + residual: the identity-shortcut blocks, where the shortcut is the block input itself).  residual_up: the
+    residual lives on the half-resolution grid and is added nearest-upsampled (the up blocks' 1x1 shortcut evaluated before
+    the upsample it commutes with); its gradient is the 2x2 sum of dy."""
     n, hs, ws_, cin = x.shape
     h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
     cout = weight.param.shape[-1]
@@ -193,7 +195,16 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     else:
         y = ctx.empty((n, oh, ow, cout), x.dtype)
         fdesc = desc
-    if residual is not None:
+    if residual is not None and residual_up:
+        assert residual.shape == (n, oh // 2, ow // 2, cout) and accumulate_into is None, (residual.shape, (n, oh, ow, cout))
+        rdesc = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | L.CONV_RESID_UPSAMPLE2X)
+        if ctx.lib.rcgan_conv_resid_up_ok(C.byref(rdesc)):
+            ctx.check(ctx.lib.rcgan_conv2d_fwd_residual(ctx.h, C.byref(rdesc), _p(x), _p(prep), _p(bias), _p(residual), _p(y)))
+        else:      # fp32 / odd shapes: the un-fused composition
+            up = ctx.empty((n, oh, ow, cout), x.dtype)
+            ctx.check(ctx.lib.rcgan_upsample2_fwd(ctx.h, n, oh, ow, cout, x.dtype, _p(residual), _p(up)))
+            ctx.check(ctx.lib.rcgan_conv2d_fwd_residual(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(up), _p(y)))
+    elif residual is not None:
         assert residual.shape == (n, oh, ow, cout) and accumulate_into is None, (residual.shape, (n, oh, ow, cout))
         ctx.check(ctx.lib.rcgan_conv2d_fwd_residual(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(residual), _p(y)))
     else:
@@ -242,7 +253,11 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
                                                         _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
             if fork:
                 ctx.check(ctx.lib.rcgan_side_join(ctx.h))
-            if residual is not None and residual.req:
+            if residual is not None and residual.req and residual_up:
+                # d(residual) = the 2x2 sum of dy (adjoint of the nearest upsample)
+                dres, racc = grad_of(ctx, residual)
+                ctx.check(ctx.lib.rcgan_upsample2_bwd(ctx.h, n, oh, ow, cout, x.dtype, _p(dy), _p(dres), racc))
+            elif residual is not None and residual.req:
                 # d(residual) = dy.  dy is dead after this closure: a residual without a gradient yet adopts the
                 # buffer (later contributions accumulate into it in place), otherwise one accumulate
                 if residual.grad is None:

@@ -40,7 +40,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
            conv_type='conv2d', channel_multiplier=0, padding='SAME',
            spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
            mask_type=None, weightnorm=None, biases=True, gain=1.,
-           _in_upsample=False, _in_relu=False, _accumulate_into=None, _residual=None, _out_meanpool=False):
+           _in_upsample=False, _in_relu=False, _accumulate_into=None, _residual=None, _out_meanpool=False, _residual_up=False):
     """cifar10/common/ops/conv2d.py:31-218 (conv2d path).  The underscore arguments are this build's
     fusion hooks (nearest-2x upsample / ReLU folded into the operand load, residual accumulate / residual add)."""
     if conv_type != 'conv2d':
@@ -62,7 +62,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
         assert filter_size == 3 and stride == 1 and not _in_upsample and _residual is None
         return O.conv2d_meanpool(g.ctx, inputs, w, b, in_relu=_in_relu, accumulate_into=_accumulate_into)
     return O.conv2d(g.ctx, inputs, w, b, filter_size, stride, in_up=_in_upsample, in_relu=_in_relu,
-                    accumulate_into=_accumulate_into, residual=_residual)
+                    accumulate_into=_accumulate_into, residual=_residual, residual_up=_residual_up)
 
 
 def Linear(inputs, input_dim, output_dim, name,

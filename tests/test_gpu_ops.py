@@ -130,6 +130,40 @@ def test_conv2d_fwd_bwd(dev, case):
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "conv dbias %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(4, 16, 16, 64, 128),        # 64 x 64 kernel
+                                  (64, 32, 32, 64, 256),       # 256 x 256 kernel
+                                  (64, 32, 32, 64, 128),       # 256 x 128 kernel
+                                  (3, 8, 8, 6, 5)])            # no matrix-core path: explicit upsample + residual
+def test_conv_residual_from_half_resolution(dev, case):
+    """y = conv3x3(x) + upsample2(r) with r on the half-resolution grid read in place by the epilogue
+    (RCGAN_CONV_RESID_UPSAMPLE2X: the up blocks' 1x1 shortcut evaluated before the upsample), and d r = the 2x2 sum of dy."""
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    n, h, w, cin, cout = case
+    if mode == "f32" and n * h * w * cin > 2 ** 21:
+        pytest.skip("large case only exercises the MFMA tiles")
+    rs = np.random.RandomState(n + cout)
+    x = _prep(rs.randn(n, h, w, cin).astype(np.float32), mode)
+    r = _prep(rs.randn(n, h // 2, w // 2, cout).astype(np.float32), mode)
+    wgt = (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    mf = mode in HALF and cin % 64 == 0 and cout % 64 == 0
+    ctx.new_step()
+    xd, rd = ctx.upload(x), ctx.upload(r)
+    xd.req = rd.req = True
+    wp, bp = FakeParam(ctx, wgt), FakeParam(ctx, b)
+    y = O.conv2d(ctx, xd, O.Weight(ctx, wp.t), bp.t, 3, residual=rd, residual_up=True)
+    w_eff = half_round(mode, wgt) if mf else wgt
+    ref = nn.conv2d_fwd(x.astype(np.float64), w_eff.astype(np.float64), 1) + b + nn.upsample2(r.astype(np.float64))
+    assert_close(ctx.download(y), ref, TOL[mode], "conv + upsampled residual %s" % (case,))
+    dy = _prep(rs.randn(*ref.shape).astype(np.float32), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    assert_close(ctx.download(rd.grad), nn.upsample2_bwd(dy.astype(np.float64)), TOL[mode], "d residual %s" % (case,))
+    dx = nn.conv2d_bwd_input(dy.astype(np.float64), w_eff.astype(np.float64), x.shape, 1)
+    assert_close(ctx.download(xd.grad), dx, TOL[mode], "dgrad beside the residual %s" % (case,))
+
+
 @pytest.mark.parametrize("cin", [64, 6])
 def test_conv_residual_block(dev, cin):
     """Identity-shortcut block x + conv2(relu(conv1(relu(x)))) with the sum folded into conv2's epilogue
