@@ -683,7 +683,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
 int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* xs, const void* const* dys,
                                   float* const* dws, float* const* dbiases, int accumulate, void* ws, size_t ws_bytes) {
   RC_REQUIRE(ctx, n >= 0 && (n == 0 || (descs && xs && dys && dws && dbiases)), "null argument");
-  static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 512; }();
+  static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 384; }();      // (512 before the sub-pixel forms: 6.67 -> 6.64 ms)
   std::vector<MfmaWgradArgs> cand(n);
   std::vector<char> takes(n, 0);
   // pass 1: which layers the grouped kernel takes, and the pixels per workgroup that gives ~target_blocks workgroups in all
@@ -728,7 +728,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     if (any_group && img.n < IMG_GROUP_MAX && img_side(d) && (d->cin <= 3 ? d->cout : d->cin) == 128) {
       ImgWArgs ia;
       int cb = 0, nwg = 0;
-      static const int img_wgs = [] { const char* e = getenv("RCGAN_WGRAD_IMG_WGS"); return e ? atoi(e) : 128; }();
+      static const int img_wgs = [] { const char* e = getenv("RCGAN_WGRAD_IMG_WGS"); return e ? atoi(e) : 96; }();       // (with 384 three-tap workgroups: 6.64 -> 6.62 ms)
       int rc = img_wgrad_plan(ctx, d, xs[i], dys[i], img_wgs, &ia, &cb, &nwg);
       if (rc) return rc;
       const long per = 32L * cb + 32;
