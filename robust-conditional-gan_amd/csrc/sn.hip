@@ -63,11 +63,21 @@ __global__ __launch_bounds__(SN_NT) void sn_fwd_rows_kernel(SnBatch batch) {
   const SnLayout L = sn_layout(it.save, k, c);
   const float* w = it.w + (long)r0 * c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = wave; r < rows; r += SN_NW) {
+  // (every row of the wavefront requested before the first reduction: one memory round trip instead of SN_RB / SN_NW)
+  float part[SN_RB / SN_NW];
+#pragma unroll
+  for (int i = 0; i < SN_RB / SN_NW; ++i) {
+    const int r = wave + i * SN_NW;
     float s = 0.f;
-    for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * it.u[j];
-    s = wave_sum(s);
-    if (lane == 0) { a_s[r] = s; L.a[r0 + r] = s; }
+    if (r < rows)
+      for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * it.u[j];
+    part[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < SN_RB / SN_NW; ++i) {
+    const int r = wave + i * SN_NW;
+    const float s = wave_sum(part[i]);
+    if (lane == 0 && r < rows) { a_s[r] = s; L.a[r0 + r] = s; }
   }
   __syncthreads();
   for (int j = tid; j < c; j += SN_NT) {
@@ -94,7 +104,8 @@ __global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
   float nb2 = 0.f;
   for (int j = tid; j < c; j += SN_NT) {
     float s = 0.f;
-    for (int q = 0; q < L.chunks; ++q) s += L.pb[(long)q * c + j];
+#pragma unroll 12
+    for (int q = 0; q < L.chunks; ++q) s += L.pb[(long)q * c + j];      // (independent loads, requested a dozen at a time)
     s *= inv_na;
     L.b[j] = s;
     nb2 += s * s;
@@ -178,11 +189,21 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_dv_kernel(SnBwdBatch batch) {
   }
   __syncthreads();
   float dva = 0.f;
-  for (int r = wave; r < rows; r += SN_NW) {
+  float part[SN_RB / SN_NW], av[SN_RB / SN_NW];
+#pragma unroll
+  for (int i = 0; i < SN_RB / SN_NW; ++i) {          // every row of the wavefront requested before the first reduction
+    const int r = wave + i * SN_NW;
     float s = 0.f;
-    for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * db_s[j];
-    s = wave_sum(s);
-    if (lane == 0) { L.dv[r0 + r] = s; dva += s * L.a[r0 + r]; }
+    if (r < rows)
+      for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * db_s[j];
+    part[i] = s;
+    av[i] = (lane == 0 && r < rows) ? L.a[r0 + r] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < SN_RB / SN_NW; ++i) {
+    const int r = wave + i * SN_NW;
+    const float s = wave_sum(part[i]);
+    if (lane == 0 && r < rows) { L.dv[r0 + r] = s; dva += s * av[i]; }
   }
   dva = block_sum_nt(lane == 0 ? dva : 0.f, red);
   if (tid == 0) L.pdva[blockIdx.x] = dva;
