@@ -68,15 +68,34 @@ __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
       const int sb = ((r.sub == 1) == (pb == 0)) ? (kw >= 1) : (kw >= 2);
       c4[q] = (long)(q * 4 + sa * 2 + sb) * r.cc + rem;
     }
-#pragma unroll 2
-    for (int z = 0; z < r.nz; ++z) {
+    // (the loads of four slabs -- sixteen values -- are requested before the first of them is added: the loop is a chain of
+    // memory round trips, not of additions)
+    int z = 0;
+    for (; z + 4 <= r.nz; z += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = r.slab[(long)(z + u) * r.stride + c4[q]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    for (; z < r.nz; ++z) {
       const float* sl = r.slab + (long)z * r.stride;
       s += (sl[c4[0]] + sl[c4[1]]) + (sl[c4[2]] + sl[c4[3]]);
     }
     if (r.sub == 2) s *= 0.25f;
   } else {
+    int z = 0;
+    for (; z + 16 <= r.nz; z += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = r.slab[(long)(z + u) * r.stride + si];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
 #pragma unroll 4
-    for (int z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
+    for (; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
   }
   float* o;
   if (i >= r.count) o = r.bias_out + (i - r.count);
