@@ -29,18 +29,20 @@ def main():
     n = sum(v[0] for v in fetch.values())
     f_avg = sum(v[0] * v[1] for v in fetch.values()) / n
     w_avg = sum(v[0] * v[1] for v in write.values()) / n
-    # algorithmic bytes of the launch mix: 512 workgroups = G step, n = 128 at 32x32 (3 forward: Conv1 and Shortcut read the
-    # 16x16 input, Conv2 the 32x32 one; 2 data gradients read 32x32 -- Conv2's and the shortcut's; Conv1's runs in its sub-pixel
-    # form on a 128-workgroup grid of another kernel since round 2); 1280 workgroups = G.Block.3 of the 5 critic batches, n = 320
+    # algorithmic bytes of the launch mix at the end of round 2 (the up blocks' shortcuts run on the low-resolution grid of other
+    # kernels; G.Block.3.Conv1's data gradient in its sub-pixel form on a 128-workgroup grid): 512 workgroups = G step, n = 128
+    # at 32x32 -- Conv1 forward (sub-pixel: reads the 16x16 input), Conv2 forward (reads 32x32 + the quarter-size shortcut in its
+    # epilogue), Conv2's data gradient (reads 32x32); 1280 workgroups = Conv1 and Conv2 forward of the 5 critic batches, n = 320
     px = {512: 128 * 1024, 1280: 320 * 1024}
     alg = {}
     for g, (cnt, _) in fetch.items():
         full = px[g] * 256 * 2
-        reads = ((full / 4 + full / 4 + full) / 3 if g == 1280 else ((full / 4 + full / 4 + full) + 2 * full) / 5) + 1.2e6
+        c1, c2, d2 = full / 4, full + full / 4, full
+        reads = ((c1 + c2) / 2 if g == 1280 else (c1 + c2 + d2) / 3) + 1.2e6
         alg[g] = reads + full
     alg_avg = sum(fetch[g][0] * alg[g] for g in fetch) / n
     out = {
-        "kernel": "conv_mfma_p8_kernel<false, true> (channel-major K order, shared epilogue with paired 16-byte stores; upsample-3x3 layers in sub-pixel form)",
+        "kernel": "conv_mfma_p8_kernel<false, true> (channel-major K order, shared epilogue with paired 16-byte stores; upsample-3x3 layers in sub-pixel form, shortcuts before the upsample)",
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes; scripts/make_profiles.sh)",
         "fetch_size_kb_avg": f_avg, "write_size_kb_avg": w_avg, "launches": n,
         "per_grid": {str(g): {"launches": fetch[g][0], "fetch_kb": fetch[g][1], "write_kb": write[g][1], "algorithmic_bytes": alg[g]} for g in sorted(fetch)},
