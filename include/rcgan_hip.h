@@ -350,6 +350,11 @@ typedef struct {
   float weight;
   const int32_t* labels_a; const float* wts_a; float* dwts_a;
   const int32_t* labels_b; const float* wts_b; float* dwts_b;
+  /* Optional (all zero = off): pool the features inside the head -- feat[s][j] = mean over hw of act(x[s][p][j]) (the relu +
+   * reduce_mean of gan_resnet.py:405-407) from the trunk's output x [n][hw][d] (x_dtype; d % 128 == 0), and write the gradient
+   * straight to dx [n][hw][d] (or NULL).  The `feat` argument is then an OUTPUT buffer [n][d]. */
+  const void* x; void* dx;
+  int x_dtype, hw, act;
 } rcgan_head_desc;
 int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
                             const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,

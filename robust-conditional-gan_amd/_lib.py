@@ -41,7 +41,8 @@ class HeadDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("d", C.c_int), ("v", C.c_int), ("e_dim", C.c_int),
                 ("rows_a", C.c_int), ("kind_a", C.c_int), ("kind_b", C.c_int), ("weight", C.c_float),
                 ("labels_a", C.c_void_p), ("wts_a", C.c_void_p), ("dwts_a", C.c_void_p),
-                ("labels_b", C.c_void_p), ("wts_b", C.c_void_p), ("dwts_b", C.c_void_p)]
+                ("labels_b", C.c_void_p), ("wts_b", C.c_void_p), ("dwts_b", C.c_void_p),
+                ("x", C.c_void_p), ("dx", C.c_void_p), ("x_dtype", C.c_int), ("hw", C.c_int), ("act", C.c_int)]
 
 
 class SnItem(C.Structure):

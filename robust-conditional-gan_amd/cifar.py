@@ -255,9 +255,9 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
             for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
                 h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
                 x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv2' % blk, _in_relu=True, _residual=x, **kw)   # shortcut + output
-        output = O.act_meanhw(ctx, x, L.ACT_RELU)                       # relu + reduce_mean over (1,2)
         if not _head:
-            return output
+            return O.act_meanhw_later(ctx, x, L.ACT_RELU)               # pooled inside Discriminator_head's launch
+        output = O.act_meanhw(ctx, x, L.ACT_RELU)                       # relu + reduce_mean over (1,2)
         output_wgan = Linear(output, DIM_D, 1, 'D.Output', **kw)
         return output, O.reshape(ctx, output_wgan, (-1,))
 

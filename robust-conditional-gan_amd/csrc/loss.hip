@@ -202,7 +202,25 @@ struct HeadArgs {
   float weight;
   const float *feat, *w_out, *sigma_out, *b_out, *table, *w_e, *sigma_e, *b_e;
   float *loss_acc, *logits, *dfeat, *dw_out, *db_out, *dtable, *dw_e, *db_e;
+  // optional: the features are pooled HERE from the trunk's output x [n][hw][d] (feat = mean over hw of act(x), written to
+  // feat_out for the parameter-gradient kernels) and the gradient goes straight back to dx [n][hw][d] -- the two
+  // act_meanhw launches around the head disappear (d % 128 == 0)
+  const void* x; void* dx; float* feat_out; int hw, act;
 };
+
+// two adjacent elements as one access (the pooled-feature path of head_logit_kernel: a lane owns a channel pair)
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
+template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b);
+template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) { const float2 v = *(const float2*)p; a = v.x; b = v.y; }
+template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& a, float& b) {
+  const uint32_t v = *(const uint32_t*)p;
+  a = bf16_to_f32((bf16_t)(v & 0xFFFFu)); b = bf16_to_f32((bf16_t)(v >> 16));
+}
+template <> __device__ __forceinline__ void st2<bf16_t>(bf16_t* p, float a, float b) {
+  *(uint32_t*)p = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+#define HEAD_XC 32          // pixels of a sample requested per memory round trip
 
 // Four short multi-workgroup launches (a single workgroup would be latency-bound: hundreds of dependent L2 round trips):
 //   embed : E[l][j]                      small-left GEMM, grid d/16: 16 columns x 16 k-lanes, all rows l
@@ -281,6 +299,8 @@ __global__ __launch_bounds__(256) void head_smallgemm_kernel(SmallGemmArgs g) {
   }
 }
 
+// T: element type of a.x (ignored when a.x is null)
+template <typename T>
 __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float* Eg, float* dlg, float* losspart, unsigned* counter) {
   extern __shared__ __attribute__((aligned(16))) float hs[];
   const int n = a.n, d = a.d, v = a.v, vp = v + 1;
@@ -293,18 +313,55 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
   const HeadPart& P = a.part[p];
   const int sr = p ? s - a.part[0].rows : s;
   const float inv_rows = 1.f / (float)P.rows;
+  const bool xm = a.x != nullptr;
+  // channel of slot q of this lane: lane + 64 q, or (pooling from x) the adjacent pair 2 lane, 2 lane + 1 of each 128-channel half
+  auto jof = [&](int q) { return xm ? 2 * lane + (q & 1) + 128 * (q >> 1) : lane + q * 64; };
   float f[HEAD_MAX_D / 64], wo[HEAD_MAX_D / 64], df[HEAD_MAX_D / 64];
   int lab_pre = -1;
   float wt_pre = 0.f;
+  const T* const xs = (const T*)a.x + (long)(s < n ? s : 0) * a.hw * d;
+  const int xcp = (a.hw + HEAD_XC - 1) / HEAD_XC, nxc = xm ? xcp * (d / 128) : 0;
+  float xa[HEAD_XC], xb[HEAD_XC];
+  // (no branch per load: pixels past the end re-read the last one and are dropped in the sum)
+  auto x_load = [&](int c) __attribute__((always_inline)) {
+    const int h = c / xcp, p0 = (c - h * xcp) * HEAD_XC;
+#pragma unroll
+    for (int u = 0; u < HEAD_XC; ++u) ld2<T>(xs + (long)min(p0 + u, a.hw - 1) * d + h * 128 + 2 * lane, xa[u], xb[u]);
+  };
   if (s < n) {
 #pragma unroll
     for (int q = 0; q < HEAD_MAX_D / 64; ++q) {
-      const int j = lane + q * 64;
-      f[q] = j < d ? a.feat[(long)s * d + j] : 0.f;
+      const int j = jof(q);
+      f[q] = (!xm && j < d) ? a.feat[(long)s * d + j] : 0.f;
       wo[q] = j < d ? a.w_out[j] : 0.f;
     }
     if (P.labels) lab_pre = P.labels[sr];
     if (P.wts && lane < v) wt_pre = P.wts[(long)sr * v + lane];
+  }
+  for (int c = 0; c < nxc; ++c) {        // (workgroup-uniform trip count; the activation switch once per chunk)
+    const int h = c / xcp, left = a.hw - (c - h * xcp) * HEAD_XC;
+    x_load(c);
+    float s0 = 0.f, s1 = 0.f;
+    if (a.act == RCGAN_ACT_RELU) {
+#pragma unroll
+      for (int u = 0; u < HEAD_XC; ++u) { s0 += u < left ? fmaxf(xa[u], 0.f) : 0.f; s1 += u < left ? fmaxf(xb[u], 0.f) : 0.f; }
+    } else {
+#pragma unroll 4
+      for (int u = 0; u < HEAD_XC; ++u) { s0 += u < left ? act_apply(a.act, xa[u]) : 0.f; s1 += u < left ? act_apply(a.act, xb[u]) : 0.f; }
+    }
+#pragma unroll
+    for (int hh = 0; hh < HEAD_MAX_D / 128; ++hh)
+      if (hh == h) { f[2 * hh] += s0; f[2 * hh + 1] += s1; }
+  }
+  if (xm) {
+    const float ih = 1.f / (float)a.hw;
+#pragma unroll
+    for (int q = 0; q < HEAD_MAX_D / 64; ++q) f[q] *= ih;
+    if (a.feat_out && s < n) {
+#pragma unroll
+      for (int h = 0; h < HEAD_MAX_D / 128; ++h)
+        if (h * 128 < d) *(float2*)(a.feat_out + (long)s * d + h * 128 + 2 * lane) = make_float2(f[2 * h], f[2 * h + 1]);
+    }
   }
   const float inv_so = a.sigma_out ? 1.f / a.sigma_out[0] : 1.f;
   const float bo = a.b_out ? a.b_out[0] : 0.f;
@@ -327,7 +384,7 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
       if (lab < 0 || lab == l) {                           // wave-uniform
         float dot = 0.f;
 #pragma unroll
-        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; dot += j < d ? f[q] * E[l * d + j] : 0.f; }
+        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = jof(q); dot += j < d ? f[q] * E[l * d + j] : 0.f; }
         const float x = wave_sum(dot) + ps;
         float tt, dd;
         loss_term(P.kind, x, &tt, &dd);
@@ -335,7 +392,7 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
         lacc += tt * wf;
         g = a.weight * dd * wf;
 #pragma unroll
-        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; df[q] += j < d ? g * E[l * d + j] : 0.f; }
+        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = jof(q); df[q] += j < d ? g * E[l * d + j] : 0.f; }
         if (lane == 0) {
           if (P.dwts) P.dwts[(long)sr * v + l] = a.weight * tt * inv_rows;
           if (a.logits) a.logits[(long)s * v + l] = x;
@@ -347,9 +404,35 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
       dsum += g;
     }
     if (lane == 0) dlg[s * vp + v] = dsum;
+#pragma unroll
+    for (int q = 0; q < HEAD_MAX_D / 64; ++q) df[q] += dsum * wo[q];
     if (a.dfeat) {
 #pragma unroll
-      for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; if (j < d) a.dfeat[(long)s * d + j] = df[q] + dsum * wo[q]; }
+      for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = jof(q); if (j < d) a.dfeat[(long)s * d + j] = df[q]; }
+    }
+    if (xm && a.dx) {
+      // d mean(act(x)) / dx: the adjoint of the pooling above, x read again (L2), a chunk of pixels per round trip
+      T* dxs = (T*)a.dx + (long)s * a.hw * d;
+      const float inv = 1.f / (float)a.hw;
+      for (int c = 0; c < nxc; ++c) {
+        const int h = c / xcp, p0 = (c - h * xcp) * HEAD_XC;
+        x_load(c);
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < HEAD_MAX_D / 128; ++hh)
+          if (hh == h) { g0 = df[2 * hh] * inv; g1 = df[2 * hh + 1] * inv; }
+        if (a.act == RCGAN_ACT_RELU) {
+#pragma unroll
+          for (int u = 0; u < HEAD_XC; ++u)
+            if (p0 + u < a.hw)
+              st2<T>(dxs + (long)(p0 + u) * d + h * 128 + 2 * lane, xa[u] > 0.f ? g0 : 0.f, xb[u] > 0.f ? g1 : 0.f);
+        } else {
+#pragma unroll 4
+          for (int u = 0; u < HEAD_XC; ++u)
+            if (p0 + u < a.hw)
+              st2<T>(dxs + (long)(p0 + u) * d + h * 128 + 2 * lane, g0 * act_grad(a.act, xa[u]), g1 * act_grad(a.act, xb[u]));
+        }
+      }
     }
   }
   // ---- loss: per-workgroup partial, summed in workgroup order by the last arrival (deterministic) -------------------
@@ -546,6 +629,12 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   }
   a.feat = feat; a.w_out = w_out; a.sigma_out = sigma_out; a.b_out = b_out; a.table = table; a.w_e = w_e; a.sigma_e = sigma_e; a.b_e = b_e;
   a.loss_acc = loss_acc; a.logits = logits; a.dfeat = dfeat; a.dw_out = dw_out; a.db_out = db_out; a.dtable = dtable; a.dw_e = dw_e; a.db_e = db_e;
+  a.x = hd->x; a.dx = hd->dx; a.hw = hd->hw; a.act = hd->act; a.feat_out = nullptr;
+  if (a.x) {
+    RC_REQUIRE(ctx, a.d % 128 == 0 && a.hw >= 1, "pooling inside the head needs d %% 128 == 0 (d %d, hw %d)", a.d, a.hw);
+    RC_REQUIRE(ctx, hd->x_dtype == RCGAN_F32 || hd->x_dtype == RCGAN_H16, "bad x dtype");
+    a.feat_out = (float*)feat;      // the features become an OUTPUT (read by the parameter-gradient kernels)
+  }
   const int vp = a.v + 1;
   const size_t need = ((size_t)a.v * a.d + (size_t)a.n * vp + (size_t)vp * a.d + 256) * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
@@ -559,8 +648,11 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   RC_LAUNCH_CHECK(ctx);
   const int nwg = cdiv(a.n, 4);
   RC_REQUIRE(ctx, nwg <= 256, "too many rows for the loss partials");
-  hipLaunchKernelGGL(head_logit_kernel, dim3(nwg), dim3(256), ((size_t)a.v * a.d + 4) * sizeof(float), ctx->stream, a, (const float*)Eg, dlg,
-                     losspart, ctx->counters() + RC_COUNTER_HEAD);
+  const size_t lds = ((size_t)a.v * a.d + 4) * sizeof(float);
+  if (a.x && hd->x_dtype == RCGAN_H16)
+    hipLaunchKernelGGL(head_logit_kernel<bf16_t>, dim3(nwg), dim3(256), lds, ctx->stream, a, (const float*)Eg, dlg, losspart, ctx->counters() + RC_COUNTER_HEAD);
+  else
+    hipLaunchKernelGGL(head_logit_kernel<float>, dim3(nwg), dim3(256), lds, ctx->stream, a, (const float*)Eg, dlg, losspart, ctx->counters() + RC_COUNTER_HEAD);
   RC_LAUNCH_CHECK(ctx);
   if (dw_out || db_out || dtable || dw_e || db_e) return head_param_grads(ctx, a, dlg, dEg);
   return RCGAN_OK;

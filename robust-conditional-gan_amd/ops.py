@@ -4,6 +4,7 @@ records a closure that runs the matching hand-written backward kernels.  This ta
 at mnist/model.py:250-262).  No arithmetic happens in Python or in PyTorch.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -697,6 +698,27 @@ def act_meanhw(ctx, x, kind):
     return y
 
 
+class PooledLater:
+    """act_meanhw(x, kind) that has not run: ops.proj_head pools the features inside its own launch and sends the gradient
+    straight back to x (the two act_meanhw launches around the head disappear); any other consumer calls materialize()."""
+
+    def __init__(self, ctx, x, kind):
+        self.ctx, self.x, self.kind = ctx, x, kind
+        n, h, w, c = x.shape
+        self.shape = (n, c)
+        self.req = x.req
+
+    def materialize(self):
+        return act_meanhw(self.ctx, self.x, self.kind)
+
+
+def act_meanhw_later(ctx, x, kind):
+    """act_meanhw for a consumer that can pool by itself (proj_head with d % 128 == 0 channels), else act_meanhw."""
+    if os.environ.get("RCGAN_HEAD_POOL", "1") == "1" and x.shape[-1] % 128 == 0 and x.shape[-1] <= HEAD_MAX_D:
+        return PooledLater(ctx, x, kind)
+    return act_meanhw(ctx, x, kind)
+
+
 def gather_rows(ctx, table, idx, n):
     """tf.nn.embedding_lookup(table, idx) (embedding.py:51); idx: int32 DT [n]."""
     v, d = table.shape
@@ -770,6 +792,7 @@ def proj_logit_all(ctx, feat, psi, E):
 
 
 HEAD_MAX_N = 1024
+HEAD_MAX_D = 256
 
 
 def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=None):
@@ -793,7 +816,16 @@ def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc,
             dw, _ = grad_of(ctx, wts)
             setattr(hd, "dwts_" + sfx, dw.ptr)
     dfeat = None
-    if feat.req and rec:
+    if isinstance(feat, PooledLater):
+        # pooled inside the launch from the trunk's output; feat becomes an output buffer for the parameter-gradient kernels
+        x = feat.x
+        hd.x, hd.x_dtype, hd.hw, hd.act = x.ptr, x.dtype, x.shape[1] * x.shape[2], feat.kind
+        if x.req and rec:
+            assert x.grad is None, "act_meanhw input has a single consumer in both models"
+            dx, _ = grad_of(ctx, x)
+            hd.dx = dx.ptr
+        feat = ctx.empty((n, d), L.F32)
+    elif feat.req and rec:
         assert feat.grad is None, "the projection head is its features' only consumer"
         dfeat, _ = grad_of(ctx, feat)
     pg = lambda t: _p(t) if (rec and t is not None) else None

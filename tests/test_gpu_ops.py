@@ -526,6 +526,60 @@ def test_proj_head(dev, case):
         assert_close(ctx.download(wd.grad), wt.grad.numpy(), 2e-5, "head dwts")
 
 
+@pytest.mark.parametrize("case", [(16, 8, 64, 128, "HINGE_REAL", "HINGE_FAKE"),      # the critic step's shape: [2B, 8, 8, 128]
+                                  (8, 8, 64, 128, "NEG_MEAN", None),                    # the generator step's
+                                  (6, 2, 9, 256, "HINGE_REAL", "HINGE_FAKE")])          # two 128-channel halves, odd pixel count
+def test_proj_head_pools_features(dev, case):
+    """proj_head fed with the trunk's output (ops.act_meanhw_later): relu + spatial mean inside the head's launch and the
+    gradient written straight to dx, against float64 autograd of relu -> mean -> head."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    n, rows_a, hw, d, kind_a, kind_b = case
+    v, ed = 10, 300
+    rs = np.random.RandomState(n * 3 + hw)
+    x = _prep(rs.randn(n, hw, 1, d).astype(np.float32), mode)
+    w_out = (rs.randn(d, 1) * 0.3).astype(np.float32); b_out = rs.randn(1).astype(np.float32)
+    table = (rs.randn(v, ed) * 0.1).astype(np.float32)
+    w_e = (rs.randn(ed, d) * 0.2).astype(np.float32); b_e = (rs.randn(d) * 0.1).astype(np.float32)
+    s_out, s_e, weight = np.float32(1.3), np.float32(0.7), 3.0
+    kinds = {"HINGE_REAL": L.LOSS_HINGE_REAL, "HINGE_FAKE": L.LOSS_HINGE_FAKE, "NEG_MEAN": L.LOSS_NEG_MEAN}
+    ctx.new_step()
+    xd = ctx.upload(x); xd.req = True
+    pw_out, pb_out, ptab, pw_e, pb_e = (FakeParam(ctx, a) for a in (w_out, b_out, table, w_e, b_e))
+    W_out = O.Weight(ctx, pw_out.t, ctx.upload(np.array([s_out]), L.F32))
+    W_e = O.Weight(ctx, pw_e.t, ctx.upload(np.array([s_e]), L.F32))
+    parts, host = [], []
+    for rows, kind in ((rows_a, kind_a), (n - rows_a, kind_b)):
+        if rows:
+            lab = rs.randint(v, size=rows).astype(np.int32)
+            parts.append((rows, kinds[kind], ctx.upload(lab), None)); host.append((rows, kind, lab))
+    loss = ctx.persistent((1,), L.F32, fill=0.0)
+    feat = O.act_meanhw_later(ctx, xd, L.ACT_RELU)
+    assert isinstance(feat, O.PooledLater)
+    O.proj_head(ctx, feat, W_out, pb_out.t, ptab.t, W_e, pb_e.t, parts, weight, loss)
+    T = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    tx, two, tbo, tt, twe, tbe = T(x), T(w_out), T(b_out), T(table), T(w_e), T(b_e)
+    tf = torch.relu(tx).mean(dim=(1, 2))
+    E = tt @ (twe / float(s_e)) + tbe
+    lg = ((tf @ (two / float(s_out))).reshape(-1) + tbo)[:, None] + tf @ E.t()
+    total, r0 = 0.0, 0
+    for rows, kind, lab in host:
+        xx = lg[r0:r0 + rows]
+        term = {"HINGE_REAL": torch.relu(1 - xx), "HINGE_FAKE": torch.relu(1 + xx), "NEG_MEAN": -xx}[kind]
+        total = total + (term * torch.nn.functional.one_hot(torch.as_tensor(lab, dtype=torch.long), v).double()).sum(1).mean()
+        r0 += rows
+    total = weight * total
+    total.backward()
+    tol = 2e-5 if mode == "f32" else TOL[mode]             # dx is stored in the activation dtype
+    assert_close(ctx.download(loss), np.array([float(total.detach())]), 1e-5, "pooled head loss")
+    assert_close(ctx.download(xd.grad), tx.grad.numpy(), tol, "pooled head dx")
+    assert_close(ctx.download(W_out.dwbar), two.grad.numpy() * float(s_out), 2e-5, "pooled head d(w_out / sigma)")
+    assert_close(ptab.grad(ctx), tt.grad.numpy(), 2e-5, "pooled head dtable")
+    assert_close(ctx.download(W_e.dwbar), twe.grad.numpy() * float(s_e), 2e-5, "pooled head d(W_e / sigma)")
+    assert_close(pb_e.grad(ctx), tbe.grad.numpy(), 2e-5, "pooled head db_e")
+
+
 def _random_cases(kind, count, seed):
     """Seeded shape sweeps for the dense / transposed-conv / batch-norm tests (sizes the fixed lists do not pin down)."""
     rs = np.random.RandomState(seed)
