@@ -137,6 +137,15 @@ typedef struct rcgan_prepare_item {
   void* prepared;            /* rcgan_conv_prepared_bytes(&desc) */
 } rcgan_prepare_item;
 int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items);
+/* The same launch with the projection head's label embeddings riding in it as extra workgroups:
+ * E[l][j] = (sum_k table[l][k] * w_e[k][j]) / sigma_e + b_e[j]  (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421).
+ * E depends on parameters only; computed here it leaves the step's dependency chain (rcgan_head_desc::E_pre).  e may be NULL. */
+typedef struct rcgan_embed_desc {
+  int v, e_dim, d;
+  const float *table, *w_e, *sigma_e /* device scalar or NULL */, *b_e /* or NULL */;
+  float* E;               /* [v][d] */
+} rcgan_embed_desc;
+int rcgan_conv_prepare_batch_embed(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e);
 
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
 /* y = conv2d_SAME(x, w) (+bias).  Replaces tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
@@ -355,6 +364,9 @@ typedef struct {
    * straight to dx [n][hw][d] (or NULL).  The `feat` argument is then an OUTPUT buffer [n][d]. */
   const void* x; void* dx;
   int x_dtype, hw, act;
+  /* Optional: E [v][d], the label embeddings table @ W_e / sigma_e + b_e computed earlier in the step by
+   * rcgan_conv_prepare_batch_embed (they depend on parameters only): the head then starts with its logit kernel. */
+  const float* E_pre;
 } rcgan_head_desc;
 int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
                             const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,

@@ -42,7 +42,13 @@ class HeadDesc(C.Structure):
                 ("rows_a", C.c_int), ("kind_a", C.c_int), ("kind_b", C.c_int), ("weight", C.c_float),
                 ("labels_a", C.c_void_p), ("wts_a", C.c_void_p), ("dwts_a", C.c_void_p),
                 ("labels_b", C.c_void_p), ("wts_b", C.c_void_p), ("dwts_b", C.c_void_p),
-                ("x", C.c_void_p), ("dx", C.c_void_p), ("x_dtype", C.c_int), ("hw", C.c_int), ("act", C.c_int)]
+                ("x", C.c_void_p), ("dx", C.c_void_p), ("x_dtype", C.c_int), ("hw", C.c_int), ("act", C.c_int),
+                ("E_pre", C.c_void_p)]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("v", C.c_int), ("e_dim", C.c_int), ("d", C.c_int),
+                ("table", C.c_void_p), ("w_e", C.c_void_p), ("sigma_e", C.c_void_p), ("b_e", C.c_void_p), ("E", C.c_void_p)]
 
 
 class SnItem(C.Structure):
@@ -84,6 +90,7 @@ SIGNATURES = {
     "rcgan_conv_prepared_bytes": (SZ, [DP]),
     "rcgan_conv_prepare": (I, [P, DP, P, P, P]),
     "rcgan_conv_prepare_batch": (I, [P, C.POINTER(PrepareItem), I]),
+    "rcgan_conv_prepare_batch_embed": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc)]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),

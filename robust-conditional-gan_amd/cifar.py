@@ -270,11 +270,8 @@ def Discriminator_projection(labels, update_collection=None):
                       update_collection=update_collection, biases=True)
 
 
-def Discriminator_head(features, parts, weight, loss_acc, update_collection=None):
-    """The tail of Discriminator (D.Output, gan_resnet.py:408-411), Discriminator_projection (:414-421), the projection
-    logit (:588; every label's logit :654-660) and the loss terms built on it (:604-606, :647, :673-684, :751-773) as ONE
-    launch with all their gradients (ops.proj_head).  update_collection: that of D.Output's spectral norm (the projection's
-    is None at every call site of the reference).  parts: see ops.proj_head."""
+def _head_weights(update_collection=None):
+    """(w_out, b_out, table, w_e, b_e) of the projection head under the reference's variable names."""
     g = Graph.current
     with variable_scope("Discriminator"):
         with variable_scope('D.Output'):
@@ -285,7 +282,18 @@ def Discriminator_head(features, parts, weight, loss_acc, update_collection=None
         with variable_scope('D.Embedding_y'):
             w_e = spectral_normed_weight(scoped('W'), update_collection=None)
             b_e = g.param(scoped('b'))
-    O.proj_head(g.ctx, features, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc)
+    return w_out, b_out, table, w_e, b_e
+
+
+def Discriminator_head(features, parts, weight, loss_acc, update_collection=None):
+    """The tail of Discriminator (D.Output, gan_resnet.py:408-411), Discriminator_projection (:414-421), the projection
+    logit (:588; every label's logit :654-660) and the loss terms built on it (:604-606, :647, :673-684, :751-773) as ONE
+    launch with all their gradients (ops.proj_head).  update_collection: that of D.Output's spectral norm (the projection's
+    is None at every call site of the reference).  parts: see ops.proj_head."""
+    g = Graph.current
+    w_out, b_out, table, w_e, b_e = _head_weights(update_collection)
+    # (the label embeddings E = table @ W_e / sigma + b_e of this step, if _prepare_all let them ride in its launch)
+    O.proj_head(g.ctx, features, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, E_pre=getattr(g, "head_E", None))
 
 
 def perm_classifier(x, perm_type='linear'):
@@ -473,7 +481,7 @@ class CifarRCGAN:
                 names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8, up))
         return names
 
-    def _prepare_all(self, which):
+    def _prepare_all(self, which, head_update=False):
         """One launch prepares every spectrally normalised conv filter the step will use (W/sigma changes with
         every power iteration).  The generator's filters are NOT normalised: their kernel layouts are refreshed
         only when the parameters change (_refresh_generator_filters)."""
@@ -481,7 +489,16 @@ class CifarRCGAN:
         for grp in which:
             if grp is not self.PG:
                 names += self._filter_names(grp)
-        self.graph.prepare_convs(names, self.ctx.act_dtype)
+        # the projection head's label embeddings depend on parameters only: they ride in the same launch (RCGAN_HEAD_EMBED_RIDE=0:
+        # the head computes them in a launch of its own, in the middle of the step's dependency chain)
+        g, embed = self.graph, None
+        g.head_E = None
+        if self.fused_head and self.PD in which and head_update is not False and os.environ.get("RCGAN_HEAD_EMBED_RIDE", "1") == "1":
+            _, _, table, w_e, b_e = _head_weights(head_update)
+            E = self.ctx.empty((table.shape[0], w_e.param.shape[-1]), L.F32)
+            embed = (table, w_e, b_e, E)
+        if g.prepare_convs(names, self.ctx.act_dtype, embed=embed):
+            g.head_E = embed[3]
 
     def _refresh_generator_filters(self):
         if self._pg_prepared_version != self.PG.version:
@@ -508,7 +525,7 @@ class CifarRCGAN:
             if not fakes_ready:
                 self._rng(inp["z"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(True, True))
-        self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD))
+        self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD), head_update=None)
         # [real ; fake] is ONE discriminator pass for every algorithm: there is no norm layer in D and the spectral-norm
         # weights of a step are computed once (prefetch_sn above), so D(real) and D(fake) of the reference's rcgan-u graph
         # (:654-660) see the same filters and the trunk is evaluated on the 2B rows together
@@ -577,7 +594,7 @@ class CifarRCGAN:
         if self.device_rng:
             self._rng(inp["z_G"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(False, True))        # D convs + D.Output: NO_OPS; projection / perm: update
-        self._prepare_all((self.PG, self.PD))
+        self._prepare_all((self.PG, self.PD), head_update=NO_OPS)
         fake = Generator(n, inp["labels_random_G"], inp["z_G"])                                      # :719
         lab = inp["labels_random_G"] if self.alg in ("biased", "unbiased") else inp["labels_biased_G"]
         if self.fused_head:

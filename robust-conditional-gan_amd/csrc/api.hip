@@ -1,5 +1,6 @@
 // extern "C" entry points: context, conv / dense dispatch (MFMA vs direct), optimiser, graphs.
 #include "conv_mfma.h"
+#include "small_gemm.h"
 #include "conv_image.h"
 
 // ---- provided by the other translation units ------------------------------------------------------
@@ -456,6 +457,19 @@ int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, in
     if (rc) return rc;
   }
   return conv_prepare_batch_launch(ctx, items, n_items);
+}
+
+int rcgan_conv_prepare_batch_embed(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e) {
+  if (e == nullptr) return rcgan_conv_prepare_batch(ctx, items, n_items);
+  RC_REQUIRE(ctx, items != nullptr && n_items >= 1, "the riding product needs at least one filter to ride with");
+  RC_REQUIRE(ctx, e->v >= 1 && e->v <= HEAD_MAX_V && e->e_dim >= 1 && e->d >= 1 && e->table && e->w_e && e->E, "bad embed desc");
+  for (int i = 0; i < n_items; ++i) {
+    int rc = check_desc(ctx, &items[i].desc);
+    if (rc) return rc;
+  }
+  // E[l][j] = (sum_k table[l][k] W_e[k][j]) / sigma_e + b_e[j]   (the first small-left GEMM of rcgan_proj_head_fwd_bwd)
+  SmallGemmArgs ge = {e->v, e->e_dim, e->d, e->table, e->e_dim, 1, e->w_e, e->sigma_e, e->b_e, e->E, nullptr, 0};
+  return conv_prepare_batch_launch(ctx, items, n_items, &ge);
 }
 
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {

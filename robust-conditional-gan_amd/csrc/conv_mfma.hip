@@ -23,6 +23,7 @@
 //   blocks into fp32 slabs that a second kernel reduces (deterministic, no atomics).
 #include <vector>
 #include "conv_mfma.h"
+#include "small_gemm.h"
 #include "mfma_util.h"
 #include "conv_image.h"
 
@@ -1262,7 +1263,8 @@ int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, con
 // batched preparation: every filter of a network in ONE launch (blockIdx.y = filter)
 struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
 // rows = the n filters, then the phase filters; row r owns workgroups [start[r], start[r+1]) of the one-dimensional grid
-struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[58]; int n, rows; };
+// ... and, last, an optional small-left GEMM (the label embeddings of the projection head: parameters only, see small_gemm.h)
+struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[59]; int n, rows, gemm_row; SmallGemmArgs gemm; };
 
 // One (64 ci x 64 co tile, tap class) unit of the summed filters of the sub-pixel forms (layouts and tap classes: see
 // conv_prepare_phase_kernel, whose values these are bit for bit -- same fp32 summation order).  The filter is read along co;
@@ -1325,7 +1327,10 @@ __device__ __forceinline__ void prepare_phase_units(const PhasePrepBatch::It& p,
 }
 
 __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
-  __shared__ bf16_t tile[64][66];
+  // (one buffer for the three row kinds: the 64 x 66 transpose tile, or the small GEMM's A chunk and reduction scratch)
+  __shared__ __attribute__((aligned(16))) float lds_u[SG_AS_FLOATS + SG_RED_FLOATS];
+  static_assert(sizeof(bf16_t) * 64 * 66 <= sizeof(float) * (SG_AS_FLOATS + SG_RED_FLOATS), "transpose tile fits");
+  bf16_t (*tile)[66] = (bf16_t (*)[66])lds_u;
   int row = 0;                                   // largest r with start[r] <= blockIdx.x (six dependent scalar loads, not 57)
 #pragma unroll
   for (int step = 32; step > 0; step >>= 1) {
@@ -1333,6 +1338,7 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
     if (r < b.rows && (int)blockIdx.x >= b.start[r]) row = r;
   }
   const int bid = (int)blockIdx.x - b.start[row], nb = b.start[row + 1] - b.start[row];
+  if (row == b.gemm_row) { small_gemm_body(b.gemm, bid, lds_u, lds_u + SG_AS_FLOATS); return; }
   if (row >= b.n) { prepare_phase_units(b.ph[row - b.n], tile, bid, nb); return; }
   const PrepItem it = b.it[row];
   const long total = (long)it.T * it.Cin * it.Cout;
@@ -1379,7 +1385,7 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
 }
 
 static int env_int(const char* name, int dflt);
-int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n) {
+int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm) {
   // the summed phase filters of the sub-pixel forms (upsample-3x3, ConvMeanPool): up to 8 of them ride as extra rows of the
   // first launch's grid, the rest (none in these networks) take the stand-alone kernel
   static const int ride = env_int("RCGAN_PREP_PHASE_RIDE", 1);
@@ -1427,6 +1433,13 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
     }
     b.rows = m + np;
     b.start[m + np] = at;
+    b.gemm_row = -1;
+    if (gemm && base == 0) {             // the riding product: cdiv(d, 16) workgroups behind everything else
+      b.gemm = *gemm;
+      b.gemm_row = b.rows++;
+      at += (gemm->d + 15) / 16;
+      b.start[b.rows] = at;
+    }
     hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(at), dim3(256), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
   }

@@ -4,6 +4,7 @@
 //   mnist/model.py:135-145, 199-221, 679-685.
 // All of this is a few KB of fp32: each op is one small launch built on wavefront reductions.
 #include "common.h"
+#include "small_gemm.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void act_meanhw_fwd_kernel(int hw, int c, int act, const T* x, float* feat) {
@@ -192,7 +193,6 @@ __global__ void softmax_rows_bwd_kernel(int rows, int cols, const float* p, cons
 // E exist, the embedding gradients collapse to V x d problems: dE[l] = sum_s dlogit[s,l] feat[s], dW_e = table^T dE,
 // dtable = dE W_e^T / sigma_e.
 // ---------------------------------------------------------------------------------------------------------
-#define HEAD_MAX_V 16
 #define HEAD_MAX_D 256
 #define HEAD_MAX_N 1024
 struct HeadPart { int rows, kind; const int32_t* labels; const float* wts; float* dwts; };
@@ -234,69 +234,10 @@ template <> __device__ __forceinline__ void st2<bf16_t>(bf16_t* p, float a, floa
 // requests its <= 20 B elements AND its share of the A chunk (-> LDS) before it waits: ONE memory round trip per chunk
 // (the 64-columns x 4-lanes form these two kernels had walked k in 38 dependent steps: 13 us for 0.4 MFLOP).
 // rowsum_out (optional): += the sum over k of row rowsum_row of A (the bias gradient of D.Output).
-#define SG_KC 320
-#define SG_UB (SG_KC / 16)
-struct SmallGemmArgs {
-  int L, K, d;
-  const float* A; int lda_l, lda_k;
-  const float* B;
-  const float* sigma;      // scale = 1 / sigma[0], or 1 if null
-  const float* bias;       // [d] or null
-  float* out;              // [L][d]
-  float* rowsum_out; int rowsum_row;
-};
 __global__ __launch_bounds__(256) void head_smallgemm_kernel(SmallGemmArgs g) {
-  __shared__ float As[(HEAD_MAX_V + 1) * SG_KC];
-  __shared__ float red[16][HEAD_MAX_V + 1][16];
-  const int t = threadIdx.x, jj = t & 15, kl = t >> 4, j = blockIdx.x * 16 + jj;
-  const int L = g.L, d = g.d;
-  float acc[HEAD_MAX_V + 1];
-#pragma unroll
-  for (int l = 0; l <= HEAD_MAX_V; ++l) acc[l] = 0.f;
-  float rs = 0.f;
-  const float scale = g.sigma ? 1.f / g.sigma[0] : 1.f;
-  const float bj = (g.bias && j < d) ? g.bias[j] : 0.f;
-  for (int kc0 = 0; kc0 < g.K; kc0 += SG_KC) {
-    const int kc = min(SG_KC, g.K - kc0);
-    float w[SG_UB];
-#pragma unroll
-    for (int u = 0; u < SG_UB; ++u) {
-      const int k = kl + 16 * u;
-      w[u] = (k < kc && j < d) ? g.B[(long)(kc0 + k) * d + j] : 0.f;
-    }
-    if (kc0) __syncthreads();                   // the previous chunk of A has been consumed
-    for (int i = t; i < L * kc; i += 256) {
-      const int l = i / kc, k = i - l * kc;
-      As[l * SG_KC + k] = g.A[(long)l * g.lda_l + (long)(kc0 + k) * g.lda_k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < SG_UB; ++u) {
-      const int k = kl + 16 * u;
-      if (k < kc) {
-#pragma unroll
-        for (int l = 0; l <= HEAD_MAX_V; ++l)
-          if (l < L) acc[l] += As[l * SG_KC + k] * w[u];
-      }
-    }
-    if (g.rowsum_out && blockIdx.x == 0 && t < 64)
-      for (int k = t; k < kc; k += 64) rs += As[g.rowsum_row * SG_KC + k];
-  }
-#pragma unroll
-  for (int l = 0; l <= HEAD_MAX_V; ++l)
-    if (l < L) red[kl][l][jj] = acc[l];
-  __syncthreads();
-  if (t < L * 16) {
-    const int l = t >> 4;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q += 2) { s0 += red[q][l][jj]; s1 += red[q + 1][l][jj]; }
-    if (j < d) g.out[l * d + j] = (s0 + s1) * scale + bj;
-  }
-  if (g.rowsum_out && blockIdx.x == 0 && t < 64) {
-    rs = wave_sum(rs);
-    if (t == 0) g.rowsum_out[0] += rs;
-  }
+  __shared__ float As[SG_AS_FLOATS];
+  __shared__ float red[SG_RED_FLOATS];
+  small_gemm_body(g, blockIdx.x, As, red);
 }
 
 // T: element type of a.x (ignored when a.x is null)
@@ -642,10 +583,14 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   float* dlg = Eg + (size_t)a.v * a.d;
   float* dEg = dlg + (size_t)a.n * vp;
   float* losspart = dEg + (size_t)vp * a.d;
-  const int dblk = cdiv(a.d, 16);
-  SmallGemmArgs ge = {a.v, a.e_dim, a.d, a.table, a.e_dim, 1, a.w_e, a.sigma_e, a.b_e, Eg, nullptr, 0};
-  hipLaunchKernelGGL(head_smallgemm_kernel, dim3(dblk), dim3(256), 0, ctx->stream, ge);
-  RC_LAUNCH_CHECK(ctx);
+  if (hd->E_pre) {
+    Eg = (float*)hd->E_pre;         // the label embeddings were computed earlier in the step (rcgan_conv_prepare_batch_embed)
+  } else {
+    const int dblk = cdiv(a.d, 16);
+    SmallGemmArgs ge = {a.v, a.e_dim, a.d, a.table, a.e_dim, 1, a.w_e, a.sigma_e, a.b_e, Eg, nullptr, 0};
+    hipLaunchKernelGGL(head_smallgemm_kernel, dim3(dblk), dim3(256), 0, ctx->stream, ge);
+    RC_LAUNCH_CHECK(ctx);
+  }
   const int nwg = cdiv(a.n, 4);
   RC_REQUIRE(ctx, nwg <= 256, "too many rows for the loss partials");
   const size_t lds = ((size_t)a.v * a.d + 4) * sizeof(float);

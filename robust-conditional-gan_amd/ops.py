@@ -88,7 +88,7 @@ class Weight:
         return self.dwbar
 
 
-def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None):
+def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None):
     """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride, hw):
     hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant.
     persistent: None -> per-step arena buffers, skipped when already prepared this step;
@@ -115,7 +115,16 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None):
         todo.append(L.PrepareItem(desc, w.param.ptr, w.sigma.ptr if w.sigma is not None else None, buf.ptr))
     if todo:
         arr = (L.PrepareItem * len(todo))(*todo)
+        if embed is not None:
+            # the projection head's label embeddings ride in the same launch: embed = (table DT, W_e Weight, b_e DT or None, E DT)
+            table, w_e, b_e, E = embed
+            v, e_dim = table.shape
+            ed = L.EmbedDesc(v, e_dim, w_e.param.shape[-1], table.ptr, w_e.param.ptr, w_e.sigma.ptr if w_e.sigma is not None else None,
+                             b_e.ptr if b_e is not None else None, E.ptr)
+            ctx.check(ctx.lib.rcgan_conv_prepare_batch_embed(ctx.h, arr, len(todo), C.byref(ed)))
+            return True
         ctx.check(ctx.lib.rcgan_conv_prepare_batch(ctx.h, arr, len(todo)))
+    return False
 
 
 def spectral_norm_batch(ctx, entries):
@@ -795,7 +804,7 @@ HEAD_MAX_N = 1024
 HEAD_MAX_D = 256
 
 
-def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=None):
+def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=None, E_pre=None):
     """The whole projection head in one launch (rcgan_proj_head_fwd_bwd): psi = Linear_SN(feat) (gan_resnet.py:408-411),
     E = Linear_SN(embed_y(l)) for every label l (:414-421), logit[s,l] = psi[s] + <feat[s], E[l]> (:588, :654-660), the loss terms
     and every gradient.  w_out / w_e: Weight handles (sigma fused); table: the embedding_map parameter.
@@ -815,6 +824,9 @@ def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc,
         if wts is not None and wts.req and rec:
             dw, _ = grad_of(ctx, wts)
             setattr(hd, "dwts_" + sfx, dw.ptr)
+    if E_pre is not None:          # label embeddings of this step's parameters, computed with the filter preparation
+        assert E_pre.shape == (v, d)
+        hd.E_pre = E_pre.ptr
     dfeat = None
     if isinstance(feat, PooledLater):
         # pooled inside the launch from the trunk's output; feat becomes an output buffer for the parameter-gradient kernels

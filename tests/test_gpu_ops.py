@@ -580,6 +580,40 @@ def test_proj_head_pools_features(dev, case):
     assert_close(pb_e.grad(ctx), tbe.grad.numpy(), 2e-5, "pooled head db_e")
 
 
+def test_label_embeddings_ride_in_filter_preparation(dev):
+    """rcgan_conv_prepare_batch_embed: the projection head's E = table @ W_e / sigma + b_e computed as extra workgroups of the batched
+    filter preparation -- against numpy, and the head fed with it (rcgan_head_desc::E_pre) against the head computing it itself."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    d, v, ed, n = 128, 10, 300, 12
+    rs = np.random.RandomState(11)
+    feat = rs.rand(n, d).astype(np.float32)
+    w_out = (rs.randn(d, 1) * 0.3).astype(np.float32); b_out = rs.randn(1).astype(np.float32)
+    table = (rs.randn(v, ed) * 0.1).astype(np.float32)
+    w_e = (rs.randn(ed, d) * 0.2).astype(np.float32); b_e = (rs.randn(d) * 0.1).astype(np.float32)
+    lab = rs.randint(v, size=n).astype(np.int32)
+    out = []
+    for ride in (True, False):
+        ctx.new_step()
+        fd = ctx.upload(feat, L.F32); fd.req = True
+        pw_out, pb_out, ptab, pw_e, pb_e = (FakeParam(ctx, a) for a in (w_out, b_out, table, w_e, b_e))
+        W_out = O.Weight(ctx, pw_out.t, ctx.upload(np.array([1.3], np.float32), L.F32))
+        W_e = O.Weight(ctx, pw_e.t, ctx.upload(np.array([0.7], np.float32), L.F32))
+        E = None
+        if ride:
+            conv_w = FakeParam(ctx, (rs.randn(3, 3, 64, 64) * 0.05).astype(np.float32))
+            E = ctx.empty((v, d), L.F32)
+            assert O.prepare_batch(ctx, [(O.Weight(ctx, conv_w.t), 3, 1, 8)], ctx.act_dtype, embed=(ptab.t, W_e, pb_e.t, E))
+            ref = table.astype(np.float64) @ (w_e.astype(np.float64) / 0.7) + b_e
+            assert_close(ctx.download(E), ref, 2e-5, "riding label embeddings")
+        loss = ctx.persistent((1,), L.F32, fill=0.0)
+        O.proj_head(ctx, fd, W_out, pb_out.t, ptab.t, W_e, pb_e.t, [(n, L.LOSS_HINGE_REAL, ctx.upload(lab), None)], 2.0, loss, E_pre=E)
+        out.append((ctx.download(loss).copy(), ctx.download(fd.grad).copy(), ctx.download(W_e.dwbar).copy(), ptab.grad(ctx).copy()))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b), "head with riding embeddings differs from the head computing them itself"
+
+
 def _random_cases(kind, count, seed):
     """Seeded shape sweeps for the dense / transposed-conv / batch-norm tests (sizes the fixed lists do not pin down)."""
     rs = np.random.RandomState(seed)
