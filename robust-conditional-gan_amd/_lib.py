@@ -51,6 +51,12 @@ class EmbedDesc(C.Structure):
                 ("table", C.c_void_p), ("w_e", C.c_void_p), ("sigma_e", C.c_void_p), ("b_e", C.c_void_p), ("E", C.c_void_p)]
 
 
+class StepInputsDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("dtype", C.c_int), ("images", C.c_void_p), ("x", C.c_void_p), ("pooled", C.c_void_p),
+                ("noise_lo", C.c_float), ("noise_hi", C.c_float), ("seed", C.c_uint64), ("rng_state", C.c_void_p),
+                ("fill", C.c_void_p), ("fill_count", C.c_size_t)]
+
+
 class SnItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("sigma", C.c_void_p), ("save", C.c_void_p),
                 ("k", C.c_int), ("c", C.c_int), ("update", C.c_int)]
@@ -91,6 +97,7 @@ SIGNATURES = {
     "rcgan_conv_prepare": (I, [P, DP, P, P, P]),
     "rcgan_conv_prepare_batch": (I, [P, C.POINTER(PrepareItem), I]),
     "rcgan_conv_prepare_batch_embed": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc)]),
+    "rcgan_conv_prepare_batch_riders": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc), C.POINTER(StepInputsDesc)]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),

@@ -221,7 +221,11 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
         if fused_pool_d(ctx, x.shape[0]):
             # ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution, ops.conv2d_meanpool); the
             # shortcuts as the reference writes them, MeanPoolConv: 1x1 convolution of the pooled input (gan_resnet.py:249-257, 346)
-            t = Conv2D(O.meanpool2(ctx, x), IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
+            # (the critic step's input rider has pooled the images already: x.pooled)
+            xp = getattr(Graph.current, "image_pool", None)
+            if xp is not None and (x.req or xp.shape != (x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3])):
+                xp = None
+            t = Conv2D(xp if xp is not None else O.meanpool2(ctx, x), IMG_DIM, DIM_D, 1, 1, 'D.Block.1.Shortcut', he_init=False, **kw)
             h = Conv2D(x, IMG_DIM, DIM_D, 3, 1, 'D.Block.1.Conv1', **kw)
             x = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.1.Conv2', _in_relu=True, _accumulate_into=t, _out_meanpool=True, **kw)
             t = Conv2D(O.meanpool2(ctx, x), DIM_D, DIM_D, 1, 1, 'D.Block.2.Shortcut', he_init=False, **kw)
@@ -330,6 +334,7 @@ class CifarRCGAN:
         self.use_graphs, self.device_rng = use_graphs, device_rng
         # the projection head + loss terms as one launch (Discriminator_head); RCGAN_FUSED_HEAD=0 keeps the op-by-op form
         self.fused_head = os.environ.get("RCGAN_FUSED_HEAD", "1") == "1" and 2 * int(batch_size) <= O.HEAD_MAX_N
+        self.ride_inputs = os.environ.get("RCGAN_RIDE_INPUTS", "1") == "1"
         if arena_bytes is None:
             arena_bytes = int(2.5e6 * 4 * self.B * 2) + (1 << 30)      # ~20 MB/sample fp32-equivalent + slack
         self.ctx = Context(device, dtype, arena_bytes=arena_bytes)
@@ -481,7 +486,7 @@ class CifarRCGAN:
                 names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8, up))
         return names
 
-    def _prepare_all(self, which, head_update=False):
+    def _prepare_all(self, which, head_update=False, inputs=None):
         """One launch prepares every spectrally normalised conv filter the step will use (W/sigma changes with
         every power iteration).  The generator's filters are NOT normalised: their kernel layouts are refreshed
         only when the parameters change (_refresh_generator_filters)."""
@@ -497,8 +502,10 @@ class CifarRCGAN:
             _, _, table, w_e, b_e = _head_weights(head_update)
             E = self.ctx.empty((table.shape[0], w_e.param.shape[-1]), L.F32)
             embed = (table, w_e, b_e, E)
-        if g.prepare_convs(names, self.ctx.act_dtype, embed=embed):
+        rode = g.prepare_convs(names, self.ctx.act_dtype, embed=embed, inputs=inputs)
+        if rode and embed is not None:
             g.head_E = embed[3]
+        return rode
 
     def _refresh_generator_filters(self):
         if self._pg_prepared_version != self.PG.version:
@@ -519,19 +526,33 @@ class CifarRCGAN:
         self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
         g.begin_step({1})
-        self.PD.zero_grad()
-        if self.device_rng:
-            self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
-            if not fakes_ready:
-                self._rng(inp["z"], 1, 0.0, 1.0)
+        # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
+        # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
+        # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
+        ride = fakes_ready and self.device_rng and self.ride_inputs and (self.PD.gradbuf.numel() % 4 == 0)
+        x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
+        real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
+        si = None
+        if ride:
+            fptr, fcount = self.PD.zero_grad(defer=True)
+            g.image_pool = ctx.empty((2 * B, 16, 16, 3), x_all.dtype)
+            si = L.StepInputsDesc(B, real.dtype, inp["images"].ptr, x_all.ptr, g.image_pool.ptr,
+                                  0.0, 1.0 / 128, self.seed * 1000003 + self.rank, self.rng_state.data_ptr(), fptr, fcount)
+        else:
+            g.image_pool = None
+            self.PD.zero_grad()
+            if self.device_rng:
+                self._rng(inp["noise"], 0, 0.0, 1.0 / 128)
+                if not fakes_ready:
+                    self._rng(inp["z"], 1, 0.0, 1.0)
         g.prefetch_sn(self._sn_entries(True, True))
-        self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD), head_update=None)
+        rode = self._prepare_all((self.PD,) if fakes_ready else (self.PG, self.PD), head_update=None, inputs=si)
+        assert rode or si is None, "the step-input rider needs the batched filter preparation"
         # [real ; fake] is ONE discriminator pass for every algorithm: there is no norm layer in D and the spectral-norm
         # weights of a step are computed once (prefetch_sn above), so D(real) and D(fake) of the reference's rcgan-u graph
         # (:654-660) see the same filters and the trunk is evaluated on the 2B rows together
-        x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
-        real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
-        ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
+        if si is None:
+            ctx.check(ctx.lib.rcgan_preprocess_cifar(ctx.h, B, inp["images"].ptr, inp["noise"].ptr, real.dtype, real.ptr))
         if fakes_ready:
             fake = self.x_all.rows(B, 2 * B)
         else:

@@ -1,6 +1,7 @@
 // extern "C" entry points: context, conv / dense dispatch (MFMA vs direct), optimiser, graphs.
 #include "conv_mfma.h"
 #include "small_gemm.h"
+#include "step_inputs.h"
 #include "conv_image.h"
 
 // ---- provided by the other translation units ------------------------------------------------------
@@ -460,16 +461,34 @@ int rcgan_conv_prepare_batch(rcgan_ctx* ctx, const rcgan_prepare_item* items, in
 }
 
 int rcgan_conv_prepare_batch_embed(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e) {
-  if (e == nullptr) return rcgan_conv_prepare_batch(ctx, items, n_items);
-  RC_REQUIRE(ctx, items != nullptr && n_items >= 1, "the riding product needs at least one filter to ride with");
-  RC_REQUIRE(ctx, e->v >= 1 && e->v <= HEAD_MAX_V && e->e_dim >= 1 && e->d >= 1 && e->table && e->w_e && e->E, "bad embed desc");
+  return rcgan_conv_prepare_batch_riders(ctx, items, n_items, e, nullptr);
+}
+
+int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
+                                    const rcgan_step_inputs_desc* si) {
+  if (e == nullptr && si == nullptr) return rcgan_conv_prepare_batch(ctx, items, n_items);
+  RC_REQUIRE(ctx, items != nullptr && n_items >= 1, "the riders need at least one filter to ride with");
   for (int i = 0; i < n_items; ++i) {
     int rc = check_desc(ctx, &items[i].desc);
     if (rc) return rc;
   }
-  // E[l][j] = (sum_k table[l][k] W_e[k][j]) / sigma_e + b_e[j]   (the first small-left GEMM of rcgan_proj_head_fwd_bwd)
-  SmallGemmArgs ge = {e->v, e->e_dim, e->d, e->table, e->e_dim, 1, e->w_e, e->sigma_e, e->b_e, e->E, nullptr, 0};
-  return conv_prepare_batch_launch(ctx, items, n_items, &ge);
+  SmallGemmArgs ge;
+  if (e) {
+    RC_REQUIRE(ctx, e->v >= 1 && e->v <= HEAD_MAX_V && e->e_dim >= 1 && e->d >= 1 && e->table && e->w_e && e->E, "bad embed desc");
+    // E[l][j] = (sum_k table[l][k] W_e[k][j]) / sigma_e + b_e[j]   (the first small-left GEMM of rcgan_proj_head_fwd_bwd)
+    ge = {e->v, e->e_dim, e->d, e->table, e->e_dim, 1, e->w_e, e->sigma_e, e->b_e, e->E, nullptr, 0};
+  }
+  StepInputsArgs sa;
+  if (si) {
+    RC_REQUIRE(ctx, si->n >= 1 && si->images && si->x && si->rng_state, "bad step-inputs desc");
+    RC_REQUIRE(ctx, si->dtype == RCGAN_F32 || si->dtype == RCGAN_H16, "bad dtype");
+    RC_REQUIRE(ctx, si->fill == nullptr || (si->fill_count % 4 == 0 && ((size_t)si->fill & 15) == 0), "fill range must be whole float4");
+    sa.n = si->n; sa.is16 = si->dtype == RCGAN_H16 ? 1 : 0; sa.img = si->images; sa.x = si->x; sa.pooled = si->pooled;
+    sa.lo = si->noise_lo; sa.hi = si->noise_hi; sa.seed = si->seed; sa.state = (uint64_t*)si->rng_state;
+    sa.counter = ctx->counters() + RC_COUNTER_INPUTS;
+    sa.fill = si->fill; sa.fill4 = si->fill ? si->fill_count / 4 : 0;
+  }
+  return conv_prepare_batch_launch(ctx, items, n_items, e ? &ge : nullptr, si ? &sa : nullptr);
 }
 
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {

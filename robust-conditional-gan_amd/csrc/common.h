@@ -49,6 +49,7 @@ struct rcgan_ctx {
 #define RC_COUNTER_BN 0        // [0,32): one per 64-channel column block of the batch-norm reductions
 #define RC_COUNTER_WGRAD 32    // [32,..): filter-gradient finish
 #define RC_COUNTER_HEAD 500    // loss partials of the fused projection head
+#define RC_COUNTER_INPUTS 501  // the step-input rider of the filter preparation (step_inputs.h)
 #define RC_COUNTER_BNSEG 512   // [512,768): segmented forward batch norm, one per (segment, 64-channel column block)
 
 // brackets one launch with events when profiling is armed for kernel id `which`

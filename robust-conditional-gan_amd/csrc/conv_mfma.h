@@ -94,4 +94,6 @@ int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const voi
               void* ws, size_t ws_bytes);
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts
 struct SmallGemmArgs;
-int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm = nullptr);
+struct StepInputsArgs;
+int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm = nullptr,
+                              const StepInputsArgs* inputs = nullptr);

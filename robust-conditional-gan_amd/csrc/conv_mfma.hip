@@ -24,6 +24,7 @@
 #include <vector>
 #include "conv_mfma.h"
 #include "small_gemm.h"
+#include "step_inputs.h"
 #include "mfma_util.h"
 #include "conv_image.h"
 
@@ -1264,7 +1265,8 @@ int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, con
 struct PrepItem { const float* w; const float* sigma; void* out; void* extra; int T, Cin, Cout, mfma, img; };
 // rows = the n filters, then the phase filters; row r owns workgroups [start[r], start[r+1]) of the one-dimensional grid
 // ... and, last, an optional small-left GEMM (the label embeddings of the projection head: parameters only, see small_gemm.h)
-struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[59]; int n, rows, gemm_row; SmallGemmArgs gemm; };
+// ... and the critic step's input work (step_inputs.h): noise, preprocessing, image pool, zero-fill
+struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[60]; int n, rows, gemm_row, inputs_row; SmallGemmArgs gemm; StepInputsArgs inputs; };
 
 // One (64 ci x 64 co tile, tap class) unit of the summed filters of the sub-pixel forms (layouts and tap classes: see
 // conv_prepare_phase_kernel, whose values these are bit for bit -- same fp32 summation order).  The filter is read along co;
@@ -1339,6 +1341,7 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
   }
   const int bid = (int)blockIdx.x - b.start[row], nb = b.start[row + 1] - b.start[row];
   if (row == b.gemm_row) { small_gemm_body(b.gemm, bid, lds_u, lds_u + SG_AS_FLOATS); return; }
+  if (row == b.inputs_row) { step_inputs_body(b.inputs, bid, nb); return; }
   if (row >= b.n) { prepare_phase_units(b.ph[row - b.n], tile, bid, nb); return; }
   const PrepItem it = b.it[row];
   const long total = (long)it.T * it.Cin * it.Cout;
@@ -1385,7 +1388,7 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
 }
 
 static int env_int(const char* name, int dflt);
-int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm) {
+int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm, const StepInputsArgs* inputs) {
   // the summed phase filters of the sub-pixel forms (upsample-3x3, ConvMeanPool): up to 8 of them ride as extra rows of the
   // first launch's grid, the rest (none in these networks) take the stand-alone kernel
   static const int ride = env_int("RCGAN_PREP_PHASE_RIDE", 1);
@@ -1438,6 +1441,20 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
       b.gemm = *gemm;
       b.gemm_row = b.rows++;
       at += (gemm->d + 15) / 16;
+      b.start[b.rows] = at;
+    }
+    b.inputs_row = -1;
+    if (inputs && base == 0) {
+      b.inputs = *inputs;
+      b.inputs_row = b.rows++;
+      // a few elements per thread: the image units, the fake half's pooled outputs and the fill share the workgroups
+      const size_t work = (size_t)inputs->n * 3 * 16 * 8 + (inputs->pooled ? (size_t)inputs->n * 768 : 0) + inputs->fill4;
+      // (measured: 256 workgroups 6.37 ms, 512: 6.42, 2048: 6.48, 64: 6.39 per iteration)
+      static const int per = env_int("RCGAN_RIDE_PER_THREAD", 16), cap = env_int("RCGAN_RIDE_MAXWG", 256);
+      size_t wgs = (work + 256 * per - 1) / (256 * per);
+      if (wgs < 1) wgs = 1;
+      if (wgs > (size_t)cap) wgs = cap;
+      at += (int)wgs;
       b.start[b.rows] = at;
     }
     hipLaunchKernelGGL(conv_prepare_batch_kernel, dim3(at), dim3(256), 0, ctx->stream, b);

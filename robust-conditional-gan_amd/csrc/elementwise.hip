@@ -1,5 +1,6 @@
 // HBM-bound elementwise / resampling kernels (grid-stride, 4 elements per thread).
 #include "common.h"
+#include "rng.h"
 
 #define EW_BLOCK 256
 static inline int ew_grid(size_t count, int per_thread = 1) {
@@ -234,25 +235,6 @@ __global__ void preprocess_cifar_kernel(int n, const int32_t* img, const float* 
 // ---- counter-based RNG (Philox4x32-10): stands in for tf.random_normal (gan_resnet.py:359) and
 // tf.random_uniform (gan_resnet.py:549).  state[0..1] = 64-bit stream offset kept on the device so a
 // captured graph draws fresh numbers on every replay; rng_advance_kernel bumps it after each use.
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
-__device__ __forceinline__ void philox4(uint64_t ctr, uint32_t seed_lo, uint32_t seed_hi, uint32_t out[4]) {
-  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5eed5eedu, c3 = 0;
-  uint32_t k0 = seed_lo, k1 = seed_hi;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c0, c1, c2, c3, k0, k1);
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 // kind 0: uniform [lo, hi)   kind 1: normal(mean=lo, std=hi)
 template <typename T>
 __global__ void rng_fill_kernel(size_t count, int kind, float lo, float hi, uint64_t seed, const uint64_t* state, T* y) {
@@ -264,7 +246,7 @@ __global__ void rng_fill_kernel(size_t count, int kind, float lo, float hi, uint
     float v[4];
     if (kind == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = lo + (hi - lo) * ((float)(r[i] >> 8) * (1.0f / 16777216.0f));
+      for (int i = 0; i < 4; ++i) v[i] = philox_uniform(r[i], lo, hi);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; i += 2) {

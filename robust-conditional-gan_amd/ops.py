@@ -88,7 +88,7 @@ class Weight:
         return self.dwbar
 
 
-def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None):
+def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, inputs=None):
     """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride, hw):
     hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant.
     persistent: None -> per-step arena buffers, skipped when already prepared this step;
@@ -115,13 +115,19 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None):
         todo.append(L.PrepareItem(desc, w.param.ptr, w.sigma.ptr if w.sigma is not None else None, buf.ptr))
     if todo:
         arr = (L.PrepareItem * len(todo))(*todo)
-        if embed is not None:
-            # the projection head's label embeddings ride in the same launch: embed = (table DT, W_e Weight, b_e DT or None, E DT)
-            table, w_e, b_e, E = embed
-            v, e_dim = table.shape
-            ed = L.EmbedDesc(v, e_dim, w_e.param.shape[-1], table.ptr, w_e.param.ptr, w_e.sigma.ptr if w_e.sigma is not None else None,
-                             b_e.ptr if b_e is not None else None, E.ptr)
-            ctx.check(ctx.lib.rcgan_conv_prepare_batch_embed(ctx.h, arr, len(todo), C.byref(ed)))
+        if embed is not None or inputs is not None:
+            ed = si = None
+            if embed is not None:
+                # the projection head's label embeddings ride in the same launch: embed = (table DT, W_e Weight, b_e DT or None, E DT)
+                table, w_e, b_e, E = embed
+                v, e_dim = table.shape
+                ed = L.EmbedDesc(v, e_dim, w_e.param.shape[-1], table.ptr, w_e.param.ptr, w_e.sigma.ptr if w_e.sigma is not None else None,
+                                 b_e.ptr if b_e is not None else None, E.ptr)
+            if inputs is not None:
+                # ... and the critic step's input work (rcgan_step_inputs_desc): a StepInputsDesc built by the caller
+                si = inputs
+            ctx.check(ctx.lib.rcgan_conv_prepare_batch_riders(ctx.h, arr, len(todo), C.byref(ed) if ed is not None else None,
+                                                              C.byref(si) if si is not None else None))
             return True
         ctx.check(ctx.lib.rcgan_conv_prepare_batch(ctx.h, arr, len(todo)))
     return False

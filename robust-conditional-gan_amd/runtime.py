@@ -342,10 +342,14 @@ class ParamGroup:
         if which == "value":
             self.version += 1
 
-    def zero_grad(self):
+    def zero_grad(self, defer=False):
+        """Clear gradients, d/dW_bar scratch and the loss scalars.  defer: do not launch -- return (pointer, float count) for a
+        launch of this step that zero-fills on the side (ops.prepare_batch(inputs=...)) BEFORE anything accumulates into them."""
         c = self.ctx
-        c.check(c.lib.rcgan_fill_f32(c.h, self.gradbuf.numel(), self.gradbuf.data_ptr(), 0.0))
         self.zero_epoch = c.epoch
+        if defer:
+            return self.gradbuf.data_ptr(), self.gradbuf.numel()
+        c.check(c.lib.rcgan_fill_f32(c.h, self.gradbuf.numel(), self.gradbuf.data_ptr(), 0.0))
 
     def set_hyper(self, lr, t):
         """{lr, t} of the next Adam launch.  Adam is launched eagerly behind the step's captured graph and the all-reduce, so the

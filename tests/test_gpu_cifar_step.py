@@ -238,6 +238,44 @@ def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
             assert rel_err(pb[k], pa[k]) <= (5e-3 if dtype == "bf16" else 2e-5), (k, rel_err(pb[k], pa[k]))
 
 
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_step_input_rider_equals_separate_launches(use_graphs):
+    """Critic steps with the device random stream: noise, preprocessing, image pool and zero-fill riding in the filter-preparation
+    launch (rcgan_conv_prepare_batch_riders) against the five separate launches -- same stream, same bits: discriminator weights,
+    losses and the stream offset after two iterations' worth of critic steps are identical."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN, N_CRITIC
+    rs = np.random.RandomState(77)
+    B = 8
+    feeds = []
+    for _ in range(2 * N_CRITIC):
+        _, raw, _ = _batches(rs, B)
+        feeds.append(raw)
+    outs = []
+    for ride in (True, False):
+        m = CifarRCGAN(algorithm="rcgan", alpha=0.6, batch_size=B, dtype="bf16", seed=5, use_graphs=use_graphs, device_rng=True,
+                       arena_bytes=2 << 30)
+        m.ride_inputs = ride
+        try:
+            for it in range(2):
+                chunk = feeds[it * N_CRITIC:(it + 1) * N_CRITIC]
+                m.set_inputs(labels_random_all=np.concatenate([r["labels_random"] for r in chunk]))
+                m.prepare_critic_fakes()
+                for raw in chunk:
+                    r = {k: v for k, v in raw.items() if k not in ("z", "noise")}
+                    m.set_inputs(labels_all=_labels_all("rcgan", raw), **r)
+                    m.d_step(iteration=it)
+            m.ctx.sync()
+            outs.append((m.get_params(), m.losses(), m.rng_state.cpu().numpy().copy()))
+        finally:
+            m.ctx.close()
+    (pa, la, sa), (pb, lb, sb) = outs
+    assert np.array_equal(sa, sb), (sa, sb)
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+
+
 def test_graph_replay_matches_eager():
     """The captured hipGraph of a D step / G step must reproduce the eager launches bit for bit."""
     rs = np.random.RandomState(23)
