@@ -1,0 +1,46 @@
+#!/bin/bash
+# Copy the summaries of one scripts/make_profiles.sh run (gpurun_out/<tag>/) into profiles/ under the round's names.
+#   bash scripts/publish_profiles.sh r02h r02
+set -e
+R=gpurun_out/$1; P=profiles/$2
+cp $R/bench_n1_default.json ${P}_bench_n1_default.json
+cp $R/bench_n1_under_rocprof.json ${P}_bench_n1_under_rocprof.json
+cp $R/bench_n1_kernel_stats.csv ${P}_bench_n1_kernel_stats.csv
+cp $R/exp_p8_fixed_cost.txt ${P}_exp_p8_fixed_cost.txt
+cp $R/exp_p8_timeline.txt ${P}_exp_p8_timeline.txt
+cp $R/probe_epilogue_store.txt ${P}_probe_epilogue_store.txt
+python3 scripts/pmc_traffic_json.py $R/pmc_FETCH_SIZE_conv_p8.txt $R/pmc_WRITE_SIZE_conv_p8.txt ${P}_pmc_traffic_conv_p8.json > /dev/null
+python3 scripts/pmc_busy_table.py $R/pmc_mfma_busy_raw.txt > ${P}_pmc_mfma_busy.txt
+F=${P}_microbench.txt
+g() { grep -v "amdgpu.ids" "$1"; }
+echo "# scripts/bench_conv.py 64  (HIP events, 20 launches each, eager; n = 2B = 128 unless noted; every layer as the reference poses it -- the up blocks' shortcuts at full resolution, D.Block.1/2.Conv2 without their pool)" > $F; g $R/microbench_conv.txt >> $F
+echo "# scripts/bench_bn.py 128  (conditional batch norm entry points, bf16: statistics / apply+ReLU / backward = 2 launches)" >> $F; g $R/microbench_bn.txt >> $F
+echo "# scripts/bench_trunk.py 128  (the fused 8x8 stage, RCGAN_FUSED_TRUNK, against its eight launches)" >> $F; g $R/microbench_trunk.txt >> $F
+echo "# scripts/step_times.py  (HIP-graph replays, B = 64)" >> $F; g $R/step_times.txt >> $F
+echo "# scripts/bench_mnist.py 256 f32" >> $F; g $R/bench_mnist.txt >> $F
+echo "# scripts/bench_wgrad_group.py  (rcgan_conv2d_bwd_weight_group on the critic step's layer set as PLAIN 3x3 layers, n = 128; grouped launches + grouped reduction)" >> $F; g $R/wgrad_group.txt >> $F
+echo "# python bench.py --no-cpu-baseline --batch 512 --steps 8 | --dtype f16 | --algorithm rcgan-u   (ms per iteration, images/s, sustained TFLOP/s at the reference's FLOP count, dominant kernel: fraction of peak at the reference's count / executed)" >> $F
+for f in b512 f16 rcganu; do [ -f $R/bench_$f.json ] && python3 -c "
+import json
+d=json.load(open('$R/bench_$f.json')); print('%-8s %8.3f ms %10.1f img/s %8.1f TFLOP/s   %.3f / %.3f' % ('$f', d['ms_per_step'], d['value'], d['config']['sustained_tflops'], d['roofline']['frac'], d['roofline']['executed_frac']))" >> $F; done
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open('${P}_bench_n1_kernel_stats.csv')))
+its=24
+cat={}
+def c(n):
+    if 'wgrad' in n or 'slab_reduce' in n: return 'filter gradients (+ slab reduction)'
+    if 'conv_mfma' in n: return 'MFMA convolutions fwd/dgrad'
+    if 'bn_' in n: return 'batch norm'
+    if 'conv_img' in n: return 'image-end convolutions'
+    if 'prepare' in n or n.startswith('sn_'): return 'spectral norm + filter preparation (+ riders)'
+    if 'head' in n or 'meanhw' in n: return 'projection head'
+    return 'other'
+tot=0
+for r in rows:
+    t=float(r['TotalDurationNs'])/1e6/its
+    cat[c(r['Name'])]=cat.get(c(r['Name']),0)+t; tot+=t
+for k,v in sorted(cat.items(), key=lambda x:-x[1]): print("%-48s %.3f ms  %.1f%%"%(k,v,100*v/tot))
+print("total %.3f ms" % tot)
+PY
+grep "p8_kernel" ${P}_pmc_mfma_busy.txt; grep "traffic_bytes_per_launch\|algorithmic_bytes_per_launch" ${P}_pmc_traffic_conv_p8.json
