@@ -702,8 +702,8 @@ static void wgrad_args_from_desc(rcgan_ctx* ctx, const rcgan_conv_desc* d, const
   a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
   a.use_tr = g_use_tr;
   a.sub = mfma_wgrad_sub_kind(d, g_use_tr);
-  if (a.sub) { a.H >>= 1; a.W >>= 1; a.up = 0; }
-  a.cells = a.sub ? 16 : d->kh * d->kw;
+  if (a.sub == 1 || a.sub == 2) { a.H >>= 1; a.W >>= 1; a.up = 0; }
+  a.cells = (a.sub == 1 || a.sub == 2) ? 16 : d->kh * d->kw;
   a.M = (long)d->n * a.H * a.W;
   a.lw = ilog2_exact(a.W); a.lh = ilog2_exact(a.H);
   if (a.lw < 0 || a.lh < 0) { a.lw = -1; a.lh = -1; }
@@ -717,7 +717,7 @@ static SlabReduceGroup::Item wgrad_reduce_item(const rcgan_conv_desc* d, const M
   it.slab = a.slab; it.stride = a.slab_stride; it.out = dw; it.count = (long)d->kh * d->kw * d->cin * d->cout;
   it.bias_out = dbias; it.nbias = nbias; it.nz = nz; it.accumulate = accumulate;
   it.bias_off = (long)a.cells * d->cin * d->cout;
-  it.sub = a.sub; it.cc = (long)d->cin * d->cout;
+  it.sub = a.sub == 3 ? 0 : a.sub; it.cc = (long)d->cin * d->cout;
   return it;
 }
 
@@ -746,7 +746,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     int nzz = mfma_wgrad_launch(ctx, a, nz, &bias_done);
     if (nzz < 0) return nzz;
     const int nb = bias_done ? d->cout : 0;
-    if (a.sub) {
+    if (a.sub == 1 || a.sub == 2) {
       SlabReduceGroup g;
       for (int q = 0; q < REDUCE_GROUP_MAX; ++q) g.it[q] = wgrad_reduce_item(d, a, dw, dbias, nb, nzz, accumulate);
       hipLaunchKernelGGL(slab_reduce2_group_kernel, dim3(cdiv(cnt + nb, 256), 1), dim3(256), 0, ctx->stream, g);
@@ -795,7 +795,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     if (mfma_wgrad3_takes(a)) {
       takes[i] = 1;
       // workgroup-passes over a pixel: 3 filter rows of three taps, or 8 (parity, row shift) tiles of two taps
-      work += (double)a.M * (a.sub ? 8 * 2.0 / 3.0 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
+      work += (double)a.M * (a.sub == 3 ? 1.0 / 3.0 : (a.sub ? 8 * 2.0 / 3.0 : a.KH)) * (a.Cin / 64) * (a.Cout / 128);
     }
   }
   static const int px_max = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_PXMAX"); return e ? atoi(e) : 6144; }();
@@ -805,6 +805,8 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   if (px > px_max) px = px_max;      // big groups (the generator step): more workgroups rather than ever longer ones
   // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
   std::vector<MfmaWgradArgs> args[3];            // three-tap kernel without / with input ReLU, per-tap kernel
+  std::vector<MfmaWgradArgs> late;               // small 1x1 layers on the two-tap body: join one of the first two
+  std::vector<unsigned> late_gx, late_gy;
   std::vector<unsigned> gxs[3], gys[3];
   std::vector<SlabReduceGroup::Item> red;
   size_t used = 0;
@@ -857,7 +859,8 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
           a.slab = (float*)((char*)ws + used);
           used += need;
           const int f = three ? (a.relu_in ? 1 : 0) : 2;
-          args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy);
+          if (three && a.sub == 3 && !a.relu_in) { late.push_back(a); late_gx.push_back(gx); late_gy.push_back(gy); }   // placed below
+          else { args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy); }
           red.push_back(wgrad_reduce_item(d, a, dws[i], dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate));
           grouped = true;
         }
@@ -867,6 +870,15 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       int rc = rcgan_conv2d_bwd_weight(ctx, d, xs[i], dys[i], dws[i], dbiases[i], accumulate, (char*)ws + ws_bytes / 2, ws_bytes - ws_bytes / 2);
       if (rc) return rc;
     }
+  }
+  // a riding 1x1 without input ReLU runs on either flavour of the three-tap kernel (the ReLU is a per-problem switch in the two-tap
+  // body): it joins the launch with the most workgroups
+  if (!late.empty()) {
+    unsigned tot[2] = {0, 0};
+    for (int f = 0; f < 2; ++f)
+      for (size_t q = 0; q < args[f].size(); ++q) tot[f] += gxs[f][q] * gys[f][q];
+    const int f = tot[1] > tot[0] ? 1 : 0;
+    for (size_t q = 0; q < late.size(); ++q) { args[f].push_back(late[q]); gxs[f].push_back(late_gx[q]); gys[f].push_back(late_gy[q]); }
   }
   // the image-end workgroups go with the launch that has the most workgroups to hide under
   int img_f = -1;

@@ -50,9 +50,15 @@ struct MfmaWgradArgs {
   // 16 matrices of Cin x Cout over M pixels instead of 9 over 4M: 4/9 of the multiply-adds.  The slab holds the 16 cells
   // [(pa*2 + pb)*4 + s*2 + d]; the slab reduction folds them into the 9 taps: dW[kh][kw] = scale * sum over the four parities of
   // G[pa][pb][S(pa, kh)][S(pb, kw)], S(sub 1) = {0: 0,1,1; 1: 0,0,1}, S(sub 2) = {0: 0,0,1; 1: 0,1,1}.
+  //   sub 3: a small 1x1 filter (a down block's shortcut) on the two-tap body -- x and dy as they are, one tile row, the second
+  //          tap idle: its filter gradient runs inside the grouped launch of the pass instead of a 16 us launch of its own
   int sub;
   int cells;              // filter cells per slab in front of the bias tail: KH*KW, or 16 in the sub-pixel form
 };
+// tile rows of the three-tap kernel's grid / multiply-adds per pixel and channel pair: reference formulation and executed
+static inline int wgrad3_rows(const MfmaWgradArgs& a) { return a.sub == 3 ? 1 : (a.sub ? 8 : a.KH); }
+static inline int wgrad3_alg_taps(const MfmaWgradArgs& a) { return a.sub == 3 ? 1 : (a.sub ? 36 : a.KH * a.KW); }
+static inline int wgrad3_exec_taps(const MfmaWgradArgs& a) { return a.sub == 3 ? 1 : (a.sub ? 16 : a.KH * a.KW); }
 
 static inline int ilog2_exact(int v) {
   int l = 0;

@@ -921,7 +921,7 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   long me = mb + a.m_chunk;
   if (me > a.M) me = a.M;
   const int sub = SUB ? a.sub : 0;
-  const int trows = SUB ? 8 : a.KH;        // tile rows: filter rows kh, or (pa, pb, s) of the sub-pixel form
+  const int trows = SUB ? (sub == 3 ? 1 : 8) : a.KH;        // tile rows: filter rows kh, or (pa, pb, s) of the sub-pixel form
   if ((int)bx >= trows * nci * nco) {      // bias-gradient workgroup (only launched when want_bias)
     // (sub 1: dy lives on the full-resolution grid, whose pixels [4 mb, 4 me) are as good a quarter-share as any)
     wgrad_bias_block<NS>(a, smem, (int)bx - trows * nci * nco, sub == 1 ? 4 * mb : mb, sub == 1 ? 4 * me : me,
@@ -935,9 +935,11 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const int ci0 = cit * 64, co0 = cot * 128;
   const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
   const int pa = kh >> 2, pb = (kh >> 1) & 1, srow = kh & 1;                 // sub-pixel form only
-  const int dh = !SUB ? kh - a.PT : (sub == 1 ? srow - 1 + pa : srow - pa);
-  // first column tap: dw = tap - 1 for the three taps, or dw in {-1, 0} / {0, +1} by the column parity
-  const int tb = !SUB ? -1 : ((sub == 1 ? pb == 0 : pb == 1) ? -1 : 0);
+  const int dh = !SUB ? kh - a.PT : (sub == 3 ? 0 : (sub == 1 ? srow - 1 + pa : srow - pa));
+  // first column tap: dw = tap - 1 for the three taps, or dw in {-1, 0} / {0, +1} by the column parity (1x1: dw = 0, second tap idle)
+  const int tb = !SUB ? -1 : (sub == 3 ? 0 : ((sub == 1 ? pb == 0 : pb == 1) ? -1 : 0));
+  const int ntap = (SUB && sub == 3) ? 1 : NT;
+  const bool relu_on = RELU && a.relu_in;      // (a grouped launch is compiled for its 3x3 layers' flavour; a riding 1x1 may differ)
   const int g = lane >> 4, li = lane & 15;
 
   // ---- DMA roles -------------------------------------------------------------------------------
@@ -1054,11 +1056,12 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
         for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+          if (SUB && t >= ntap) continue;        // (workgroup-uniform: the 1x1 form)
           bf16x8_t xf[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             uint4 v = __builtin_bit_cast(uint4, tr_pair(sb + offx[t][j], 16 * 128));
-            if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+            if (SUB ? relu_on : RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
             if (t == 0) { v.x &= maskl[0]; v.y &= maskl[1]; v.z &= maskl[2]; v.w &= maskl[3]; }
             if (t == NT - 1) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
             xf[j] = __builtin_bit_cast(bf16x8_t, v);
@@ -1076,6 +1079,7 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   float* slab = a.slab + (long)by * a.slab_stride;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (SUB && t >= ntap) continue;
     // slab cell: tap (kh, t), or [(pa*2 + pb)*4 + s*2 + d] with d = t, the rank among this parity's two taps
     const int cell = !SUB ? kh * 3 + t : (kh >> 1) * 4 + srow * 2 + t;
 #pragma unroll
@@ -1690,6 +1694,10 @@ static bool wgrad3_shape(int kh, int kw, int h, int w) {
   return kh == 3 && kw == 3 && ilog2_exact(w) >= 0 && ilog2_exact(h) >= 0 && w >= 4 && w <= 32;
 }
 
+static bool wgrad3_geom(const MfmaWgradArgs& a) {     // (sub-pixel and 1x1 forms: the grid of the reduction index decides)
+  return a.sub ? wgrad3_shape(3, 3, a.H, a.W) : (wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1);
+}
+
 static int wgrad3_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("RCGAN_WGRAD_IMPL"); v = (e && (e[0] == 'r' || e[0] == 'g')) ? 0 : 1; }
@@ -1720,7 +1728,15 @@ int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
 // as an ordinary 3x3 filter gradient (shape the three-tap kernel does not take, RCGAN_WGRAD_SUBPIXEL=0)
 int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr) {
   static const int on = env_int("RCGAN_WGRAD_SUBPIXEL", 1);
-  if (!on || !use_tr || !wgrad3_enabled() || !mfma_wgrad_eligible(d) || d->kh != 3 || d->kw != 3) return 0;
+  if (!use_tr || !wgrad3_enabled() || !mfma_wgrad_eligible(d)) return 0;
+  if (d->kh == 1 && d->kw == 1) {
+    // a SMALL 1x1 (the down blocks' shortcuts: 0.27 GFLOP at the bench batch) rides in the grouped launch on the two-tap body; a big
+    // one keeps the per-tap kernel's 128 x 128 tiles (a staged pixel feeds one tap's MFMAs here: a third of the arithmetic intensity)
+    static const double max_gflop = env_int("RCGAN_WGRAD_1X1_GROUP_MAXMFLOP", 600) * 1e6;
+    const double fl = 2.0 * d->n * d->h * d->w * (double)d->cin * d->cout;
+    return fl <= max_gflop && !(d->flags & (RCGAN_CONV_OUT_MEANPOOL2 | RCGAN_CONV_IN_UPSAMPLE2X)) && wgrad3_shape(3, 3, d->h, d->w) ? 3 : 0;
+  }
+  if (!on || d->kh != 3 || d->kw != 3) return 0;
   const bool up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) != 0, pool = (d->flags & RCGAN_CONV_OUT_MEANPOOL2) != 0;
   if (up == pool || (d->h & 1) || (d->w & 1)) return 0;
   if (!wgrad3_shape(3, 3, d->h / 2, d->w / 2)) return 0;
@@ -1728,7 +1744,7 @@ int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr) {
 }
 
 int mfma_wgrad_sub_splits(const rcgan_conv_desc* d, long M) {
-  const long tiles3 = 8L * (d->cin / 64) * (d->cout / 128);
+  const long tiles3 = (d->kh == 1 ? 1L : 8L) * (d->cin / 64) * (d->cout / 128);
   return (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, M);
 }
 
@@ -1742,8 +1758,8 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
     attr = true;
   }
   {
-    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * (a.sub ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
-                 2.0 * (double)a.M * (a.sub ? 16 : a.KH * a.KW) * a.Cin * a.Cout);
+    ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, 2.0 * (double)a.M * wgrad3_alg_taps(a) * a.Cin * a.Cout,
+                 2.0 * (double)a.M * wgrad3_exec_taps(a) * a.Cin * a.Cout);
     hipLaunchKernelGGL((conv_mfma_wgrad3_kernel<NS, RELU>), grid, dim3(256), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -1753,8 +1769,8 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done) {
   *bias_done = false;
   if (a.sub && !mfma_wgrad3_takes(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
-  if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1) {
-    long tiles3 = (long)(a.sub ? 8 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
+  if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_geom(a)) {
+    long tiles3 = (long)wgrad3_rows(a) * (a.Cin / 64) * (a.Cout / 128);
     int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);
     if (want > nz) want = nz;
     a.m_chunk = ((a.M + want - 1) / want + 63) / 64 * 64;
@@ -1796,12 +1812,12 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
 
 // the three-tap kernel's plan for one problem (also what mfma_wgrad_launch does): grid and pixel chunk, or false
 bool mfma_wgrad3_takes(const MfmaWgradArgs& a) {
-  return wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1;
+  return wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_geom(a);
 }
 
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block) {
-  if (!(wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1)) return false;
-  long tiles3 = (long)(a.sub ? 8 : a.KH) * (a.Cin / 64) * (a.Cout / 128);
+  if (!(wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_geom(a))) return false;
+  long tiles3 = (long)wgrad3_rows(a) * (a.Cin / 64) * (a.Cout / 128);
   // pixel chunks: alone, enough of them for ~512 workgroups; in a group the caller fixes the pixels per workgroup for all
   // layers (equal workgroup run times, and far fewer fp32 slabs to write and reduce than 512 workgroups per layer)
   int want = px_per_block > 0 ? (int)wgrad_clamp_splits(cdiv(a.M, px_per_block), a.M)
@@ -1825,8 +1841,8 @@ static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
   }
   double fl = 0, fx = 0;
   for (int p = 0; p < g.n; ++p) {
-    fl += 2.0 * (double)g.a[p].M * (g.a[p].sub ? 36 : g.a[p].KH * g.a[p].KW) * g.a[p].Cin * g.a[p].Cout;
-    fx += 2.0 * (double)g.a[p].M * (g.a[p].sub ? 16 : g.a[p].KH * g.a[p].KW) * g.a[p].Cin * g.a[p].Cout;
+    fl += 2.0 * (double)g.a[p].M * wgrad3_alg_taps(g.a[p]) * g.a[p].Cin * g.a[p].Cout;
+    fx += 2.0 * (double)g.a[p].M * wgrad3_exec_taps(g.a[p]) * g.a[p].Cin * g.a[p].Cout;
   }
   {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl, fx);
