@@ -150,7 +150,7 @@ int rcgan_conv_prepare_batch_embed(rcgan_ctx* ctx, const rcgan_prepare_item* ite
  * be five launches at the head of the step's dependency chain): dequantisation noise noise[i] ~ U[noise_lo, noise_hi) drawn from the
  * device stream exactly as rcgan_rng_fill(kind 0) over n*3072 floats would (the stream then advances by as much), the preprocessing
  * of rcgan_preprocess_cifar into rows [0, n) of x [2n,32,32,3] (gan_resnet.py:548-551), the 2x2 mean pool of all 2n images
- * (rows [n, 2n) = the fakes must already be in x; pooled [2n,16,16,3] or NULL: D.Block.1's shortcut input, :239-240, :346) and a
+ * (rows [n, 2n) = the fakes: already in x, or copied there from a slice of `fakes`; pooled [2n,16,16,3] or NULL: D.Block.1's shortcut input, :239-240, :346) and a
  * zero-fill of fill_count floats (the gradient slab; or NULL).  Same bits as the separate entry points.  e / si may be NULL. */
 typedef struct rcgan_step_inputs_desc {
   int n, dtype;
@@ -159,6 +159,9 @@ typedef struct rcgan_step_inputs_desc {
   float noise_lo, noise_hi;
   uint64_t seed; void* rng_state;
   float* fill; size_t fill_count;
+  /* optional: the step's fakes are slice *fake_slice (a device counter, moved on mod n_slices by the launch) of
+   * fakes [n_slices][n][32][32][3]: copied into rows [n, 2n) of x by the same launch.  NULL: they are in x already. */
+  const void* fakes; void* fake_slice; int n_slices;
 } rcgan_step_inputs_desc;
 int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
                                     const rcgan_step_inputs_desc* si);

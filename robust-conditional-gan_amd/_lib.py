@@ -54,7 +54,8 @@ class EmbedDesc(C.Structure):
 class StepInputsDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("dtype", C.c_int), ("images", C.c_void_p), ("x", C.c_void_p), ("pooled", C.c_void_p),
                 ("noise_lo", C.c_float), ("noise_hi", C.c_float), ("seed", C.c_uint64), ("rng_state", C.c_void_p),
-                ("fill", C.c_void_p), ("fill_count", C.c_size_t)]
+                ("fill", C.c_void_p), ("fill_count", C.c_size_t),
+                ("fakes", C.c_void_p), ("fake_slice", C.c_void_p), ("n_slices", C.c_int)]
 
 
 class SnItem(C.Structure):

@@ -391,6 +391,8 @@ class CifarRCGAN:
         self.loss_d = self.PD.scalar(0)
         self.loss_g = self.PG.scalar(0)
         self.rng_state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+        self.slice_ctr = torch.zeros(4, dtype=torch.int32, device=ctx.device)     # which slice of fakes_all the next critic step takes
+        self._slice_mirror = 0
         self.seed = seed
         self._graphs = {}
         self.iteration = 0
@@ -519,6 +521,9 @@ class CifarRCGAN:
         return self.inp["C_const"]                                               # gan_resnet.py:524
 
     # ---------------------------------------------------------------------------------- D step
+    def _rides_inputs(self):
+        return self.device_rng and self.ride_inputs and self.PD.gradbuf.numel() % 4 == 0
+
     def _d_body(self, fakes_ready=False):
         """Forward + backward of disc_cost (gan_resnet.py:557-697) on this rank's shard.  fakes_ready: the generator
         forward of this step was evaluated by prepare_critic_fakes; its images are in the fake rows of self.x_all."""
@@ -529,7 +534,7 @@ class CifarRCGAN:
         # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
         # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
         # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
-        ride = fakes_ready and self.device_rng and self.ride_inputs and (self.PD.gradbuf.numel() % 4 == 0)
+        ride = fakes_ready and self._rides_inputs()
         x_all = self.x_all if fakes_ready else ctx.empty((2 * B, OUTPUT_DIM))
         real, fake_dst = x_all.rows(0, B), x_all.rows(B, 2 * B)
         si = None
@@ -537,7 +542,8 @@ class CifarRCGAN:
             fptr, fcount = self.PD.zero_grad(defer=True)
             g.image_pool = ctx.empty((2 * B, 16, 16, 3), x_all.dtype)
             si = L.StepInputsDesc(B, real.dtype, inp["images"].ptr, x_all.ptr, g.image_pool.ptr,
-                                  0.0, 1.0 / 128, self.seed * 1000003 + self.rank, self.rng_state.data_ptr(), fptr, fcount)
+                                  0.0, 1.0 / 128, self.seed * 1000003 + self.rank, self.rng_state.data_ptr(), fptr, fcount,
+                                  self.fakes_all.ptr, self.slice_ctr.data_ptr(), N_CRITIC)       # the launch also fetches its fake batch
         else:
             g.image_pool = None
             self.PD.zero_grad()
@@ -692,6 +698,10 @@ class CifarRCGAN:
         device unless device_rng=False)."""
         self._run("gf", self._gf_body)
         self._fakes_left = N_CRITIC
+        if self._slice_mirror != 0:          # the previous batch was not used up: the device's slice counter goes back to 0
+            with torch.cuda.stream(self.ctx.stream):
+                self.slice_ctr.zero_()
+            self._slice_mirror = 0
 
     def d_step(self, iteration=None):
         """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""
@@ -701,8 +711,13 @@ class CifarRCGAN:
             k = N_CRITIC - self._fakes_left
             self._fakes_left -= 1
             ctx = self.ctx
-            with torch.cuda.stream(ctx.stream):
-                ctx.view(self.x_all.rows(self.B, 2 * self.B)).copy_(ctx.view(self.fakes_all.rows(k * self.B, (k + 1) * self.B)), non_blocking=True)
+            if self._rides_inputs():
+                # the step's launch fetches slice slice_ctr (a device counter it moves on itself); the host mirrors it
+                assert self._slice_mirror == k, (self._slice_mirror, k)
+                self._slice_mirror = (k + 1) % N_CRITIC
+            else:
+                with torch.cuda.stream(ctx.stream):
+                    ctx.view(self.x_all.rows(self.B, 2 * self.B)).copy_(ctx.view(self.fakes_all.rows(k * self.B, (k + 1) * self.B)), non_blocking=True)
             self._run("d_fakes", lambda: self._d_body(True))
         else:
             self._run("d", self._d_body)

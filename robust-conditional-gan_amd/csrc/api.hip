@@ -487,6 +487,9 @@ int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* it
     sa.lo = si->noise_lo; sa.hi = si->noise_hi; sa.seed = si->seed; sa.state = (uint64_t*)si->rng_state;
     sa.counter = ctx->counters() + RC_COUNTER_INPUTS;
     sa.fill = si->fill; sa.fill4 = si->fill ? si->fill_count / 4 : 0;
+    sa.fakes = si->fakes; sa.slice = (unsigned*)si->fake_slice; sa.nslices = si->n_slices;
+    RC_REQUIRE(ctx, si->fakes == nullptr || (si->fake_slice != nullptr && si->n_slices >= 1 && ((size_t)si->fakes & 15) == 0 && ((size_t)si->x & 15) == 0),
+               "fake slices need a device counter and 16-byte aligned tensors");
   }
   return conv_prepare_batch_launch(ctx, items, n_items, e ? &ge : nullptr, si ? &sa : nullptr);
 }

@@ -17,6 +17,10 @@ struct StepInputsArgs {
   uint64_t seed; uint64_t* state;
   unsigned* counter;           // arrival counter (self-resetting): the last workgroup advances the stream by n*3072/4 quads
   float* fill; size_t fill4;   // fill4 float4 of zeros at fill (or null)
+  // optional: the step's fake batch is slice slice[0] of fakes [nslices][n][32][32][3] (the generator forwards of the iteration's
+  // critic steps, evaluated as one pass): copied into rows [n, 2n) of x here, pooled from the source; the last workgroup moves
+  // slice[0] on (mod nslices).  Null: the fakes are in x already.
+  const void* fakes; unsigned* slice; int nslices;
 };
 
 __device__ __forceinline__ float si_round(float v, int is16) { return is16 ? bf16_to_f32(f32_to_bf16(v)) : v; }
@@ -30,9 +34,13 @@ __device__ __forceinline__ float si_load(const void* p, size_t i, int is16) {
 // bid / nb: this workgroup's index / the number of workgroups of the rider (256 threads each)
 __device__ __forceinline__ void step_inputs_body(const StepInputsArgs& a, int bid, int nb) {
   const uint64_t base = a.state[0];
+  const unsigned k = a.fakes ? a.slice[0] : 0u;
+  const size_t esz = a.is16 ? 2 : 4;
+  const char* const fsrc = a.fakes ? (const char*)a.fakes + (size_t)k * a.n * 3072 * esz : (const char*)a.x + (size_t)a.n * 3072 * esz;
   const size_t u_real = (size_t)a.n * 3 * 16 * 8;                 // (image, channel, row pair, column quad)
   const size_t u_fake = a.pooled ? (size_t)a.n * 16 * 16 * 3 : 0;   // pooled outputs of the fake half
-  const size_t total = u_real + u_fake + a.fill4;
+  const size_t u_copy = a.fakes ? (size_t)a.n * 3072 * esz / 16 : 0;  // 16-byte pieces of the fake batch
+  const size_t total = u_real + u_fake + a.fill4 + u_copy;
   for (size_t u = (size_t)bid * 256 + threadIdx.x; u < total; u += (size_t)nb * 256) {
     if (u < u_real) {
       const int t = (int)(u & 7), i = (int)((u >> 3) & 15);
@@ -65,12 +73,15 @@ __device__ __forceinline__ void step_inputs_body(const StepInputsArgs& a, int bi
       const int ch = (int)(o % 3);
       const size_t p = o / 3;
       const int x2 = (int)(p & 15), y2 = (int)((p >> 4) & 15);
-      const size_t b = (size_t)a.n + (p >> 8);
+      const size_t b = p >> 8;                                       // image of the fake batch
       const size_t s0 = ((b * 32 + 2 * y2) * 32 + 2 * x2) * 3 + ch;
-      const float m = (si_load(a.x, s0, a.is16) + si_load(a.x, s0 + 96, a.is16) + si_load(a.x, s0 + 3, a.is16) + si_load(a.x, s0 + 99, a.is16)) * 0.25f;
+      const float m = (si_load(fsrc, s0, a.is16) + si_load(fsrc, s0 + 96, a.is16) + si_load(fsrc, s0 + 3, a.is16) + si_load(fsrc, s0 + 99, a.is16)) * 0.25f;
       si_store(a.pooled, (size_t)a.n * 768 + o, m, a.is16);
-    } else {
+    } else if (u < u_real + u_fake + a.fill4) {
       ((float4*)a.fill)[u - u_real - u_fake] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const size_t c = u - u_real - u_fake - a.fill4;
+      ((uint4*)((char*)a.x + (size_t)a.n * 3072 * esz))[c] = ((const uint4*)fsrc)[c];
     }
   }
   // every workgroup read the stream offset above; the last one to arrive moves it on
@@ -79,6 +90,7 @@ __device__ __forceinline__ void step_inputs_body(const StepInputsArgs& a, int bi
     const unsigned prev = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == (unsigned)nb - 1u) {
       a.state[0] = base + ((uint64_t)a.n * 3072 + 3) / 4;
+      if (a.fakes) a.slice[0] = (k + 1u) % (unsigned)a.nslices;
       __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
