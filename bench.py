@@ -32,8 +32,37 @@ import torch  # noqa: E402
 
 N_CRITIC = 5
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 (= fp16) MFMA peak, MI355X_MICROARCH.md
-POOL = 8                      # synthetic batches resident on the device
+POOL = 32                     # synthetic batches resident on the device (2048 images at B = 64: the critic cannot memorise them in a bench run)
 BATCH_CRITIC_FAKES = os.environ.get("RCGAN_BATCH_CRITIC_FAKES", "1") == "1"
+
+
+def synthetic_images(rs, labels, kind=None):
+    """Synthetic "real" images, uint8 CHW [n, 3072].  kind "smooth" (default): a fixed low-frequency colour pattern per class
+    plus per-image low-pass noise squashed to the pixel range -- natural-image-like second-order statistics that carry the label,
+    which the critic cannot separate from the generator's (equally smooth) output within a few hundred updates, so the bench
+    runs in the regime training runs in (hinge terms active, d_loss around 1-2, every step back-propagates non-zero
+    gradients).  kind "uniform" (round 1/2): U{0..255} per pixel -- the critic saturates the hinge within ~25 iterations and
+    5 of 6 steps back-propagate exact zeros (same time per step, unrepresentative values)."""
+    kind = kind or os.environ.get("RCGAN_BENCH_IMAGES", "smooth")
+    n = len(labels)
+    if kind == "uniform":
+        return rs.randint(0, 256, size=(n, 3072))
+    trs = np.random.RandomState(4242)
+    yy, xx = np.mgrid[0:32, 0:32] / 32.0
+    tmpl = np.zeros((10, 3, 32, 32))
+    for c in range(10):
+        for ch in range(3):
+            for _ in range(3):
+                fx, fy = trs.randint(0, 3, size=2)
+                px, py = trs.uniform(0, 2 * np.pi, size=2)
+                tmpl[c, ch] += trs.uniform(0.3, 1.0) * np.cos(2 * np.pi * fx * xx + px) * np.cos(2 * np.pi * fy * yy + py)
+    noise = rs.randn(n, 3, 32, 32)
+    for _ in range(4):          # separable [1 2 1]/4 blur, wrap-around: sigma ~ 1.4 pixels
+        noise = (np.roll(noise, 1, 2) + 2 * noise + np.roll(noise, -1, 2)) / 4
+        noise = (np.roll(noise, 1, 3) + 2 * noise + np.roll(noise, -1, 3)) / 4
+    noise /= noise.std()
+    img = np.tanh(0.6 * tmpl[np.asarray(labels)] + 0.6 * noise)
+    return np.clip(np.floor((img * 0.5 + 0.5) * 256.0), 0, 255).astype(np.int64).reshape(n, 3072)
 
 
 def build_pool(m, rank, alpha):
@@ -42,8 +71,8 @@ def build_pool(m, rank, alpha):
     B = m.B
     rs = np.random.RandomState(1234 + rank)
     n = POOL * B
-    images = rs.randint(0, 256, size=(n, 3072))
     clean = rs.randint(10, size=n)
+    images = synthetic_images(rs, clean)
     Cm = D.C_ALPHA(alpha)
     lab, rnd, bia, inv = D.corrupt_labels(clean, Cm, rs)
     dev = m.ctx.device
@@ -149,9 +178,16 @@ def effective_cores():
 def cpu_baseline(alpha, batch):
     """The same iteration on the host cores (kind "port": TensorFlow 1.5, the reference's CPU path, is not installable):
     oracle/torch_port.py -- the PyTorch-CPU restatement of the reference graph (autograd + TF-form Adam, fp32) -- on all
-    usable cores (scheduler affinity capped by the cgroup CPU quota) at the benchmark's own per-GPU batch.  Bounded sample: one warm-up and one timed D step + G step; the iteration is
-    5 D steps + 1 G step, so images/sec = 5*B / (5*t_D + t_G).  (The single-process numpy oracle, the parity checker, runs
-    the same step at B=16 in ~2.1 s / ~4.1 s: ~5.4 images/sec.)"""
+    usable cores (scheduler affinity capped by the cgroup CPU quota) at the benchmark's own per-GPU batch.  Bounded sample
+    (SURVEY 8d): one warm-up and THREE timed (D step, G step) pairs; the iteration is 5 D steps + 1 G step, so
+    images/sec = 5*B / (5*mean t_D + mean t_G) -- ``value``: the work the GPU run does.
+    ``reference_faithful``: the reference's D-step session.run also fetches gen_cost (gan_resnet.py:936-947), i.e. one more
+    Generator(2B) + Discriminator(2B) forward per critic step that only feeds the log; timed (3 samples) and added:
+    5*B / (5*(t_D + t_log) + t_G).
+    ``mnist_cfg1``: BASELINE configs[0] (MNIST RCGAN B=64, alpha 0.5): iteration = 1 D + 2 G updates (mnist/model.py:347-372)
+    by the numpy oracle (oracle/mnist.py) with its BLAS threads capped at the same core count, 5 timed iterations after a
+    warm-up; the faithful variant adds three forward evaluations of the loss graph for the reference's five logging-only
+    .eval() calls (model.py:374-398: 3 x [G + D(fake)] + 2 x D(real); the stand-in runs one D(real) forward more)."""
     from oracle import cifar as oc
     from oracle.torch_port import CifarTorchTrainer
     B = batch
@@ -160,28 +196,84 @@ def cpu_baseline(alpha, batch):
     Cm = oc.c_alpha(alpha)
     cores = effective_cores()
     torch.set_num_threads(cores)
+    cfg = dict(algorithm="rcgan", C=Cm)
 
     def batches():
         lab = rs.randint(10, size=B)
-        db = dict(real=oc.preprocess_real(rs.randint(0, 256, size=(B, 3072)), rs.uniform(0, 1 / 128., size=(B, 3072))).astype(np.float32),
+        db = dict(real=oc.preprocess_real(synthetic_images(rs, lab), rs.uniform(0, 1 / 128., size=(B, 3072))).astype(np.float32),
                   labels=lab, labels_random=rs.randint(10, size=B), labels_biased=rs.randint(10, size=B),
                   inv_weights=np.linalg.inv(Cm)[lab], z=rs.randn(B, 128))
         gb = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B), z=rs.randn(2 * B, 128))
         return db, gb
-    tr = CifarTorchTrainer(P, U, dict(algorithm="rcgan", C=Cm), lr=2e-4)
+    tr = CifarTorchTrainer(P, U, cfg, lr=2e-4)
     db, gb = batches()
     tr.d_step(db)                      # warm-up (thread pool, oneDNN primitive caches)
     tr.g_step(gb)
-    db, gb = batches()
-    t0 = time.time()
-    tr.d_step(db)
-    t1 = time.time()
-    tr.g_step(gb)
-    t2 = time.time()
-    td, tg = t1 - t0, t2 - t1
-    return {"value": round(5 * B / (5 * td + tg), 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "PyTorch-CPU restatement (oracle/torch_port.py), CIFAR RCGAN B=%d fp32, %d threads: 1 D step (%.2fs) + 1 G step (%.2fs) "
-                      "timed after one warm-up of each; iteration = 5 D + 1 G" % (B, cores, td, tg)}
+    tds, tgs, tls = [], [], []
+    for _ in range(3):
+        db, gb = batches()
+        t0 = time.time()
+        tr.d_step(db)
+        t1 = time.time()
+        tr.g_step(gb)
+        t2 = time.time()
+        with torch.no_grad():          # the logging-only fetch of gen_cost inside the reference's D-step run
+            tr.net.gen_cost(cfg, gb)
+        tr.net.U_new = {}
+        t3 = time.time()
+        tds.append(t1 - t0), tgs.append(t2 - t1), tls.append(t3 - t2)
+    td, tg, tl = float(np.mean(tds)), float(np.mean(tgs)), float(np.mean(tls))
+    out = {"value": round(5 * B / (5 * td + tg), 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "PyTorch-CPU restatement (oracle/torch_port.py), CIFAR RCGAN B=%d fp32, %d threads: 3 timed (D step, G step) pairs after one "
+                     "warm-up, mean D %.2fs G %.2fs; iteration = 5 D + 1 G" % (B, cores, td, tg),
+           "reference_faithful": {"value": round(5 * B / (5 * (td + tl) + tg), 3), "unit": "images/sec",
+                                  "sample": "the same + the gen_cost forward the reference's D-step session.run fetches for its log "
+                                            "(gan_resnet.py:936-947): G(2B)+D(2B) forward, mean %.2fs per critic step" % tl}}
+    try:
+        out["mnist_cfg1"] = cpu_baseline_mnist(cores)
+    except Exception as e:             # the MNIST line is an extra: never lose the bench line over it
+        out["mnist_cfg1"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline_mnist(cores, B=64, alpha=0.5, iters=5):
+    """BASELINE configs[0]: MNIST 28x28 RCGAN (run_rcgan.sh), bs=64, 50 % uniform label noise, CPU path."""
+    from threadpoolctl import threadpool_limits
+    from oracle import labels as LB
+    from oracle import mnist as om
+    rs = np.random.RandomState(1)
+    Cm = LB.one_coin(alpha)
+    eye = np.eye(10, dtype=np.float32)
+    cfg = dict(algorithm="rcgan", disc_type="projection", estimate_confuse=False, loss_fn="hinge", perm_regularizer=True, perm_multiplier=10.0,
+               spectral_norm=True, C=Cm, concat_y=False, concat_y_layers=(), max_norm=True, confuse_multiplier=10.0)
+
+    def batch():
+        yr = rs.randint(10, size=B)
+        return dict(images=rs.rand(B, 28, 28, 1).astype(np.float32), z=rs.uniform(-1, 1, size=(B, 100)).astype(np.float32),
+                    y_real=eye[yr], y_gen=eye[rs.randint(10, size=B)], y_fake=eye[rs.randint(10, size=B)],
+                    y_real_weights=np.linalg.inv(Cm)[yr].astype(np.float32))
+    P, S, U = om.init_params(0, "projection", False, True, True, ())
+    tr = om.Trainer(P, S, U, cfg)
+    with threadpool_limits(limits=cores):
+        b = batch()
+        tr.d_step(b), tr.g_step(b), tr.g_step(b)
+        ts, tl = [], []
+        for _ in range(iters):
+            b = batch()
+            t0 = time.time()
+            tr.d_step(b), tr.g_step(b), tr.g_step(b)
+            t1 = time.time()
+            for _ in range(3):
+                om.losses(om.Net(tr.P, {k: v.copy() for k, v in tr.S.items()}, dict(tr.U), "d", cfg, np.float32), b)
+            t2 = time.time()
+            ts.append(t1 - t0), tl.append(t2 - t1)
+    t, l = float(np.mean(ts)), float(np.mean(tl))
+    return {"value": round(B / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "numpy oracle (oracle/mnist.py), MNIST RCGAN B=%d fp32, SN projection D, %d timed iterations (1 D + 2 G updates) after one "
+                      "warm-up, mean %.2fs" % (B, iters, t),
+            "reference_faithful": {"value": round(B / (t + l), 3), "unit": "images/sec",
+                                   "sample": "the same + 3 forward evaluations of the loss graph per iteration for the reference's five "
+                                             "logging-only evals (model.py:374-398), mean %.2fs" % l}}
 
 
 def main():
@@ -194,6 +286,10 @@ def main():
     ap.add_argument("--algorithm", default="rcgan")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-stub", type=int, default=0,
+                    help="single GPU only: run the world-size-N data-parallel step schedule (two gradient buckets per step, the first on the "
+                         "communication stream beside the backward pass, optimiser inside the captured graph) against the in-ABI test-double "
+                         "communicator -- measures what the schedule itself costs; no RCCL traffic")
     ap.add_argument("--lr", type=float, default=2e-4, help="Adam learning rate (reference: 2e-4, gan_resnet.py:--lr)")
     args = ap.parse_args()
     default_wl = args.batch == 64 and args.dtype == "bf16" and args.algorithm == "rcgan"
@@ -201,8 +297,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    force_dist = os.environ.get("RCGAN_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
-    if world > 1 or force_dist:
+    if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if "MASTER_ADDR" not in os.environ:
@@ -213,17 +308,8 @@ def main():
 
     alpha = 0.6
     m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0, lr=args.lr,
-                   device=local, use_graphs=not args.no_graphs, device_rng=True, world_size=world, rank=rank)
-    if force_dist:
-        m.world = 2          # take the all-reduce branch; grad_scale 1/2 cancels against the doubled "sum" below
-        from rcgan_amd import dp as _dp
-        _orig = _dp.allreduce_sum_
-        def _twice(flat, stream=None):
-            _orig(flat, stream)
-            with torch.cuda.stream(stream):
-                flat.mul_(2.0)
-            return flat
-        _dp.allreduce_sum_ = _twice
+                   device=local, use_graphs=not args.no_graphs, device_rng=True,
+                   world_size=(args.dp_stub if args.dp_stub > 1 else world), rank=rank, comm=("stub" if args.dp_stub > 1 else None))
     pool = build_pool(m, rank, alpha)
     dcount = [0]
     warm = max(args.warmup, 2)      # iteration 0 has no G step; graphs are captured on first use
@@ -261,6 +347,11 @@ def main():
                "config": {"workload": "CIFAR-10 32x32 SNGAN-projection ResNet %s, per-GPU batch %d, iteration = 1 G step (2B fakes) + 5 D steps (B real + B fake)"
                                       % (args.algorithm.upper(), args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
+                          "gradient_exchange": ("none (single rank)" if m.world == 1 else
+                                                "in-ABI %s all-reduce(sum) of the fp32 gradient slabs inside the step's graph, 2 buckets per step%s, optimiser %s"
+                                                % ("RCCL" if m.comm_kind == "rccl" else "TEST-DOUBLE (--dp-stub %d: schedule only, no traffic)" % args.dp_stub,
+                                                   " (first on the communication stream beside the backward pass)" if m.dp_overlap else "",
+                                                   "in the graph" if m.dp_adam_in_graph else "after the graph")),
                           "critic_generator_forwards": ("one pass over N_CRITIC x B samples, batch-norm statistics per critic step"
                                                         if BATCH_CRITIC_FAKES else "inside every critic step"),
                           "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
@@ -272,7 +363,7 @@ def main():
     else:
         if args.dtype in ("bf16", "f16"):
             kernel_roofline(m, pool, default_wl)      # keep ranks in lock-step through the extra (all-reducing) iteration
-    if world > 1 or force_dist:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     m.ctx.close()

@@ -417,6 +417,55 @@ int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, f
                        float lr, float t, float beta1, float beta2, float eps, float clip, float grad_scale);
 int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float value);
 
+/* ---- gradient (loss) scaling for 16-bit activations ------------------------------------------------------------------------
+ * The reference trains in fp32 (no counterpart in gan_resnet.py); BASELINE config 5 asks for fp16 activations, whose 5 exponent
+ * bits need the loss -- hence every activation gradient -- scaled up.  rcgan_set_grad_scale: from now on every GRADIENT the loss
+ * kernels emit (rcgan_loss_fwd_bwd, rcgan_bce_onehot_fwd_bwd, rcgan_proj_head_fwd_bwd) is multiplied by
+ * host_scale * (*dev_scale if dev_scale != NULL); the loss VALUES they accumulate stay unscaled.  dev_scale is DEVICE memory read at
+ * execution time, so a captured step follows a scale that changes between replays.  Default: 1, NULL. */
+int rcgan_set_grad_scale(rcgan_ctx* ctx, float host_scale, const float* dev_scale);
+/* Dynamic loss scaling.  ls_state: DEVICE float[4] = {scale, applied steps since the last change, non-finite flag, skipped steps}.
+ *   rcgan_grad_finite_check : raises the flag if g[0,count) holds an inf / nan (after the all-reduce: every rank sees the same sum);
+ *   rcgan_adam_tf_dyn       : rcgan_adam_tf_host that (a) does nothing when the flag is raised (the step is skipped), (b) divides the
+ *                             gradient by the current scale on top of grad_scale, (c) takes t = *t_dev + 1 (t_dev: DEVICE float[1],
+ *                             the number of APPLIED updates of this group -- a skipped step does not advance the bias correction);
+ *   rcgan_loss_scale_update : after the optimiser launches of a step: flag raised -> scale = max(scale/2, min_scale), flag cleared,
+ *                             skipped++; else t_dev0 / t_dev1 (either may be NULL) += 1 and after growth_interval applied steps in
+ *                             a row scale = min(2*scale, max_scale). */
+int rcgan_grad_finite_check(rcgan_ctx* ctx, size_t count, const float* g, float* ls_state);
+int rcgan_adam_tf_dyn(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v, float lr, const float* t_dev,
+                      float beta1, float beta2, float eps, float clip, float grad_scale, const float* ls_state);
+int rcgan_loss_scale_update(rcgan_ctx* ctx, float* ls_state, float* t_dev0, float* t_dev1, float growth_interval, float min_scale,
+                            float max_scale);
+
+/* ---- data-parallel gradient exchange (RCCL over xGMI) ------------------------------------------------------------------------
+ * Replaces the reference's in-graph towers (cifar10/gan_resnet.py:529-546 tf.split over DEVICES, :697,786 tf.add_n(costs) / len(DEVICES)):
+ * one process per GPU holds one tower; the gradients of the MEAN cost are the all-reduce SUM of the ranks' gradient buckets times
+ * 1/world (applied by the optimiser kernel's grad_scale).  Every call is asynchronous on a stream and may be captured into the step's
+ * hipGraph; RCGAN_ERCCL on any RCCL failure (rcgan_last_error carries ncclGetErrorString).
+ *   rcgan_comm_unique_id       rank 0: 128 opaque bytes (ncclUniqueId) to hand to every rank (the host side moves them: file, TCP store, ...)
+ *   rcgan_comm_init            collective over the `world` ranks: ncclCommInitRank on the context's device
+ *   rcgan_comm_init_stub       single-process test double: "every rank holds what this rank holds", i.e. sum = world * x -- lets one GPU run
+ *                              the whole world > 1 step schedule (buckets, side stream, in-graph optimiser) and compare it with world = 1
+ *   rcgan_allreduce_sum        in place, fp32, on the context's stream
+ *   rcgan_allreduce_sum_buckets  the same for several buckets as ONE RCCL group
+ *   rcgan_allreduce_sum_async  on the communication stream, ordered after everything queued on the context's stream so far: the bucket must
+ *                              be final; later launches of the backward pass run beside it (xGMI transfers under compute)
+ *   rcgan_allreduce_join       the context's stream waits for the asynchronous buckets (before the optimiser reads them) */
+#define RCGAN_COMM_ID_BYTES 128
+int rcgan_comm_unique_id(void* id_out);
+int rcgan_comm_init(rcgan_ctx* ctx, const void* id, int world, int rank);
+int rcgan_comm_init_stub(rcgan_ctx* ctx, int world);
+int rcgan_comm_destroy(rcgan_ctx* ctx);
+int rcgan_comm_world(rcgan_ctx* ctx);
+int rcgan_allreduce_sum(rcgan_ctx* ctx, float* buf, size_t count);
+int rcgan_allreduce_sum_buckets(rcgan_ctx* ctx, int n, float* const* bufs, const size_t* counts);
+int rcgan_allreduce_sum_async(rcgan_ctx* ctx, float* buf, size_t count);
+int rcgan_allreduce_join(rcgan_ctx* ctx);
+/* {a, b} -> p[0..1] by a one-thread launch on the stream: sets the DEVICE {lr, t} of rcgan_adam_tf in front of a replayed graph without a
+ * host-to-device copy. */
+int rcgan_set2_f32(rcgan_ctx* ctx, float* p, float a, float b);
+
 /* ---- self test ---------------------------------------------------------------------------------------- */
 /* Runs the MFMA / ds_read_b64_tr_b16 fragment-layout probes on the device (call once, outside graph
  * capture).  Fails iff the MFMA operand layout this library assumes does not hold; a failed

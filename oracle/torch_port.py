@@ -73,6 +73,18 @@ class CifarTorch:
         self.U = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in U.items()}
         self.U_new = {}
         self.dtype = dtype
+        # hinge terms of the last disc_cost: name -> the relu ARGUMENT (1 - D(real), 1 + D(fake)) as evaluated here; and an optional
+        # imposed activity pattern name -> bool array (tests/test_gpu_fullbatch_steps.py: the device's own pattern, so that a
+        # logit within rounding distance of the hinge does not turn into a whole-sample difference of the gradients)
+        self.hinge_args = {}
+        self.hinge_mask = None
+
+    def hinge(self, name, t):
+        """relu(t) of a hinge term (gan_resnet.py:604-605,639-640,673-674); with an imposed activity pattern: t * mask."""
+        self.hinge_args[name] = t.detach().clone()
+        if self.hinge_mask is not None and name in self.hinge_mask:
+            return t * torch.as_tensor(np.asarray(self.hinge_mask[name]), dtype=self.dtype).reshape(t.shape)
+        return F.relu(t)
 
     def conv(self, x, name, sn=False, update=True):
         w = self.P[name + "/Filters"]
@@ -160,20 +172,20 @@ class CifarTorch:
             E = self.projection(np.arange(10))
             dfake = wf[:, None] + ff @ E.t()
             y = self.C(cfg)[torch.as_tensor(b["labels_random"], dtype=torch.long)]
-            cost = (F.relu(1 + dfake) * y).sum(1).mean() + F.relu(1 - dreal).mean()
+            cost = (self.hinge("fake", 1 + dfake) * y).sum(1).mean() + self.hinge("real", 1 - dreal).mean()
         else:
             feat, wgan = self.discriminator(torch.cat([real, fake], 0), True)
             if alg in ("biased", "rcgan"):
                 lab = np.concatenate([b["labels"], b["labels_random"] if alg == "biased" else b["labels_biased"]])
                 d = wgan + (feat * self.projection(lab)).sum(1)
-                cost = F.relu(1 - d[:B]).mean() + F.relu(1 + d[B:]).mean()
+                cost = self.hinge("real", 1 - d[:B]).mean() + self.hinge("fake", 1 + d[B:]).mean()
             else:
                 cols = []
                 for j in range(10):
                     lab = np.concatenate([np.full(B, j), b["labels_random"]])
                     d = wgan + (feat * self.projection(lab)).sum(1)
-                    cols.append(F.relu(1 - d[:B]).reshape(B, 1))
-                    fl = F.relu(1 + d[B:]).mean()
+                    cols.append(self.hinge("real%d" % j, 1 - d[:B]).reshape(B, 1))
+                    fl = self.hinge("fake", 1 + d[B:]).mean()
                 w = torch.as_tensor(b["inv_weights"], dtype=self.dtype)
                 cost = (torch.cat(cols, 1) * w).sum(1).mean() + fl
         if cfg.get("perm_classifier"):

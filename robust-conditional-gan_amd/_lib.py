@@ -159,6 +159,20 @@ SIGNATURES = {
     "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),
     "rcgan_adam_tf_host": (I, [P, SZ, P, P, P, P, F, F, F, F, F, F, F]),
     "rcgan_fill_f32": (I, [P, SZ, P, F]),
+    "rcgan_comm_unique_id": (I, [P]),
+    "rcgan_comm_init": (I, [P, P, I, I]),
+    "rcgan_comm_init_stub": (I, [P, I]),
+    "rcgan_comm_destroy": (I, [P]),
+    "rcgan_comm_world": (I, [P]),
+    "rcgan_allreduce_sum": (I, [P, P, SZ]),
+    "rcgan_allreduce_sum_buckets": (I, [P, I, P, P]),
+    "rcgan_allreduce_sum_async": (I, [P, P, SZ]),
+    "rcgan_allreduce_join": (I, [P]),
+    "rcgan_set2_f32": (I, [P, P, F, F]),
+    "rcgan_set_grad_scale": (I, [P, F, P]),
+    "rcgan_grad_finite_check": (I, [P, SZ, P, P]),
+    "rcgan_adam_tf_dyn": (I, [P, SZ, P, P, P, P, F, P, F, F, F, F, F, P]),
+    "rcgan_loss_scale_update": (I, [P, P, P, P, F, F, F]),
     "rcgan_selftest": (I, [P]),
     "rcgan_query": (I, [P, I]),
 }

@@ -191,6 +191,8 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         output = Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = O.reshape(ctx, output, (-1, 4, 4, DIM_G * 8))
         output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels, segments)
+        if Graph.current.early_g is not None and output.req:
+            ctx.record(Graph.current.early_g)       # backward: G.Block.2 .. G.Output are done here -> their bucket leaves early
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels, segments)
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels, segments)
         with variable_scope('G.OutputNorm'):
@@ -242,6 +244,8 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
             h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
             t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
             x = O.meanpool2(ctx, t)
+        if Graph.current.early_d is not None and x.req:
+            ctx.record(Graph.current.early_d)       # backward: D.Block.3 .. the head are done here -> their bucket leaves early
         if FUSED_TRUNK and O.d_trunk_ok(ctx, x):
             # D.Block.3 .. D.Block.6 (identity shortcuts, 8 x 8 pixels): one launch for the eight convolutions (ops.d_trunk)
             g, blocks = Graph.current, []
@@ -289,7 +293,7 @@ def _head_weights(update_collection=None):
     return w_out, b_out, table, w_e, b_e
 
 
-def Discriminator_head(features, parts, weight, loss_acc, update_collection=None):
+def Discriminator_head(features, parts, weight, loss_acc, update_collection=None, logits=None):
     """The tail of Discriminator (D.Output, gan_resnet.py:408-411), Discriminator_projection (:414-421), the projection
     logit (:588; every label's logit :654-660) and the loss terms built on it (:604-606, :647, :673-684, :751-773) as ONE
     launch with all their gradients (ops.proj_head).  update_collection: that of D.Output's spectral norm (the projection's
@@ -297,7 +301,7 @@ def Discriminator_head(features, parts, weight, loss_acc, update_collection=None
     g = Graph.current
     w_out, b_out, table, w_e, b_e = _head_weights(update_collection)
     # (the label embeddings E = table @ W_e / sigma + b_e of this step, if _prepare_all let them ride in its launch)
-    O.proj_head(g.ctx, features, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, E_pre=getattr(g, "head_E", None))
+    O.proj_head(g.ctx, features, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=logits, E_pre=getattr(g, "head_E", None))
 
 
 def perm_classifier(x, perm_type='linear'):
@@ -324,7 +328,7 @@ class CifarRCGAN:
                  perm_classifier=False, perm_multiplier=1.0, perm_type="linear",
                  confuse_init=False, confuse_init_diag=0.2, confuse_multiplier=1.0, confuse_lr_decay=False,
                  device=0, use_graphs=True, device_rng=True, arena_bytes=None, world_size=1, rank=0,
-                 variables=None, loss_scale=None):
+                 variables=None, loss_scale=None, dynamic_loss_scale=None, loss_scale_growth_interval=2000, comm=None):
         if algorithm not in ALGORITHMS:
             raise ValueError("Unknown algorithm %s" % algorithm)
         self.alg, self.alpha, self.B, self.lr = algorithm, alpha, int(batch_size), lr
@@ -343,6 +347,19 @@ class CifarRCGAN:
         # subnormal): every loss term -- hence every activation and filter gradient -- is multiplied by a power of two,
         # the fp32 filter gradients are divided by it inside the Adam kernel (grad_scale).  1 for bf16 / fp32.
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if ctx.act_dtype == L.F16 else 1.0)
+        # fp16: DYNAMIC loss scaling by default -- loss_scale is the initial value; after the all-reduce of an optimiser step the
+        # gradient slab is checked for inf / nan on the device, an overflowed step is skipped and halves the scale, 2000 applied
+        # steps in a row double it (rcgan_grad_finite_check / rcgan_adam_tf_dyn / rcgan_loss_scale_update; no host round trip).
+        # The loss kernels read the scale from device memory (rcgan_set_grad_scale) and apply it to the gradients only: the loss
+        # values are never scaled.  dynamic_loss_scale=False keeps the scale fixed (no overflow check).
+        self.dynamic_ls = (ctx.act_dtype == L.F16) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
+        self.ls_growth_interval = float(loss_scale_growth_interval)
+        if self.dynamic_ls:
+            self.ls_state = torch.tensor([self.loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=ctx.device)
+            ctx.check(ctx.lib.rcgan_set_grad_scale(ctx.h, 1.0, C.c_void_p(self.ls_state.data_ptr())))
+        else:
+            self.ls_state = None
+            ctx.check(ctx.lib.rcgan_set_grad_scale(ctx.h, self.loss_scale, None))
         if variables is None:
             variables = create_variables(seed, algorithm, perm_classifier, perm_type, confuse_init, confuse_init_diag)
         gs, ds, cs, U = variables
@@ -355,6 +372,31 @@ class CifarRCGAN:
             ctx.view(t).copy_(torch.from_numpy(np.ascontiguousarray(v.reshape(-1))))
             self.state[k] = t
         self.graph = Graph(ctx, self.groups, self.state)
+        # Data parallel (world_size > 1; gan_resnet.py:529-546,697,786): the gradient slabs are all-reduced INSIDE the C ABI
+        # (rcgan_allreduce_sum*, RCCL over xGMI) and inside the step's captured graph, in two buckets per step: the layers whose
+        # backward finishes first (D.Block.3 .. head | G.Block.2 .. G.Output) leave on the communication stream while the rest of the
+        # backward pass runs, the remainder follows on the step's stream; the optimiser launch is part of the same graph.
+        #   comm: None -> RCCL (one process per GPU, dp.init_comm);  "stub" -> the single-process test double (every rank holds what
+        #   this rank holds), which lets ONE GPU run and verify the whole world > 1 schedule.
+        #   "rccl-self" (world_size 1) -> a ONE-rank RCCL communicator under the same schedule: real ncclAllReduce calls, captured and
+        #   replayed, on a single GPU.
+        self.comm_kind = None
+        self.dp_active = self.world > 1 or comm == "rccl-self"
+        if self.dp_active:
+            from . import dp
+            self.comm_kind = comm or "rccl"
+            if self.comm_kind not in ("rccl", "stub", "rccl-self") or (self.comm_kind == "rccl-self" and self.world != 1):
+                raise ValueError("Unknown comm %s for world_size %d" % (comm, self.world))
+            dp.init_comm(ctx, self.world, self.rank, stub=(self.comm_kind == "stub"))
+        # RCGAN_DP_OVERLAP=1: the early bucket (below).  Measured on one MI355X against the test-double communicator (bench.py --dp-stub 8,
+        # i.e. WITHOUT any traffic to hide): 6.73 -> 7.46 ms per iteration, ~0.12 ms per optimiser step for the second filter-gradient
+        # group + second spectral-norm backward + the fork / join -- more than the ~0.08 ms a 4.9 MB all-reduce takes over xGMI.
+        # The whole-slab exchange on the step's own stream costs 0.03 ms per iteration on the same measure, so that is the default.
+        self.dp_overlap = self.dp_active and os.environ.get("RCGAN_DP_OVERLAP", "0") == "1"
+        self.dp_adam_in_graph = self.dp_active and not self.dynamic_ls and os.environ.get("RCGAN_DP_GRAPH_ADAM", "1") == "1"
+        # first parameter of the early bucket of each group (everything from there to the end of the slab)
+        self._early_lo = {id(self.PD): self.PD.offsets["Discriminator/D.Block.3.Conv1/Filters"],
+                          id(self.PG): self.PG.offsets["Generator/G.Block.2.Shortcut/Filters"]}
         B = self.B
         f32, i32, act = L.F32, "i32", ctx.act_dtype
         P = ctx.persistent
@@ -395,6 +437,9 @@ class CifarRCGAN:
         self._slice_mirror = 0
         self.seed = seed
         self._graphs = {}
+        # inspection hook: a persistent fp32 [2B, 10] buffer the fused projection head also writes its logits to (logit of the
+        # sample's label, or of every label where the loss weights all of them); None in production.  Set before the first step.
+        self.head_logits = None
         self.iteration = 0
         self._pg_prepared_version = -1
         torch.cuda.synchronize()
@@ -531,6 +576,7 @@ class CifarRCGAN:
         self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
         g.begin_step({1})
+        g.early_d = self._dp_early(self.PD) if self.dp_overlap else None
         # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
         # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
         # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
@@ -563,7 +609,7 @@ class CifarRCGAN:
             fake = self.x_all.rows(B, 2 * B)
         else:
             fake = Generator(B, inp["labels_random"], inp["z"], out=fake_dst)             # :540-546
-        w = self.loss_scale
+        w = 1.0       # (the gradient scale of 16-bit activations is applied inside the loss kernels: rcgan_set_grad_scale)
         if self.fused_head:
             feat = Discriminator(x_all, None, update_collection=None, _head=False)        # :584
             lab_r, lab_f = inp["labels_all"].rows(0, B), inp["labels_all"].rows(B, 2 * B)
@@ -574,7 +620,7 @@ class CifarRCGAN:
                 parts = [(B, L.LOSS_HINGE_REAL, None, inp["inv_weights"]), (B, L.LOSS_HINGE_FAKE, inp["labels_random"], None)]
             else:                              # biased / rcgan (:585-606): labels_all = [labels ; labels_random | labels_biased]
                 parts = [(B, L.LOSS_HINGE_REAL, lab_r, None), (B, L.LOSS_HINGE_FAKE, lab_f, None)]
-            Discriminator_head(feat, parts, w, self.loss_d, update_collection=None)
+            Discriminator_head(feat, parts, w, self.loss_d, update_collection=None, logits=self.head_logits)
         elif self.alg == "rcgan-u":
             feat_a, wgan_a = Discriminator(x_all, None, update_collection=None)
             feat, wgan = O.rows(ctx, feat_a, 0, B), O.rows(ctx, wgan_a, 0, B)
@@ -604,8 +650,9 @@ class CifarRCGAN:
                 O.loss_term(ctx, L.LOSS_HINGE_FAKE, disc_fake, w, self.loss_d)           # :639,648
         if self.perm:
             logits = perm_classifier(real, self.perm_type)                               # :692
-            O.bce_onehot_term(ctx, logits, inp["labels"], self.loss_scale, self.loss_d)              # :693-695
+            O.bce_onehot_term(ctx, logits, inp["labels"], 1.0, self.loss_d)                          # :693-695
         ctx.backward()
+        self._dp_finish([self.PD])
 
     # ---------------------------------------------------------------------------------- G step
     def _g_body(self):
@@ -615,6 +662,7 @@ class CifarRCGAN:
         self._refresh_generator_filters()
         ctx.new_step()
         g.begin_step({0, 2} if self.PC is not None else {0})
+        g.early_g = self._dp_early(self.PG) if self.dp_overlap else None
         self.PG.zero_grad()
         if self.PC is not None:
             self.PC.zero_grad()
@@ -631,13 +679,14 @@ class CifarRCGAN:
                 parts = [(n, L.LOSS_NEG_MEAN, None, y_conf)]                                         # :751,759
             else:
                 parts = [(n, L.LOSS_NEG_MEAN, lab, None)]                                            # :763,773
-            Discriminator_head(feat, parts, self.loss_scale, self.loss_g, update_collection=NO_OPS)
+            Discriminator_head(feat, parts, 1.0, self.loss_g, update_collection=NO_OPS, logits=self.head_logits)
         else:
             self._g_head_unfused(fake, lab, n)
         if self.perm:
             logits = perm_classifier(fake, self.perm_type)                                           # :781
-            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult * self.loss_scale, self.loss_g)      # :782-784
+            O.bce_onehot_term(ctx, logits, inp["labels_random_G"], self.perm_mult, self.loss_g)      # :782-784
         ctx.backward()
+        self._dp_finish([self.PG] + ([self.PC] if self.PC is not None else []))
 
     def _g_head_unfused(self, fake, lab, n):
         ctx, inp = self.ctx, self.inp
@@ -646,11 +695,11 @@ class CifarRCGAN:
             E = Discriminator_projection(inp["arange"], update_collection=None)                      # :736
             disc_fake = O.proj_logit_all(ctx, feat, wgan, E)
             y_conf = O.gather_rows(ctx, self.confusion_matrix(), inp["labels_random_G"], n)          # :757-758
-            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, self.loss_scale, self.loss_g, wts=y_conf)               # :751,759
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g, wts=y_conf)               # :751,759
         else:
             emb = Discriminator_projection(lab, update_collection=None)                              # :725,731
             disc_fake = O.proj_logit(ctx, feat, wgan, emb)                                           # :763
-            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, self.loss_scale, self.loss_g)                        # :773
+            O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g)                           # :773
 
     # ---------------------------------------------------------------------------------- stepping
     def _run(self, key, body):
@@ -670,10 +719,57 @@ class CifarRCGAN:
             return                      # the warm-up execution already did this step's work
         ctx.graph_launch(self._graphs[key])
 
-    def _allreduce(self, group):
-        if self.world > 1:
-            from .dp import allreduce_sum_
-            allreduce_sum_(group.grad, self.ctx.stream)
+    # ---------------------------------------------------------------------------------- data parallel
+    def _dp_early(self, grp):
+        """Tape closure for the point of the backward pass where the group's LAST layers are done: flush their filter gradients,
+        run their spectral-norm backward, and start the all-reduce of slab[lo:] on the communication stream."""
+        ctx, lo = self.ctx, self._early_lo[id(grp)]
+        state = {"sent": False}
+        grp._dp_early_state = state
+
+        def fire():
+            ctx.flush_wgrads()
+            for bw in ctx.sn_partial:
+                bw(lambda name: name in grp.offsets and grp.offsets[name] >= lo)
+            ctx.check(ctx.lib.rcgan_allreduce_sum_async(ctx.h, C.c_void_p(grp.grad.data_ptr() + 4 * lo), grp.count - lo))
+            state["sent"] = True
+        return fire
+
+    def _dp_finish(self, groups):
+        """End of a step's backward pass: all-reduce what has not left yet (ONE RCCL group), join the communication stream, and --
+        static loss scale -- run the optimiser inside the same captured graph."""
+        ctx = self.ctx
+        if not self.dp_active or not ctx.recording:   # (forward-only evaluations -- eval_d_cost -- exchange and update nothing)
+            return
+        ptrs, counts = [], []
+        for grp in groups:
+            st = getattr(grp, "_dp_early_state", None)
+            hi = self._early_lo[id(grp)] if (st is not None and st["sent"]) else grp.count
+            grp._dp_early_state = None
+            if hi > 0:
+                ptrs.append(grp.grad.data_ptr())
+                counts.append(hi)
+        n = len(ptrs)
+        ctx.check(ctx.lib.rcgan_allreduce_sum_buckets(ctx.h, n, (C.c_void_p * n)(*ptrs), (C.c_size_t * n)(*counts)))
+        ctx.check(ctx.lib.rcgan_allreduce_join(ctx.h))
+        if self.dp_adam_in_graph:
+            for grp in groups:
+                grp.adam_captured(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
+
+    def _optimise_or_publish(self, steps):
+        """After a step's launch: the optimiser (eager) -- or, when it ran inside the step's graph, only its host-side bookkeeping."""
+        if self.dp_adam_in_graph:
+            for grp, _ in steps:
+                grp.version += 1
+            return
+        self._optimise(steps)
+
+    def _pre_step(self, steps):
+        """In front of a step's launch: {lr, t} of the optimiser launches the step's graph contains."""
+        if self.dp_adam_in_graph:
+            for grp, lr in steps:
+                grp.t += 1
+                grp.set_hyper_device(lr, grp.t)
 
     def _gf_body(self):
         ctx, g, B, inp = self.ctx, self.graph, self.B, self.inp
@@ -707,6 +803,8 @@ class CifarRCGAN:
         """One critic update (disc_train_op, gan_resnet.py:802-804) on the current static inputs."""
         it = self.iteration if iteration is None else iteration
         self._refresh_generator_filters()
+        steps = [(self.PD, self.lr * lr_decay(it))]
+        self._pre_step(steps)
         if self._fakes_left > 0:
             k = N_CRITIC - self._fakes_left
             self._fakes_left -= 1
@@ -721,10 +819,7 @@ class CifarRCGAN:
             self._run("d_fakes", lambda: self._d_body(True))
         else:
             self._run("d", self._d_body)
-        self._allreduce(self.PD)
-        self.PD.t += 1
-        self.PD.set_hyper(self.lr * lr_decay(it), self.PD.t)
-        self.PD.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
+        self._optimise_or_publish(steps)
 
     def g_step(self, iteration=None):
         """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op
@@ -732,24 +827,46 @@ class CifarRCGAN:
         it = self.iteration if iteration is None else iteration
         self._fakes_left = 0                 # images prepared by prepare_critic_fakes belong to the generator before this update
         self._refresh_generator_filters()
-        self._run("g", self._g_body)
-        self._allreduce(self.PG)
-        self.PG.t += 1
-        self.PG.set_hyper(self.lr * lr_decay(it), self.PG.t)
-        self.PG.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
-        self._refresh_generator_filters()
+        steps = [(self.PG, self.lr * lr_decay(it))]
         if self.PC is not None:
-            self._allreduce(self.PC)
-            self.PC.t += 1
-            clr = self.lr * self.confuse_multiplier * (lr_decay(it) if self.confuse_lr_decay else 1.0)
-            self.PC.set_hyper(clr, self.PC.t)
-            self.PC.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
+            steps.append((self.PC, self.lr * self.confuse_multiplier * (lr_decay(it) if self.confuse_lr_decay else 1.0)))
+        self._pre_step(steps)
+        self._run("g", self._g_body)
+        self._optimise_or_publish(steps)
+        self._refresh_generator_filters()
+
+    def _optimise(self, steps):
+        """TF-form Adam (beta1 0, beta2 0.9: gan_resnet.py:802-817) on the groups of one optimiser step: [(group, lr)].  The gradient
+        slabs hold world * scale times the mean gradient (all-reduce SUM over the ranks, loss scale of the 16-bit build)."""
+        ctx = self.ctx
+        if not self.dynamic_ls:
+            for grp, lr in steps:
+                grp.t += 1
+                grp.set_hyper(lr, grp.t)
+                grp.adam(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
+            return
+        # dynamic loss scale: one verdict for the whole step (an overflow anywhere skips every group's update)
+        for grp, lr in steps:
+            grp.t += 1                      # nominal count; the bias correction uses the device's count of APPLIED updates
+            grp.finite_check(self.ls_state)
+        for grp, lr in steps:
+            grp.set_hyper(lr, grp.t)
+            grp.adam_dyn(self.ls_state, 0.0, 0.9, grad_scale=1.0 / self.world)
+        tds = [C.c_void_p(g.t_dev.data_ptr()) for g, _ in steps] + [None]
+        ctx.check(ctx.lib.rcgan_loss_scale_update(ctx.h, C.c_void_p(self.ls_state.data_ptr()), tds[0], tds[1], self.ls_growth_interval,
+                                                  1.0, float(1 << 24)))
+
+    def loss_scale_state(self):
+        """{scale, good_steps, skipped_steps} of the dynamic loss scale as it stands on the stream now (synchronises)."""
+        if self.ls_state is None:
+            return dict(scale=self.loss_scale, good_steps=None, skipped_steps=0)
+        self.ctx.sync()
+        s = self.ls_state.cpu().numpy()
+        return dict(scale=float(s[0]), good_steps=int(s[1]), skipped_steps=int(s[3]))
 
     def losses(self):
         ctx = self.ctx
-        d = float(ctx.download(self.loss_d)[0]) / self.loss_scale
-        g = float(ctx.download(self.loss_g)[0]) / self.loss_scale
-        return d, g
+        return float(ctx.download(self.loss_d)[0]), float(ctx.download(self.loss_g)[0])
 
     def enqueue_losses(self):
         """Asynchronous read-back of (disc_cost, gen_cost) as they stand on the stream now: two device scalars -> one slot of a
@@ -772,8 +889,7 @@ class CifarRCGAN:
             return []
         assert self._loss_tickets - min(tickets) <= 1024, "loss ring overrun: fetch at least every 1024 tickets"
         self.ctx.sync()
-        return [(float(self._loss_ring[t % 1024, 0]) / self.loss_scale, float(self._loss_ring[t % 1024, 1]) / self.loss_scale)
-                for t in tickets]
+        return [(float(self._loss_ring[t % 1024, 0]), float(self._loss_ring[t % 1024, 1])) for t in tickets]
 
     def eval_d_cost(self):
         """disc_cost on the current D-step inputs, forward only -- the reference's dev-cost pass ``session.run([disc_cost])``
@@ -788,7 +904,7 @@ class CifarRCGAN:
         finally:
             ctx.recording = rec
             self._fakes_left = left
-        return float(ctx.download(self.loss_d)[0]) / self.loss_scale
+        return float(ctx.download(self.loss_d)[0])
 
     # ---------------------------------------------------------------------------------- inspection
     def get_params(self):
@@ -799,8 +915,11 @@ class CifarRCGAN:
         return out
 
     def get_grads(self, group):
-        """Gradients of the last step (the loss scale of the fp16 build divided out; a power of two, exact)."""
-        return {n: group.get(n, "grad") / np.float32(self.loss_scale) for n in group.names}
+        """Gradients of the last step (the loss scale of the fp16 build divided out; a power of two, exact).  Under dynamic loss
+        scaling: the scale the step RAN with -- if the step's verdict changed it afterwards (overflow -> halved, growth -> doubled)
+        ask before the optimiser launch or accept the factor of two."""
+        scale = self.loss_scale_state()["scale"] * (self.world if self.dp_active else 1)      # data parallel: the slab holds the SUM over the ranks
+        return {n: group.get(n, "grad") / np.float32(scale) for n in group.names}
 
     def get_state(self):
         return {k: self.ctx.download(v).reshape(1, -1) for k, v in self.state.items()}
@@ -815,13 +934,16 @@ class CifarRCGAN:
                 out[n] = grp.get(n)
                 out[n + "/Adam"] = grp.get(n, "m")
                 out[n + "/Adam_1"] = grp.get(n, "v")
-            out["_opt/%s/step" % gname] = np.array([grp.t], np.int64)
+            out["_opt/%s/step" % gname] = np.array([grp.steps_applied()], np.int64)
         for k, v in self.get_state().items():
             out[k] = v
         out["_iteration"] = np.array([self.iteration], np.int64)
         # AdamOptimizer's own step state, in the reference's creation order: disc_opt, gen_opt, confusion (:802-817)
         from .host import adam_power_tensors
-        opts = [(self.PD.t, 0.0, 0.9), (self.PG.t, 0.0, 0.9)] + ([(self.PC.t, 0.0, 0.9)] if self.PC is not None else [])
+        opts = [(self.PD.steps_applied(), 0.0, 0.9), (self.PG.steps_applied(), 0.0, 0.9)] + \
+            ([(self.PC.steps_applied(), 0.0, 0.9)] if self.PC is not None else [])
+        if self.ls_state is not None:
+            out["_loss_scale"] = self.ls_state.cpu().numpy().astype(np.float32)
         out.update(adam_power_tensors(opts))
         return out
 
@@ -843,6 +965,11 @@ class CifarRCGAN:
                 sfx = {"Discriminator": "", "Generator": "_1", "confusion": "_2"}[gname]
                 if "beta2_power" + sfx in sd:
                     grp.t = steps_from_beta_power(float(np.asarray(sd["beta2_power" + sfx])), 0.9)
+        for grp in self.groups:
+            grp.t_dev = None                 # re-created from grp.t by the next dynamic-loss-scale update
+        if self.ls_state is not None and "_loss_scale" in sd:
+            with torch.cuda.stream(self.ctx.stream):
+                self.ls_state.copy_(torch.from_numpy(np.asarray(sd["_loss_scale"], np.float32).reshape(4)))
         if "_iteration" in sd:
             self.iteration = int(np.asarray(sd["_iteration"]).reshape(-1)[0])
         ctx = self.ctx

@@ -111,8 +111,19 @@ __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
   *o = s;
 }
 
+// Dynamic loss scaling (fp16 activations).  ls: DEVICE float[4] = {scale, good steps since the last change, non-finite flag, skipped steps}.
+// With ls the optimiser kernels (a) return without touching anything when the flag is set -- the step is skipped, (b) divide the
+// gradient by the CURRENT scale on top of grad_scale, (c) take t = *tdev + 1 (tdev counts the APPLIED updates: a skipped step does
+// not advance the bias correction).
+struct AdamDyn { const float* ls; const float* tdev; };
+
 __global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float lr_v, float t_v,
-                               float beta1, float beta2, float eps, float clip, float grad_scale) {
+                               float beta1, float beta2, float eps, float clip, float grad_scale, AdamDyn dyn) {
+  if (dyn.ls) {
+    if (dyn.ls[2] != 0.f) return;
+    grad_scale /= dyn.ls[0];
+    t_v = dyn.tdev[0] + 1.f;
+  }
   // the arithmetic form of TF's ApplyAdam kernel: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
   // m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); w -= (m*alpha)/(sqrt(v)+eps), all in fp32
   // {lr, t}: device memory (a captured launch replayed with new values) or kernel arguments (hyper == nullptr)
@@ -132,7 +143,12 @@ __global__ void adam_tf_kernel(size_t count, float* w, const float* g, float* m,
 // the same update on four consecutive parameters per thread (16-byte accesses, one memory round trip per thread for slabs of up to
 // 8M parameters): ranges whose start and length are multiples of four floats
 __global__ void adam_tf_vec4_kernel(size_t count4, float4* w, const float4* g, float4* m, float4* v, const float* hyper, float lr_v, float t_v,
-                                    float beta1, float beta2, float eps, float clip, float grad_scale) {
+                                    float beta1, float beta2, float eps, float clip, float grad_scale, AdamDyn dyn) {
+  if (dyn.ls) {
+    if (dyn.ls[2] != 0.f) return;
+    grad_scale /= dyn.ls[0];
+    t_v = dyn.tdev[0] + 1.f;
+  }
   const float lr = hyper ? hyper[0] : lr_v, t = hyper ? hyper[1] : t_v;
   const float alpha = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
@@ -154,19 +170,49 @@ __global__ void adam_tf_vec4_kernel(size_t count4, float4* w, const float4* g, f
   }
 }
 
+__global__ void set2_kernel(float* p, float a, float b) { p[0] = a; p[1] = b; }
+
+// any non-finite value in g[0, count) raises the flag ls[2] (a benign race: every writer stores the same 1.0)
+__global__ void grad_finite_check_kernel(size_t count, const float* g, float* ls) {
+  bool bad = false;
+  const size_t n4 = count / 4, stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = tid; i < n4; i += stride) {
+    const float4 q = ((const float4*)g)[i];
+    // x - x is 0 for finite x, NaN for +-inf and NaN
+    const float z = (q.x - q.x) + (q.y - q.y) + (q.z - q.z) + (q.w - q.w);
+    bad |= !(z == 0.f);
+  }
+  for (size_t i = n4 * 4 + tid; i < count; i += stride) bad |= !((g[i] - g[i]) == 0.f);
+  if (bad) ls[2] = 1.f;
+}
+
+// one thread: skipped step -> halve the scale; applied step -> advance the groups' update counters, double the scale after
+// `interval` applied steps in a row
+__global__ void loss_scale_update_kernel(float* ls, float* t0, float* t1, float interval, float min_scale, float max_scale) {
+  if (ls[2] != 0.f) {
+    ls[0] = fmaxf(ls[0] * 0.5f, min_scale);
+    ls[1] = 0.f; ls[2] = 0.f; ls[3] += 1.f;
+  } else {
+    if (t0) t0[0] += 1.f;
+    if (t1) t1[0] += 1.f;
+    ls[1] += 1.f;
+    if (ls[1] >= interval) { if (ls[0] < max_scale) ls[0] = fminf(ls[0] * 2.f, max_scale); ls[1] = 0.f; }
+  }
+}
+
 static void adam_launch(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v, const float* hyper, float lr, float t,
-                        float beta1, float beta2, float eps, float clip, float grad_scale) {
+                        float beta1, float beta2, float eps, float clip, float grad_scale, AdamDyn dyn = {nullptr, nullptr}) {
   const bool vec = count % 4 == 0 && (((size_t)w | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
   if (vec) {
     size_t blocks = (count / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(adam_tf_vec4_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count / 4, (float4*)w, (const float4*)g, (float4*)m,
-                       (float4*)v, hyper, lr, t, beta1, beta2, eps, clip, grad_scale);
+                       (float4*)v, hyper, lr, t, beta1, beta2, eps, clip, grad_scale, dyn);
   } else {
     size_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, w, g, m, v, hyper, lr, t, beta1, beta2, eps, clip,
-                       grad_scale);
+                       grad_scale, dyn);
   }
 }
 
@@ -217,6 +263,10 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
     c->num_cus = cus;
   }
   c->dbg_stamps = nullptr;
+  c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stub = false; c->comm_stream = nullptr;
+  c->comm_fork = nullptr; c->comm_join = nullptr; c->comm_pending = false;
+  c->gscale_host = 1.f;
+  c->gscale_dev = nullptr;
   c->zero_page = nullptr;
   if (hipMalloc(&c->zero_page, RC_ZERO_PAGE_BYTES) != hipSuccess || hipMemset(c->zero_page, 0, RC_ZERO_PAGE_BYTES) != hipSuccess) {
     delete c;
@@ -229,6 +279,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
 
 int rcgan_destroy(rcgan_ctx* ctx) {
   if (!ctx) return RCGAN_EINVALID_ARG;
+  (void)rcgan_comm_destroy(ctx);
   for (int i = 0; i < 64; ++i)
     if (ctx->event_made[i]) (void)hipEventDestroy(ctx->events[i]);
   for (auto g : ctx->graphs)
@@ -1000,6 +1051,48 @@ int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, f
                        float beta2, float eps, float clip, float grad_scale) {
   if (count == 0) return RCGAN_OK;
   adam_launch(ctx, count, w, g, m, v, nullptr, lr, t, beta1, beta2, eps, clip, grad_scale);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_set2_f32(rcgan_ctx* ctx, float* p, float a, float b) {
+  RC_REQUIRE(ctx, p != nullptr, "null pointer");
+  hipLaunchKernelGGL(set2_kernel, dim3(1), dim3(1), 0, ctx->stream, p, a, b);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_set_grad_scale(rcgan_ctx* ctx, float host_scale, const float* dev_scale) {
+  RC_REQUIRE(ctx, host_scale > 0.f, "grad scale %g", (double)host_scale);
+  ctx->gscale_host = host_scale;
+  ctx->gscale_dev = dev_scale;
+  return RCGAN_OK;
+}
+
+int rcgan_grad_finite_check(rcgan_ctx* ctx, size_t count, const float* g, float* ls_state) {
+  RC_REQUIRE(ctx, g != nullptr && ls_state != nullptr && ((size_t)g & 15) == 0, "null / misaligned argument");
+  if (count == 0) return RCGAN_OK;
+  size_t blocks = (count / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(grad_finite_check_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, count, g, ls_state);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_adam_tf_dyn(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v, float lr, const float* t_dev, float beta1,
+                      float beta2, float eps, float clip, float grad_scale, const float* ls_state) {
+  RC_REQUIRE(ctx, t_dev != nullptr && ls_state != nullptr, "null t_dev / ls_state");
+  if (count == 0) return RCGAN_OK;
+  adam_launch(ctx, count, w, g, m, v, nullptr, lr, 0.f, beta1, beta2, eps, clip, grad_scale, AdamDyn{ls_state, t_dev});
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_loss_scale_update(rcgan_ctx* ctx, float* ls_state, float* t_dev0, float* t_dev1, float growth_interval, float min_scale,
+                            float max_scale) {
+  RC_REQUIRE(ctx, ls_state != nullptr && growth_interval >= 1.f && min_scale > 0.f && max_scale >= min_scale, "bad loss-scale arguments");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, ctx->stream, ls_state, t_dev0, t_dev1, growth_interval, min_scale, max_scale);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

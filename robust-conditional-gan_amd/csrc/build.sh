@@ -5,7 +5,7 @@
 # usage: build.sh [bf16|f16|all]   (default all)
 set -e
 cd "$(dirname "$0")"
-SRCS="api.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_mfma8.hip conv_trunk.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
+SRCS="api.hip comm.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_mfma8.hip conv_trunk.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 WHAT=${1:-all}
 
@@ -14,7 +14,12 @@ build_one() {   # $1 = object dir, $2 = output, $3 = extra flags
   pids=()
   for s in $SRCS; do
     o=$1/${s%.hip}.o
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_mfma.h -nt "$o" ] || [ conv_image.h -nt "$o" ] || [ mfma_util.h -nt "$o" ] || [ ../../include/rcgan_hip.h -nt "$o" ]; then
+    stale=0
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ build.sh -nt "$o" ]; then stale=1; fi
+    for h in *.h ../../include/*.h; do        # every header: an object is rebuilt when ANY of them is newer
+      if [ "$stale" = 0 ] && [ "$h" -nt "$o" ]; then stale=1; fi
+    done
+    if [ "$stale" = 1 ]; then
       $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC $3 -c "$s" -o "$o" &
       pids+=($!)
     fi

@@ -29,6 +29,18 @@ struct rcgan_ctx {
   hipStream_t main_stream, side_stream;
   hipEvent_t fork_ev, join_ev;
   bool on_side;
+  // gradient (loss) scaling of 16-bit activations (rcgan_set_grad_scale): every gradient the loss kernels emit is multiplied by
+  // gscale_host * (gscale_dev ? *gscale_dev : 1); the loss VALUES they accumulate stay unscaled
+  float gscale_host;
+  const float* gscale_dev;
+  // data-parallel gradient exchange (comm.hip): an RCCL communicator (or the single-process test double), its own stream for
+  // buckets exchanged beside the rest of the backward pass, fork / join events (capturable)
+  void* comm;          // ncclComm_t
+  int comm_world, comm_rank;
+  bool comm_stub;      // rcgan_comm_init_stub: "every rank holds what this rank holds" -> sum = world * x
+  hipStream_t comm_stream;
+  hipEvent_t comm_fork, comm_join;
+  bool comm_pending;   // an asynchronous bucket has not been joined yet
   void* dbg_stamps;    // rcgan_debug_stamps
   int num_cus;         // compute units of the device (grid size of the persistent kernels)
   void* zero_page;     // 36 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);

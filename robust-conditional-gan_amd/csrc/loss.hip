@@ -119,9 +119,13 @@ __device__ __forceinline__ void loss_term(int kind, float x, float* t, float* d)
   }
 }
 
+// gs_host * (*gs_dev): the gradient (loss) scale of 16-bit activations -- applied to the gradients only, the loss value stays unscaled
+__device__ __forceinline__ float grad_scale_of(float gs_host, const float* gs_dev) { return gs_dev ? gs_host * gs_dev[0] : gs_host; }
+
 __global__ __launch_bounds__(256) void loss_kernel(int kind, int rows, int cols, const float* x, const float* wts, float weight,
-                                                    float* loss_acc, float* dlogit, float* dwts) {
+                                                    float* loss_acc, float* dlogit, float* dwts, float gs_host, const float* gs_dev) {
   __shared__ float red[4];
+  const float gw = weight * grad_scale_of(gs_host, gs_dev);
   const long total = (long)rows * cols;
   const float inv_rows = 1.f / (float)rows;
   const float inv_all = 1.f / (float)total;
@@ -131,16 +135,17 @@ __global__ __launch_bounds__(256) void loss_kernel(int kind, int rows, int cols,
     loss_term(kind, x[i], &t, &d);
     float wf = wts ? wts[i] * inv_rows : inv_all;
     acc += t * wf;
-    if (dlogit) dlogit[i] = weight * d * wf;
-    if (dwts) dwts[i] = weight * t * inv_rows;
+    if (dlogit) dlogit[i] = gw * d * wf;
+    if (dwts) dwts[i] = gw * t * inv_rows;
   }
   acc = block_sum256(acc, red);
   if (threadIdx.x == 0 && loss_acc) *loss_acc += weight * acc;
 }
 
 __global__ __launch_bounds__(256) void bce_onehot_kernel(int rows, int cols, const float* x, const int32_t* labels, float weight,
-                                                          float* loss_acc, float* dx) {
+                                                          float* loss_acc, float* dx, float gs_host, const float* gs_dev) {
   __shared__ float red[4];
+  const float gw = weight * grad_scale_of(gs_host, gs_dev);
   const long total = (long)rows * cols;
   const float inv_all = 1.f / (float)total;
   float acc = 0.f;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void bce_onehot_kernel(int rows, int cols, con
     float z = labels[r] == cidx ? 1.f : 0.f;
     float v = x[i];
     acc += (fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)))) * inv_all;
-    if (dx) dx[i] = weight * (1.f / (1.f + expf(-v)) - z) * inv_all;
+    if (dx) dx[i] = gw * (1.f / (1.f + expf(-v)) - z) * inv_all;
   }
   acc = block_sum256(acc, red);
   if (threadIdx.x == 0 && loss_acc) *loss_acc += weight * acc;
@@ -200,6 +205,7 @@ struct HeadArgs {
   int n, d, v, e_dim;
   HeadPart part[2];
   float weight;
+  float gs_host; const float* gs_dev;      // gradient scale (rcgan_set_grad_scale)
   const float *feat, *w_out, *sigma_out, *b_out, *table, *w_e, *sigma_e, *b_e;
   float *loss_acc, *logits, *dfeat, *dw_out, *db_out, *dtable, *dw_e, *db_e;
   // optional: the features are pooled HERE from the trunk's output x [n][hw][d] (feat = mean over hw of act(x), written to
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
   const HeadPart& P = a.part[p];
   const int sr = p ? s - a.part[0].rows : s;
   const float inv_rows = 1.f / (float)P.rows;
+  const float gw = a.weight * grad_scale_of(a.gs_host, a.gs_dev);
   const bool xm = a.x != nullptr;
   // channel of slot q of this lane: lane + 64 q, or (pooling from x) the adjacent pair 2 lane, 2 lane + 1 of each 128-channel half
   auto jof = [&](int q) { return xm ? 2 * lane + (q & 1) + 128 * (q >> 1) : lane + q * 64; };
@@ -331,11 +338,11 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
         loss_term(P.kind, x, &tt, &dd);
         const float wf = (P.wts ? __shfl(wt_pre, l) : 1.f) * inv_rows;
         lacc += tt * wf;
-        g = a.weight * dd * wf;
+        g = gw * dd * wf;
 #pragma unroll
         for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = jof(q); df[q] += j < d ? g * E[l * d + j] : 0.f; }
         if (lane == 0) {
-          if (P.dwts) P.dwts[(long)sr * v + l] = a.weight * tt * inv_rows;
+          if (P.dwts) P.dwts[(long)sr * v + l] = gw * tt * inv_rows;
           if (a.logits) a.logits[(long)s * v + l] = x;
         }
       } else if (lane == 0 && a.logits) {
@@ -533,7 +540,8 @@ int rcgan_proj_logit_all_bwd(rcgan_ctx* ctx, int n, int d, int v, const float* f
 int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float* x, const float* wts, float weight,
                        float* loss_acc, float* dlogit, float* dwts) {
   RC_REQUIRE(ctx, kind >= 0 && kind <= RCGAN_LOSS_CE_ZEROS, "kind %d", kind);
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, ctx->stream, kind, rows, cols, x, wts, weight, loss_acc, dlogit, dwts);
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, ctx->stream, kind, rows, cols, x, wts, weight, loss_acc, dlogit, dwts, ctx->gscale_host,
+                     ctx->gscale_dev);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
@@ -561,6 +569,7 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   RC_REQUIRE(ctx, hd->rows_a >= 1 && hd->rows_a <= hd->n, "rows_a %d of %d", hd->rows_a, hd->n);
   HeadArgs a;
   a.n = hd->n; a.d = hd->d; a.v = hd->v; a.e_dim = hd->e_dim; a.weight = hd->weight;
+  a.gs_host = ctx->gscale_host; a.gs_dev = ctx->gscale_dev;
   a.part[0] = {hd->rows_a, hd->kind_a, hd->labels_a, hd->wts_a, hd->dwts_a};
   a.part[1] = {hd->n - hd->rows_a, hd->kind_b, hd->labels_b, hd->wts_b, hd->dwts_b};
   for (int p = 0; p < 2; ++p) {
@@ -605,7 +614,8 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
 
 int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels, float weight,
                              float* loss_acc, float* dx) {
-  hipLaunchKernelGGL(bce_onehot_kernel, dim3(1), dim3(256), 0, ctx->stream, rows, cols, x, labels, weight, loss_acc, dx);
+  hipLaunchKernelGGL(bce_onehot_kernel, dim3(1), dim3(256), 0, ctx->stream, rows, cols, x, labels, weight, loss_acc, dx, ctx->gscale_host,
+                     ctx->gscale_dev);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

@@ -87,7 +87,9 @@ __device__ __forceinline__ void step_inputs_body(const StepInputsArgs& a, int bi
   // every workgroup read the stream offset above; the last one to arrive moves it on
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acq_rel: this workgroup's reads of state[0] / slice[0] (above, before the barrier) are ordered before its arrival, and the
+    // last arriver's stores below after every other workgroup's arrival
+    const unsigned prev = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == (unsigned)nb - 1u) {
       a.state[0] = base + ((uint64_t)a.n * 3072 + 3) / 4;
       if (a.fakes) a.slice[0] = (k + 1u) % (unsigned)a.nslices;

@@ -32,6 +32,37 @@ def allreduce_sum_(flat, stream=None):
     return flat
 
 
+def init_comm(ctx, world, rank, stub=False):
+    """Create the context's in-ABI communicator (rcgan_comm_init: RCCL over xGMI, one rank per process / GPU).  The 128-byte RCCL
+    unique id of rank 0 reaches the other ranks through torch.distributed when a process group exists, else through a TCP store at
+    MASTER_ADDR:MASTER_PORT+1 (the launcher's environment).  stub: the single-process test double (rcgan_comm_init_stub)."""
+    import ctypes as C
+    import os
+    if stub:
+        ctx.check(ctx.lib.rcgan_comm_init_stub(ctx.h, int(world)))
+        return
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        rc = ctx.lib.rcgan_comm_unique_id(buf)
+        if rc != 0:
+            from ._lib import RcganError
+            raise RcganError(rc, "rcgan_comm_unique_id failed (is librccl.so loadable?)")
+    if world == 1:
+        ident = bytes(buf.raw)
+    elif dist.is_available() and dist.is_initialized():
+        objs = [bytes(buf.raw) if rank == 0 else None]
+        dist.broadcast_object_list(objs, src=0, device=ctx.device if dist.get_backend() == "nccl" else None)
+        ident = objs[0]
+    else:
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29533")) + 1
+        store = dist.TCPStore(addr, port, world, is_master=(rank == 0))
+        if rank == 0:
+            store.set("rcgan_comm_id", bytes(buf.raw))
+        ident = store.get("rcgan_comm_id")
+    ctx.check(ctx.lib.rcgan_comm_init(ctx.h, C.c_char_p(bytes(ident)), int(world), int(rank)))
+
+
 def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

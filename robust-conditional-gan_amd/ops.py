@@ -65,8 +65,11 @@ class Weight:
 
     @staticmethod
     def _key(desc, nbytes):
-        # the prepared layout depends only on whether the MFMA path takes this shape
-        return (desc.kh, desc.kw, desc.cin, desc.cout, desc.dtype, desc.stride, desc.flags & L.CONV_FORCE_DIRECT, nbytes)
+        # the prepared layout depends on whether the MFMA path takes this shape and on which resampling the layer folds in: the
+        # summed sub-pixel filters of CONV_IN_UPSAMPLE2X and CONV_OUT_MEANPOOL2 have the same size and different contents
+        # (only 3x3 layers carry them: mfma_phase_filters)
+        resample = (L.CONV_IN_UPSAMPLE2X | L.CONV_OUT_MEANPOOL2) if (desc.kh == 3 and desc.kw == 3) else 0
+        return (desc.kh, desc.kw, desc.cin, desc.cout, desc.dtype, desc.stride, desc.flags & (L.CONV_FORCE_DIRECT | resample), nbytes)
 
     def prepared(self, desc):
         ctx = self.ctx
@@ -169,17 +172,24 @@ def spectral_norm_batch(ctx, entries):
                 w.dwbar = DT(base + off * 4, w.param.shape, L.F32, ctx.arena.buf)
                 off += (w.param.size + 63) // 64 * 64
 
-    def bw():
+    done = set()
+
+    def bw(only=None):
+        """dW_bar -> dW through the power iteration for every weight not handled yet (only: predicate on the parameter name --
+        the data-parallel step finishes the gradients of its first bucket early, Context.sn_partial)."""
         ctx.flush_wgrads()          # the deferred filter gradients write the dW_bar this closure consumes
-        todo = [(w, s) for w, s in zip(weights, saves) if w.dwbar is not None and w.param.req]
+        todo = [(i, w, s) for i, (w, s) in enumerate(zip(weights, saves))
+                if i not in done and w.dwbar is not None and w.param.req and (only is None or only(w.param.name))]
         if not todo:
             return
         bi = (L.SnBwdItem * len(todo))()
-        for i, (w, (save, k, c)) in enumerate(todo):
-            bi[i] = L.SnBwdItem(w.param.ptr, w.dwbar.ptr, w.param.grad.ptr, save.ptr, k, c, 1)
+        for j, (i, w, (save, k, c)) in enumerate(todo):
+            bi[j] = L.SnBwdItem(w.param.ptr, w.dwbar.ptr, w.param.grad.ptr, save.ptr, k, c, 1)
+            done.add(i)
         ctx.check(ctx.lib.rcgan_sn_bwd(ctx.h, bi, len(todo)))
     if any(p.req for p, _, _ in entries):
         ctx.record(bw)
+        ctx.sn_partial.append(bw)
     return weights
 
 

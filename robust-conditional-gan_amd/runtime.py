@@ -131,9 +131,11 @@ class Context:
         self.ws2 = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device) if self.overlap else None
         self.ws2_ptr = self.ws2.data_ptr() if self.overlap else 0
         self.tape = []
+        self.sn_partial = []        # spectral-norm backward closures of this step that take a parameter-name predicate
         self.pending_wgrads = []
         self.group_wgrads = os.environ.get("RCGAN_GROUP_WGRAD", "1") == "1"     # see defer_wgrad
         self.recording = True
+        self.capturing = False      # between graph_begin() and graph_end(): launches are recorded into a hipGraph
         self._keep = []
         self.check(self.lib.rcgan_selftest(self.h))
         self.uses_tr_read = self.lib.rcgan_query(self.h, L.QUERY_TR_READ)
@@ -239,6 +241,7 @@ class Context:
 
     def new_step(self):
         self.tape = []
+        self.sn_partial = []
         self.pending_wgrads = []
         self.arena.reset()
         self.epoch += 1
@@ -246,9 +249,11 @@ class Context:
     # ------------------------------------------------------------------ graphs
     def graph_begin(self):
         self.check(self.lib.rcgan_graph_begin(self.h))
+        self.capturing = True
 
     def graph_end(self):
         gid = C.c_int(-1)
+        self.capturing = False
         self.check(self.lib.rcgan_graph_end(self.h, C.byref(gid)))
         return gid.value
 
@@ -296,6 +301,8 @@ class ParamGroup:
         self.v = torch.zeros(self.count, dtype=torch.float32, device=dev)
         self._lr, self._t = 0.0, 0.0      # {lr, t} of the next Adam launch (set_hyper)
         self.t = 0
+        self.hyper = None       # DEVICE float[2] = {lr, t} of the captured Adam launch (set_hyper_device)
+        self.t_dev = None       # dynamic loss scaling: DEVICE float[1], the number of APPLIED updates (adam_dyn)
         self.version = 0        # bumped by every write to the values (set / adam): keys caches of derived layouts
         host = np.zeros(self.count, np.float32)
         for name, shape, init in specs:
@@ -351,13 +358,62 @@ class ParamGroup:
             return self.gradbuf.data_ptr(), self.gradbuf.numel()
         c.check(c.lib.rcgan_fill_f32(c.h, self.gradbuf.numel(), self.gradbuf.data_ptr(), 0.0))
 
+    def set_hyper_device(self, lr, t):
+        """{lr, t} of the next CAPTURED Adam launch (adam_captured): written to device memory by a one-thread launch on the stream
+        in front of the step's graph -- no host-to-device copy, and a replayed graph reads fresh values."""
+        c = self.ctx
+        if self.hyper is None:
+            self.hyper = torch.zeros(2, dtype=torch.float32, device=c.device)
+        if float(t) >= float(1 << 24):
+            raise OverflowError("Adam step counter %d is not exactly representable as fp32" % int(t))
+        c.check(c.lib.rcgan_set2_f32(c.h, self.hyper.data_ptr(), float(lr), float(t)))
+
+    def adam_captured(self, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0):
+        """The capturable Adam launch: {lr, t} read from device memory (set_hyper_device), rcgan_adam_tf."""
+        c = self.ctx
+        assert self.hyper is not None, "set_hyper_device first"
+        c.check(c.lib.rcgan_adam_tf(c.h, self.count, self.value.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                    self.hyper.data_ptr(), beta1, beta2, eps, clip, grad_scale))
+
+    def finite_check(self, ls_state):
+        """Raise ls_state's non-finite flag if this group's gradient slab holds an inf / nan (rcgan_grad_finite_check)."""
+        c = self.ctx
+        if self.t_dev is None:
+            self.t_dev = torch.full((1,), float(max(self.t - 1, 0)), dtype=torch.float32, device=c.device)
+        c.check(c.lib.rcgan_grad_finite_check(c.h, self.count, self.grad.data_ptr(), ls_state.data_ptr()))
+
+    def adam_dyn(self, ls_state, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0):
+        """Adam under dynamic loss scaling (rcgan_adam_tf_dyn): skipped when ls_state's non-finite flag is raised, the gradient divided
+        by the current scale, t = applied updates + 1 read from device memory.  lr from set_hyper."""
+        c = self.ctx
+        if c.capturing:
+            raise RuntimeError("ParamGroup.adam_dyn() bakes lr into the launch and must not be captured into a hipGraph")
+        c.check(c.lib.rcgan_adam_tf_dyn(c.h, self.count, self.value.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                        self._lr, self.t_dev.data_ptr(), beta1, beta2, eps, clip, grad_scale, ls_state.data_ptr()))
+        self.version += 1
+
+    def steps_applied(self):
+        """Optimiser updates actually applied: the device's count under dynamic loss scaling (skipped steps excluded), else t."""
+        if self.t_dev is None:
+            return self.t
+        self.ctx.sync()
+        return int(round(float(self.t_dev.cpu()[0])))
+
     def set_hyper(self, lr, t):
         """{lr, t} of the next Adam launch.  Adam is launched eagerly behind the step's captured graph and the all-reduce, so the
         two values travel as kernel arguments (rcgan_adam_tf_host): no host-to-device copy per optimiser step."""
         self._lr, self._t = float(lr), float(t)
 
     def adam(self, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0, lo=0, hi=None):
+        """Eager TF-form Adam launch with {lr, t} as kernel arguments.  NOT capturable: a hipGraph would replay the learning
+        rate and the bias-correction step of capture time for ever -- inside a captured step use adam_captured (the
+        device-side {lr, t} of rcgan_adam_tf).  t travels as fp32: exact up to 2^24 optimiser steps."""
         c = self.ctx
+        if c.capturing:
+            raise RuntimeError("ParamGroup.adam() bakes lr / t into the launch and must not be captured into a hipGraph: "
+                               "use adam_captured()")
+        if self._t >= float(1 << 24):
+            raise OverflowError("Adam step counter %d is not exactly representable as fp32" % int(self._t))
         hi = self.count if hi is None else hi
         o = lo * 4
         c.check(c.lib.rcgan_adam_tf_host(c.h, hi - lo, self.value.data_ptr() + o, self.grad.data_ptr() + o,

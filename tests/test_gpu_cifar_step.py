@@ -353,3 +353,114 @@ def test_packed_feed_equals_named_inputs():
             assert np.array_equal(m.ctx.download(m.inp[k]), got[k]), k
     finally:
         m.ctx.close()
+
+
+def test_dynamic_loss_scale_skips_overflowed_steps_and_recovers():
+    """fp16 activations, dynamic loss scale (rcgan_grad_finite_check / rcgan_adam_tf_dyn / rcgan_loss_scale_update): from an
+    absurd initial scale every step overflows in the backward pass -- the update is skipped (weights, Adam slots and the
+    bias-correction count untouched), the scale halves -- until the gradients fit; then steps apply, and after
+    growth_interval applied steps in a row the scale doubles.  No inf / nan ever reaches the weights."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+    rs = np.random.RandomState(5)
+    B = 8
+    C, raw, gb = _batches(rs, B)
+    m = CifarRCGAN(algorithm="rcgan", alpha=0.6, batch_size=B, dtype="f16", seed=0, use_graphs=True, device_rng=False,
+                   loss_scale=2.0 ** 40, loss_scale_growth_interval=3, arena_bytes=2 << 30)
+    assert m.dynamic_ls
+    try:
+        m.set_inputs(labels_all=_labels_all("rcgan", raw), **raw)
+        p0 = m.get_params()
+        m.d_step(iteration=0)
+        st = m.loss_scale_state()
+        assert st["skipped_steps"] == 1 and st["scale"] == 2.0 ** 39, st
+        p1 = m.get_params()
+        for k in p0:
+            assert np.array_equal(p0[k], p1[k]), "a skipped step changed " + k
+        assert m.PD.steps_applied() == 0 and float(m.PD.m.abs().max()) == 0.0 and float(m.PD.v.abs().max()) == 0.0
+        applied_at = None
+        for i in range(60):
+            m.d_step(iteration=0)
+            st = m.loss_scale_state()
+            if m.PD.steps_applied() > 0:
+                applied_at = st
+                break
+        assert applied_at is not None, st
+        assert applied_at["scale"] == 2.0 ** (40 - applied_at["skipped_steps"]) and 2.0 ** 8 <= applied_at["scale"] <= 2.0 ** 30, applied_at
+        d_loss, _ = m.losses()
+        assert np.isfinite(d_loss) and 0.1 < d_loss < 10.0, d_loss          # the loss value is never scaled
+        # generator step under the same scale: both of its groups are checked
+        m.set_inputs(**gb)
+        m.g_step(iteration=1)
+        # growth: three applied steps in a row double the scale (an overflow in between would reset the count)
+        s0, k0 = m.loss_scale_state(), m.PD.steps_applied()
+        for _ in range(6):
+            m.d_step(iteration=1)
+        s1 = m.loss_scale_state()
+        skipped = s1["skipped_steps"] - s0["skipped_steps"]
+        assert m.PD.steps_applied() + skipped - k0 == 6
+        if skipped == 0:       # (good_steps + 6) // 3 doublings, never beyond 2^24 and never downwards
+            want = s0["scale"]
+            for _ in range((s0["good_steps"] + 6) // 3):
+                want = want if want >= 2.0 ** 24 else min(2 * want, 2.0 ** 24)
+            assert s1["scale"] == want and s1["good_steps"] == (s0["good_steps"] + 6) % 3, (s0, s1)
+        for k, v in m.get_params().items():
+            assert np.isfinite(v).all(), k
+    finally:
+        m.ctx.close()
+
+
+def test_dynamic_loss_scale_equals_static_scale_without_overflow():
+    """With no overflow and no growth the dynamic path (scale read from device memory, finite check, device-side step count)
+    is the static path bit for bit: weights after two critic steps and a generator step."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+    rs = np.random.RandomState(6)
+    B = 8
+    C, raw, gb = _batches(rs, B)
+    outs = []
+    for dyn in (False, True):
+        m = CifarRCGAN(algorithm="rcgan-u", alpha=0.6, batch_size=B, dtype="f16", seed=0, use_graphs=True, device_rng=False,
+                       perm_classifier=True, confuse_init=True, dynamic_loss_scale=dyn, arena_bytes=2 << 30)
+        try:
+            for it in range(2):
+                m.set_inputs(labels_all=_labels_all("rcgan-u", raw), **raw)
+                m.d_step(iteration=it)
+            m.set_inputs(**gb)
+            m.g_step(iteration=1)
+            m.set_inputs(labels_all=_labels_all("rcgan-u", raw), **raw)
+            m.d_step(iteration=1)                    # replays of both graphs' captures come after this point in training
+            assert m.loss_scale_state()["skipped_steps"] == 0
+            outs.append((m.get_params(), m.losses()))
+        finally:
+            m.ctx.close()
+    (pa, la), (pb, lb) = outs
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+
+
+def test_grad_finite_check_finds_any_non_finite_value():
+    """rcgan_grad_finite_check through the raw C ABI: inf / nan anywhere in the slab (first element, a vector-tail element,
+    the very last one) raises the flag; finite slabs -- denormals and the largest finite float included -- do not."""
+    import ctypes as C
+    import torch
+    from tests.gpu_util import make_ctx
+    ctx = make_ctx("bf16")
+    try:
+        n = 1000003
+        base = torch.randn(n, device=ctx.device)
+        base[7] = 3.4028234e38
+        base[8] = 1e-45
+        for pos, val, want in [(None, 0.0, 0.0), (0, float("inf"), 1.0), (n - 1, float("nan"), 1.0), (n - 2, float("-inf"), 1.0),
+                               (123456, float("nan"), 1.0)]:
+            g = base.clone()
+            if pos is not None:
+                g[pos] = val
+            ls = torch.tensor([1024.0, 0, 0, 0], dtype=torch.float32, device=ctx.device)
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.rcgan_grad_finite_check(ctx.h, n, C.c_void_p(g.data_ptr()), C.c_void_p(ls.data_ptr())))
+            ctx.sync()
+            assert float(ls[2]) == want, (pos, val, ls)
+    finally:
+        ctx.close()

@@ -1,0 +1,243 @@
+"""The data-parallel step of the CIFAR engine (gan_resnet.py:529-546 tower split, :697,786 mean of the tower costs).
+
+The product's world > 1 path: per optimiser step the gradient slab(s) all-reduced inside the C ABI (rcgan_allreduce_sum*) and inside the
+step's captured graph, and the optimiser launch in the same graph; optionally (RCGAN_DP_OVERLAP=1) in two buckets, the layers whose
+backward finishes first leaving on the communication stream beside the rest of the backward pass.  This file checks it three ways:
+
+  1. on ONE GPU against the in-ABI test-double communicator (rcgan_comm_init_stub: "every rank holds what this rank holds", so the
+     all-reduce sum is world * x and the mean is x again): the world-size-N schedule must reproduce the world-size-1 run -- bit for
+     bit without the early bucket, to fp32 summation order with it (the early flush regroups the filter-gradient launches);
+  2. on ONE GPU with a real one-rank RCCL communicator (comm="rccl-self"): ncclAllReduce captured into the step graphs and replayed;
+  3. with TWO processes on two GPUs over RCCL (skipped below 2 GPUs): ranks fed different shards end two iterations with
+     bit-identical weights (the same summed gradients reached every rank) and different tower losses.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _feeds(rs, B, n_iter, alg):
+    from rcgan_amd.cifar import N_CRITIC
+    C = ((1 - 0.6) / 9.0) * np.ones((10, 10)) + (0.6 - (1 - 0.6) / 9.0) * np.eye(10)
+    Cinv = np.linalg.inv(C)
+    its = []
+    for _ in range(n_iter):
+        lra = rs.randint(10, size=N_CRITIC * B)
+        ds = []
+        for k in range(N_CRITIC):
+            lab = rs.randint(10, size=B)
+            lb = rs.randint(10, size=B)
+            d = dict(images=rs.randint(0, 256, size=(B, 3072)), labels=lab, labels_random=lra[k * B:(k + 1) * B], labels_biased=lb,
+                     inv_weights=Cinv[lab].astype(np.float32))
+            d["labels_all"] = np.concatenate([lab, d["labels_random"] if alg in ("biased", "unbiased") else lb])
+            ds.append(d)
+        g = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B))
+        its.append((lra, ds, g))
+    return its
+
+
+def _run_iterations(m, its, grads_after_first=None):
+    """The production loop (bench.py / train_cifar.py): prepare_critic_fakes + N_CRITIC critic steps + a generator step."""
+    for it, (lra, ds, g) in enumerate(its):
+        m.set_feed("gf", m.pack_feed("gf", labels_random_all=lra))
+        m.prepare_critic_fakes()
+        for k, d in enumerate(ds):
+            m.set_feed("d", m.pack_feed("d", **d))
+            m.d_step(iteration=it)
+            if grads_after_first is not None and it == 0 and k == 0:
+                grads_after_first.update(m.get_grads(m.PD))
+        m.set_feed("g", m.pack_feed("g", **g))
+        m.g_step(iteration=it + 1)
+    m.ctx.sync()
+    return m.get_params(), m.losses(), m.get_state()
+
+
+def _same_trajectory(pa, pb, lr=2e-4):
+    """Two runs that differ only in fp32 summation order: Adam (beta1 = 0) moves every weight by ~lr per step whatever the size of
+    its gradient, so a ~0 gradient whose sign flips leaves the two runs 2*lr apart in that element (zero-initialised biases consist of
+    nothing but such steps).  Same trajectory = finite, no element further apart than the steps taken allow, and at most 5 % of a
+    tensor's elements more than one step apart."""
+    for k in pa:
+        assert np.isfinite(pb[k]).all(), k
+        if k.startswith("Generator/") and k.endswith("/Biases"):
+            continue        # a per-channel constant in front of a batch norm: the true gradient is 0, every step is a coin flip
+        d = np.abs(pb[k].astype(np.float64) - pa[k])
+        assert float(d.max()) <= 2 * lr * 12 + 1e-6 and float(np.mean(d > lr)) <= 5e-2, (k, float(d.max()), float(np.mean(d > lr)))
+
+
+def _model(alg, dtype, B, **kw):
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+    perm = alg == "rcgan-u"
+    return CifarRCGAN(algorithm=alg, alpha=0.6, batch_size=B, dtype=dtype, seed=3, perm_classifier=perm, confuse_init=perm,
+                      use_graphs=True, device_rng=True, arena_bytes=2 << 30, **kw)
+
+
+@pytest.mark.parametrize("alg,dtype,world", [("rcgan", "bf16", 2), ("rcgan-u", "bf16", 8), ("rcgan", "f16", 4)])
+def test_stub_world_without_early_bucket_is_bit_identical_to_single_rank(alg, dtype, world, monkeypatch):
+    """The DEFAULT world-size-N schedule (no early bucket, RCGAN_DP_OVERLAP=0): in-graph all-reduce of the whole slabs + in-graph
+    optimiser (bf16) / dynamic-loss-scale optimiser after the graph (fp16).  sum = N * x and grad_scale = 1/N are exact in fp32:
+    weights, losses and spectral-norm state after two iterations (capture + replays) equal the single-rank run bit for bit."""
+    rs = np.random.RandomState(11)
+    B = 8
+    its = _feeds(rs, B, 2, alg)
+    outs = []
+    for w in (1, world):
+        monkeypatch.setenv("RCGAN_DP_OVERLAP", "0")
+        m = _model(alg, dtype, B, world_size=w, comm=("stub" if w > 1 else None))
+        try:
+            assert m.dp_active == (w > 1) and not m.dp_overlap
+            assert m.dp_adam_in_graph == (w > 1 and dtype != "f16")
+            outs.append(_run_iterations(m, its))
+        finally:
+            m.ctx.close()
+    (pa, la, sa), (pb, lb, sb) = outs
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("alg,dtype", [("rcgan", "bf16"), ("rcgan-u", "bf16"), ("rcgan", "f16")])
+def test_stub_world_with_early_bucket_matches_single_rank(alg, dtype, monkeypatch):
+    """The overlapped schedule (RCGAN_DP_OVERLAP=1; off by default, see cifar.py): D.Block.3 .. head (G.Block.2 .. G.Output) leave on the communication stream in the middle of
+    the backward pass.  The early flush regroups the filter-gradient launches (other pixel splits, other fp32 summation order), so
+    the first critic step's gradients agree to 2e-5 norm-relative per tensor.  After two iterations (12 optimiser steps) the
+    weights agree to 2e-2 norm-relative: Adam with beta1 = 0 moves a weight by ~lr * sign(g) per step whatever |g| is, so a
+    sign flip of a ~0 gradient under another summation order is a 2*lr difference that the following bf16 steps amplify --
+    the same spread two runs of the single-rank engine with different filter-gradient groupings show."""
+    rs = np.random.RandomState(12)
+    B = 8
+    its = _feeds(rs, B, 2, alg)
+    outs = []
+    monkeypatch.setenv("RCGAN_DP_OVERLAP", "1")
+    for w in (1, 2):
+        m = _model(alg, dtype, B, world_size=w, comm=("stub" if w > 1 else None))
+        try:
+            assert m.dp_overlap == (w > 1)
+            g1 = {}
+            outs.append(_run_iterations(m, its, g1) + (g1,))
+        finally:
+            m.ctx.close()
+    (pa, la, sa, ga), (pb, lb, sb, gb) = outs
+    gmax = max(float(np.abs(v).max()) for v in ga.values())
+    for k in ga:
+        if float(np.abs(ga[k]).max()) > 1e-3 * gmax:
+            assert rel_err(gb[k], ga[k]) <= 2e-5, ("gradient of the first critic step", k, rel_err(gb[k], ga[k]))
+    _same_trajectory(pa, pb)
+    assert abs(la[0] - lb[0]) <= 2e-2 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) <= 2e-2 * max(1.0, abs(la[1])), (la, lb)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_one_rank_rccl_communicator_in_captured_graphs(overlap, monkeypatch):
+    """A real RCCL communicator with one rank (comm="rccl-self"): ncclAllReduce on the step's stream and on the communication
+    stream, captured into the D / G step graphs and replayed; sum over one rank = identity, so the run equals the plain one.
+    Skipped when librccl cannot be loaded."""
+    import ctypes as C
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import _lib
+    if _lib.load().rcgan_comm_unique_id(C.create_string_buffer(128)) != 0:
+        pytest.skip("librccl.so not loadable")
+    rs = np.random.RandomState(13)
+    B = 8
+    its = _feeds(rs, B, 2, "rcgan")
+    outs = []
+    monkeypatch.setenv("RCGAN_DP_OVERLAP", overlap)
+    for comm in (None, "rccl-self"):
+        m = _model("rcgan", "bf16", B, world_size=1, comm=comm)
+        try:
+            assert m.dp_active == (comm is not None)
+            g1 = {}
+            outs.append(_run_iterations(m, its, g1) + (g1,))
+        finally:
+            m.ctx.close()
+    (pa, la, sa, ga), (pb, lb, sb, gb) = outs
+    gmax = max(float(np.abs(v).max()) for v in ga.values())
+    for k in ga:
+        if float(np.abs(ga[k]).max()) > 1e-3 * gmax:
+            assert rel_err(gb[k], ga[k]) <= 2e-5, (k, rel_err(gb[k], ga[k]))
+    _same_trajectory(pa, pb)
+
+
+def test_allreduce_abi_errors_and_buckets():
+    """C ABI: all-reduce without a communicator -> RCGAN_EINVALID_ARG with a message; the test double scales every bucket of a
+    group by the world size, the asynchronous bucket is complete after the join."""
+    import ctypes as C
+    import torch
+    from rcgan_amd import _lib as L
+    from tests.gpu_util import make_ctx
+    ctx = make_ctx("bf16")
+    try:
+        a = torch.arange(1000, dtype=torch.float32, device=ctx.device)
+        rc = ctx.lib.rcgan_allreduce_sum(ctx.h, C.c_void_p(a.data_ptr()), a.numel())
+        assert rc == -1 and b"communicator" in ctx.lib.rcgan_last_error(ctx.h)
+        ctx.check(ctx.lib.rcgan_comm_init_stub(ctx.h, 4))
+        assert ctx.lib.rcgan_comm_world(ctx.h) == 4
+        assert ctx.lib.rcgan_comm_init_stub(ctx.h, 2) == -1            # already initialised
+        b = torch.ones(77, dtype=torch.float32, device=ctx.device)
+        c = torch.full((5000,), 0.5, dtype=torch.float32, device=ctx.device)
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.rcgan_allreduce_sum_async(ctx.h, C.c_void_p(c.data_ptr()), c.numel()))
+        ptrs, counts = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr()), (C.c_size_t * 2)(a.numel(), b.numel())
+        ctx.check(ctx.lib.rcgan_allreduce_sum_buckets(ctx.h, 2, ptrs, counts))
+        ctx.check(ctx.lib.rcgan_allreduce_join(ctx.h))
+        ctx.sync()
+        assert torch.equal(a.cpu(), 4 * torch.arange(1000, dtype=torch.float32)) and float(b.sum()) == 4 * 77 and float(c.sum()) == 2.0 * 5000
+        ctx.check(ctx.lib.rcgan_comm_destroy(ctx.h))
+        assert ctx.lib.rcgan_comm_world(ctx.h) == 1
+        assert L.ERRORS[-5] == "RCGAN_ERCCL"
+    finally:
+        ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two processes, two GPUs, RCCL
+# ------------------------------------------------------------------------------------------------------------------
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN
+    rs = np.random.RandomState(100 + rank)          # every rank its own shard
+    B = 8
+    its = _feeds(rs, B, 2, "rcgan")
+    m = CifarRCGAN(algorithm="rcgan", alpha=0.6, batch_size=B, dtype="bf16", seed=3, use_graphs=True, device_rng=True, device=rank,
+                   world_size=world, rank=rank, arena_bytes=2 << 30)       # the unique id travels through the TCP store (no process group)
+    try:
+        p, losses, st = _run_iterations(m, its)
+        q.put((rank, {k: v for k, v in p.items()}, losses))
+    finally:
+        m.ctx.close()
+
+
+def test_two_ranks_over_rccl_end_with_identical_weights():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29611, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, params, losses = q.get(timeout=600)
+        res[r] = (params, losses)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), "ranks diverged: " + k
+    assert res[0][1] != res[1][1]          # different shards: different tower losses

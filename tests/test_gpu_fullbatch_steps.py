@@ -1,0 +1,392 @@
+"""Full-batch step parity of the PRODUCTION path at every BASELINE.json configuration (single-GPU legs).
+
+What runs is exactly what bench.py / train_cifar.py run: packed feeds (set_feed), the device random stream
+(device_rng=True: z and the dequantisation noise drawn on the GPU, the critic step's input work riding in the
+filter-preparation launch), ``prepare_critic_fakes()`` + N_CRITIC ``d_step()`` + ``g_step()``, hipGraph capture on the
+first call of each step kind and graph REPLAYS after it.  At these batch sizes the engine takes the routes the toy
+batches of tests/test_gpu_cifar_step.py never reach (256x256 MFMA tiles, sub-pixel phase convolutions on whole tiles,
+five-segment batch norm, grouped sub-pixel filter gradients).
+
+Checker = oracle/torch_port.py (PyTorch-CPU autograd restatement of gan_resnet.py:557-786, fp32 -- the arithmetic the
+TensorFlow reference computes in) evaluated at the DEVICE's own weights / u vectors before every step, on the same fed
+batch and on the very z / noise values the device drew (the test mirrors the Philox stream with rcgan_rng_fill on a
+copy of the stream offset and asserts both offsets agree at the end).  Per optimiser step it checks
+  * the loss,
+  * every parameter gradient (norm-relative error and cosine per tensor, bounds below),
+  * the spectral-norm u vectors after the step,
+  * the optimiser: w_after == TF-form Adam(w_before, the device's own gradient, m, v, t, lr*decay) re-computed in numpy
+    fp32 to 2.5e-7 of the weight scale (2 ulp) -- so "gradient parity" and "update given the gradient" are both pinned on the whole slab.
+
+Hinge terms: a critic-step gradient is a sum of +-1/B contributions of the samples on the active side of the hinge, so ONE
+logit within 16-bit rounding distance of the hinge moves whole tensors by ~1/B of their norm (observed: two such samples of
+64 -> 6 % on the trunk filters, 15 % on the label embedding).  The test therefore reads the logits the device's projection
+head computed (inspection hook CifarRCGAN.head_logits: the same launches with one more output pointer), imposes the DEVICE's
+activity pattern on the oracle's hinge terms, and requires every sample whose pattern differs to lie within ``delta`` of the
+hinge in the oracle as well -- what is compared is then the gradient of the same piecewise-linear branch.
+
+Tolerances (16-bit activations, fp32 master weights / accumulation), norm-relative per tensor; measured on MI355X:
+  bf16 B=64   critic steps <= 1.8e-2 (bound 3e-2, cosine >= 0.999); generator step (the gradient crosses ~45 stored bf16 layers)
+              <= 5.7e-2 rcgan / 9.5e-2 rcgan-u (bounds 9e-2 / 1.4e-1), G.Input/W -- per-element products of z with the deepest
+              activation gradient, where the noise does not average -- 0.10-0.13 (bounds 0.16 / 0.19); cosine >= 0.985
+  fp16 B=512  critic steps <= 2.3e-3 (bound 6e-3); generator step <= 8e-3 (2e-2), G.Input/W 3e-2 (6e-2)
+The B=8 test's generator bound of 0.25 does not survive here.  MNIST cfg2 (fp32, B=256) is checked against the float64 numpy
+oracle at 2e-3 norm-relative (or 4x the fp32 oracle's own distance from float64).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cifar as oc
+from tests.gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.environ.get("RCGAN_PARITY_REPORT")      # optional: append the measured errors of every case to this file
+TOL_SCALE = float(os.environ.get("RCGAN_PARITY_TOL_SCALE", "1"))      # calibration runs only: widen every gradient bound
+
+
+def _report(tag, rows):
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write(json.dumps({"case": tag, "rows": rows}) + "\n")
+
+
+def _adam_np(w, g, m, v, t, lr, b1=0.0, b2=0.9, eps=1e-8):
+    """tf.train.AdamOptimizer's ApplyAdam arithmetic in fp32 (gan_resnet.py:802-817)."""
+    f = np.float32
+    lr_t = f(lr) * np.sqrt(f(1) - f(b2) ** f(t)).astype(f) / (f(1) - f(b1) ** f(t))
+    m2 = (f(b1) * m + f(1 - b1) * g).astype(f)
+    v2 = (f(b2) * v + f(1 - b2) * g * g).astype(f)
+    return (w - f(lr_t) * m2 / (np.sqrt(v2) + f(eps))).astype(f), m2, v2
+
+
+class _Shadow:
+    """Mirror of the model's device random stream: same seed, a private copy of the stream offset."""
+
+    def __init__(self, m):
+        self.m = m
+        self.state = m.rng_state.clone()
+
+    def draw(self, shape, dtype, kind, lo, hi):
+        m, ctx = self.m, self.m.ctx
+        t = ctx.persistent(shape, dtype)
+        ctx.check(ctx.lib.rcgan_rng_fill(ctx.h, t.size, t.dtype, kind, lo, hi, m.seed * 1000003 + m.rank,
+                                         C.c_void_p(self.state.data_ptr()), C.c_void_p(t.ptr)))
+        return ctx.download(t).astype(np.float64)
+
+
+def _grad_rows(tag, got, ref, tol, cos_min, B, special=None):
+    """Per-tensor comparison -> (report rows, list of violations).  A row is (name, norm-relative error, cosine, scale ratio
+    <got, ref> / <ref, ref>)."""
+    rows, bad = [], []
+    special = special or {}
+    cos_min = cos_min if TOL_SCALE == 1 else -1.0
+    gmax = max(float(np.abs(g).max()) for g in ref.values())
+    for k, gref in ref.items():
+        a = got[k]
+        assert np.isfinite(a).all(), "%s %s: non-finite gradient" % (tag, k)
+        floor = 1e-3 * gmax
+        if np.size(gref) <= 1:
+            # one-element gradients (D.Output/b) are sums of +-1/B hinge indicators: a logit crossing the hinge under 16-bit
+            # rounding moves them by whole 1/B steps
+            d = abs(float(np.ravel(a)[0]) - float(np.ravel(gref)[0]))
+            rows.append((k, d, None, None))
+            if d > 2.5 / B:
+                bad.append("%s %s: %.3e vs %.3e" % (tag, k, float(np.ravel(a)[0]), float(np.ravel(gref)[0])))
+        elif float(np.abs(gref).max()) > floor:
+            e = rel_err(a, gref)
+            a64 = a.astype(np.float64)
+            cos = float((a64 * gref).sum() / (np.linalg.norm(a64) * np.linalg.norm(gref) + 1e-30))
+            ratio = float((a64 * gref).sum() / ((gref * gref).sum() + 1e-300))
+            rows.append((k, e, cos, ratio))
+            bound = special.get(k, tol) * TOL_SCALE
+            if not (e <= bound and cos >= cos_min):
+                bad.append("%s %s: norm-rel %.3e (bound %.1e) cos %.5f scale %.4f" % (tag, k, e, bound, cos, ratio))
+        else:       # a true gradient of ~0 (conv biases in front of a batch norm)
+            err = float(np.abs(a - gref).max()) / floor
+            rows.append((k, err, None, None))
+            if err > 0.5:
+                bad.append("%s %s: %.3e of the floor" % (tag, k, err))
+    return rows, bad
+
+
+def _torch_grads(P, U, cfg, batch, which, hinge_mask=None, delta=0.05):
+    """Gradients of disc_cost / gen_cost at (P, U) by the PyTorch-CPU restatement in fp32.  hinge_mask: the DEVICE's hinge
+    activity pattern {term: bool array}, imposed on the oracle's hinge terms; a sample whose own pattern differs must sit within
+    ``delta`` of the hinge in the oracle too (16-bit rounding of a logit), anything else is a real disagreement.  Returns the
+    number of such flipped samples as well."""
+    import torch
+    from oracle.torch_port import CifarTorch
+    net = CifarTorch(P, U, torch.float32)
+    net.hinge_mask = hinge_mask
+    flips = 0
+    if which == "D":
+        cost = net.disc_cost(cfg, batch)
+        names = [k for k in net.P if k.startswith("Discriminator/")]
+        if hinge_mask is not None:
+            for name, mask in hinge_mask.items():
+                t = net.hinge_args[name].numpy()
+                diff = (t > 0) != np.asarray(mask).reshape(t.shape)
+                flips += int(diff.sum())
+                assert (np.abs(t[diff]) < delta).all(), "hinge term %s: device and oracle disagree far from the hinge: %s" % (name, t[diff])
+    else:
+        cost = net.gen_cost(cfg, batch)
+        names = [k for k in net.P if k.startswith("Generator/") or k == "confusion_logits"]
+    grads = torch.autograd.grad(cost, [net.P[k] for k in names], allow_unused=True)
+    out = {k: (g.detach().numpy().astype(np.float64) if g is not None else np.zeros(P[k].shape)) for k, g in zip(names, grads)}
+    U_new = {k: v.detach().numpy() for k, v in net.U_new.items()}
+    return float(cost.detach()), out, U_new, flips
+
+
+def _device_hinge_pattern(alg, B, logits, labels, second, labels_random):
+    """The hinge activity pattern of the critic step the device just ran, from the logits its projection head wrote
+    ([2B, 10]: the logit of the sample's label, or of every label where the loss weights all of them)."""
+    ar = np.arange(B)
+    if alg == "rcgan-u":        # real: the noisy label's logit; fake: every label's logit (gan_resnet.py:654-684)
+        return {"real": 1 - logits[ar, labels] > 0, "fake": 1 + logits[B:, :] > 0}
+    if alg == "unbiased":       # real: every label's logit (:613-647); fake: labels_random
+        m = {"real%d" % j: 1 - logits[:B, j] > 0 for j in range(10)}
+        m["fake"] = 1 + logits[B + ar, labels_random] > 0
+        return m
+    return {"real": 1 - logits[ar, labels] > 0, "fake": 1 + logits[B + ar, second] > 0}
+
+
+def _group_snapshot(grp):
+    return {n: (grp.get(n), grp.get(n, "m"), grp.get(n, "v")) for n in grp.names}
+
+
+def _check_adam(tag, grp, before, grads, t, lr):
+    worst = 0.0
+    for n in grp.names:
+        w0, m0, v0 = before[n]
+        w1, _, _ = _adam_np(w0, grads[n].astype(np.float32), m0, v0, t, lr)
+        d = float(np.abs(grp.get(n) - w1).max()) / max(1.0, float(np.abs(w1).max()))
+        worst = max(worst, d)
+        assert d <= 2.5e-7, "%s Adam update of %s: max difference %.3e (one fp32 ulp of the weight scale = 1.2e-7)" % (tag, n, d)
+    return worst
+
+
+def _cifar_production_iteration(alg, perm, perm_type, B, dtype, d_tol, g_tol, g_in_tol, loss_tol, iterations=1, delta=0.05):
+    import torch
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import _lib as L
+    from rcgan_amd.cifar import N_CRITIC, CifarRCGAN, create_variables, lr_decay
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    variables = create_variables(0, alg, perm, perm_type, True, 0.2)          # confuse_init as run_rcganu.sh
+    jit = np.random.RandomState(3)
+    gs, ds, cs, U = variables
+
+    def jitter(specs):      # de-trivialise zero-initialised tensors (biases, condBN tables) so their gradients matter
+        out = []
+        for n, shp, v in specs:
+            if n.endswith("/Biases") or n.endswith("/b") or "CondBatchNorm" in n:
+                v = (v + 0.1 * jit.randn(*shp)).astype(np.float32)
+            out.append((n, shp, v))
+        return out
+    variables = (jitter(gs), jitter(ds), cs, U)
+    m = CifarRCGAN(algorithm=alg, alpha=0.6, batch_size=B, dtype=dtype, seed=11, perm_classifier=perm, perm_multiplier=1.0,
+                   perm_type=perm_type, confuse_init=True, use_graphs=True, device_rng=True, variables=variables)
+    assert m._rides_inputs(), "the production critic step rides its input work in the filter-preparation launch"
+    # inspection hook: the fused projection head also writes its logits here (the same launches; one more output pointer)
+    m.head_logits = m.ctx.persistent((2 * B, 10), L.F32, fill=0.0)
+    act = m.ctx.act_dtype
+    Cm = oc.c_alpha(0.6)
+    cfg = dict(algorithm=alg, C=Cm, perm_classifier=perm, perm_type=perm_type, perm_multiplier=1.0)
+    rs = np.random.RandomState(5)
+    sh = _Shadow(m)
+    lr = 2e-4
+    tag0 = "%s B=%d %s" % (alg, B, dtype)
+    try:
+        for it in range(iterations):
+            # ---------------------------------------------------------------- N_CRITIC critic steps
+            labels_random_all = rs.randint(10, size=N_CRITIC * B)
+            m.set_feed("gf", m.pack_feed("gf", labels_random_all=labels_random_all))
+            z_all = sh.draw((N_CRITIC * B, 128), act, 1, 0.0, 1.0)
+            m.prepare_critic_fakes()
+            for k in range(N_CRITIC):
+                lab = rs.randint(10, size=B)
+                raw = dict(images=rs.randint(0, 256, size=(B, 3072)), labels=lab, labels_random=labels_random_all[k * B:(k + 1) * B],
+                           labels_biased=rs.randint(10, size=B), inv_weights=np.linalg.inv(Cm)[lab].astype(np.float32))
+                second = raw["labels_random"] if alg in ("biased", "unbiased") else raw["labels_biased"]
+                m.set_feed("d", m.pack_feed("d", labels_all=np.concatenate([lab, second]), **raw))
+                noise = sh.draw((B, 3072), L.F32, 0, 0.0, 1.0 / 128)
+                P, Uo = m.get_params(), m.get_state()
+                before = _group_snapshot(m.PD)
+                m.d_step(iteration=it)
+                d_loss, _ = m.losses()
+                got = m.get_grads(m.PD)
+                batch = dict(real=oc.preprocess_real(raw["images"], noise).astype(np.float32), labels=lab, labels_random=raw["labels_random"],
+                             labels_biased=raw["labels_biased"], inv_weights=raw["inv_weights"], z=z_all[k * B:(k + 1) * B])
+                pattern = _device_hinge_pattern(alg, B, m.ctx.download(m.head_logits), lab, second, raw["labels_random"])
+                cost, ref, U_new, flips = _torch_grads(P, Uo, cfg, batch, "D", pattern, delta)
+                tag = "%s it %d critic step %d" % (tag0, it, k)
+                assert abs(d_loss - cost) <= loss_tol * max(1.0, abs(cost)), (tag, d_loss, cost)
+                rows, bad = _grad_rows(tag, got, ref, d_tol, 0.999, B)
+                st = m.get_state()
+                for key, val in U_new.items():
+                    e = rel_err(st[key], val)
+                    assert e <= 2e-2, "%s u %s: %.3e" % (tag, key, e)
+                worst = _check_adam(tag, m.PD, before, got, m.PD.t, lr * lr_decay(it))
+                _report(tag, dict(loss=(d_loss, cost), adam_max_abs=worst, hinge_flips=flips, grads=rows))
+                assert not bad, "\n".join(bad)
+            # ---------------------------------------------------------------- generator step
+            gb = dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B))
+            m.set_feed("g", m.pack_feed("g", **gb))
+            z_G = sh.draw((2 * B, 128), act, 1, 0.0, 1.0)
+            P, Uo = m.get_params(), m.get_state()
+            before = _group_snapshot(m.PG)
+            before_c = _group_snapshot(m.PC) if m.PC is not None else None
+            m.g_step(iteration=it + 1)
+            _, g_loss = m.losses()
+            got = m.get_grads(m.PG)
+            if m.PC is not None:
+                got.update(m.get_grads(m.PC))
+            cost, ref, U_new, _ = _torch_grads(P, Uo, cfg, dict(z=z_G, **gb), "G")
+            tag = "%s it %d generator step" % (tag0, it)
+            assert abs(g_loss - cost) <= 4 * loss_tol * max(1.0, abs(cost)), (tag, g_loss, cost)
+            rows, bad = _grad_rows(tag, got, ref, g_tol, 0.985, 2 * B, special={"Generator/G.Input/W": g_in_tol})
+            st = m.get_state()
+            for key, val in U_new.items():
+                e = rel_err(st[key], val)
+                assert e <= 2e-2, "%s u %s: %.3e" % (tag, key, e)
+            worst = _check_adam(tag, m.PG, before, got, m.PG.t, lr * lr_decay(it + 1))
+            if m.PC is not None:
+                worst = max(worst, _check_adam(tag + " (confusion)", m.PC, before_c, got, m.PC.t, lr * m.confuse_multiplier))
+            _report(tag, dict(loss=(g_loss, cost), adam_max_abs=worst, grads=rows))
+            assert not bad, "\n".join(bad)
+        # the test drew exactly what the device drew
+        m.ctx.sync()
+        assert np.array_equal(sh.state.cpu().numpy(), m.rng_state.cpu().numpy()), (sh.state.cpu().numpy(), m.rng_state.cpu().numpy())
+        assert "d_fakes" in m._graphs and "g" in m._graphs and "gf" in m._graphs
+    finally:
+        m.ctx.close()
+
+
+def test_cfg3_rcgan_b64_bf16_production_iteration():
+    """BASELINE configs[2]: CIFAR RCGAN, per-GPU batch 64, bf16.  Two iterations: the second one is graph replays only."""
+    _cifar_production_iteration("rcgan", False, "linear", 64, "bf16", d_tol=3e-2, g_tol=9e-2, g_in_tol=1.6e-1, loss_tol=5e-3, iterations=2)
+
+
+def test_cfg4_rcganu_b64_bf16_production_iteration():
+    """BASELINE configs[3], one rank's shard: RCGAN-U (learned confusion matrix, permutation regulariser, confuse_init as
+    run_rcganu.sh), per-GPU batch 64, bf16."""
+    _cifar_production_iteration("rcgan-u", True, "linear", 64, "bf16", d_tol=3e-2, g_tol=1.4e-1, g_in_tol=1.9e-1, loss_tol=5e-3)
+
+
+def test_cfg5_rcgan_b512_f16_production_iteration():
+    """BASELINE configs[4], one rank's shard: per-GPU batch 512, fp16 activations (loss scale 1024)."""
+    _cifar_production_iteration("rcgan", False, "linear", 512, "f16", d_tol=6e-3, g_tol=2e-2, g_in_tol=6e-2, loss_tol=1e-3, delta=0.02)
+
+
+@pytest.mark.parametrize("alg", ["biased", "unbiased"])
+def test_other_algorithms_b64_bf16_production_iteration(alg):
+    _cifar_production_iteration(alg, False, "linear", 64, "bf16", d_tol=3e-2, g_tol=9e-2, g_in_tol=1.6e-1, loss_tol=5e-3)
+
+
+def test_rcganu_2layer_perm_classifier_b64_bf16():
+    """perm_type='2layer' (gan_resnet.py:469-480: SN-Linear 3072->128->10 without a nonlinearity) on the production path."""
+    _cifar_production_iteration("rcgan-u", True, "2layer", 64, "bf16", d_tol=3e-2, g_tol=1.4e-1, g_in_tol=1.9e-1, loss_tol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# MNIST cfg2: B = 256, fp32, spectral-norm projection discriminator, iteration = 1 D run + 2 G runs (model.py:347-372)
+# ------------------------------------------------------------------------------------------------------------------
+def _mnist_cmp(tag, got, g64, g32):
+    rows = []
+    gmax = max(float(np.abs(g).max()) for g in g64.values())
+    for k, gref in g64.items():
+        a = got[k]
+        assert np.isfinite(a).all(), k
+        scale = max(float(np.abs(gref).max()), 1e-3 * gmax)
+        err = float(np.abs(a - gref).max()) / scale
+        nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
+        own = float(np.linalg.norm(g32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
+        rows.append((k, nrm, own))
+        assert nrm <= max(2e-3, 4 * own) and err <= 1e-1, "%s %s: norm-rel %.3e max %.3e (fp32 oracle %.3e)" % (tag, k, nrm, err, own)
+    return rows
+
+
+@pytest.mark.parametrize("est", [False, True])
+def test_cfg2_mnist_b256_fp32_iteration(est):
+    """BASELINE configs[1].  Stepwise on the captured graphs (d_step, g_step, g_step: first call eager + capture, a second
+    iteration replays) with the float64 oracle re-synchronised to the device state before every run; then the production
+    ``iteration()`` (first generator run fused with the discriminator run) from the same start must land on the same weights."""
+    import rcgan_amd  # noqa: F401
+    from oracle import labels as LB
+    from oracle import mnist as om
+    from rcgan_amd.mnist import MnistRCGAN, create_variables
+    B = 256
+    rs = np.random.RandomState(41)
+    C_ = LB.one_coin(0.3)
+    eye = np.eye(10, dtype=np.float32)
+
+    def batch():
+        yr = rs.randint(10, size=B)
+        return dict(images=rs.rand(B, 28, 28, 1).astype(np.float32), z=rs.uniform(-1, 1, size=(B, 100)).astype(np.float32),
+                    y_real=eye[yr], y_gen=eye[rs.randint(10, size=B)], y_fake=eye[rs.randint(10, size=B)],
+                    y_real_weights=np.linalg.inv(C_)[yr].astype(np.float32))
+    batches = [batch(), batch()]
+    cfg = dict(algorithm="rcgan", disc_type="projection", estimate_confuse=est, loss_fn="hinge", perm_regularizer=True, perm_multiplier=10.0,
+               spectral_norm=True, C=C_, concat_y=False, concat_y_layers=(), max_norm=True, confuse_multiplier=10.0)
+
+    s_keys, u_keys = [set(d) for d in create_variables(0, "projection", est, True, True, ())[3:5]]
+
+    def make():
+        variables = create_variables(0, "projection", est, True, True, ())
+        return MnistRCGAN(algorithm="rcgan", alpha=0.3, batch_size=B, dtype="f32", disc_type="projection", loss_fn="hinge",
+                          estimate_confuse=est, perm_regularizer=True, perm_multiplier=10.0, spectral_norm=True, max_norm=True,
+                          use_graphs=True, variables=variables)
+
+    def sync(m):
+        p, st = m.get_params(), m.get_state()
+        S = {k: st[k].copy() for k in s_keys}
+        U = {k: st[k].copy() for k in u_keys}
+        return {k: v.copy() for k, v in p.items()}, S, U
+
+    m = make()
+    try:
+        for it, b in enumerate(batches):
+            m.set_inputs(**b)
+            P, S, U = sync(m)
+            L64, g64 = om.d_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float64)
+            _, g32 = om.d_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float32)
+            m.d_step()
+            got = m.losses()
+            for k in ("d_loss_real", "d_loss_fake", "class_loss_real"):
+                assert abs(got[k] - L64[k]) <= 2e-5 * max(1.0, abs(L64[k])), (it, k, got[k], L64[k])
+            rows = _mnist_cmp("MNIST B=256 it %d D run" % it, m.get_grads(m.PD), g64, g32)
+            _report("mnist est=%s it %d D" % (est, it), dict(grads=rows))
+            for run in range(2):
+                P, S, U = sync(m)
+                L64, g64 = om.g_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float64)
+                _, g32 = om.g_grads(P, {k: v.copy() for k, v in S.items()}, dict(U), cfg, b, dtype=np.float32)
+                m.g_step()
+                got = m.losses()
+                for k in ("g_loss", "class_loss_fake"):
+                    assert abs(got[k] - L64[k]) <= 2e-5 * max(1.0, abs(L64[k])), (it, run, k, got[k], L64[k])
+                gg = m.get_grads(m.PG)
+                if m.PC is not None:
+                    gg.update(m.get_grads(m.PC))
+                rows = _mnist_cmp("MNIST B=256 it %d G run %d" % (it, run), gg, g64, g32)
+                _report("mnist est=%s it %d G%d" % (est, it, run), dict(grads=rows))
+        stepwise = (m.get_params(), m.get_state(), m.losses())
+    finally:
+        m.ctx.close()
+    m = make()
+    try:
+        for b in batches:
+            m.set_inputs(**b)
+            m.iteration()
+        pa, sa, la = stepwise
+        pb, sb, lb = m.get_params(), m.get_state(), m.losses()
+        for k in pa:
+            assert rel_err(pb[k], pa[k]) <= 2e-5, ("iteration() vs stepwise: parameter", k, rel_err(pb[k], pa[k]))
+        for k in sa:
+            assert rel_err(sb[k], sa[k]) <= 1e-4, ("iteration() vs stepwise: state", k, rel_err(sb[k], sa[k]))
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    finally:
+        m.ctx.close()

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import nn, cifar
-from tests import torch_ref as TR
+from oracle import torch_port as TR
 
 
 def _rs(seed=0):
