@@ -23,6 +23,14 @@ GEN_BS_MULTIPLE = 2
 # ------------------------------------------------------------------------------------------
 # parameter creation in the reference's variable-creation order
 # ------------------------------------------------------------------------------------------
+class _Streams(np.random.RandomState):
+    """numpy's stream (the reference's numpy initialisers) + ``.tf``: a separate stream standing in for TensorFlow's generators."""
+
+    def __init__(self, seed):
+        super().__init__(seed)
+        self.tf = np.random.RandomState((int(seed) + 0x7F4A7C15) % (1 << 32))
+
+
 def _uniform(rs, stdev, size):
     # conv2d.py:83-88 / linear.py:54-61
     return rs.uniform(low=-stdev * np.sqrt(3), high=stdev * np.sqrt(3), size=size).astype("float32")
@@ -39,23 +47,33 @@ def _trunc_normal(rs, size, stddev=1.0):
 
 
 def _conv_params(P, U, rs, name, cin, cout, k, he_init, sn):
+    """One Conv2D call (conv2d.py:31-218).  P None: the variables exist already (reuse=True) -- the numpy draw of the initial
+    filter values still happens (conv2d.py:118-140 compute filter_values before tf.get_variable) and is thrown away."""
     fan_in = cin * k * k
     fan_out = cout * k * k
     stdev = np.sqrt(4. / (fan_in + fan_out)) if he_init else np.sqrt(2. / (fan_in + fan_out))
-    P[name + "/Filters"] = _uniform(rs, stdev, (k, k, cin, cout))
+    w = _uniform(rs, stdev, (k, k, cin, cout))
+    if P is None:
+        return
+    P[name + "/Filters"] = w
     if sn:
-        U[name + "/filters/spectral_norm/u"] = _trunc_normal(rs, (1, cout))
+        U[name + "/filters/spectral_norm/u"] = _trunc_normal(rs.tf, (1, cout))
     P[name + "/Biases"] = np.zeros((cout,), "float32")
 
 
 def _linear_params(P, U, rs, name, cin, cout, sn):
-    P[name + "/W"] = _uniform(rs, np.sqrt(2. / (cin + cout)), (cin, cout))   # linear.py:76-80 (first matching branch)
+    w = _uniform(rs, np.sqrt(2. / (cin + cout)), (cin, cout))   # linear.py:76-80 (first matching branch); drawn on every call
+    if P is None:
+        return
+    P[name + "/W"] = w
     if sn:
-        U[name + "/spectral_norm/u"] = _trunc_normal(rs, (1, cout))
+        U[name + "/spectral_norm/u"] = _trunc_normal(rs.tf, (1, cout))
     P[name + "/b"] = np.zeros((cout,), "float32")
 
 
 def _condbn_params(P, name, c):
+    if P is None:
+        return
     P[name + "/CondBatchNorm/offset"] = np.zeros((VOCAB, c), "float32")
     P[name + "/CondBatchNorm/scale"] = np.ones((VOCAB, c), "float32")
 
@@ -65,7 +83,7 @@ def confusion_logits_init(confuse_init, confuse_init_diag=0.2, rs=None):
     if not confuse_init:
         # TF default initializer for get_variable: glorot_uniform
         lim = np.sqrt(6.0 / (VOCAB + VOCAB))
-        return (rs or np.random.RandomState(0)).uniform(-lim, lim, size=(VOCAB, VOCAB)).astype("float32")
+        return (rs.tf if rs is not None else np.random.RandomState(0)).uniform(-lim, lim, size=(VOCAB, VOCAB)).astype("float32")
     if confuse_init_diag > 0.99 and VOCAB == 10.:
         aa = 7.0
     else:
@@ -76,14 +94,7 @@ def confusion_logits_init(confuse_init, confuse_init_diag=0.2, rs=None):
     return c
 
 
-def init_params(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="linear",
-                confuse_init=False, confuse_init_diag=0.2):
-    """Returns (P, U): trainable params and non-trainable SN ``u`` vectors, dict name -> float32 array."""
-    rs = np.random.RandomState(seed)
-    P, U = {}, {}
-    if algorithm == "rcgan-u":
-        P["confusion_logits"] = confusion_logits_init(confuse_init, confuse_init_diag, rs)
-    # Generator (gan_resnet.py:356-371)
+def _generator_call(P, U, rs):                 # gan_resnet.py:356-371
     _linear_params(P, U, rs, "Generator/G.Input", Z_DIM, 4 * 4 * DIM_G * 8, sn=False)
     for k, cin in ((1, DIM_G * 8), (2, DIM_G * 2), (3, DIM_G * 2)):
         nm = "Generator/G.Block.%d" % k
@@ -94,7 +105,9 @@ def init_params(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="lin
         _conv_params(P, U, rs, nm + ".Conv2", DIM_G * 2, DIM_G * 2, 3, he_init=True, sn=False)
     _condbn_params(P, "Generator/G.OutputNorm", DIM_G * 2)
     _conv_params(P, U, rs, "Generator/G.Output", DIM_G * 2, 3, 3, he_init=False, sn=False)
-    # Discriminator (gan_resnet.py:331-353, 374-421)
+
+
+def _discriminator_call(P, U, rs):             # gan_resnet.py:331-353, 374-412
     d = "Discriminator/"
     _conv_params(P, U, rs, d + "D.Block.1.Shortcut", 3, DIM_D, 1, he_init=False, sn=True)
     _conv_params(P, U, rs, d + "D.Block.1.Conv1", 3, DIM_D, 3, he_init=True, sn=True)
@@ -106,8 +119,45 @@ def init_params(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="lin
         _conv_params(P, U, rs, d + "D.Block.%d.Conv1" % k, DIM_D, DIM_D, 3, he_init=True, sn=True)
         _conv_params(P, U, rs, d + "D.Block.%d.Conv2" % k, DIM_D, DIM_D, 3, he_init=True, sn=True)
     _linear_params(P, U, rs, d + "D.Output", DIM_D, 1, sn=True)
-    P[d + "Embedding.Label/embedding_map"] = rs.uniform(-0.08, 0.08, size=(VOCAB, EMB_DIM)).astype("float32")
+
+
+def _projection_call(P, U, rs):                # gan_resnet.py:414-421, embedding.py:27-40
+    d = "Discriminator/"
+    table = rs.uniform(-0.08, 0.08, size=(VOCAB, EMB_DIM)).astype("float32")
+    if P is not None:
+        P[d + "Embedding.Label/embedding_map"] = table
     _linear_params(P, U, rs, d + "D.Embedding_y", EMB_DIM, DIM_D, sn=True)
+
+
+N_TOWERS = 2       # len(DEVICES), gan_resnet.py:186-188
+
+
+def init_params(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="linear",
+                confuse_init=False, confuse_init_diag=0.2):
+    """Returns (P, U): trainable params and non-trainable SN ``u`` vectors, dict name -> float32 array.
+    The reference draws its filters / matrices / embedding table from numpy's global stream (conv2d.py:83-88, linear.py:54-61,
+    embedding.py:29-34) while it BUILDS THE GRAPH, one draw per Conv2D / Linear / embed_y call -- also for calls that reuse
+    existing variables (second tower's Generator :541-546, the ten extra projections of 'unbiased' :615-622, the second
+    Discriminator + projection of 'rcgan-u' :654-657), whose values are thrown away but move the stream.  Following that call
+    order reproduces the reference's initial values bit for bit from ``np.random.seed(seed)`` (tests/golden/ref_cifar_*.npz,
+    generated by running the reference's own main()).  The spectral-norm ``u`` vectors (sn.py:36) and a default-initialised
+    confusion matrix (gan_resnet.py:501-503) come from TensorFlow's own generators: a SECOND stream."""
+    rs = _Streams(seed)
+    P, U = {}, {}
+    if algorithm == "rcgan-u":
+        P["confusion_logits"] = confusion_logits_init(confuse_init, confuse_init_diag, rs)
+    _generator_call(P, U, rs)
+    for _ in range(N_TOWERS - 1):
+        _generator_call(None, None, rs)
+    _discriminator_call(P, U, rs)
+    _projection_call(P, U, rs)
+    if algorithm == "unbiased":
+        for _ in range(VOCAB):
+            _projection_call(None, None, rs)
+    elif algorithm == "rcgan-u":
+        _discriminator_call(None, None, rs)
+        _projection_call(None, None, rs)
+    d = "Discriminator/"
     if perm_classifier:
         if perm_type == "linear":
             _linear_params(P, U, rs, d + "D.d_perm_classifier_h1", OUTPUT_DIM, VOCAB, sn=True)

@@ -42,37 +42,95 @@ FUSED_TRUNK = os.environ.get("RCGAN_FUSED_TRUNK", "0") == "1"
 # ------------------------------------------------------------------------------------------------------
 class _Init:
     def __init__(self, seed):
+        # rs: numpy's stream -- the reference draws its filters / matrices / embedding table from np.random in graph-construction
+        # order (conv2d.py:83-88, linear.py:54-61, embedding.py:29-34), reproduced here bit for bit from np.random.seed(seed)
+        # (tests/golden/ref_cifar_*.npz).  rs_tf: what TensorFlow's own generators initialise (the spectral-norm u vectors, sn.py:36;
+        # a default-initialised confusion matrix, gan_resnet.py:501-503) comes from a second stream and leaves the first alone.
         self.rs = np.random.RandomState(seed)
+        self.rs_tf = np.random.RandomState((int(seed) + 0x7F4A7C15) % (1 << 32))
         self.G, self.D, self.Cm, self.U = [], [], [], {}
 
     def uniform(self, stdev, shape):          # conv2d.py:83-88, linear.py:54-61
         return self.rs.uniform(low=-stdev * np.sqrt(3), high=stdev * np.sqrt(3), size=shape).astype("float32")
 
     def trunc_normal(self, shape):            # tf.truncated_normal_initializer() for u (sn.py:36)
-        x = self.rs.normal(0.0, 1.0, size=shape)
+        x = self.rs_tf.normal(0.0, 1.0, size=shape)
         while True:
             bad = np.abs(x) > 2.0
             if not bad.any():
                 return x.astype("float32")
-            x[bad] = self.rs.normal(0.0, 1.0, size=int(bad.sum()))
+            x[bad] = self.rs_tf.normal(0.0, 1.0, size=int(bad.sum()))
 
     def conv(self, dst, name, cin, cout, k, he, sn):
+        """dst None: a call of Conv2D on an EXISTING variable (a second tower, reuse=True) -- the reference draws the initial
+        filter values from numpy before it asks for the variable (conv2d.py:118-140), so the draw happens and is discarded."""
         fan_in, fan_out = cin * k * k, cout * k * k
         sd = np.sqrt((4. if he else 2.) / (fan_in + fan_out))      # conv2d.py:103-106
-        dst.append((name + "/Filters", (k, k, cin, cout), self.uniform(sd, (k, k, cin, cout))))
+        w = self.uniform(sd, (k, k, cin, cout))
+        if dst is None:
+            return
+        dst.append((name + "/Filters", (k, k, cin, cout), w))
         if sn:
             self.U[name + "/filters/spectral_norm/u"] = self.trunc_normal((1, cout))
         dst.append((name + "/Biases", (cout,), np.zeros(cout, "float32")))
 
     def linear(self, dst, name, cin, cout, sn):
-        dst.append((name + "/W", (cin, cout), self.uniform(np.sqrt(2. / (cin + cout)), (cin, cout))))   # linear.py:76-80
+        w = self.uniform(np.sqrt(2. / (cin + cout)), (cin, cout))   # linear.py:76-80; drawn on every call (linear.py:54-80)
+        if dst is None:
+            return
+        dst.append((name + "/W", (cin, cout), w))
         if sn:
             self.U[name + "/spectral_norm/u"] = self.trunc_normal((1, cout))
         dst.append((name + "/b", (cout,), np.zeros(cout, "float32")))
 
-    def condbn(self, dst, name, c):           # normalization.py:49-52
+    def condbn(self, dst, name, c):           # normalization.py:49-52 (constant initialisers: no draw)
+        if dst is None:
+            return
         dst.append((name + "/CondBatchNorm/offset", (VOCAB_SIZE, c), np.zeros((VOCAB_SIZE, c), "float32")))
         dst.append((name + "/CondBatchNorm/scale", (VOCAB_SIZE, c), np.ones((VOCAB_SIZE, c), "float32")))
+
+    # ---- one CALL of each model function of gan_resnet.py: dst = the list the variables go to, or None for a reuse=True call
+    def generator(self, dst):                 # Generator, gan_resnet.py:356-371
+        self.linear(dst, "Generator/G.Input", Z_DIM, 4 * 4 * DIM_G * 8, False)
+        for blk, cin in ((1, DIM_G * 8), (2, DIM_G * 2), (3, DIM_G * 2)):
+            nm = "Generator/G.Block.%d" % blk
+            self.conv(dst, nm + ".Shortcut", cin, DIM_G * 2, 1, False, False)
+            self.condbn(dst, nm + ".N1", cin)
+            self.conv(dst, nm + ".Conv1", cin, DIM_G * 2, 3, True, False)
+            self.condbn(dst, nm + ".N2", DIM_G * 2)
+            self.conv(dst, nm + ".Conv2", DIM_G * 2, DIM_G * 2, 3, True, False)
+        self.condbn(dst, "Generator/G.OutputNorm", DIM_G * 2)
+        self.conv(dst, "Generator/G.Output", DIM_G * 2, IMG_DIM, 3, False, False)
+
+    def discriminator(self, dst):             # Discriminator, gan_resnet.py:374-412
+        d = "Discriminator/"
+        self.conv(dst, d + "D.Block.1.Shortcut", IMG_DIM, DIM_D, 1, False, True)
+        self.conv(dst, d + "D.Block.1.Conv1", IMG_DIM, DIM_D, 3, True, True)
+        self.conv(dst, d + "D.Block.1.Conv2", DIM_D, DIM_D, 3, True, True)
+        self.conv(dst, d + "D.Block.2.Shortcut", DIM_D, DIM_D, 1, False, True)
+        self.conv(dst, d + "D.Block.2.Conv1", DIM_D, DIM_D, 3, True, True)
+        self.conv(dst, d + "D.Block.2.Conv2", DIM_D, DIM_D, 3, True, True)
+        for blk in (3, 4, 5, 6):
+            self.conv(dst, d + "D.Block.%d.Conv1" % blk, DIM_D, DIM_D, 3, True, True)
+            self.conv(dst, d + "D.Block.%d.Conv2" % blk, DIM_D, DIM_D, 3, True, True)
+        self.linear(dst, d + "D.Output", DIM_D, 1, True)
+
+    def projection(self, dst):                # Discriminator_projection, gan_resnet.py:414-421
+        d = "Discriminator/"
+        table = self.rs.uniform(-0.08, 0.08, size=(VOCAB_SIZE, EMBEDDING_DIM)).astype("float32")     # embedding.py:29-34
+        if dst is not None:
+            dst.append((d + "Embedding.Label/embedding_map", (VOCAB_SIZE, EMBEDDING_DIM), table))
+        self.linear(dst, d + "D.Embedding_y", EMBEDDING_DIM, DIM_D, True)
+
+    def perm(self, dst, perm_type):           # perm_classifier, gan_resnet.py:458-483
+        d = "Discriminator/"
+        if perm_type == "linear":
+            self.linear(dst, d + "D.d_perm_classifier_h1", OUTPUT_DIM, VOCAB_SIZE, True)
+        elif perm_type == "2layer":
+            self.linear(dst, d + "D.d_perm_classifier_h1", OUTPUT_DIM, 128, True)
+            self.linear(dst, d + "D.d_perm_classifier_h2", 128, VOCAB_SIZE, True)
+        else:
+            raise ValueError('Unknown perm_type {}'.format(perm_type))
 
 
 def confusion_logits_initial(confuse_init, confuse_init_diag, rs):
@@ -90,45 +148,37 @@ def confusion_logits_initial(confuse_init, confuse_init_diag, rs):
     return m
 
 
+N_TOWERS = 2      # len(DEVICES): two towers even on one device (gan_resnet.py:186-188)
+
+
 def create_variables(seed=0, algorithm="rcgan", perm_classifier=False, perm_type="linear",
                      confuse_init=False, confuse_init_diag=0.2):
-    """-> (G specs, D specs, C specs, U dict); specs are (name, shape, initial value)."""
+    """-> (G specs, D specs, C specs, U dict); specs are (name, shape, initial value).
+    The numpy-initialised values equal the reference's under ``np.random.seed(seed)`` bit for bit (pinned by
+    tests/golden/ref_cifar_*.npz, which scripts/make_golden_reference.py produces by running the reference's own main()).  That needs
+    the reference's graph-construction ORDER including the calls that create nothing: every Conv2D / Linear / embed_y call draws
+    its initial values before asking for the variable, so the second tower's Generator (reuse=True, gan_resnet.py:541-546), the
+    ten extra projections of 'unbiased' (:615-622) and the second Discriminator + projection of 'rcgan-u' (:654-657) consume the
+    stream in front of the variables created after them."""
+    if algorithm not in ALGORITHMS:
+        raise ValueError("Unknown algorithm %s" % algorithm)
     it = _Init(seed)
     if algorithm == "rcgan-u":
         it.Cm.append(("confusion_logits", (VOCAB_SIZE, VOCAB_SIZE),
-                      confusion_logits_initial(confuse_init, confuse_init_diag, it.rs)))
-    it.linear(it.G, "Generator/G.Input", Z_DIM, 4 * 4 * DIM_G * 8, False)
-    for blk, cin in ((1, DIM_G * 8), (2, DIM_G * 2), (3, DIM_G * 2)):
-        nm = "Generator/G.Block.%d" % blk
-        it.conv(it.G, nm + ".Shortcut", cin, DIM_G * 2, 1, False, False)
-        it.condbn(it.G, nm + ".N1", cin)
-        it.conv(it.G, nm + ".Conv1", cin, DIM_G * 2, 3, True, False)
-        it.condbn(it.G, nm + ".N2", DIM_G * 2)
-        it.conv(it.G, nm + ".Conv2", DIM_G * 2, DIM_G * 2, 3, True, False)
-    it.condbn(it.G, "Generator/G.OutputNorm", DIM_G * 2)
-    it.conv(it.G, "Generator/G.Output", DIM_G * 2, IMG_DIM, 3, False, False)
-    d = "Discriminator/"
-    it.conv(it.D, d + "D.Block.1.Shortcut", IMG_DIM, DIM_D, 1, False, True)
-    it.conv(it.D, d + "D.Block.1.Conv1", IMG_DIM, DIM_D, 3, True, True)
-    it.conv(it.D, d + "D.Block.1.Conv2", DIM_D, DIM_D, 3, True, True)
-    it.conv(it.D, d + "D.Block.2.Shortcut", DIM_D, DIM_D, 1, False, True)
-    it.conv(it.D, d + "D.Block.2.Conv1", DIM_D, DIM_D, 3, True, True)
-    it.conv(it.D, d + "D.Block.2.Conv2", DIM_D, DIM_D, 3, True, True)
-    for blk in (3, 4, 5, 6):
-        it.conv(it.D, d + "D.Block.%d.Conv1" % blk, DIM_D, DIM_D, 3, True, True)
-        it.conv(it.D, d + "D.Block.%d.Conv2" % blk, DIM_D, DIM_D, 3, True, True)
-    it.linear(it.D, d + "D.Output", DIM_D, 1, True)
-    it.D.append((d + "Embedding.Label/embedding_map", (VOCAB_SIZE, EMBEDDING_DIM),
-                 it.rs.uniform(-0.08, 0.08, size=(VOCAB_SIZE, EMBEDDING_DIM)).astype("float32")))   # embedding.py:29-34
-    it.linear(it.D, d + "D.Embedding_y", EMBEDDING_DIM, DIM_D, True)
+                      confusion_logits_initial(confuse_init, confuse_init_diag, it.rs_tf)))
+    it.generator(it.G)                        # tower 0 creates (gan_resnet.py:541-546) ...
+    for _ in range(N_TOWERS - 1):
+        it.generator(None)                    # ... the other towers reuse
+    it.discriminator(it.D)                    # tower 0 of the critic cost (:584-586)
+    it.projection(it.D)
+    if algorithm == "unbiased":
+        for _ in range(VOCAB_SIZE):
+            it.projection(None)               # :615-622
+    elif algorithm == "rcgan-u":
+        it.discriminator(None)                # :654-657
+        it.projection(None)
     if perm_classifier:
-        if perm_type == "linear":
-            it.linear(it.D, d + "D.d_perm_classifier_h1", OUTPUT_DIM, VOCAB_SIZE, True)
-        elif perm_type == "2layer":
-            it.linear(it.D, d + "D.d_perm_classifier_h1", OUTPUT_DIM, 128, True)
-            it.linear(it.D, d + "D.d_perm_classifier_h2", 128, VOCAB_SIZE, True)
-        else:
-            raise ValueError('Unknown perm_type {}'.format(perm_type))
+        it.perm(it.D, perm_type)              # :686-695, created at the end of tower 0
     return it.G, it.D, it.Cm, it.U
 
 
