@@ -150,7 +150,10 @@ def kernel_roofline(m, pool, default_workload=True):
     tfs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_conv_p8.json")))
     if default_workload and tfs:                         # the counters were collected on the default workload only; newest round
         with open(tfs[-1]) as f:
-            traffic = float(json.load(f)["traffic_bytes_per_launch"])
+            tj = json.load(f)
+        # ... and only a measurement of THIS build of the kernels counts (the profile records the hash of the sources it ran)
+        if tj.get("source_sha16") == L.source_hash():
+            traffic = float(tj["traffic_bytes_per_launch"])
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "kernel": "conv_mfma_p8_kernel", "launches_per_iteration": n.value,

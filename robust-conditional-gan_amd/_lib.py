@@ -21,6 +21,21 @@ ERRORS = {-1: "RCGAN_EINVALID_ARG", -2: "RCGAN_EUNSUPPORTED_SHAPE", -3: "RCGAN_E
           -4: "RCGAN_EHIP", -5: "RCGAN_ERCCL"}
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources and the ABI header: profiles record it so that a measurement taken on another
+    build of the kernels is never attached to this one (bench.py roofline.traffic)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class RcganError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s (%d): %s" % (ERRORS.get(code, "RCGAN_E?"), code, msg))

@@ -7,8 +7,11 @@ usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_p8.txt> <pmc_WRIT
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KB and counts the 128-byte requests of a wide
 coalesced stream at 64 bytes on gfx950 -> x2; WRITE_SIZE (KB) as reported."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def parse(path):
@@ -41,7 +44,10 @@ def main():
         reads = ((c1 + c2) / 2 if g == 1280 else (c1 + c2 + d2) / 3) + 1.2e6
         alg[g] = reads + full
     alg_avg = sum(fetch[g][0] * alg[g] for g in fetch) / n
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import _lib
     out = {
+        "source_sha16": _lib.source_hash(),      # bench.py attaches the figure to a run only on the same build of the kernels
         "kernel": "conv_mfma_p8_kernel<false, true> (channel-major K order, shared epilogue with paired 16-byte stores; upsample-3x3 layers in sub-pixel form, shortcuts before the upsample)",
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes; scripts/make_profiles.sh)",
         "fetch_size_kb_avg": f_avg, "write_size_kb_avg": w_avg, "launches": n,
