@@ -200,11 +200,14 @@ def _dtype(tag):
     return {"f": DT, "i": torch.int64, "b": torch.bool}[tag.kind]
 
 
+NONE_DIM = 1          # what an unknown (None) placeholder dimension is probed with: the harness sets it to the batch size
+
+
 class Placeholder(Tensor):
     def __init__(self, dtype, shape=None, name=None):
         super().__init__(None, [], name)
         self._dt = _dtype(dtype)
-        self._shape = tuple(shape) if shape is not None else ()
+        self._shape = tuple(NONE_DIM if d is None else builtins_int(d) for d in shape) if shape is not None else ()
         self._probe_val = torch.zeros(self._shape, dtype=self._dt)
 
 
@@ -225,6 +228,7 @@ class Variable(Tensor):
         self._shape = tuple(v.shape)
         self._probe_val = self.value.detach()
         self.name = (name or "Variable") + ":0"
+        self.constraint = None
         S.variables[self.name] = self
         self.op = types.SimpleNamespace(name=self.name[:-2])
 
@@ -241,8 +245,13 @@ class Variable(Tensor):
 
 
 class _Scope:
-    def __init__(self, name, reuse):
-        self.name, self.reuse = name, reuse
+    def __init__(self, name, reuse, depth=None):
+        self.name, self.reuse, self.depth = name, reuse, depth
+
+    def reuse_variables(self):
+        self.reuse = True
+        if self.depth is not None:
+            S.scope[self.depth] = (S.scope[self.depth][0], True)
 
 
 @contextlib.contextmanager
@@ -250,7 +259,7 @@ def variable_scope(name_or_scope=None, reuse=None, default_name=None):
     name = name_or_scope.name if isinstance(name_or_scope, _Scope) else name_or_scope
     S.scope.append((name, bool(reuse)))
     try:
-        yield _Scope("/".join(n for n, _ in S.scope), reuse)
+        yield _Scope("/".join(n for n, _ in S.scope), reuse, len(S.scope) - 1)
     finally:
         S.scope.pop()
 
@@ -325,7 +334,7 @@ def glorot_uniform_initializer(seed=None, dtype=None):
     return t
 
 
-def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True, regularizer=None, collections=None):
+def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True, regularizer=None, collections=None, constraint=None):
     full = "/".join([n for n, _ in S.scope] + [name]) + ":0"
     reuse = any(r for _, r in S.scope)
     if full in S.variables:
@@ -346,6 +355,7 @@ def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True,
         val, init_kind = np.asarray(initializer), ("value",)
     v = Variable(val, name=full[:-2], trainable=trainable)
     v.init_kind = init_kind
+    v.constraint = constraint          # applied to the variable after every optimiser update (tf.get_variable(constraint=...))
     return v
 
 
@@ -379,6 +389,8 @@ def _op(fn, *inputs, **kw):
 
 
 def reshape(t, shape, name=None):
+    if isinstance(shape, Shape):
+        shape = shape.as_list()
     shp = [builtins_int(s) for s in shape] if not isinstance(shape, Tensor) else None
     if shp is None:
         raise NotImplementedError("dynamic reshape")
@@ -553,12 +565,16 @@ def _conv2d(x, w, strides, padding):
 
 
 def _conv2d_transpose(x, w, output_shape, strides, padding):
-    """conv2d_transpose(value, filter[kh,kw,out,in], output_shape) = the gradient of conv2d w.r.t. its input."""
-    shp = [builtins_int(s) for s in output_shape]
-    probe = torch.zeros(shp, dtype=x.dtype, requires_grad=True)
-    y = _conv2d(probe, w, strides, padding)
-    (g,) = torch.autograd.grad(y, probe, grad_outputs=x, create_graph=True)
-    return g
+    """conv2d_transpose(value, filter[kh,kw,out,in], output_shape) = the gradient of conv2d(SAME) w.r.t. its input of shape
+    output_shape: the un-padded transposed convolution cropped at the forward convolution's leading pad."""
+    n, oh, ow, oc = [builtins_int(s) for s in output_shape]
+    sh, sw = strides[1], strides[2]
+    kh, kw = w.shape[0], w.shape[1]
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=(sh, sw))
+    pt, _ = _same_pad(oh, kh, sh) if padding == "SAME" else (0, 0)
+    pl, _ = _same_pad(ow, kw, sw) if padding == "SAME" else (0, 0)
+    full = F.pad(full, (0, max(0, pl + ow - full.shape[3]), 0, max(0, pt + oh - full.shape[2])))
+    return full[:, :, pt:pt + oh, pl:pl + ow].permute(0, 2, 3, 1)
 
 
 nn = types.SimpleNamespace(
@@ -593,6 +609,7 @@ class Session:
 
     def __init__(self, config=None, graph=None):
         self.graph = object()
+        Session._default = self
 
     def __enter__(self):
         Session._default = self
@@ -650,7 +667,8 @@ class Session:
 
 
 class _NoOp:
-    pass
+    def run(self, *a, **k):
+        return None
 
 
 def global_variables_initializer():
@@ -700,7 +718,10 @@ class AdamOptimizer:
                     m = m + (g - m) * (1.0 - opt.b1)
                     v = v + (g * g - v) * (1.0 - opt.b2)
                     opt.m[var.name], opt.v[var.name] = m, v
-                    Session._pending.append((var, var.value.detach() - (m * lr_t) / (torch.sqrt(v) + opt.eps)))
+                    new = var.value.detach() - (m * lr_t) / (torch.sqrt(v) + opt.eps)
+                    if var.constraint is not None:
+                        new = _static_value(var.constraint(constant(new)))
+                    Session._pending.append((var, new))
             return torch.zeros(())
         return Tensor(fn, [_wrap(self.lr)] + [g for g, _ in gv], name="apply_adam_%d" % self.index)
 
@@ -756,16 +777,21 @@ class _Flags:
         self._vals[name] = _Flags.overrides.get(name, default)
 
     def __getattr__(self, name):
+        if name.endswith("__flags"):
+            return dict(self._vals)
         try:
             return self._vals[name]
         except KeyError:
             raise AttributeError(name)
 
+    def __setattr__(self, name, value):
+        self._vals[name] = value
+
 
 class _FlagsModule:
     def __init__(self):
         self.FLAGS = _Flags()
-        for n in ("string", "integer", "float", "boolean", "bool"):
+        for n in ("string", "integer", "float", "boolean", "bool", "list"):
             setattr(self, "DEFINE_" + n, self.FLAGS._define)
 
 
@@ -783,8 +809,40 @@ class _GFile:
 
 
 gfile = types.SimpleNamespace(GFile=_GFile)
+
+
+def _contrib_batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, updates_collections="update_ops", is_training=True,
+                        scope=None, reuse=None, fused=None, zero_debias_moving_mean=False, **kw):
+    """tf.contrib.layers.batch_norm as mnist/ops.py:38-44 calls it (decay, updates_collections=None, epsilon, scale=True, is_training,
+    scope): variables beta / gamma / moving_mean / moving_variance under ``scope``; training mode normalises with the biased batch
+    variance and moves the averages in place (control dependency of the output) -- the moving variance with the UNBIASED batch
+    variance, as the fused kernel does; inference mode uses the moving statistics."""
+    assert updates_collections is None and center and scale
+    c = builtins_int(inputs.get_shape()[-1])
+    with variable_scope(scope, reuse=reuse):
+        beta = get_variable("beta", [c], initializer=constant_initializer(0.0))
+        gamma = get_variable("gamma", [c], initializer=constant_initializer(1.0))
+        mm = get_variable("moving_mean", [c], initializer=constant_initializer(0.0), trainable=False)
+        mv = get_variable("moving_variance", [c], initializer=constant_initializer(1.0), trainable=False)
+    if not is_training:
+        return _op(lambda x, g, b, m, v: (x - m) * torch.rsqrt(v + epsilon) * g + b, inputs, gamma, beta, mm, mv)
+    nd = len(inputs.get_shape())
+    axes = tuple(range(nd - 1))
+    mean = _op(lambda x: x.mean(dim=axes), inputs)
+    var = _op(lambda x: ((x - x.mean(dim=axes, keepdim=True)) ** 2).mean(dim=axes), inputs)
+
+    def unbiased(x, v):
+        n = 1
+        for a in axes:
+            n *= x.shape[a]
+        return v * (n / max(n - 1, 1))
+    uvar = _op(unbiased, inputs, var)
+    up_m = mm.assign(_op(lambda m, b: (m - (m - b) * (1.0 - decay)).detach(), mm, mean))
+    up_v = mv.assign(_op(lambda m, b: (m - (m - b) * (1.0 - decay)).detach(), mv, uvar))
+    with control_dependencies([up_m, up_v]):
+        return _op(lambda x, m, v, g, b: (x - m) * torch.rsqrt(v + epsilon) * g + b, inputs, mean, var, gamma, beta)
 contrib = types.SimpleNamespace(layers=types.SimpleNamespace(variance_scaling_initializer=lambda **kw: glorot_uniform_initializer(),
-                                                            batch_norm=None, layer_norm=None, instance_norm=None),
+                                                            batch_norm=_contrib_batch_norm, layer_norm=None, instance_norm=None),
                                 slim=types.SimpleNamespace(model_analyzer=types.SimpleNamespace(analyze_vars=lambda *a, **k: None)))
 image = types.SimpleNamespace()
 logging = types.SimpleNamespace(info=lambda *a, **k: None, warn=lambda *a, **k: None)

@@ -221,3 +221,138 @@ def test_sample_grid_layout_equals_the_reference(tmp_path):
         host.save_images(z[key + "_in"][..., 0].astype(np.uint8), path)           # what train_mnist.py passes: [n, 28, 28] uint8
         got = np.asarray(Image.open(path)).astype(np.float64)
         assert got.shape == z[key + "_grid"].shape and np.array_equal(got, z[key + "_grid"]), key
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MNIST: mnist/main.py -> model.DCGAN (build_model + train) run by scripts/make_golden_reference_mnist.py
+# ----------------------------------------------------------------------------------------------------------------------
+MNIST_CASES = [("rcgan", dict(algorithm="rcgan", disc_type="projection", estimate_confuse=False, loss_fn="hinge", spectral_norm=True, max_norm=True)),
+               ("rcganu", dict(algorithm="rcgan", disc_type="projection", estimate_confuse=True, loss_fn="hinge", spectral_norm=True, max_norm=True)),
+               ("biased", dict(algorithm="biased", disc_type="vanilla", estimate_confuse=False, loss_fn="ce", spectral_norm=False, max_norm=False))]
+
+
+def _mnist_initial_values(z):
+    """Every variable of the recorded run, regenerated from the look-alike's seed in creation order (all MNIST initialisers are
+    TensorFlow-side generators: ops.py:57,74,108, sn.py:36) and checked against the stored sha256."""
+    rs = np.random.RandomState(int(z["tf_seed"]))
+    vals = {}
+    for name, shp, kind, std, h in zip(z["var_names"], z["var_shapes"], z["var_init_kind"], z["var_init_std"], z["var_init_sha256"]):
+        name, kind = str(name), str(kind)
+        shape = tuple(int(x) for x in str(shp).split(","))
+        if kind == "truncated_normal":
+            x = rs.normal(0.0, 1.0, size=shape)
+            while True:
+                bad = np.abs(x) > 2.0
+                if not bad.any():
+                    break
+                x[bad] = rs.normal(0.0, 1.0, size=int(bad.sum()))
+            v = (float(std) * x).astype(np.float32)
+        elif kind == "random_normal":
+            v = (float(std) * rs.normal(size=shape)).astype(np.float32)
+        elif kind == "glorot_uniform":
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            v = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+        else:
+            v = (np.ones(shape) if name.endswith(("gamma", "moving_variance")) else np.zeros(shape)).astype(np.float32)
+        assert sha(v) == str(h), name
+        vals[name] = v
+    return vals
+
+
+@pytest.mark.parametrize("case,cfg", MNIST_CASES)
+def test_mnist_variable_set_equals_the_reference(case, cfg):
+    import rcgan_amd  # noqa: F401
+    from oracle import mnist as om
+    from rcgan_amd.mnist import create_variables
+    z = np.load(os.path.join(GOLDEN, "ref_mnist_%s.npz" % case))
+    names = [str(n) for n in z["var_names"]]
+    shapes = {n: tuple(int(x) for x in str(s).split(",")) for n, s in zip(names, z["var_shapes"])}
+    kinds = dict(zip(names, [str(k) for k in z["var_init_kind"]]))
+    stds = dict(zip(names, [float(s) for s in z["var_init_std"]]))
+    trainable = [n for n, t in zip(names, z["var_trainable"]) if t]
+    proj = cfg["disc_type"] == "projection"
+    gs, ds, cs, S, U = create_variables(0, cfg["disc_type"], cfg["estimate_confuse"], True, cfg["spectral_norm"], ())
+    P, So, Uo = om.init_params(0, cfg["disc_type"], cfg["estimate_confuse"], True, cfg["spectral_norm"], ())
+    # creation order of the trainable variables (model.py:96-262: confusion_logits, generator, discriminator, classifier)
+    assert list(P) == trainable
+    assert sorted(n for n, _, _ in gs + ds + cs) == sorted(trainable)
+    assert set(S) | set(U) == set(names) - set(trainable) == set(So) | set(Uo)
+    for n, shp, v in gs + ds + cs:
+        assert tuple(shp) == shapes[n] == tuple(v.shape) == tuple(P[n].shape), n
+        if kinds[n] == "constant":
+            assert np.array_equal(v, P[n]) and len(np.unique(v)) == 1, n
+        elif kinds[n] == "truncated_normal":         # conv filters (ops.py:57): N(0, 0.02) re-drawn beyond two sigma
+            assert np.abs(v).max() <= 2 * stds[n] * (1 + 1e-6) and abs(v.std() / (0.8796 * stds[n]) - 1) < (0.05 if v.size >= 2000 else 0.5), (n, v.std())
+        elif kinds[n] == "random_normal":            # deconv filters / dense matrices (ops.py:74,108): N(0, 0.02), not truncated
+            assert abs(v.std() / stds[n] - 1) < (0.05 if v.size >= 2000 else 0.5) and (v.size < 5000 or np.abs(v).max() > 2 * stds[n]), (n, v.std())
+    for n in U:
+        assert kinds[n] == "truncated_normal" and stds[n] == 1.0 and U[n].shape == shapes[n]
+    # which optimiser owns what (model.py:243-262): d_vars = names containing 'd_' (the classifier lands there), g_vars, the confusion matrix
+    assert sorted(str(n) for n in z["optimiser0_vars"]) == sorted(n for n, _, _ in ds)
+    assert sorted(str(n) for n in z["optimiser1_vars"]) == sorted(n for n, _, _ in gs)
+    if cfg["estimate_confuse"]:
+        assert [str(n) for n in z["optimiser2_vars"]] == ["confusion_logits"] and float(z["optimiser2_hyper"][0]) == pytest.approx(2e-4 * 10.0)
+    for i in (0, 1):
+        assert tuple(z["optimiser%d_hyper" % i][1:]) == (0.5, 0.999, 1e-8) and float(z["optimiser%d_hyper" % i][0]) == pytest.approx(2e-4)
+    # the max-norm constraint (ops.py:102-111) sits on exactly the projection head's dense layers
+    constrained = sorted(n for n, c in zip(names, z["var_constrained"]) if c)
+    want = sorted(n for n in trainable if n.startswith(("discriminator/d_h4_lin", "discriminator/d_h5_y_lin"))) if (proj and cfg["max_norm"]) else []
+    assert constrained == want
+
+
+@pytest.mark.parametrize("case,cfg", MNIST_CASES)
+def test_mnist_oracle_replays_the_first_iteration_of_the_reference(case, cfg):
+    """One D run and two G runs (model.py:347-372) by the numpy oracle in float64 on the recorded feeds, from the regenerated initial
+    values: the gradients the reference's optimisers applied, the variables after each update (max-norm clip and the generator's
+    batch-norm moving averages included), and the losses the reference logs after the iteration (model.py:374-390)."""
+    from oracle import labels as LB
+    from oracle import mnist as om
+    z = np.load(os.path.join(GOLDEN, "ref_mnist_%s.npz" % case))
+    vals = _mnist_initial_values(z)
+    trainable = [str(n) for n, t in zip(z["var_names"], z["var_trainable"]) if t]
+    P = {n: vals[n].astype(np.float64) for n in trainable}
+    S = {n: v.astype(np.float64) for n, v in vals.items() if n.endswith(("moving_mean", "moving_variance"))}
+    U = {n: v.astype(np.float64) for n, v in vals.items() if n.endswith("/u")}
+    ocfg = dict(cfg, perm_regularizer=True, perm_multiplier=10.0, C=LB.one_coin(0.5), concat_y=False, concat_y_layers=(), confuse_multiplier=10.0)
+    tr = om.Trainer(P, S, U, ocfg)
+    kinds = [str(k) for k in z["run_kinds"]]
+    assert kinds[:3] == ["0", "1+2", "1+2"] if cfg["estimate_confuse"] else kinds[:3] == ["0", "1", "1"]
+    b = dict(images=z["run00/feed/real_images"], z=z["run00/feed/z"], y_real=z["run00/feed/y_real"], y_gen=z["run00/feed/y_gen"],
+             y_fake=z["run00/feed/y_fake"], y_real_weights=z["run00/feed/y_real_weights"])
+
+    def cmp(p, grads):
+        gmax = max(float(z[k]) for k in z.files if k.startswith(p + "grad_norm/"))
+        for k, g in grads.items():
+            ref = float(z[p + "grad_norm/" + k])
+            assert abs(np.linalg.norm(g) - ref) <= 1e-6 * max(ref, 1e-9 * gmax), (p, k, np.linalg.norm(g), ref)
+        _check_tensors(z, p + "grad/", grads, 1e-6, skip_below=1e-9 * gmax)
+        for k in [k for k in z.files if k.startswith(p + "after/")]:
+            name = k[len(p + "after/"):]
+            if name.startswith("discriminator/") and name.endswith(("moving_mean", "moving_variance")):
+                continue        # the critic's moving averages are never read; their update order inside one run is TensorFlow's business
+            got = {**P, **S, **U}[name]
+            ref = z[k].astype(np.float64)
+            scale = max(float(np.abs(ref).max()), 1e-4)
+            # (Adam divides by |g| + eps: where |g| ~ 1e-5 a 1e-9 difference of the gradient shows as 1e-6 of the step)
+            assert float(np.abs(sample(got) - ref).max()) <= 1e-5 * scale, (k, float(np.abs(sample(got) - ref).max()), scale)
+
+    for dt in (P, S, U):
+        for k in dt:
+            dt[k] = dt[k].astype(np.float64)
+    _, g = om.d_grads(P, S, U, ocfg, b, dtype=np.float64)
+    om.apply_adam(P, g, tr.ad, tr.lr, tr.beta1, tr.clip)
+    cmp("run00/", g)
+    for run in (1, 2):
+        _, g = om.g_grads(P, S, U, ocfg, b, dtype=np.float64)
+        gc = {k: g.pop(k) for k in list(g) if k == "confusion_logits"}
+        om.apply_adam(P, g, tr.ag, tr.lr, tr.beta1)
+        if gc:
+            om.apply_adam(P, gc, tr.ac, tr.lr * 10.0, tr.beta1)
+        cmp("run%02d/" % run, {**g, **gc})
+    # the three logging evals are three session runs, and every run of the critic advances the spectral-norm power iteration
+    # (sn.py:53-58, update_collection=None): errD_fake, errD_real and errG each see a different u
+    got = []
+    for key in ("d_loss_fake", "d_loss_real", "g_loss"):
+        L = om.losses(om.Net(P, S, U, "d", ocfg, np.float64), b)
+        got.append(float(L[key].v))
+    assert np.allclose(got, z["log_losses_after_it0"], rtol=1e-7, atol=1e-9), (got, z["log_losses_after_it0"])
