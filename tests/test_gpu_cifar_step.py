@@ -208,7 +208,7 @@ def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
     step, as the reference runs it) on the same z / labels / real batches: discriminator weights after the five Adam
     updates and the last critic loss agree.  (Adam moves a weight whose gradient is ~0 by up to lr per step whatever the
     gradient's size, so single elements may differ by up to 5 * 2 * lr = 2e-3 absolute in fp32 -- the max-error bound is 3e-3 of
-    the tensor's scale; the norm-relative error, the criterion that matters, stays <= 2e-5.)"""
+    the tensor's scale; the norm-relative error, the criterion that matters, stays <= 5e-5.)"""
     from rcgan_amd.cifar import N_CRITIC
     rs = np.random.RandomState(41)
     B = 4
@@ -236,7 +236,7 @@ def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
     for k in pa:
         if k.startswith("Discriminator") or "D." in k:
             assert_close(pb[k], pa[k], tol, "D weights after %d critic steps: %s" % (N_CRITIC, k))
-            assert rel_err(pb[k], pa[k]) <= (5e-3 if dtype == "bf16" else 2e-5), (k, rel_err(pb[k], pa[k]))
+            assert rel_err(pb[k], pa[k]) <= (5e-3 if dtype == "bf16" else 5e-5), (k, rel_err(pb[k], pa[k]))
 
 
 @pytest.mark.parametrize("use_graphs", [False, True])

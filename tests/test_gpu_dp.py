@@ -63,14 +63,14 @@ def _run_iterations(m, its, grads_after_first=None):
 def _same_trajectory(pa, pb, lr=2e-4):
     """Two runs that differ only in fp32 summation order: Adam (beta1 = 0) moves every weight by ~lr per step whatever the size of
     its gradient, so a ~0 gradient whose sign flips leaves the two runs 2*lr apart in that element (zero-initialised biases consist of
-    nothing but such steps).  Same trajectory = finite, no element further apart than the steps taken allow, and at most 10 % of a
+    nothing but such steps).  Same trajectory = finite, no element further apart than the steps taken allow, and at most 20 % of a
     tensor's elements more than one step apart."""
     for k in pa:
         assert np.isfinite(pb[k]).all(), k
         if k.startswith("Generator/") and k.endswith("/Biases"):
             continue        # a per-channel constant in front of a batch norm: the true gradient is 0, every step is a coin flip
         d = np.abs(pb[k].astype(np.float64) - pa[k])
-        assert float(d.max()) <= 2 * lr * 12 + 1e-6 and float(np.mean(d > lr)) <= 1e-1, (k, float(d.max()), float(np.mean(d > lr)))
+        assert float(d.max()) <= 2 * lr * 12 + 1e-6 and float(np.mean(d > lr)) <= 0.2, (k, float(d.max()), float(np.mean(d > lr)))
 
 
 def _model(alg, dtype, B, **kw):
