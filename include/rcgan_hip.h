@@ -417,6 +417,22 @@ int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, f
                        float lr, float t, float beta1, float beta2, float eps, float clip, float grad_scale);
 int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float value);
 
+/* ---- batch statistics out of the producing convolution (tf.nn.moments of normalization.py:47 fused into conv2d.py:181-216) ----------------
+ * For the convolutions the 256 x 256 eight-wave kernel takes (rcgan_conv_stats_ok: 16-bit activations, Cout = 256, whole 256-pixel tiles,
+ * the 32 x 32 generator block at n >= 50), rcgan_conv2d_fwd_stats is rcgan_conv2d_fwd_residual that also leaves, per pixel tile, the column
+ * sums of the STORED output (bias, residual and the 16-bit rounding included) and of its squares in tile_sums (rcgan_conv_stats_bytes);
+ * rcgan_bn_stats_from_tiles turns them into mean / rstd [nseg][Cout] of nseg equal runs of samples (biased variance, as rcgan_bn_stats):
+ * the statistics pass over the activation tensor (one full read) disappears.  rcgan_bn_apply_segments: the apply half of
+ * rcgan_bn_fwd_segments for statistics obtained that way. */
+int rcgan_conv_stats_ok(const rcgan_conv_desc* d);
+size_t rcgan_conv_stats_bytes(const rcgan_conv_desc* d);
+int rcgan_conv2d_fwd_stats(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
+                           const void* residual, void* y, float* tile_sums);
+int rcgan_bn_stats_from_tiles(rcgan_ctx* ctx, const rcgan_conv_desc* d, int nseg, float eps, const float* tile_sums, float* mean, float* rstd);
+int rcgan_bn_apply_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
+                            const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
+                            void* y, void* ws, size_t ws_bytes);
+
 /* ---- gradient (loss) scaling for 16-bit activations ------------------------------------------------------------------------
  * The reference trains in fp32 (no counterpart in gan_resnet.py); BASELINE config 5 asks for fp16 activations, whose 5 exponent
  * bits need the loss -- hence every activation gradient -- scaled up.  rcgan_set_grad_scale: from now on every GRADIENT the loss

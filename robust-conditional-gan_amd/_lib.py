@@ -174,6 +174,11 @@ SIGNATURES = {
     "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),
     "rcgan_adam_tf_host": (I, [P, SZ, P, P, P, P, F, F, F, F, F, F, F]),
     "rcgan_fill_f32": (I, [P, SZ, P, F]),
+    "rcgan_conv_stats_ok": (I, [DP]),
+    "rcgan_conv_stats_bytes": (SZ, [DP]),
+    "rcgan_conv2d_fwd_stats": (I, [P, DP, P, P, P, P, P, P]),
+    "rcgan_bn_stats_from_tiles": (I, [P, DP, I, F, P, P, P]),
+    "rcgan_bn_apply_segments": (I, [P, I, I, I, I, I, I, P, P, P, P, P, P, I, P, P, SZ]),
     "rcgan_comm_unique_id": (I, [P]),
     "rcgan_comm_init": (I, [P, P, I, I]),
     "rcgan_comm_init_stub": (I, [P, I]),

@@ -207,10 +207,10 @@ SHORTCUT_BEFORE_UPSAMPLE = os.environ.get("RCGAN_SHORTCUT_LOW", "1") == "1"
 
 
 def UpsampleConv(inputs, output_dim, filter_size=3, name=None, spectral_normed=False, update_collection=None,
-                 he_init=True, biases=True, _in_relu=False, _accumulate_into=None):
+                 he_init=True, biases=True, _in_relu=False, _accumulate_into=None, _bn_next=False):
     return Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, 1, name, spectral_normed=spectral_normed,
                   update_collection=update_collection, he_init=he_init, biases=biases,
-                  _in_upsample=True, _in_relu=_in_relu, _accumulate_into=_accumulate_into)
+                  _in_upsample=True, _in_relu=_in_relu, _accumulate_into=_accumulate_into, _bn_next=_bn_next)
 
 
 def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels, segments=1):
@@ -224,11 +224,12 @@ def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels, se
         shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
     with variable_scope(name + '.N1'):
         out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
-    out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1')
+    # (_bn_next: a batch norm follows -- on the big grids its statistics come out of this convolution's epilogue, ops.conv2d)
+    out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1', _bn_next=True)
     with variable_scope(name + '.N2'):
         out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
     if low:
-        return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _residual=shortcut, _residual_up=True)
+        return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _residual=shortcut, _residual_up=True, _bn_next=True)
     return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _accumulate_into=shortcut)
 
 

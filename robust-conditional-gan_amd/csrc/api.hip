@@ -582,6 +582,7 @@ static void fill_mfma_args(const rcgan_conv_desc* d, MfmaConvArgs& a) {
   a.stamps = nullptr;
   a.wph = nullptr; a.phase = 0;
   a.resid_up = 0;
+  a.stats = nullptr;
 }
 
 // RCGAN_CONV_RESID_UPSAMPLE2X: the matrix-core epilogue reads the half-resolution residual in place (power-of-two output grid)
@@ -591,6 +592,68 @@ int rcgan_conv_resid_up_ok(const rcgan_conv_desc* d) {
 
 int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y) {
   return rcgan_conv2d_fwd_residual(ctx, d, x, prepared, bias, nullptr, y);
+}
+
+// ---- batch-norm statistics out of the producing convolution's epilogue (conv_mfma8.hip) -------------------------------------
+// the forward launch rcgan_conv2d_fwd_residual would issue for this descriptor on the matrix-core path
+static void stats_conv_args(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
+                            const void* residual, void* y, MfmaConvArgs& a) {
+  fill_mfma_args(d, a);
+  a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+  if (mfma_phase_filters(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
+  a.resid = (const bf16_t*)residual;
+  a.resid_up = (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X)) ? 1 : 0;
+  a.zero = (const bf16_t*)(ctx ? ctx->zero_page : (void*)16);
+  a.Cin = d->cin; a.Cout = d->cout;
+  a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+  a.relu_in = 0; a.accumulate = 0;
+}
+
+int rcgan_conv_stats_ok(const rcgan_conv_desc* d) {
+  if (!d || !mfma_eligible(d) || d->stride != 1 || d->cout != 256) return 0;
+  if (d->flags & (RCGAN_CONV_OUT_MEANPOOL2 | RCGAN_CONV_ACCUMULATE | RCGAN_CONV_IN_RELU | RCGAN_CONV_FORCE_DIRECT)) return 0;
+  if (((long)d->n * d->h * d->w) % 256 != 0 || (long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31)) return 0;
+  if ((d->flags & RCGAN_CONV_RESID_UPSAMPLE2X) && !rcgan_conv_resid_up_ok(d)) return 0;
+  MfmaConvArgs a;
+  int dummy = 0;
+  stats_conv_args(nullptr, d, nullptr, &dummy, nullptr, nullptr, nullptr, a);
+  // (an upsample-3x3 layer must take its sub-pixel form or not be upsampled at all: the finisher knows these two tile orders)
+  if (a.up && !(mfma_phase_filters(d) && mfma_conv8_phase_form(a))) return 0;
+  return mfma_conv_is_p8(a) ? 1 : 0;
+}
+
+size_t rcgan_conv_stats_bytes(const rcgan_conv_desc* d) {
+  return d ? (size_t)((long)d->n * d->h * d->w / 256) * d->cout * 2 * sizeof(float) : 0;
+}
+
+int rcgan_conv2d_fwd_stats(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
+                           const void* residual, void* y, float* tile_sums) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_REQUIRE(ctx, tile_sums != nullptr, "null tile_sums");
+  RC_REQUIRE(ctx, rcgan_conv_stats_ok(d), "this convolution does not produce tile statistics (rcgan_conv_stats_ok)");
+  MfmaConvArgs a;
+  stats_conv_args(ctx, d, x, prepared, bias, residual, y, a);
+  a.stats = tile_sums;
+  return mfma_conv_launch(ctx, a);
+}
+
+int rcgan_bn_stats_from_tiles(rcgan_ctx* ctx, const rcgan_conv_desc* d, int nseg, float eps, const float* tile_sums, float* mean, float* rstd) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_REQUIRE(ctx, rcgan_conv_stats_ok(d) && tile_sums && mean && rstd, "bad arguments");
+  RC_REQUIRE(ctx, nseg >= 1 && d->n % nseg == 0, "%d samples in %d segments", d->n, nseg);
+  const long px = (long)d->h * d->w;                  // output pixels per sample
+  const double count = (double)(d->n / nseg) * (double)px;
+  if (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) {
+    // sub-pixel form: tile index = (phase, sample, low-resolution pixels / 256)
+    const long tps = px / 4 / 256;                    // tiles per sample and phase
+    RC_REQUIRE(ctx, tps >= 1 && (px / 4) % 256 == 0, "sub-pixel tiles must hold whole 256-pixel runs of one sample");
+    return bn_tile_stats_finish_launch(ctx, tile_sums, d->cout, nseg, (int)((d->n / nseg) * tps), 4, (long)d->n * tps, count, eps, mean, rstd);
+  }
+  RC_REQUIRE(ctx, px % 256 == 0 || 256 % px == 0, "tiles must not straddle segments");
+  RC_REQUIRE(ctx, ((long)(d->n / nseg) * px) % 256 == 0, "a segment must be whole tiles");
+  return bn_tile_stats_finish_launch(ctx, tile_sums, d->cout, nseg, (int)((long)(d->n / nseg) * px / 256), 1, 0, count, eps, mean, rstd);
 }
 
 int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,

@@ -5,6 +5,7 @@
 // once for the per-group sums and once for the apply.  Reductions are two-level and deterministic
 // (per-row-group partials in fp32, combined in fp64) -- no atomics.
 #include "common.h"
+#include "conv_mfma.h"
 
 #define MAX_LABELS 16
 
@@ -997,6 +998,51 @@ static inline long tree_group_rows(long rows, int c) {
   return rpg;
 }
 
+// mean / rstd of `nseg` segments from the per-tile column sums a convolution's epilogue left (conv_mfma8.hip): part[tile][c][2] =
+// (sum, sum of squares) over the tile's 256 pixels.  Segment s owns the tiles [g * group_stride + s * tps, + tps) of every group g
+// (one group, or the four phases of the sub-pixel form).  grid (c / 16, nseg) x 256 threads: 16 channels x 16 tile subsets, every
+// thread's loads independent of one another (one memory round trip), all sums in a fixed order in fp64.
+__global__ __launch_bounds__(256) void bn_tile_stats_finish_kernel(const float* __restrict__ part, int c, int tps, int ngroups, long group_stride,
+                                                                   double inv_count, float eps, float* mean, float* rstd) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, sub = threadIdx.x >> 4, ch = blockIdx.x * 16 + cl, sg = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  for (int g = 0; g < ngroups; ++g) {
+    const long t0 = (long)g * group_stride + (long)sg * tps;
+    for (int tb = sub; tb < tps; tb += 16 * 8) {
+      float2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int t = tb + q * 16;
+        v[q] = t < tps ? *(const float2*)(part + ((t0 + t) * c + ch) * 2) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s1 += (double)v[q].x; s2 += (double)v[q].y; }
+    }
+  }
+  red[0][sub][cl] = s1; red[1][sub][cl] = s2;
+  __syncthreads();
+  if (sub == 0) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { a1 += red[0][q][cl]; a2 += red[1][q][cl]; }
+    const double mu = a1 * inv_count;
+    double var = a2 * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[(long)sg * c + ch] = (float)mu;
+    rstd[(long)sg * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+int bn_tile_stats_finish_launch(rcgan_ctx* ctx, const float* part, int c, int nseg, int tiles_per_seg, int ngroups, long group_stride,
+                                double count, float eps, float* mean, float* rstd) {
+  RC_REQUIRE(ctx, c % 16 == 0 && tiles_per_seg >= 1, "bad tile statistics layout");
+  hipLaunchKernelGGL(bn_tile_stats_finish_kernel, dim3(c / 16, nseg), dim3(256), 0, ctx->stream, part, c, tiles_per_seg, ngroups, group_stride,
+                     1.0 / count, eps, mean, rstd);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
 extern "C" {
 
 size_t rcgan_bn_workspace_bytes(int rows, int c) {
@@ -1120,6 +1166,21 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(gx, nseg), dim3(256), 0, ctx->stream,
                                                    nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, (const float*)mean, (const float*)rstd,
                                                    act, (T*)y, n_per_seg));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_bn_apply_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_sample, int c, int n_labels, int dtype, const void* x,
+                            const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
+                            void* y, void* ws, size_t ws_bytes) {
+  RC_REQUIRE(ctx, nseg >= 1 && n_per_seg >= 1, "segments %d x %d", nseg, n_per_seg);
+  if (nseg == 1) return rcgan_bn_apply_fwd(ctx, n_per_seg, rows_per_sample, c, n_labels, dtype, x, labels, gamma, beta, mean, rstd, act, y, ws, ws_bytes);
+  RC_REQUIRE(ctx, bn_fused_ok(c), "segmented apply needs the fused path (channels %d)", c);
+  const long rows = (long)n_per_seg * rows_per_sample;
+  const long nchunks = rows * c / 8;
+  const int gx = apply_grid_fused(nchunks, c);
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(gx, nseg), dim3(256), 0, ctx->stream,
+                                                   nchunks, rows_per_sample, c, (const T*)x, labels, gamma, beta, mean, rstd, act, (T*)y, n_per_seg));
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

@@ -27,6 +27,9 @@ struct MfmaConvArgs {
   // gradient of that form, wph = [Cin][(u*4 + v)*Cout + co] (16 taps at source stride 2 over the full-resolution dy).
   const bf16_t* wph;
   int phase;
+  // eight-wave 256 x 256 kernel only: per-tile column sums of the stored output and of its squares, [pixel tile][Cout][2] fp32 --
+  // the batch-norm statistics of the layer behind this convolution come out of its epilogue (bn.hip: bn_tile_stats_finish_kernel)
+  float* stats;
 };
 
 struct MfmaWgradArgs {
@@ -74,6 +77,10 @@ int conv_prepare_phase_launch(rcgan_ctx* ctx, int n, const float* const* ws, con
                               const int* kinds);
 bool mfma_pool_ok(const rcgan_conv_desc* d);
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
+int bn_tile_stats_finish_launch(rcgan_ctx* ctx, const float* part, int c, int nseg, int tiles_per_seg, int ngroups, long group_stride,
+                                double count, float eps, float* mean, float* rstd);      // bn.hip
+bool mfma_conv_is_p8(const MfmaConvArgs& a);              // routed to the 256 x 256 eight-wave kernel
+bool mfma_conv8_phase_form(const MfmaConvArgs& a);        // ... which evaluates it in the sub-pixel (phase-major tile) form
 int mfma_wgrad_splits(const rcgan_conv_desc* d, long M);
 bool mfma_wgrad3_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
 bool mfma_wgrad3_takes(const MfmaWgradArgs& a);

@@ -1648,10 +1648,20 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return RCGAN_OK;
 }
 
+// an ordinary (phase 0 on entry) forward / data-gradient launch that mfma_conv_launch routes to the 256 x 256 eight-wave kernel
+bool mfma_conv_is_p8(const MfmaConvArgs& a) {
+  if (a.phase != 0 || a.Cin % 64 || a.Cout % 256 || a.zero == nullptr) return false;
+  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);
+  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);
+  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
+  return off32 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
+}
+
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
   MfmaConvArgs a = a_in;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
+  if (a.stats && !mfma_conv_is_p8(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel (rcgan_conv_stats_ok)");
   if (a.phase == 1) {
     // forced sub-pixel form (the data gradient of a ConvMeanPool: a.wt is not a usable fallback): same routing as below
     static const int p8_min1 = env_int("RCGAN_P8_MINBLK", 200), p8n_min1 = env_int("RCGAN_P8N_MINBLK", 190), ks2_max1 = env_int("RCGAN_KS2_MAXBLK", 576);

@@ -34,7 +34,16 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
-template <bool RELU, bool XCDSWZ>
+// 16-lane (one DPP row) all-reduce in a fixed order: pairs, quads, half rows, rows
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+template <bool RELU, bool XCDSWZ, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALF = 128 * 128;                 // bytes of one half-tile (128 rows x 128 B)
@@ -269,8 +278,38 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 
   // epilogue: lane holds out[pixel (lane&15)][co .. co+3], co = 4*(lane>>4)
   stamp(3);
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
-                RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+  if constexpr (STATS) {
+    // batch-norm statistics of the layer behind this convolution: column sums of the stored tile (bias, residual, rounding
+    // included) and of its squares.  Lane partials -> 16 pixel lanes (DPP) -> the two pixel halves (LDS) -> [tile][Cout][2].
+    float st[2][16];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) st[p][k] = 0.f;
+    conv_epilogue<4, 8, RowPhase, true>(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
+                                        RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh, st);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) st[p][k] = row16_sum(st[p][k]);
+    float* const red = (float*)smem;            // [pixel half][256 channels][2]: the tile buffers are dead (last barrier of the K loop)
+    if ((lane & 15) == 0) {
+      const int row = lane >> 4;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = wn * 64 + (2 * p + (row & 1)) * 16 + (row >> 1) * 8 + e;
+          red[(wm * 256 + c) * 2 + 0] = st[p][e];
+          red[(wm * 256 + c) * 2 + 1] = st[p][8 + e];
+        }
+    }
+    __syncthreads();
+    a.stats[((long)mt * a.Cout + co0) * 2 + tid] = red[tid] + red[512 + tid];
+  } else {
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
+                  RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+  }
   if (a.stamps) {
     stamp(4);
     wait_vm<0>();
@@ -686,19 +725,19 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
                 RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
 }
 
-template <bool RELU, bool XCDSWZ>
+template <bool RELU, bool XCDSWZ, bool STATS = false>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 4 * 128 * 128 + 16 * 256 * sizeof(unsigned);     // tile buffers + tap-source table (<= 16 taps)
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * (a.phase == 2 ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
                  2.0 * (double)a.M * (a.phase == 2 ? 16 : a.phase == 1 ? 4 : a.KH * a.KW) * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ>), grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ, STATS>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -746,6 +785,16 @@ static int launch8n(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return RCGAN_OK;
 }
 
+static int up_phase_enabled() {
+  static const int v = [] { const char* e = getenv("RCGAN_UP_PHASE"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+// sub-pixel form of an upsample-3x3 convolution (MfmaConvArgs::wph): power-of-two images, whole tiles per phase
+bool mfma_conv8_phase_form(const MfmaConvArgs& a) {
+  return up_phase_enabled() && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % 256) == 0;
+}
+
 // wide = 256 output channels per workgroup (Cout % 256 == 0), else 128
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   static int swz = -1, cm = -1;
@@ -753,9 +802,7 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 1; }
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("RCGAN_P8_PERSIST"); persist = e ? atoi(e) : 0; }
-  // sub-pixel form of an upsample-3x3 convolution (MfmaConvArgs::wph): power-of-two images, whole tiles per phase
-  static const int up_phase = [] { const char* e = getenv("RCGAN_UP_PHASE"); return e ? atoi(e) : 1; }();
-  const bool phase = up_phase && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % 256) == 0;
+  const bool phase = mfma_conv8_phase_form(a);
   if (wide) {
     MfmaConvArgs b = a;
     b.phase = a.phase ? a.phase : (phase ? 1 : 0);
@@ -764,9 +811,14 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
     if (persist && !b.phase && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
       return b.relu_in ? launch8p<true>(ctx, b, swz) : launch8p<false>(ctx, b, swz);
+    if (b.stats) {        // tile statistics in the epilogue (the batch-normed layers read a batch-normed, ReLU-ed tensor: no input ReLU form)
+      if (b.relu_in || b.Cout != 256 || b.M % 256 != 0 || b.accumulate || b.mask) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics: unsupported form");
+      return swz ? launch8<false, true, true>(ctx, b) : launch8<false, false, true>(ctx, b);
+    }
     if (swz) return b.relu_in ? launch8<true, true>(ctx, b) : launch8<false, true>(ctx, b);
     return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }
+  if (a.stats) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel");
   MfmaConvArgs b = a;
   b.phase = a.phase ? a.phase : (phase ? 1 : 0);
   return b.relu_in ? launch8n<true>(ctx, b) : launch8n<false>(ctx, b);

@@ -117,13 +117,16 @@ struct RowPhase {
   }
 };
 
-template <int NI, int NJ, typename Map = RowIdent>
+// STATS: also accumulate, per lane, the column sums of the STORED values (after the 16-bit rounding) and of their squares over
+// the wavefront's pixel rows -- st[p][e] / st[p][8 + e] for channel co_wave + (2p + (row & 1)) * 16 + (row >> 1) * 8 + e, row =
+// lane >> 4 -- from which the producing kernel builds per-tile batch-norm statistics (conv_mfma8.hip).
+template <int NI, int NJ, typename Map = RowIdent, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const float* __restrict__ bias, const bf16_t* mask,
                                               const bf16_t* resid, bf16_t* out, int accumulate, long M, int Cout,
                                               long m_wave /* first pixel of the wavefront's rows */,
                                               int co_wave /* first channel of the wavefront's columns */, int lane, Map rowmap = Map(),
                                               int res_lw = -1 /* >= 1: resid lives on the half-resolution grid of a 2^res_lh x 2^res_lw image */,
-                                              int res_lh = 0) {
+                                              int res_lh = 0, float (*st)[16] = nullptr) {
   static_assert(NI % 2 == 0, "channel fragments are stored in pairs");
   constexpr int NP = NI / 2;
   const int row = lane >> 4;
@@ -204,7 +207,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const floa
           }
         }
       }
-      if (ok) *(uint4*)(out + offs(j, p)) = make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(y[0], y[1]), pack_h16x2(y[2], y[3]));
+      const uint4 pk = make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(y[0], y[1]), pack_h16x2(y[2], y[3]));
+      if (ok) *(uint4*)(out + offs(j, p)) = pk;
+      if (STATS && ok) {
+        const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = h16_lo(w[q]), hi = h16_hi(w[q]);
+          st[p][2 * q] += lo; st[p][2 * q + 1] += hi;
+          st[p][8 + 2 * q] += lo * lo; st[p][8 + 2 * q + 1] += hi * hi;
+        }
+      }
     }
   }
 }

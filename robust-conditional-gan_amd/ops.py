@@ -196,15 +196,25 @@ def spectral_norm_batch(ctx, entries):
 # ----------------------------------------------------------------------------------------------------
 # convolution / dense
 # ----------------------------------------------------------------------------------------------------
+# Batch-norm statistics out of the producing convolution's epilogue (rcgan_conv2d_fwd_stats; G.Block.3's two convolutions on the
+# 256 x 256 kernel).  Parity-tested (test_conv_tile_statistics_equal_a_statistics_pass) and measured in round 3 on one MI355X, same
+# box A/B: 6.349 ms per iteration without, 6.354-6.362 with -- the four statistics passes it removes (98 us) come back as the
+# finisher launch (4 x 9.6 us), a colder apply pass (+23 us: the statistics pass had pulled the tensor into the Infinity Cache) and
+# the epilogue's extra registers (the kernel sits at its 256-register budget: 16 spills).  Off unless RCGAN_FUSE_BN_STATS=1.
+FUSE_BN_STATS = os.environ.get("RCGAN_FUSE_BN_STATS", "0") == "1"
+
+
 def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumulate_into=None, force_direct=False,
-           residual=None, residual_up=False):
+           residual=None, residual_up=False, want_stats=False):
     """SAME conv on NHWC x with HWIO weight [k,k,cin,cout] (tf.nn.conv2d + bias_add: mnist/ops.py:62-65,
     cifar10/common/ops/conv2d.py:181-216).  in_up / in_relu fold the preceding nearest-2x upsample
     (gan_resnet.py:263-264) and ReLU into the operand load; accumulate_into adds the result into an
     existing tensor (the residual sum of gan_resnet.py:328); residual adds another tensor in the epilogue
     (y = conv + residual: the identity-shortcut blocks, where the shortcut is the block input itself).  residual_up: the
     residual lives on the half-resolution grid and is added nearest-upsampled (the up blocks' 1x1 shortcut evaluated before
-    the upsample it commutes with); its gradient is the 2x2 sum of dy."""
+    the upsample it commutes with); its gradient is the 2x2 sum of dy.
+    want_stats: the caller will batch-normalise the result -- where the producing kernel can, the per-tile column sums of the stored
+    output come out of its epilogue (rcgan_conv2d_fwd_stats) and are attached as ``y.tile_stats`` for batch_norm_act."""
     n, hs, ws_, cin = x.shape
     h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
     cout = weight.param.shape[-1]
@@ -221,7 +231,17 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     else:
         y = ctx.empty((n, oh, ow, cout), x.dtype)
         fdesc = desc
-    if residual is not None and residual_up:
+    sdesc = None
+    if want_stats and FUSE_BN_STATS and accumulate_into is None and not in_relu and x.dtype != L.F32:
+        sd = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_RESID_UPSAMPLE2X if (residual is not None and residual_up) else 0))
+        if ctx.lib.rcgan_conv_stats_ok(C.byref(sd)):
+            sdesc = sd
+    if sdesc is not None:
+        assert residual is None or residual.shape == ((n, oh // 2, ow // 2, cout) if residual_up else (n, oh, ow, cout))
+        sums = ctx.empty((ctx.lib.rcgan_conv_stats_bytes(C.byref(sdesc)) // 4,), L.F32)
+        ctx.check(ctx.lib.rcgan_conv2d_fwd_stats(ctx.h, C.byref(sdesc), _p(x), _p(prep), _p(bias), _p(residual), _p(y), _p(sums)))
+        y.tile_stats = (sdesc, sums)
+    elif residual is not None and residual_up:
         assert residual.shape == (n, oh // 2, ow // 2, cout) and accumulate_into is None, (residual.shape, (n, oh, ow, cout))
         rdesc = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | L.CONV_RESID_UPSAMPLE2X)
         if ctx.lib.rcgan_conv_resid_up_ok(C.byref(rdesc)):
@@ -487,20 +507,29 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
     back, each normalised with its own statistics -- several Generator() calls of the reference evaluated as one."""
     n, rps, c = _rows(x)
     rows = n * rps
+    tile = getattr(x, "tile_stats", None) if moving is None else None      # statistics left by the producing convolution's epilogue
     if segments > 1:
         if (ctx.recording and (x.req or gamma.req or beta.req)) or moving is not None or n % segments:
             raise NotImplementedError("segmented batch norm is forward-only (no gradient, no moving statistics)")
         mean = ctx.empty((segments, c), L.F32)
         rstd = ctx.empty((segments, c), L.F32)
         y = ctx.empty(x.shape, x.dtype)
+        if tile is not None:
+            ctx.check(ctx.lib.rcgan_bn_stats_from_tiles(ctx.h, C.byref(tile[0]), segments, eps, _p(tile[1]), _p(mean), _p(rstd)))
+            ctx.check(ctx.lib.rcgan_bn_apply_segments(ctx.h, segments, n // segments, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma), _p(beta),
+                                                      _p(mean), _p(rstd), act, _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            return y
         ctx.check(ctx.lib.rcgan_bn_fwd_segments(ctx.h, segments, n // segments, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma),
                                                 _p(beta), eps, act, _p(mean), _p(rstd), _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         return y
     mean = ctx.empty((c,), L.F32)
     rstd = ctx.empty((c,), L.F32)
     mm, mv = moving if moving is not None else (None, None)
-    ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), _p(mm), _p(mv), decay,
-                                     C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+    if tile is not None:
+        ctx.check(ctx.lib.rcgan_bn_stats_from_tiles(ctx.h, C.byref(tile[0]), 1, eps, _p(tile[1]), _p(mean), _p(rstd)))
+    else:
+        ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), _p(mm), _p(mv), decay,
+                                         C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
     y = ctx.empty(x.shape, x.dtype)
     ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma), _p(beta), _p(mean), _p(rstd),
                                          act, _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))

@@ -19,10 +19,11 @@ def _graph():
     return g
 
 
-def spectral_normed_weight(W_name, u=None, num_iters=1, update_collection=None, with_sigma=False, reuse=False):
-    """cifar10/common/ops/sn.py:17-75.  ``W_name`` is the variable's full name (the TF version takes
-    the tensor; here the variable store resolves it).  update_collection None -> u is updated by this
-    execution; NO_OPS -> u untouched.  Returns the Weight handle (W_bar = W / sigma, fused downstream)."""
+def spectral_normed_weight(W, u=None, num_iters=1, update_collection=None, with_sigma=False, reuse=False):
+    """cifar10/common/ops/sn.py:17-75.  ``W``: the weight tensor as in the reference (a parameter handle from the variable
+    store, Graph.param) -- or, as a convenience, its full variable name.  update_collection None -> u is updated by this
+    execution; NO_OPS -> u untouched.  Returns the Weight handle (W_bar = W / sigma, never materialised: the division is fused
+    into the consumers' operand load)."""
     if num_iters != 1:
         raise NotImplementedError("num_iters != 1 is never used by the reference")
     if update_collection not in (None, NO_OPS):
@@ -30,6 +31,9 @@ def spectral_normed_weight(W_name, u=None, num_iters=1, update_collection=None, 
     g = _graph()
     with variable_scope('spectral_norm'):
         uname = u if u is not None else scoped('u')
+    W_name = W if isinstance(W, str) else W.name
+    if not isinstance(W_name, str) or not g.has(W_name):
+        raise ValueError("spectral_normed_weight needs a variable of the store (got %r)" % (W,))
     w = g.sn_weight(W_name, uname, update_collection is None)
     if with_sigma:
         return w, w.sigma
@@ -40,7 +44,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
            conv_type='conv2d', channel_multiplier=0, padding='SAME',
            spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
            mask_type=None, weightnorm=None, biases=True, gain=1.,
-           _in_upsample=False, _in_relu=False, _accumulate_into=None, _residual=None, _out_meanpool=False, _residual_up=False):
+           _in_upsample=False, _in_relu=False, _accumulate_into=None, _residual=None, _out_meanpool=False, _residual_up=False, _bn_next=False):
     """cifar10/common/ops/conv2d.py:31-218 (conv2d path).  The underscore arguments are this build's
     fusion hooks (nearest-2x upsample / ReLU folded into the operand load, residual accumulate / residual add)."""
     if conv_type != 'conv2d':
@@ -52,7 +56,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
         fname = scoped('Filters')
         if spectral_normed:
             with variable_scope('filters'):
-                w = spectral_normed_weight(fname, update_collection=update_collection)
+                w = spectral_normed_weight(g.param(fname), update_collection=update_collection)      # conv2d.py:169-171
         else:
             w = g.weight(fname)
         b = g.param(scoped('Biases')) if biases else None
@@ -62,7 +66,7 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
         assert filter_size == 3 and stride == 1 and not _in_upsample and _residual is None
         return O.conv2d_meanpool(g.ctx, inputs, w, b, in_relu=_in_relu, accumulate_into=_accumulate_into)
     return O.conv2d(g.ctx, inputs, w, b, filter_size, stride, in_up=_in_upsample, in_relu=_in_relu,
-                    accumulate_into=_accumulate_into, residual=_residual, residual_up=_residual_up)
+                    accumulate_into=_accumulate_into, residual=_residual, residual_up=_residual_up, want_stats=_bn_next)
 
 
 def Linear(inputs, input_dim, output_dim, name,
@@ -75,7 +79,7 @@ def Linear(inputs, input_dim, output_dim, name,
     with variable_scope(name):
         wname = scoped('W')
         if spectral_normed:
-            w = spectral_normed_weight(wname, update_collection=update_collection)
+            w = spectral_normed_weight(g.param(wname), update_collection=update_collection)          # linear.py:163-168
         else:
             w = g.weight(wname)
         b = g.param(scoped('b')) if biases else None

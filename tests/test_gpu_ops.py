@@ -1091,3 +1091,60 @@ def test_grouped_filter_gradients_equal_single_calls():
                 assert_close(ctx.download(dbs[1]), ctx.download(dbs[0]), 2e-6, "layer %d bias gradient" % i)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("case", [
+    # n, low-resolution h = w (the convolution's stored input), upsampled?, residual on the half-resolution grid?, segments
+    (64, 32, False, False, 1),      # G.Block.3.Conv2-like without shortcut: 256 tiles
+    (128, 16, True, False, 1),      # G.Block.3.Conv1 (sub-pixel form: phase-major tiles), generator step
+    (128, 32, False, True, 1),      # G.Block.3.Conv2 + upsampled shortcut
+    (160, 16, True, False, 5),      # five critic-step segments (phase form)
+    (160, 32, False, True, 5),
+])
+def test_conv_tile_statistics_equal_a_statistics_pass(case, monkeypatch):
+    """rcgan_conv2d_fwd_stats + rcgan_bn_stats_from_tiles (batch statistics out of the 256 x 256 kernel's epilogue) against the plain
+    convolution followed by rcgan_bn_stats on its output: the stored tensor is bit-identical, mean / rstd agree to fp32 summation
+    order, per segment; and batch_norm_act picks the tile statistics up (same normalised tensor to one 16-bit rounding)."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    n, hs, up, resid, nseg = case
+    monkeypatch.setattr(O, "FUSE_BN_STATS", True)          # (opt-in in production: RCGAN_FUSE_BN_STATS=1, see ops.py)
+    ctx = make_ctx("bf16", arena=3 << 30)
+    try:
+        rs = np.random.RandomState(n + hs)
+        cin = cout = 256
+        h = hs * 2 if up else hs
+        x = ctx.upload(rs.randn(n, hs, hs, cin).astype(np.float32))
+        w = FakeParam(ctx, (rs.randn(3, 3, cin, cout) * 0.03).astype(np.float32))
+        b = FakeParam(ctx, (rs.randn(cout) * 0.5).astype(np.float32))
+        r = ctx.upload(rs.randn(n, h // 2, h // 2, cout).astype(np.float32)) if resid else None
+        ctx.recording = False
+        W = O.Weight(ctx, w.t, None)
+        desc = L.ConvDesc(n, h, h, cin, cout, 3, 3, 1, x.dtype, (L.CONV_IN_UPSAMPLE2X if up else 0) | (L.CONV_RESID_UPSAMPLE2X if resid else 0))
+        assert ctx.lib.rcgan_conv_stats_ok(C.byref(desc)) == 1
+        y0 = O.conv2d(ctx, x, W, b.t, 3, in_up=up, residual=r, residual_up=resid, want_stats=False)
+        y1 = O.conv2d(ctx, x, W, b.t, 3, in_up=up, residual=r, residual_up=resid, want_stats=True)
+        assert y0.tile_stats is None and y1.tile_stats is not None
+        a0, a1 = ctx.download(y0), ctx.download(y1)
+        assert np.array_equal(a0, a1)
+        mean = ctx.empty((nseg, cout), L.F32)
+        rstd = ctx.empty((nseg, cout), L.F32)
+        ctx.check(ctx.lib.rcgan_bn_stats_from_tiles(ctx.h, C.byref(y1.tile_stats[0]), nseg, 1e-5, C.c_void_p(y1.tile_stats[1].ptr),
+                                                    C.c_void_p(mean.ptr), C.c_void_p(rstd.ptr)))
+        m1, r1 = ctx.download(mean), ctx.download(rstd)
+        seg = a0.reshape(nseg, -1, cout).astype(np.float64)
+        m_ref = seg.mean(axis=1)
+        r_ref = 1.0 / np.sqrt(seg.var(axis=1) + 1e-5)
+        assert np.abs(m1 - m_ref).max() <= 2e-6 * max(1.0, np.abs(m_ref).max()), np.abs(m1 - m_ref).max()
+        assert np.abs(r1 / r_ref - 1).max() <= 2e-6, np.abs(r1 / r_ref - 1).max()
+        # the batch norm behind it: statistics from the tiles vs from its own pass over the tensor
+        lab = ctx.upload(rs.randint(10, size=n))
+        gam = FakeParam(ctx, (1 + 0.1 * rs.randn(10, cout)).astype(np.float32))
+        bet = FakeParam(ctx, (0.1 * rs.randn(10, cout)).astype(np.float32))
+        z0 = ctx.download(O.batch_norm_act(ctx, y0, gam.t, bet.t, act=L.ACT_RELU, labels=lab, n_labels=10, segments=nseg))
+        z1 = ctx.download(O.batch_norm_act(ctx, y1, gam.t, bet.t, act=L.ACT_RELU, labels=lab, n_labels=10, segments=nseg))
+        assert np.abs(z1 - z0).max() <= 2.0 ** -7 * max(1.0, np.abs(z0).max()) and np.mean(z1 != z0) < 1e-3, (np.abs(z1 - z0).max(), np.mean(z1 != z0))
+    finally:
+        ctx.recording = True
+        ctx.close()
