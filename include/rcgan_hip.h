@@ -360,11 +360,16 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
  * eight layers with the activations in LDS.  16-bit activations only; x0 / outs / masks are [n][8][8][128].
  *   forward  (backward = 0): layer 2b = h_b = conv1(relu(x_b)) + bias, layer 2b+1 = x_{b+1} = x_b + conv2(relu(h_b)) + bias;
  *            outs[i] receives layer i's output (outs[7] is the stage's output, the others are what the backward pass needs).
- *   backward (backward = 1): x0 = gradient of the stage's output; layers run last to first: prepared[0] / masks[0] belong to
- *            block 6's conv2 (mask = h_6), prepared[1] / masks[1] to its conv1 (mask = x_6), ...; outs[2j] = dh (gradient at
+ *   backward (backward = 1): x0 = gradient of the stage's output; layers run last to first: masks[0] belongs to
+ *            block 6's conv2 (mask = h_6), masks[1] to its conv1 (mask = x_6), ...; outs[2j] = dh (gradient at
  *            conv1's output), outs[2j+1] = dx (gradient at the block's input; outs[7] is the gradient of the stage's input).
- * prepared[i]: rcgan_conv_prepare layout of a 3x3 128 -> 128 filter (forward rows, then data-gradient rows). */
-int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* const* prepared, const float* const* bias,
+ * rcgan_dtrunk_prepare: prepared[i] = rcgan_conv_prepare layout of layer i's 3x3 128 -> 128 filter in FORWARD order (forward rows,
+ * then data-gradient rows) -> frag (rcgan_dtrunk_fragment_bytes()): both directions' filters re-laid fragment-major -- the 16 bytes a
+ * lane feeds one MFMA with are contiguous per wavefront and K-step, so the stage's filter loads are whole KiB blocks; one launch per
+ * set of weights, shared by the forward and the backward pass. */
+size_t rcgan_dtrunk_fragment_bytes(void);
+int rcgan_dtrunk_prepare(rcgan_ctx* ctx, const void* const* prepared, void* frag);
+int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
                  const void* const* masks, void* const* outs);
 /* Fused projection head: pooled features -> psi (D.Output, SN linear d -> 1), label embeddings E = table @ W_e / sigma_e + b_e
  * (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421), logits psi + <feat, E[l]> (:588, :654-660), loss terms and ALL

@@ -167,6 +167,8 @@ SIGNATURES = {
     "rcgan_loss_fwd_bwd": (I, [P, I, I, I, P, P, F, P, P, P]),
     "rcgan_bce_onehot_fwd_bwd": (I, [P, I, I, P, P, F, P, P]),
     "rcgan_dtrunk": (I, [P, I, I, P, P, P, P, P]),
+    "rcgan_dtrunk_prepare": (I, [P, P, P]),
+    "rcgan_dtrunk_fragment_bytes": (SZ, []),
     "rcgan_proj_head_fwd_bwd": (I, [P, C.POINTER(HeadDesc)] + [P] * 16 + [P, SZ]),
     "rcgan_recover_mse_fwd_bwd": (I, [P, I, I, I, I, P, P, P, P, P, P, P, SZ]),
     "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),

@@ -29,12 +29,11 @@ OUTPUT_DIM = 3072
 N_CRITIC = 5
 GEN_BS_MULTIPLE = 2
 ALGORITHMS = ("rcgan", "rcgan-u", "biased", "unbiased")
-# The 8x8 discriminator stage as one launch each way (ops.d_trunk / conv_trunk.hip).  Parity-tested, but NOT faster on MI355X
-# (scripts/bench_trunk.py, n = 128: 78 us fused vs 73 us for the eight launches; n = 1024: 327 vs 218 us): a workgroup's
-# filter stream (295 KB per layer) arrives by LDS-DMA at ~74 GB/s per CU with at most three taps (24 KiB per wavefront) in
-# flight next to the activations in LDS -- 4 us per layer against 2.1 us of MFMA work; without the DMA the four one-per-SIMD
-# wavefronts still take 5.6 us per layer (LDS read -> MFMA latency with nothing else to issue).  Off unless RCGAN_FUSED_TRUNK=1.
-FUSED_TRUNK = os.environ.get("RCGAN_FUSED_TRUNK", "0") == "1"
+# The 8x8 discriminator stage -- D.Block.3 .. D.Block.6, eight 3x3 convolutions -- as one launch each way (ops.d_trunk /
+# conv_trunk.hip: a workgroup carries one image through all eight layers, activations in LDS, each wavefront's filters of a whole
+# layer in registers, filters re-laid fragment-major once per step).  Round 3, MI355X, n = 128: 49.6 us forward / 51.8 us data
+# gradient against 68.2 / 71.4 us for the eight launches (n = 256: 54 vs 113 us).  RCGAN_FUSED_TRUNK=0 restores the layer-wise blocks.
+FUSED_TRUNK = os.environ.get("RCGAN_FUSED_TRUNK", "1") == "1"
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -399,7 +399,10 @@ def d_trunk(ctx, x, blocks):
         flat += [(w1, b1), (w2, b2)]
     preps = [w.prepared(desc) for w, _ in flat]
     outs = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
-    ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 0, _p(x), arr(preps), arr([b for _, b in flat]), None, arr(outs)))
+    # the stage's filters re-laid fragment-major, both directions, once per set of weights (the arena keeps it until the backward pass)
+    frag = DT(ctx.arena.alloc(ctx.lib.rcgan_dtrunk_fragment_bytes()), (ctx.lib.rcgan_dtrunk_fragment_bytes(),), "u8", ctx.arena.buf)
+    ctx.check(ctx.lib.rcgan_dtrunk_prepare(ctx.h, arr(preps), _p(frag)))
+    ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 0, _p(x), _p(frag), arr([b for _, b in flat]), None, arr(outs)))
     y = outs[7]
     params = [t for w, b in flat for t in (w.param, b)]
     if _track(ctx, y, x, *params):
@@ -411,10 +414,9 @@ def d_trunk(ctx, x, blocks):
             hs = [outs[0], outs[2], outs[4], outs[6]]                    # h_3 .. h_6
             xs = [x, outs[1], outs[3], outs[5]]                          # x_3 .. x_6 (block inputs)
             order = [(3, 1), (3, 0), (2, 1), (2, 0), (1, 1), (1, 0), (0, 1), (0, 0)]      # (block index, conv index)
-            preps_b = [flat[2 * bi + ci][0].prepared(desc) for bi, ci in order]
             masks = [hs[bi] if ci == 1 else xs[bi] for bi, ci in order]
             gouts = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
-            ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 1, _p(dy), arr(preps_b), None, arr(masks), arr(gouts)))
+            ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 1, _p(dy), _p(frag), None, arr(masks), arr(gouts)))
             for j, bi in enumerate((3, 2, 1, 0)):
                 dh, dy_k = gouts[2 * j], (dy if j == 0 else gouts[2 * j - 1])
                 for (w, b), xin, g in ((flat[2 * bi + 1], hs[bi], dy_k), (flat[2 * bi], xs[bi], dh)):

@@ -30,9 +30,12 @@ def main():
         ctx.check(lib.rcgan_conv_prepare(h, C.byref(desc), P(w.ptr), None, P(pr)))
         preps.append(pr)
     arr = lambda ps: (C.c_void_p * 8)(*ps)
-    fwd = lambda: ctx.check(lib.rcgan_dtrunk(h, n, 0, P(x.ptr), arr(preps), None, None, arr([o.ptr for o in outs])))
+    frag = ctx.arena.alloc(lib.rcgan_dtrunk_fragment_bytes())
+    prep = lambda: ctx.check(lib.rcgan_dtrunk_prepare(h, arr(preps), P(frag)))
+    prep()
+    fwd = lambda: ctx.check(lib.rcgan_dtrunk(h, n, 0, P(x.ptr), P(frag), None, None, arr([o.ptr for o in outs])))
     masks = [outs[6], outs[5], outs[4], outs[3], outs[2], outs[1], outs[0], x]
-    bwd = lambda: ctx.check(lib.rcgan_dtrunk(h, n, 1, P(x.ptr), arr(preps[::-1]), None, arr([m.ptr for m in masks]), arr([o.ptr for o in gouts])))
+    bwd = lambda: ctx.check(lib.rcgan_dtrunk(h, n, 1, P(x.ptr), P(frag), None, arr([m.ptr for m in masks]), arr([o.ptr for o in gouts])))
 
     def layerwise_fwd():
         t = x
@@ -44,10 +47,22 @@ def main():
     def layerwise_bwd():
         for k in range(8):
             ctx.check(lib.rcgan_conv2d_bwd_data(h, C.byref(desc), P(x.ptr), P(preps[k]), P(outs[k].ptr), P(gouts[k].ptr), P(ctx.ws_ptr), ctx.ws_bytes))
-    abl = lambda k: (lambda: ctx.check(lib.rcgan_dtrunk(h, n, k << 4, P(x.ptr), arr(preps), None, None, arr([o.ptr for o in outs]))))
+    if os.environ.get("STAMPS"):
+        import torch
+        st = torch.zeros(n * 24, dtype=torch.int64, device=ctx.device)
+        fwd(); fwd()
+        ctx.check(lib.rcgan_debug_stamps(h, P(st.data_ptr())))
+        fwd()
+        ctx.sync()
+        ctx.check(lib.rcgan_debug_stamps(h, None))
+        t = st.cpu().numpy().reshape(n, 24).astype(np.float64)
+        d = np.diff(t[:, :18], axis=1) / 2270.0
+        print("per-workgroup segments, us @2.27 GHz (mean over %d workgroups): prologue %.2f" % (n, d[:, 0].mean()))
+        for ly in range(8):
+            print("  layer %d: K loop %.2f  epilogue+barrier %.2f" % (ly, d[:, 1 + 2 * ly].mean(), d[:, 2 + 2 * ly].mean()))
+        print("  total %.2f" % ((t[:, 17] - t[:, 0]).mean() / 2270.0))
     reps = 30
-    extra = [("  ablation %d (see conv_trunk.hip)" % k, abl(k)) for k in (1, 2, 3, 4)] if os.environ.get("ABL") else []
-    for name, fn in extra + [("fused forward", fwd), ("8 launches forward", layerwise_fwd), ("fused backward", bwd), ("8 launches data gradient", layerwise_bwd)]:
+    for name, fn in [("fragment-major filter copy", prep), ("fused forward", fwd), ("8 launches forward", layerwise_fwd), ("fused backward", bwd), ("8 launches data gradient", layerwise_bwd)]:
         fn(); fn()
         ctx.event_record(0)
         for _ in range(reps):

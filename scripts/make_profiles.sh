@@ -4,7 +4,7 @@
 # Writes text / csv / json summaries under gpurun_out/<tag>/ (the rocpd databases themselves are deleted); the ones to be judged
 # are then copied into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -40,5 +40,16 @@ python3 scripts/exp_p8_fixed_cost.py > "$OUT/exp_p8_fixed_cost.txt" 2>&1
 python3 scripts/exp_p8_timeline.py 320 256 3 > "$OUT/exp_p8_timeline.txt" 2>&1
 python3 scripts/step_times.py > "$OUT/step_times.txt" 2>&1
 python3 scripts/bench_mnist.py 256 f32 > "$OUT/bench_mnist.txt" 2>&1
+python3 scripts/bench_wgrad_group.py > "$OUT/wgrad_group.txt" 2>&1
+python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512.json" 2> /dev/null
+python3 bench.py --no-cpu-baseline --dtype f16 > "$OUT/bench_f16.json" 2> /dev/null
+python3 bench.py --no-cpu-baseline --dtype f16 --batch 512 --steps 8 > "$OUT/bench_f16_b512.json" 2> /dev/null
+python3 bench.py --no-cpu-baseline --algorithm rcgan-u > "$OUT/bench_rcganu.json" 2> /dev/null
+# the world-size-8 step schedule against the in-ABI test-double communicator (no traffic): what the schedule itself costs
+python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8.json" 2> /dev/null
+RCGAN_DP_OVERLAP=1 python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8_overlap.json" 2> /dev/null
+RCGAN_FUSE_BN_STATS=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_fuse_bn_stats.json" 2> /dev/null
+python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_smooth.txt" 2>&1
+RCGAN_BENCH_IMAGES=uniform python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_uniform.txt" 2>&1
 [ -x scripts/probes/_bin/epilogue_store ] && ./scripts/probes/_bin/epilogue_store > "$OUT/probe_epilogue_store.txt" 2>&1
 ls -la "$OUT"
