@@ -25,7 +25,7 @@ for f in b512 f16 f16_b512 rcganu dpstub8 dpstub8_overlap fuse_bn_stats; do [ -s
 import json
 d=json.load(open('$R/bench_$f.json')); print('%-16s %8.3f ms %10.1f img/s %8.1f TFLOP/s   %.3f / %.3f' % ('$f', d['ms_per_step'], d['value'], d['config']['sustained_tflops'], d['roofline']['frac'], d['roofline']['executed_frac']))" >> $F; done
 echo "# scripts/exp_bench_data.py 60 32: d_loss / g_loss of the bench workload, smooth class-conditional images (default) vs uniform noise (rounds 1-2)" >> $F
-for k in smooth uniform; do [ -f $R/bench_data_$k.txt ] && { echo "## $k"; grep "^it" $R/bench_data_$k.txt | awk '{printf "%s:%s/%s  ", \$2, \$4, \$6} END {print ""}'; } >> $F; done
+for k in smooth uniform; do [ -f $R/bench_data_$k.txt ] && { echo "## $k"; grep "^it" $R/bench_data_$k.txt | awk '{printf "%s:%s/%s  ", $2, $4, $6} END {print ""}'; } >> $F; done
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('${P}_bench_n1_kernel_stats.csv')))
