@@ -96,6 +96,8 @@ int rcgan_debug_stamps(rcgan_ctx* ctx, void* stamps);
  * Replaces the per-step sess.run dispatch (gan_resnet.py:931,938; mnist/model.py:347-372). */
 int rcgan_graph_begin(rcgan_ctx* ctx);
 int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id);
+/* Leave a capture that a failed launch has made impossible to finish; what was recorded is dropped (nothing of it ran). */
+int rcgan_graph_abort(rcgan_ctx* ctx);
 int rcgan_graph_launch(rcgan_ctx* ctx, int graph_id);
 int rcgan_graph_destroy(rcgan_ctx* ctx, int graph_id);
 

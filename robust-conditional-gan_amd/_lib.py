@@ -17,6 +17,7 @@ CONV_IN_UPSAMPLE2X, CONV_IN_RELU, CONV_ACCUMULATE, CONV_FORCE_DIRECT, CONV_OUT_M
 LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_CE_ONES, LOSS_CE_ZEROS = 0, 1, 2, 3, 4
 QUERY_TR_READ = 0
 
+RCGAN_EHIP, RCGAN_ERCCL = -4, -5
 ERRORS = {-1: "RCGAN_EINVALID_ARG", -2: "RCGAN_EUNSUPPORTED_SHAPE", -3: "RCGAN_EWORKSPACE_TOO_SMALL",
           -4: "RCGAN_EHIP", -5: "RCGAN_ERCCL"}
 
@@ -107,6 +108,7 @@ SIGNATURES = {
     "rcgan_prof_executed_flops": (I, [P, C.POINTER(C.c_double)]),
     "rcgan_graph_begin": (I, [P]),
     "rcgan_graph_end": (I, [P, C.POINTER(I)]),
+    "rcgan_graph_abort": (I, [P]),
     "rcgan_graph_launch": (I, [P, I]),
     "rcgan_graph_destroy": (I, [P, I]),
     "rcgan_conv_prepared_bytes": (SZ, [DP]),

@@ -9,6 +9,8 @@ captured into a hipGraph, gradients all-reduced over RCCL on flat slabs.
 import ctypes as C
 import os
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -763,10 +765,20 @@ class CifarRCGAN:
             ctx.graph_begin()
             try:
                 body()
-            finally:
                 gid = ctx.graph_end()
+            except L.RcganError as e:
+                ctx.graph_abort()
+                if not (self.dp_active and e.code == L.RCGAN_ERCCL):
+                    raise
+                # a communicator whose collectives cannot be recorded: this step keeps running launch by launch (every rank runs
+                # the same software and takes the same branch, so the ranks stay in step)
+                warnings.warn("step %r: the all-reduce could not be captured (%s); running it uncaptured" % (key, e))
+                gid = None
             self._graphs[key] = gid
             return                      # the warm-up execution already did this step's work
+        if self._graphs[key] is None:
+            body()
+            return
         ctx.graph_launch(self._graphs[key])
 
     # ---------------------------------------------------------------------------------- data parallel

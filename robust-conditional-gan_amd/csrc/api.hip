@@ -398,6 +398,18 @@ int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id) {
   return RCGAN_OK;
 }
 
+int rcgan_graph_abort(rcgan_ctx* ctx) {
+  // Leave a capture that cannot be completed (a launch inside it failed): what was recorded is dropped, nothing was executed.
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  if (!ctx->capturing) return RCGAN_OK;
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(ctx->stream, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return RCGAN_OK;
+}
+
 int rcgan_graph_launch(rcgan_ctx* ctx, int id) {
   RC_REQUIRE(ctx, id >= 0 && id < (int)ctx->graphs.size() && ctx->graphs[id], "graph id %d", id);
   RC_HIP(ctx, hipGraphLaunch(ctx->graphs[id], ctx->stream));

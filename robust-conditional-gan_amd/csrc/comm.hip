@@ -8,6 +8,7 @@
 // links its own copy) shares that instance instead of bringing a second one into the address space.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -77,6 +78,8 @@ int allreduce_on(rcgan_ctx* ctx, hipStream_t stream, float* const* bufs, const s
   RC_REQUIRE(ctx, ctx->comm != nullptr || ctx->comm_stub, "no communicator: call rcgan_comm_init first");
   for (int i = 0; i < n; ++i) RC_REQUIRE(ctx, bufs[i] != nullptr || counts[i] == 0, "null bucket %d", i);
   if (ctx->comm_stub) {
+    // fault injection for the tests of the host side's fallback: a communicator whose all-reduce cannot be recorded into a graph
+    if (ctx->capturing && getenv("RCGAN_COMM_STUB_FAIL_IN_CAPTURE")) RC_FAIL(ctx, RCGAN_ERCCL, "test double: all-reduce refused inside a capture");
     for (int i = 0; i < n; ++i) {
       if (counts[i] == 0) continue;
       size_t blocks = (counts[i] + 255) / 256;

@@ -258,6 +258,10 @@ class Context:
         self.check(self.lib.rcgan_graph_end(self.h, C.byref(gid)))
         return gid.value
 
+    def graph_abort(self):
+        self.capturing = False
+        self.check(self.lib.rcgan_graph_abort(self.h))
+
     def graph_launch(self, gid):
         self.check(self.lib.rcgan_graph_launch(self.h, gid))
 

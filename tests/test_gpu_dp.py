@@ -107,6 +107,35 @@ def test_stub_world_without_early_bucket_is_bit_identical_to_single_rank(alg, dt
         assert np.array_equal(sa[k], sb[k]), k
 
 
+def test_communicator_that_cannot_be_captured_falls_back_to_uncaptured_steps(monkeypatch):
+    """A communicator whose all-reduce fails inside a stream capture (the test double with RCGAN_COMM_STUB_FAIL_IN_CAPTURE set):
+    the step drops the capture (rcgan_graph_abort), warns, and keeps running launch by launch -- same weights as the single-rank
+    run, bit for bit; steps without a collective (the batched critic fakes) stay captured."""
+    rs = np.random.RandomState(14)
+    B = 8
+    its = _feeds(rs, B, 2, "rcgan")
+    outs = []
+    monkeypatch.setenv("RCGAN_DP_OVERLAP", "0")
+    for w in (1, 2):
+        if w > 1:
+            monkeypatch.setenv("RCGAN_COMM_STUB_FAIL_IN_CAPTURE", "1")
+        m = _model("rcgan", "bf16", B, world_size=w, comm=("stub" if w > 1 else None))
+        try:
+            if w > 1:
+                with pytest.warns(UserWarning, match="could not be captured"):
+                    outs.append(_run_iterations(m, its))
+                kinds = {k: (g is None) for k, g in m._graphs.items()}
+                assert any(kinds.values()) and not all(kinds.values()), kinds
+            else:
+                outs.append(_run_iterations(m, its))
+        finally:
+            m.ctx.close()
+    (pa, la, sa), (pb, lb, sb) = outs
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+
+
 @pytest.mark.parametrize("alg,dtype", [("rcgan", "bf16"), ("rcgan-u", "bf16"), ("rcgan", "f16")])
 def test_stub_world_with_early_bucket_matches_single_rank(alg, dtype, monkeypatch):
     """The overlapped schedule (RCGAN_DP_OVERLAP=1; off by default, see cifar.py): D.Block.3 .. head (G.Block.2 .. G.Output) leave on the communication stream in the middle of
