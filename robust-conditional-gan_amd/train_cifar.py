@@ -29,6 +29,9 @@ def define_flags():
     f.DEFINE_string("parent_dir", '.', "parent directory for checkpoints")
     f.DEFINE_string("expt_dir", None, "directory for expts")
     f.DEFINE_integer("inception_freq", 2500, "frequncy of inception score calculation")
+    f.DEFINE_integer("inception_samples", 50000, "samples per Inception score (gan_resnet.py:962 hard-codes 50000)")
+    f.DEFINE_string("inception_logits_fn", None, "package.module:callable -- the Inception-v3 classifier of the Inception score "
+                    "(float32 [128,3,32,32] in [-1,1] -> [128, >= 1000] logits); the reference downloads one through TF-GAN")
     f.DEFINE_integer("sample_freq", 2500, "frequncy of dev cost calc. and sample pics")
     f.DEFINE_integer("generated_label_accuracy_freq", 2500, "frequncy of generated label accruacy")
     f.DEFINE_integer("sample_save_freq", 0, "frequncy of saving samples")
@@ -95,9 +98,14 @@ def main(argv=None):
     INCEPTION_FREQUENCY = FLAGS.inception_freq
     SAMPLE_FREQUENCY = FLAGS.sample_every if FLAGS.sample_every > 0 else FLAGS.sample_freq
     SAMPLE_SAVE_FREQUENCY = FLAGS.sample_save_freq
-    if INCEPTION_FREQUENCY and INCEPTION_FREQUENCY <= FLAGS.niters:
+    inception_fn = None
+    if FLAGS.inception_logits_fn:
+        from .inception_score import load_logits_fn
+        inception_fn = load_logits_fn(FLAGS.inception_logits_fn)
+    elif INCEPTION_FREQUENCY and INCEPTION_FREQUENCY <= FLAGS.niters:
         logging.warning("--inception_freq %d: the Inception score needs the Inception-v3 graph the reference downloads at import "
-                        "(common/inception/inception_score_.py:24-48); it is not part of the checkout and is skipped", INCEPTION_FREQUENCY)
+                        "(common/inception/inception_score_.py:31-48); it is not part of the checkout -- pass "
+                        "--inception_logits_fn module:callable to score with your own copy; skipped", INCEPTION_FREQUENCY)
 
     if world > 1:
         import torch
@@ -159,6 +167,14 @@ def main(argv=None):
         logging.info('generated label accuracy: {}'.format(acc))
         return acc
 
+    def inception_score(n):
+        # gan_resnet.py:836-845: 100 samples with uniformly random labels per Generator call, n / 100 calls
+        from .inception_score import get_inception_score, samples_as_the_reference_feeds_them
+        all_samples = [m.sample(np.random.randint(10, size=100).astype('int32'), np.random.normal(size=(100, Z_DIM)).astype('float32'))
+                       for _ in range(int(n / 100))]
+        return get_inception_score(samples_as_the_reference_feeds_them(np.concatenate(all_samples, axis=0)), inception_fn)
+
+    inception_score_max = 0.0                                                  # gan_resnet.py:917
     from .dp import mean_over_ranks
     pending = []                       # (iteration, ticket) of losses read back asynchronously
 
@@ -200,6 +216,14 @@ def main(argv=None):
             plot.plot('sec_per_iter', time.time() - t0)
         elif len(pending) >= 512:
             drain_losses()
+        if rank == 0 and inception_fn is not None and INCEPTION_FREQUENCY and iteration % INCEPTION_FREQUENCY == INCEPTION_FREQUENCY - 1:
+            logging.info('starting inception score computation.')               # gan_resnet.py:960-967
+            score = inception_score(FLAGS.inception_samples)
+            inception_score_max = max(inception_score_max, score[0])
+            plot.plot('inception_50k', score[0])
+            plot.plot('inception_50k_std', score[1])
+            plot.plot('inception_50k_max', inception_score_max)
+            logging.info('finished inception score computation.')
         if rank == 0 and SAMPLE_SAVE_FREQUENCY and iteration % SAMPLE_SAVE_FREQUENCY == SAMPLE_SAVE_FREQUENCY - 1:   # :965-969
             logging.info('starting saving samples.')
             samples_for_save, _ = save_samples(10000)

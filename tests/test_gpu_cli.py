@@ -40,8 +40,14 @@ def test_train_cli_layout_and_restore(tmp_path, caplog):
     assert "Inception score needs the Inception-v3 graph" in log
     assert ck.endswith("model.ckpt-2") and os.path.exists(os.path.join(d, "checkpoint", "model.ckpt-0.index"))   # every early iteration
     # second launch restores the newest checkpoint (gan_resnet.py:910-914) and keeps training
-    d2 = main(argv)
+    # ... this time with a classifier for the Inception score (the reference's comes from a TF-GAN download): the trainer draws
+    # --inception_samples random-label samples, scores them and plots inception_50k / _std / _max (gan_resnet.py:836-845,960-967)
+    caplog.clear()
+    with caplog.at_level(logging.INFO):
+        d2 = main(argv + ["--inception_logits_fn", "tests.tools.fake_inception:logits", "--inception_samples", "300"])
     assert d2 == d
+    assert "finished inception score computation." in caplog.text and "Inception score needs" not in caplog.text
+    assert glob.glob(os.path.join(d, "inception_50k.jpg")) and glob.glob(os.path.join(d, "inception_50k_max.jpg"))
     sd2 = load_checkpoint(latest_checkpoint(os.path.join(d, "checkpoint")))
     assert int(sd2["_opt/Discriminator/step"][0]) == 2 * int(sd["_opt/Discriminator/step"][0])
 

@@ -179,7 +179,7 @@ def test_torch_port_replays_five_critic_runs_and_the_generator_run(tag, alg, fla
         cost = sum(costs) / ntow
         names = [k for k in net.P if k.startswith("Discriminator/")]
         grads = torch.autograd.grad(cost, [net.P[k] for k in names])
-        assert abs(float(cost) - z[p + "fetched"][0]) <= 1e-9 * max(1.0, abs(float(cost))), (run, float(cost), z[p + "fetched"][0])
+        assert abs(float(cost.detach()) - z[p + "fetched"][0]) <= 1e-9 * max(1.0, abs(float(cost.detach()))), (run, float(cost.detach()), z[p + "fetched"][0])
         update(names, grads, "D", 2e-4 * oc.lr_decay(int(z[p + "feed/iteration"])))
     p = "run05/"
     zs = _draws(z, p)[1]
