@@ -77,6 +77,8 @@ def define_flags():
     f.DEFINE_integer("synthetic_size", 7000, "number of synthetic samples")
     f.DEFINE_integer("seed", 0, "variable-initialisation seed")
     f.DEFINE_integer("save_every", 700, "checkpoint / sample-grid period in updates (the reference hard-codes 700)")
+    f.DEFINE_string("label_classifier_fn", None, "package.module:callable -- the MNIST classifier of the generated-label accuracy "
+                    "(float [100,28,28,1] -> 100 class indices); the reference reads ./mnist_dcnn/graph_optimized.pb")
     f.DEFINE_integer("sample_epochs", 5, "samples_<epoch>.npy period (the reference hard-codes 5)")
     return f
 
@@ -171,6 +173,10 @@ def main(argv=None):
     sample_z = np.random.uniform(-1, 1, size=(B, Z_DIM))
     picks = [i for c in range(10) for i in np.where(y_gen[:, c] == 1)[0][0:10]]
     sample_inputs, sample_labels = data_X[picks[0:100]], y_gen[picks[0:100]]
+    label_classifier = None
+    if FLAGS.label_classifier_fn:
+        from .inception_score import load_logits_fn
+        label_classifier = load_logits_fn(FLAGS.label_classifier_fn)
     start_time = time.time()
     for epoch in range(FLAGS.epoch if do_train else 0):
         batch_idxs = int(min(len(data_X), FLAGS.train_size)) // B
@@ -214,7 +220,13 @@ def main(argv=None):
             old = os.path.join(sample_dir, "samples_" + str(epoch - FLAGS.sample_epochs) + '.npy')
             if epoch + 1 != FLAGS.sample_epochs and os.path.exists(old):
                 os.remove(old)
-            print('######EPOCH={}, mean generated label accuracy=skipped (needs mnist_dcnn/graph_optimized.pb)'.format(epoch))
+            if label_classifier is not None and n == 100:
+                from .eval_mnist import generated_label_accuracy
+                print('######EPOCH={}, mean generated label accuracy={}'.format(
+                    epoch, generated_label_accuracy('mnist', np.array(samples), label_classifier)))
+            else:
+                print('######EPOCH={}, mean generated label accuracy=skipped (needs mnist_dcnn/graph_optimized.pb; '
+                      '--label_classifier_fn module:callable scores with your own classifier)'.format(epoch))
     final_state = None
     if rank == 0:
         final_state = m.state_dict()

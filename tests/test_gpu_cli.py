@@ -104,10 +104,17 @@ def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     out4 = capsys.readouterr().out
     assert " [*] Failed to find a checkpoint" in out4 and "Epoch: [ 0] [   0/   5]" in out4
     assert latest_checkpoint(os.path.join(d4, "mnist_100_28_28")) is not None
+    assert "mean generated label accuracy=skipped" in out4
     # biased preset: vanilla D, CE loss, real_match, no SN / max-norm; plus the --add_noise schedule
     d3 = main(["--algorithm", "biased", "--alpha", "0.6", "--disc_type", "vanilla", "--loss_fn", "ce", "--real_match",
                "--noestimate_confuse", "--add_noise", "--noise_alpha", "0.3", "--noise_start", "1", "--noise_end", "2",
                "--nospectral_norm", "--nomax_norm", "--checkpoint_dir", root, "--checkpoint", "e2", "--epoch", "2",
-               "--batch_size", "64", "--synthetic", "--synthetic_size", "256", "--train", "--recover_epoch", "0"])
+               "--batch_size", "64", "--synthetic", "--synthetic_size", "256", "--train", "--recover_epoch", "0",
+               "--sample_epochs", "2", "--label_classifier_fn", "tests.tools.fake_mnist_classifier:predict"])
+    out3 = capsys.readouterr().out
+    # generated-label accuracy through a supplied classifier (utils.py:273-306; the reference's .pb is not in the checkout)
+    import re
+    mm = re.search(r"######EPOCH=1, mean generated label accuracy=([0-9.]+)", out3)
+    assert mm is not None and 0.0 <= float(mm.group(1)) <= 1.0, out3[-400:]
     sd3 = load_checkpoint(latest_checkpoint(os.path.join(d3, "mnist_64_28_28")))
     assert sd3["discriminator/d_h3_lin/Matrix"].shape[1] == 1024 and all(np.isfinite(v).all() for v in sd3.values())
