@@ -393,11 +393,19 @@ typedef struct {
   /* Optional: E [v][d], the label embeddings table @ W_e / sigma_e + b_e computed earlier in the step by
    * rcgan_conv_prepare_batch_embed (they depend on parameters only): the head then starts with its logit kernel. */
   const float* E_pre;
+  /* Optional: DEFERRED parameter gradients.  Nothing in the backward pass waits for dw_out / db_out / dtable / dw_e / db_e, so
+   * with defer_ws set (>= (n*(v+1) + (v+1)*d) floats that stay untouched until the gradients have been written) the call launches
+   * the logit kernel only and leaves the two parameter-gradient launches pending in the context: the next rcgan_dtrunk backward
+   * launch carries the first as extra workgroups, the next rcgan_conv2d_bwd_weight_group launch the second, and rcgan_head_flush
+   * launches on the spot whatever is still pending (call it before anything reads those gradients).  Same values. */
+  void* defer_ws;
+  size_t defer_ws_bytes;
 } rcgan_head_desc;
 int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
                             const float* b_out, const float* table, const float* w_e, const float* sigma_e, const float* b_e,
                             float* loss_acc, float* logits, float* dfeat, float* dw_out, float* db_out, float* dtable, float* dw_e,
                             float* db_e, void* ws, size_t ws_bytes);
+int rcgan_head_flush(rcgan_ctx* ctx);
 int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels,
                              float weight, float* loss_acc, float* dx);
 /* recover_labels objective (mnist/model.py:533-537): gen [r*ydim, pix] = one generated image per (real sample r, label y),

@@ -59,7 +59,7 @@ class HeadDesc(C.Structure):
                 ("labels_a", C.c_void_p), ("wts_a", C.c_void_p), ("dwts_a", C.c_void_p),
                 ("labels_b", C.c_void_p), ("wts_b", C.c_void_p), ("dwts_b", C.c_void_p),
                 ("x", C.c_void_p), ("dx", C.c_void_p), ("x_dtype", C.c_int), ("hw", C.c_int), ("act", C.c_int),
-                ("E_pre", C.c_void_p)]
+                ("E_pre", C.c_void_p), ("defer_ws", C.c_void_p), ("defer_ws_bytes", C.c_size_t)]
 
 
 class EmbedDesc(C.Structure):
@@ -171,6 +171,7 @@ SIGNATURES = {
     "rcgan_dtrunk": (I, [P, I, I, P, P, P, P, P]),
     "rcgan_dtrunk_prepare": (I, [P, P, P]),
     "rcgan_dtrunk_fragment_bytes": (SZ, []),
+    "rcgan_head_flush": (I, [P]),
     "rcgan_proj_head_fwd_bwd": (I, [P, C.POINTER(HeadDesc)] + [P] * 16 + [P, SZ]),
     "rcgan_recover_mse_fwd_bwd": (I, [P, I, I, I, I, P, P, P, P, P, P, P, SZ]),
     "rcgan_softmax_rows_fwd": (I, [P, I, I, P, P]),

@@ -263,6 +263,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
     c->num_cus = cus;
   }
   c->dbg_stamps = nullptr;
+  c->head_stage = 0;
   c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stub = false; c->comm_stream = nullptr;
   c->comm_fork = nullptr; c->comm_join = nullptr; c->comm_pending = false;
   c->gscale_host = 1.f;
@@ -1020,10 +1021,23 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     }
     RC_REQUIRE(ctx, img_f >= 0, "image-end filter gradients planned without a grouped launch");
   }
+  // the projection head's deferred parameter sums (head_rider.h) ride in the three-tap launch with the most workgroups
+  int head_f = -1;
+  if (ctx->head_stage == 2) {
+    if (img_f == 0 || img_f == 1) head_f = img_f;
+    else {
+      unsigned best = 0;
+      for (int f = 0; f < 2; ++f) {
+        unsigned tot = 0;
+        for (size_t q = 0; q < args[f].size() && q < WGRAD_GROUP_MAX_HOST; ++q) tot += gxs[f][q] * gys[f][q];
+        if (!args[f].empty() && tot >= best) { best = tot; head_f = f; }
+      }
+    }
+  }
   for (int f = 0; f < 3; ++f)
     if (!args[f].empty()) {
       int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data(), f == 2 ? 1 : 0,
-                                        f == img_f ? &img : nullptr);
+                                        f == img_f ? &img : nullptr, f == head_f);
       if (rc) return rc;
     }
   for (size_t i0 = 0; i0 < red.size(); i0 += REDUCE_GROUP_MAX) {

@@ -42,6 +42,10 @@ struct rcgan_ctx {
   hipEvent_t comm_fork, comm_join;
   bool comm_pending;   // an asynchronous bucket has not been joined yet
   void* dbg_stamps;    // rcgan_debug_stamps
+  // deferred parameter gradients of the projection head (head_rider.h): 0 = nothing pending, 1 = dE GEMM + parameter sums,
+  // 2 = parameter sums; the argument block is loss.hip's
+  int head_stage;
+  alignas(8) unsigned char head_blob[640];
   int num_cus;         // compute units of the device (grid size of the persistent kernels)
   void* zero_page;     // 36 KiB of device memory: bytes [0,256) stay zero (halo source of the LDS-DMA kernels);
                        // bytes [1024,4096) are self-resetting arrival counters of the "last workgroup finishes" kernels

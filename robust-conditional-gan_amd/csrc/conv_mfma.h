@@ -87,7 +87,7 @@ bool mfma_wgrad3_takes(const MfmaWgradArgs& a);
 int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr);
 int mfma_wgrad_sub_splits(const rcgan_conv_desc* d, long M);
 int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
-                             const ImgWGroup* img);
+                             const ImgWGroup* img, bool carry_head = false);
 bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);

@@ -27,6 +27,7 @@
 #include "step_inputs.h"
 #include "mfma_util.h"
 #include "conv_image.h"
+#include "head_rider.h"
 
 #define LDS_PITCH 72          // elements per LDS row in the fwd kernel (64 + 8 pad)
 #define WG_PITCH 144          // elements per LDS row in the wgrad kernel (128 + 16 pad = 288 B)
@@ -1118,16 +1119,20 @@ struct WgradGroup {
   unsigned gx[WGRAD_GROUP_MAX];
   MfmaWgradArgs a[WGRAD_GROUP_MAX];
   ImgWGroup img;
+  HeadWgradRider head;      // the projection head's deferred parameter sums: head.blocks workgroups behind the image-end ones (three-tap launches only)
 };
+static_assert(sizeof(WgradGroup) <= 4096, "kernel argument block");
 
 template <int NS, bool RELU>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup g) {
   // (the branch is marked unlikely so that its code is laid out BEHIND the three-tap body: with the image-end code in front the
   // same, instruction-for-instruction identical hot loop ran 40 % slower -- 198 vs 141 us for the critic step's eleven layers)
   const unsigned b = blockIdx.x;
-  if (__builtin_expect(b >= g.first[g.n], 0)) {         // the image-end workgroups trail the grid
+  if (__builtin_expect(b >= g.first[g.n], 0)) {         // the image-end workgroups trail the grid, the head's trail them
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_img[];
-    img_wgrad_group_body(g.img, b - g.first[g.n], smem_img);
+    const unsigned bb = b - g.first[g.n];
+    if (bb >= g.img.first[IMG_GROUP_MAX]) head_wgrad_body(g.head.a, g.head.dEg, (int)(bb - g.img.first[IMG_GROUP_MAX]), (float*)smem_img);
+    else img_wgrad_group_body(g.img, bb, smem_img);
     return;
   }
   int p = 0;
@@ -1856,7 +1861,7 @@ static int launch_wgrad3_group(rcgan_ctx* ctx, const WgradGroup& g) {
   }
   {
     ProfScope ps(ctx, RCGAN_PROF_WGRAD_MFMA, fl, fx);
-    hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.img.first[IMG_GROUP_MAX] + g.first[g.n]), dim3(256), lds, ctx->stream, g);
+    hipLaunchKernelGGL((conv_mfma_wgrad3_group_kernel<NS, RELU>), dim3(g.img.first[IMG_GROUP_MAX] + g.first[g.n] + g.head.blocks), dim3(256), lds, ctx->stream, g);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -1894,10 +1899,13 @@ bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy) {
 // args[i] planned by mfma_wgrad3_plan (family 0; all with the same relu_in) or mfma_wgrad_tap_plan (family 1)
 // img (optional): image-end problems that ride in the FIRST launch
 int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
-                             const ImgWGroup* img) {
+                             const ImgWGroup* img, bool carry_head) {
   static_assert(ImgWGeom<128>::LDS <= 4 * (40 * 128 + 32 * 256), "image-end body needs more LDS than the three-tap kernel");
+  static_assert((HEAD_MAX_V + 1) * HEAD_MAX_D * 4 <= 4 * (40 * 128 + 32 * 256), "head body needs more LDS than the three-tap kernel");
   for (int i0 = 0; i0 < n; i0 += WGRAD_GROUP_MAX) {
     WgradGroup g;
+    g.head.blocks = 0;
+    if (carry_head && family != 1 && i0 == 0) (void)head_take_wgrad(ctx, &g.head);
     if (img && i0 == 0) g.img = *img;
     else { g.img.n = 0; for (int q = 0; q <= IMG_GROUP_MAX; ++q) g.img.first[q] = 0; }
     g.n = (n - i0 < WGRAD_GROUP_MAX) ? n - i0 : WGRAD_GROUP_MAX;

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "conv_mfma.h"
+#include "head_rider.h"
 #include "mfma_util.h"
 
 namespace {
@@ -42,6 +43,10 @@ struct TrunkArgs {
   bf16_t* out[TR_LAYERS];                 // [n][64][128] per layer
   int backward;
   unsigned long long* stamps;             // diagnostics (rcgan_debug_stamps): 24 s_memtime stamps per workgroup, normally null
+  // rider: the projection head's deferred dE = dlogit^T feat (head_rider.h) on workgroups n .. n + cdiv(d, 16) - 1 of the backward
+  // launch -- the stage's own workgroups occupy one CU each, at n = 128 half the chip is free beside them
+  int n;
+  SmallGemmArgs gemm;
 };
 
 __device__ __forceinline__ void trunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -59,6 +64,10 @@ __device__ __forceinline__ void trunk_barrier() { asm volatile("s_waitcnt lgkmcn
 // K-step ahead of their MFMAs).  The compiler keeps the loads in program order; its own counted vmcnt waits do the rest.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TRW_LDS = 2 * TR_BUF + TR_LAYERS * TR_C * 4;      // two activation images + biases
+static_assert((SG_AS_FLOATS + SG_RED_FLOATS) * 4 <= TRW_LDS, "the riding small GEMM needs more LDS than the stage");
+#ifndef TRW_ABLATE
+#define TRW_ABLATE 0      // diagnostics only (scripts/probes): 1 = no pixel-fragment reads after the first two K-steps, 2 = no filter reloads
+#endif
 constexpr int TRW_ASTEPS = 32;            // K-steps whose filter fragments live in AccVGPRs (2 x 4 registers each: 256); the other 4 in VGPRs
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
@@ -111,6 +120,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void trw_for(F&& 
 template <bool BWD>
 __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (BWD && __builtin_expect((int)blockIdx.x >= a.n, 0)) {          // rider workgroups (see TrunkArgs)
+    small_gemm_body(a.gemm, (int)blockIdx.x - a.n, (float*)smem, (float*)smem + SG_AS_FLOATS);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, kc = lane >> 4;
@@ -217,7 +230,11 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
     xread(0, xf[0]);
     trw_for<0, 36>([&](auto ic) __attribute__((always_inline)) {
       constexpr int s = decltype(ic)::value;
+#if TRW_ABLATE & 1
+      if constexpr (s + 1 < 2) xread(s + 1, xf[(s + 1) & 1]);
+#else
       if constexpr (s + 1 < 36) xread(s + 1, xf[(s + 1) & 1]);       // one K-step ahead of its MFMAs
+#endif
       trw_wait();
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -226,7 +243,9 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
           if constexpr (s < TRW_ASTEPS) trw_mfma_a(acc[ct][pt], WA[s][ct], xf[s & 1][pt]);
           else trw_mfma_v(acc[ct][pt], WV[s - TRW_ASTEPS][ct], xf[s & 1][pt]);
         }
+#if !(TRW_ABLATE & 2)
       wload(ic, wnext);
+#endif
     });
 
     stamp(2 + 2 * L);
@@ -299,6 +318,9 @@ int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void
   a.x0 = (const bf16_t*)x0;
   a.backward = backward & 1;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;
+  a.n = n;
+  a.gemm = SmallGemmArgs{};
+  const int riders = ((backward & 1) && head_take_gemm(ctx, &a.gemm)) ? cdiv(a.gemm.d, 16) : 0;
   const size_t elems = (size_t)9 * TR_C * TR_C;
   for (int i = 0; i < TR_LAYERS; ++i) {
     RC_REQUIRE(ctx, outs[i], "layer %d: null pointer", i);
@@ -314,7 +336,7 @@ int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void
     RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_trunk_rw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRW_LDS));
     attr_set = true;
   }
-  if (backward & 1) hipLaunchKernelGGL((conv_trunk_rw_kernel<true>), dim3(n), dim3(256), TRW_LDS, ctx->stream, a);
+  if (backward & 1) hipLaunchKernelGGL((conv_trunk_rw_kernel<true>), dim3(n + riders), dim3(256), TRW_LDS, ctx->stream, a);
   else hipLaunchKernelGGL((conv_trunk_rw_kernel<false>), dim3(n), dim3(256), TRW_LDS, ctx->stream, a);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;

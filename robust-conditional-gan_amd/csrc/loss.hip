@@ -198,21 +198,7 @@ __global__ void softmax_rows_bwd_kernel(int rows, int cols, const float* p, cons
 // E exist, the embedding gradients collapse to V x d problems: dE[l] = sum_s dlogit[s,l] feat[s], dW_e = table^T dE,
 // dtable = dE W_e^T / sigma_e.
 // ---------------------------------------------------------------------------------------------------------
-#define HEAD_MAX_D 256
-#define HEAD_MAX_N 1024
-struct HeadPart { int rows, kind; const int32_t* labels; const float* wts; float* dwts; };
-struct HeadArgs {
-  int n, d, v, e_dim;
-  HeadPart part[2];
-  float weight;
-  float gs_host; const float* gs_dev;      // gradient scale (rcgan_set_grad_scale)
-  const float *feat, *w_out, *sigma_out, *b_out, *table, *w_e, *sigma_e, *b_e;
-  float *loss_acc, *logits, *dfeat, *dw_out, *db_out, *dtable, *dw_e, *db_e;
-  // optional: the features are pooled HERE from the trunk's output x [n][hw][d] (feat = mean over hw of act(x), written to
-  // feat_out for the parameter-gradient kernels) and the gradient goes straight back to dx [n][hw][d] -- the two
-  // act_meanhw launches around the head disappear (d % 128 == 0)
-  const void* x; void* dx; float* feat_out; int hw, act;
-};
+#include "head_rider.h"
 
 // two adjacent elements as one access (the pooled-feature path of head_logit_kernel: a lane owns a channel pair)
 template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
@@ -399,45 +385,9 @@ __global__ __launch_bounds__(256) void head_logit_kernel(HeadArgs a, const float
   }
 }
 
-// items: [0, ed*d) dW_e;  then ed wavefront-items for dtable (one k each);  then d items for dw_out and d for db_e
 __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, const float* dEg) {
   extern __shared__ __attribute__((aligned(16))) float hs[];
-  const int d = a.d, v = a.v, ed = a.e_dim;
-  float* dE = hs;                   // [v+1][d]
-  for (int i = threadIdx.x; i < (v + 1) * d; i += 256) dE[i] = dEg[i];
-  __syncthreads();
-  const int nb_w = (ed * d + 255) / 256;                  // blocks of the dW_e range
-  const int nb_t = (ed + 3) / 4;                          // blocks of the dtable range (4 wavefronts = 4 k per block)
-  const int b = blockIdx.x;
-  if (b < nb_w) {
-    const int o = b * 256 + threadIdx.x;
-    if (o < ed * d && a.dw_e) {
-      const int k = o / d, j = o - k * d;
-      float acc = 0.f;
-      for (int l = 0; l < v; ++l) acc += a.table[l * ed + k] * dE[l * d + j];
-      a.dw_e[o] += acc;
-    }
-  } else if (b < nb_w + nb_t) {
-    const int k = (b - nb_w) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k < ed && a.dtable) {
-      const float inv_se = a.sigma_e ? 1.f / a.sigma_e[0] : 1.f;
-      float w[HEAD_MAX_D / 64];
-#pragma unroll
-      for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; w[q] = j < d ? a.w_e[(long)k * d + j] : 0.f; }
-      for (int l = 0; l < v; ++l) {
-        float dot = 0.f;
-#pragma unroll
-        for (int q = 0; q < HEAD_MAX_D / 64; ++q) { const int j = lane + q * 64; dot += j < d ? w[q] * dE[l * d + j] : 0.f; }
-        dot = wave_sum(dot);
-        if (lane == 0) a.dtable[(long)l * ed + k] += dot * inv_se;
-      }
-    }
-  } else {
-    for (int j = threadIdx.x; j < d; j += 256) {
-      if (a.dw_out) a.dw_out[j] += dE[v * d + j];
-      if (a.db_e) { float tot = 0.f; for (int l = 0; l < v; ++l) tot += dE[l * d + j]; a.db_e[j] += tot; }
-    }
-  }
+  head_wgrad_body(a, dEg, blockIdx.x, hs);
 }
 
 static inline int g1(long total) {
@@ -546,17 +496,41 @@ int rcgan_loss_fwd_bwd(rcgan_ctx* ctx, int kind, int rows, int cols, const float
   return RCGAN_OK;
 }
 
-// dE (small-left GEMM over the samples) and the parameter gradients from the dlogit rows the logit kernel left in the scratch
-static int head_param_grads(rcgan_ctx* ctx, const HeadArgs& a, const float* dlg, float* dEg) {
+// dE[l] = sum_s dlogit[s,l] feat[s]  (row v: the psi column -> dw_out; its sum over the samples -> db_out)
+static SmallGemmArgs head_de_gemm(const HeadArgs& a, const float* dlg, float* dEg) {
   const int vp = a.v + 1;
-  // dE[l] = sum_s dlogit[s,l] feat[s]  (row v: the psi column -> dw_out; its sum over the samples -> db_out)
-  SmallGemmArgs gd = {vp, a.n, a.d, dlg, 1, vp, a.feat, nullptr, nullptr, dEg, a.db_out, a.v};
-  hipLaunchKernelGGL(head_smallgemm_kernel, dim3(cdiv(a.d, 16)), dim3(256), 0, ctx->stream, gd);
-  RC_LAUNCH_CHECK(ctx);
-  const int blocks = cdiv(a.e_dim * a.d, 256) + cdiv(a.e_dim, 4) + 1;
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), (size_t)vp * a.d * sizeof(float), ctx->stream, a, (const float*)dEg);
+  return SmallGemmArgs{vp, a.n, a.d, dlg, 1, vp, a.feat, nullptr, nullptr, dEg, a.db_out, a.v};
+}
+
+// dE (small-left GEMM over the samples) and the parameter gradients from the dlogit rows the logit kernel left in the scratch
+static int head_param_grads(rcgan_ctx* ctx, const HeadArgs& a, const float* dlg, float* dEg, int from_stage = 1) {
+  if (from_stage <= 1) {
+    hipLaunchKernelGGL(head_smallgemm_kernel, dim3(cdiv(a.d, 16)), dim3(256), 0, ctx->stream, head_de_gemm(a, dlg, dEg));
+    RC_LAUNCH_CHECK(ctx);
+  }
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(head_wgrad_blocks(a)), dim3(256), (size_t)(a.v + 1) * a.d * sizeof(float), ctx->stream, a, (const float*)dEg);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
+}
+
+// the deferred form (head_rider.h): what the two launches above need, parked in the context until a launch carries it
+struct HeadDeferred { HeadArgs a; const float* dlg; float* dEg; };
+static_assert(sizeof(HeadDeferred) <= sizeof(((rcgan_ctx*)nullptr)->head_blob), "rcgan_ctx::head_blob too small");
+
+bool head_take_gemm(rcgan_ctx* ctx, SmallGemmArgs* out) {
+  if (ctx->head_stage != 1) return false;
+  const HeadDeferred* h = (const HeadDeferred*)ctx->head_blob;
+  *out = head_de_gemm(h->a, h->dlg, h->dEg);
+  ctx->head_stage = 2;
+  return true;
+}
+
+bool head_take_wgrad(rcgan_ctx* ctx, HeadWgradRider* out) {
+  if (ctx->head_stage != 2) return false;
+  const HeadDeferred* h = (const HeadDeferred*)ctx->head_blob;
+  out->a = h->a; out->dEg = h->dEg; out->blocks = head_wgrad_blocks(h->a);
+  ctx->head_stage = 0;
+  return true;
 }
 
 int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const float* feat, const float* w_out, const float* sigma_out,
@@ -592,6 +566,18 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   float* dlg = Eg + (size_t)a.v * a.d;
   float* dEg = dlg + (size_t)a.n * vp;
   float* losspart = dEg + (size_t)vp * a.d;
+  const bool want_params = dw_out || db_out || dtable || dw_e || db_e;
+  const bool defer = hd->defer_ws != nullptr && want_params;
+  if (defer) {        // dlogit and dE outlive this call: they live in the caller's buffer, not in the shared workspace
+    const size_t dneed = ((size_t)a.n * vp + (size_t)vp * a.d) * sizeof(float);
+    if (hd->defer_ws_bytes < dneed) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "defer_ws: need %zu have %zu", dneed, hd->defer_ws_bytes);
+    dlg = (float*)hd->defer_ws;
+    dEg = dlg + (size_t)a.n * vp;
+  }
+  if (ctx->head_stage) {            // an earlier head's deferred launches were never carried: they go first
+    int rc = rcgan_head_flush(ctx);
+    if (rc) return rc;
+  }
   if (hd->E_pre) {
     Eg = (float*)hd->E_pre;         // the label embeddings were computed earlier in the step (rcgan_conv_prepare_batch_embed)
   } else {
@@ -608,8 +594,23 @@ int rcgan_proj_head_fwd_bwd(rcgan_ctx* ctx, const rcgan_head_desc* hd, const flo
   else
     hipLaunchKernelGGL(head_logit_kernel<float>, dim3(nwg), dim3(256), lds, ctx->stream, a, (const float*)Eg, dlg, losspart, ctx->counters() + RC_COUNTER_HEAD);
   RC_LAUNCH_CHECK(ctx);
-  if (dw_out || db_out || dtable || dw_e || db_e) return head_param_grads(ctx, a, dlg, dEg);
+  if (defer) {
+    HeadDeferred* h = (HeadDeferred*)ctx->head_blob;
+    h->a = a; h->dlg = dlg; h->dEg = dEg;
+    ctx->head_stage = 1;
+    return RCGAN_OK;
+  }
+  if (want_params) return head_param_grads(ctx, a, dlg, dEg);
   return RCGAN_OK;
+}
+
+int rcgan_head_flush(rcgan_ctx* ctx) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  if (!ctx->head_stage) return RCGAN_OK;
+  const HeadDeferred h = *(const HeadDeferred*)ctx->head_blob;
+  const int stage = ctx->head_stage;
+  ctx->head_stage = 0;
+  return head_param_grads(ctx, h.a, h.dlg, h.dEg, stage);
 }
 
 int rcgan_bce_onehot_fwd_bwd(rcgan_ctx* ctx, int rows, int cols, const float* x, const int32_t* labels, float weight,

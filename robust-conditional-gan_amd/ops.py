@@ -849,6 +849,8 @@ def proj_logit_all(ctx, feat, psi, E):
 
 HEAD_MAX_N = 1024
 HEAD_MAX_D = 256
+# the head's parameter-gradient launches ride in the 8x8 stage's backward launch and the grouped filter-gradient launch (head_rider.h)
+HEAD_RIDERS = os.environ.get("RCGAN_HEAD_RIDERS", "1") != "0"
 
 
 def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc, logits=None, E_pre=None):
@@ -888,6 +890,10 @@ def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc,
         assert feat.grad is None, "the projection head is its features' only consumer"
         dfeat, _ = grad_of(ctx, feat)
     pg = lambda t: _p(t) if (rec and t is not None) else None
+    if rec and HEAD_RIDERS and (w_out.req or w_e.req or table.req):
+        # deferred parameter gradients (rcgan_head_desc::defer_ws): dlogit and dE in the step arena until the launches that carry them
+        nbytes = (n * (v + 1) + (v + 1) * d) * 4
+        hd.defer_ws, hd.defer_ws_bytes = ctx.arena.alloc(nbytes), nbytes
     dw_out = w_out.grad_target() if (rec and w_out.req) else None
     dw_e = w_e.grad_target() if (rec and w_e.req) else None
     db_out = b_out.grad if (b_out is not None and b_out.req) else None

@@ -230,15 +230,17 @@ class Context:
         self.pending_wgrads.append((desc, x, dy, dw, dbias))
 
     def flush_wgrads(self):
+        """All queued filter gradients as one grouped call; the projection head's deferred parameter gradients (ops.proj_head) ride
+        in its launch, and whatever of them is still pending afterwards is launched on the spot."""
         pend = self.pending_wgrads
-        if not pend:
-            return
-        self.pending_wgrads = []
-        n = len(pend)
-        descs = (L.ConvDesc * n)(*[p[0] for p in pend])
-        arr = lambda k: (C.c_void_p * n)(*[(p[k].ptr if p[k] is not None else None) for p in pend])
-        xs, dys, dws, dbs = arr(1), arr(2), arr(3), arr(4)
-        self.check(self.lib.rcgan_conv2d_bwd_weight_group(self.h, n, descs, xs, dys, dws, dbs, 1, C.c_void_p(self.ws_ptr), self.ws_bytes))
+        if pend:
+            self.pending_wgrads = []
+            n = len(pend)
+            descs = (L.ConvDesc * n)(*[p[0] for p in pend])
+            arr = lambda k: (C.c_void_p * n)(*[(p[k].ptr if p[k] is not None else None) for p in pend])
+            xs, dys, dws, dbs = arr(1), arr(2), arr(3), arr(4)
+            self.check(self.lib.rcgan_conv2d_bwd_weight_group(self.h, n, descs, xs, dys, dws, dbs, 1, C.c_void_p(self.ws_ptr), self.ws_bytes))
+        self.check(self.lib.rcgan_head_flush(self.h))
 
     def new_step(self):
         self.tape = []
