@@ -373,6 +373,13 @@ size_t rcgan_dtrunk_fragment_bytes(void);
 int rcgan_dtrunk_prepare(rcgan_ctx* ctx, const void* const* prepared, void* frag);
 int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
                  const void* const* masks, void* const* outs);
+/* The same stage with the discriminator's relu + mean over the 8 x 8 pixels (gan_resnet.py:405-407) at its boundary.  Forward: feat
+ * (optional) receives the pooled features [n][128] fp32 of the stored 16-bit output.  Backward: with feat = the gradient of the pooled
+ * features and xlast = outs[7] of the forward call, the incoming gradient dy[p][c] = xlast[p][c] > 0 ? feat[c] / 64 : 0 is formed
+ * inside the launch and written to dy_out [n][8][8][128] for the last layer's filter gradient (x0 may be NULL).  The projection head
+ * then runs on [n][128] features without touching the activations. */
+int rcgan_dtrunk_pooled(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
+                        const void* const* masks, void* const* outs, float* feat, const void* xlast, void* dy_out);
 /* Fused projection head: pooled features -> psi (D.Output, SN linear d -> 1), label embeddings E = table @ W_e / sigma_e + b_e
  * (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421), logits psi + <feat, E[l]> (:588, :654-660), loss terms and ALL
  * gradients in one launch.  Rows [0, rows_a) form part a, rows [rows_a, n) part b (real | fake of the critic step, :604-606);

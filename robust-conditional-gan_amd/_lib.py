@@ -169,6 +169,7 @@ SIGNATURES = {
     "rcgan_loss_fwd_bwd": (I, [P, I, I, I, P, P, F, P, P, P]),
     "rcgan_bce_onehot_fwd_bwd": (I, [P, I, I, P, P, F, P, P]),
     "rcgan_dtrunk": (I, [P, I, I, P, P, P, P, P]),
+    "rcgan_dtrunk_pooled": (I, [P, I, I, P, P, P, P, P, P, P, P]),
     "rcgan_dtrunk_prepare": (I, [P, P, P]),
     "rcgan_dtrunk_fragment_bytes": (SZ, []),
     "rcgan_head_flush": (I, [P]),

@@ -36,6 +36,9 @@ ALGORITHMS = ("rcgan", "rcgan-u", "biased", "unbiased")
 # layer in registers, filters re-laid fragment-major once per step).  Round 3, MI355X, n = 128: 49.6 us forward / 51.8 us data
 # gradient against 68.2 / 71.4 us for the eight launches (n = 256: 54 vs 113 us).  RCGAN_FUSED_TRUNK=0 restores the layer-wise blocks.
 FUSED_TRUNK = os.environ.get("RCGAN_FUSED_TRUNK", "1") == "1"
+# the discriminator's relu + spatial mean comes out of the stage's launch, and its gradient goes back into the backward launch
+# (rcgan_dtrunk_pooled): the projection head runs on [n, 128] features.  RCGAN_POOL_IN_TRUNK=0: the head pools by itself.
+POOL_IN_TRUNK = os.environ.get("RCGAN_POOL_IN_TRUNK", "1") == "1"
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -310,7 +313,7 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
                             ws.append(spectral_normed_weight(fname, update_collection=update_collection))
                         ws.append(g.param(scoped('Biases')))
                 blocks.append(tuple(ws))
-            x = O.d_trunk(ctx, x, blocks)
+            x = O.d_trunk(ctx, x, blocks, pool=(L.ACT_RELU if POOL_IN_TRUNK else None))
         else:
             for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
                 h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)

@@ -47,6 +47,14 @@ struct TrunkArgs {
   // launch -- the stage's own workgroups occupy one CU each, at n = 128 half the chip is free beside them
   int n;
   SmallGemmArgs gemm;
+  // the discriminator's pooled features (gan_resnet.py:405-407: relu, mean over the 64 pixels) at the stage's boundary:
+  //   forward : feat != null -> feat[n][128] = mean_p relu(out[7][n][p][:]) of the stored 16-bit values, from the last layer's epilogue
+  //   backward: feat != null -> the incoming gradient is built in the prologue from dfeat = feat[n][128] and xlast = the stage's
+  //             stored output: dy[p][c] = xlast[p][c] > 0 ? dfeat[c] / 64 : 0, rounded to 16 bits (x0 unused)
+  // -- what the projection head's own pooling (loss.hip, HeadArgs::x) computes, without its 2 + 2 memory round trips
+  float* feat;
+  const bf16_t* xlast;
+  bf16_t* dy_out;                         // backward with feat: the formed gradient [n][64][128] (the last layer's filter gradient reads it)
 };
 
 __device__ __forceinline__ void trunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -171,12 +179,27 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
   uint2 R[2][4];
   const long gbase = img * 64 * TR_C;
   __syncthreads();                        // the zero fill is complete before the first interior write
+  const bool pooled_in = BWD && a.feat != nullptr;        // (workgroup-uniform)
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < 2; ++ct) {
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pooled_in) {
+      g4 = *(const float4*)(a.feat + img * TR_C + co4[ct]);
+      const float inv = 1.f / 64.f;
+      g4.x *= inv; g4.y *= inv; g4.z *= inv; g4.w *= inv;
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int p = pt * 16 + r;
-      const uint2 v = *(const uint2*)(a.x0 + gbase + (long)p * TR_C + co4[ct]);
+      uint2 v;
+      if (pooled_in) {
+        const uint2 xl = *(const uint2*)(a.xlast + gbase + (long)p * TR_C + co4[ct]);
+        v.x = pack_h16x2(h16_lo(xl.x) > 0.f ? g4.x : 0.f, h16_hi(xl.x) > 0.f ? g4.y : 0.f);
+        v.y = pack_h16x2(h16_lo(xl.y) > 0.f ? g4.z : 0.f, h16_hi(xl.y) > 0.f ? g4.w : 0.f);
+        *(uint2*)(a.dy_out + gbase + (long)p * TR_C + co4[ct]) = v;
+      } else {
+        v = *(const uint2*)(a.x0 + gbase + (long)p * TR_C + co4[ct]);
+      }
       R[ct][pt] = v;
       uint2 nx = v;
       if (!BWD) { nx.x = relu_bf16x2(v.x); nx.y = relu_bf16x2(v.y); }
@@ -184,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
       const int slot = co4[ct] >> 3;
       *(uint2*)(smem + ppi * TR_ROW + ((slot ^ (ppi & 15)) << 4) + (kc & 1) * 8) = nx;
     }
+  }
   trunk_barrier();
   stamp(1);
 
@@ -282,6 +306,26 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
     trunk_barrier();
     stamp(3 + 2 * L);
   }
+  if (!BWD && a.feat != nullptr) {
+    // the pooled features: the last layer left relu(out[7]) in LDS as "the next layer's input" (image (TR_LAYERS & 1), interior pixels
+    // of the padded 10 x 10 grid, 16-byte slots swizzled with the pixel index).  Thread (channel pair cp = tid & 63, pixel quarter
+    // q = tid >> 6) sums 16 pixels; the quarters meet in LDS (the other image is dead).  Kept out of the layer loop on purpose.
+    const unsigned char* fin = smem + (TR_LAYERS & 1) * TR_BUF;
+    float* part = (float*)(smem + ((TR_LAYERS + 1) & 1) * TR_BUF);       // [4][128]
+    const int cp = tid & 63, q = tid >> 6;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int p = q * 16 + i, pp = ((p >> 3) + 1) * 10 + (p & 7) + 1;
+      const uint32_t v = *(const uint32_t*)(fin + pp * TR_ROW + ((((2 * cp) >> 3) ^ (pp & 15)) << 4) + ((2 * cp) & 7) * 2);
+      s0 += h16_lo(v); s1 += h16_hi(v);
+    }
+    part[q * 128 + 2 * cp] = s0;
+    part[q * 128 + 2 * cp + 1] = s1;
+    __syncthreads();
+    if (tid < 128)
+      a.feat[img * TR_C + tid] = ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) * (1.f / 64.f);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last layer's (unused) fragment loads must not outlive the registers
 }
 
@@ -312,13 +356,26 @@ int rcgan_dtrunk_prepare(rcgan_ctx* ctx, const void* const* prepared, void* frag
 // stage's CURRENT weights.
 int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
                  const void* const* masks, void* const* outs) {
-  RC_REQUIRE(ctx, n >= 1 && x0 && frag && outs, "bad arguments");
+  return rcgan_dtrunk_pooled(ctx, n, backward, x0, frag, bias, masks, outs, nullptr, nullptr, nullptr);
+}
+
+// The same stage with the discriminator's relu + spatial mean at its boundary (TrunkArgs::feat).  Forward: feat (optional) receives
+// the pooled features [n][128] fp32.  Backward: with feat (= the gradient of the pooled features) and xlast (= the stage's stored
+// forward output outs[7]) the incoming gradient is formed inside the launch, written to dy_out, and x0 is not read (pass NULL).
+int rcgan_dtrunk_pooled(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
+                        const void* const* masks, void* const* outs, float* feat, const void* xlast, void* dy_out) {
+  RC_REQUIRE(ctx, n >= 1 && frag && outs, "bad arguments");
+  RC_REQUIRE(ctx, ((backward & 1) && feat) ? (xlast != nullptr && dy_out != nullptr) : x0 != nullptr,
+             "the stage needs its input (or, backward, feat + xlast + dy_out)");
   RC_REQUIRE(ctx, (backward & 1) ? masks != nullptr : true, "the backward pass needs the saved activations");
   TrunkArgs a;
   a.x0 = (const bf16_t*)x0;
   a.backward = backward & 1;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;
   a.n = n;
+  a.feat = feat;
+  a.xlast = (const bf16_t*)xlast;
+  a.dy_out = (bf16_t*)dy_out;
   a.gemm = SmallGemmArgs{};
   const int riders = ((backward & 1) && head_take_gemm(ctx, &a.gemm)) ? cdiv(a.gemm.d, 16) : 0;
   const size_t elems = (size_t)9 * TR_C * TR_C;

@@ -3,6 +3,16 @@
 #pragma once
 #include "common.h"
 
+// 16-lane (one DPP row) all-reduce in a fixed order: pairs, quads, half rows, rows
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+
 #if RCGAN_HALF_FP16
 typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;      // (historical name: eight 16-bit operand elements)
 #define H16_ONE 0x3C00u                                             /* 1.0 */

@@ -384,14 +384,17 @@ def d_trunk_ok(ctx, x):
     return x.dtype != L.F32 and tuple(x.shape[1:]) == (8, 8, 128)
 
 
-def d_trunk(ctx, x, blocks):
+def d_trunk(ctx, x, blocks, pool=None):
     """D.Block.3 .. D.Block.6 of the CIFAR discriminator -- four identity-shortcut residual blocks
     x' = x + Conv2(relu(Conv1(relu(x)))) (gan_resnet.py:275-328 with resample=None, :398-404) -- as ONE launch each way
     (rcgan_dtrunk): a workgroup carries one image through all eight 3x3 convolutions with the activations in LDS.
     blocks: [(Weight conv1, bias1, Weight conv2, bias2)] x 4.  Same values as eight conv2d calls up to the summation order
-    inside a convolution (the rounding points -- 16-bit activations between layers, fp32 residual adds -- are the same)."""
+    inside a convolution (the rounding points -- 16-bit activations between layers, fp32 residual adds -- are the same).
+    pool=ACT_RELU: the launch also leaves mean_hw(relu(y)) -- the discriminator's features, gan_resnet.py:405-407 -- in y.pooled, and
+    a consumer that takes them (act_meanhw_later -> proj_head) hands the features' gradient back through y.pool_grad: the backward
+    launch forms the incoming gradient itself, nobody reads or writes the [n, 8, 8, 128] activations around the head."""
     n = x.shape[0]
-    assert d_trunk_ok(ctx, x) and len(blocks) == 4
+    assert d_trunk_ok(ctx, x) and len(blocks) == 4 and pool in (None, L.ACT_RELU)
     desc = L.ConvDesc(n, 8, 8, 128, 128, 3, 3, 1, x.dtype, L.CONV_IN_RELU)
     arr = lambda ts: (C.c_void_p * 8)(*[(t.ptr if t is not None else None) for t in ts])
     flat = []                                                  # (Weight, bias) of the eight layers in execution order
@@ -402,21 +405,29 @@ def d_trunk(ctx, x, blocks):
     # the stage's filters re-laid fragment-major, both directions, once per set of weights (the arena keeps it until the backward pass)
     frag = DT(ctx.arena.alloc(ctx.lib.rcgan_dtrunk_fragment_bytes()), (ctx.lib.rcgan_dtrunk_fragment_bytes(),), "u8", ctx.arena.buf)
     ctx.check(ctx.lib.rcgan_dtrunk_prepare(ctx.h, arr(preps), _p(frag)))
-    ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 0, _p(x), _p(frag), arr([b for _, b in flat]), None, arr(outs)))
+    feat = ctx.empty((n, 128), L.F32) if pool is not None else None
+    ctx.check(ctx.lib.rcgan_dtrunk_pooled(ctx.h, n, 0, _p(x), _p(frag), arr([b for _, b in flat]), None, arr(outs), _p(feat), None, None))
     y = outs[7]
+    y.pooled, y.pool_grad = ((feat, pool) if feat is not None else None), None
     params = [t for w, b in flat for t in (w.param, b)]
     if _track(ctx, y, x, *params):
         def bw():
-            dy = y.grad
-            if dy is None:
+            dy, dfeat = y.grad, y.pool_grad
+            if dy is None and dfeat is None:
                 return
+            if dfeat is not None:
+                assert dy is None, "the stage's output has one consumer: the pooled features or the activations"
+                dy = ctx.empty(x.shape, x.dtype)      # written by the launch (formed from dfeat): the last layer's filter gradient reads it
             # layers last to first: block 6 conv2 (mask h_6), block 6 conv1 (mask x_6), block 5 conv2, ...
             hs = [outs[0], outs[2], outs[4], outs[6]]                    # h_3 .. h_6
             xs = [x, outs[1], outs[3], outs[5]]                          # x_3 .. x_6 (block inputs)
             order = [(3, 1), (3, 0), (2, 1), (2, 0), (1, 1), (1, 0), (0, 1), (0, 0)]      # (block index, conv index)
             masks = [hs[bi] if ci == 1 else xs[bi] for bi, ci in order]
             gouts = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
-            ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 1, _p(dy), _p(frag), None, arr(masks), arr(gouts)))
+            if dfeat is not None:
+                ctx.check(ctx.lib.rcgan_dtrunk_pooled(ctx.h, n, 1, None, _p(frag), None, arr(masks), arr(gouts), _p(dfeat), _p(y), _p(dy)))
+            else:
+                ctx.check(ctx.lib.rcgan_dtrunk(ctx.h, n, 1, _p(dy), _p(frag), None, arr(masks), arr(gouts)))
             for j, bi in enumerate((3, 2, 1, 0)):
                 dh, dy_k = gouts[2 * j], (dy if j == 0 else gouts[2 * j - 1])
                 for (w, b), xin, g in ((flat[2 * bi + 1], hs[bi], dy_k), (flat[2 * bi], xs[bi], dh)):
@@ -768,8 +779,25 @@ class PooledLater:
         return act_meanhw(self.ctx, self.x, self.kind)
 
 
+class PooledByProducer:
+    """act_meanhw(x, kind) whose values the producer of x already left in x.pooled (d_trunk): a consumer that computes the
+    features' gradient itself (proj_head) hands it back through x.pool_grad; any other consumer calls materialize()."""
+
+    def __init__(self, ctx, x, kind):
+        self.ctx, self.x, self.kind = ctx, x, kind
+        self.feat = x.pooled[0]
+        self.shape = self.feat.shape
+        self.req = x.req
+
+    def materialize(self):
+        return act_meanhw(self.ctx, self.x, self.kind)
+
+
 def act_meanhw_later(ctx, x, kind):
     """act_meanhw for a consumer that can pool by itself (proj_head with d % 128 == 0 channels), else act_meanhw."""
+    pooled = x.pooled
+    if pooled is not None and pooled[1] == kind:
+        return PooledByProducer(ctx, x, kind)
     if os.environ.get("RCGAN_HEAD_POOL", "1") == "1" and x.shape[-1] % 128 == 0 and x.shape[-1] <= HEAD_MAX_D:
         return PooledLater(ctx, x, kind)
     return act_meanhw(ctx, x, kind)
@@ -877,7 +905,14 @@ def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc,
         assert E_pre.shape == (v, d)
         hd.E_pre = E_pre.ptr
     dfeat = None
-    if isinstance(feat, PooledLater):
+    if isinstance(feat, PooledByProducer):
+        x = feat.x
+        feat = feat.feat
+        if x.req and rec:
+            assert x.grad is None and x.pool_grad is None, "the pooled features have a single consumer in both models"
+            dfeat = ctx.empty((n, d), L.F32)
+            x.pool_grad = dfeat
+    elif isinstance(feat, PooledLater):
         # pooled inside the launch from the trunk's output; feat becomes an output buffer for the parameter-gradient kernels
         x = feat.x
         hd.x, hd.x_dtype, hd.hw, hd.act = x.ptr, x.dtype, x.shape[1] * x.shape[2], feat.kind

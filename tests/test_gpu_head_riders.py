@@ -83,3 +83,32 @@ def test_flush_launches_what_no_launch_carried():
         assert rc == -3
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("alg,dtype", [("rcgan", "bf16"), ("rcgan-u", "bf16"), ("rcgan", "f16")])
+def test_pooling_inside_the_stage_matches_pooling_inside_the_head(alg, dtype, monkeypatch):
+    """RCGAN_POOL_IN_TRUNK (rcgan_dtrunk_pooled: features out of the 8x8 stage's launch, their gradient into its backward launch)
+    against the head pooling by itself: the features differ by fp32 summation order, so the first critic step's gradients agree to
+    1e-5 per tensor and two iterations stay on one trajectory (tests/test_gpu_dp._same_trajectory)."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import cifar as cm
+    from tests.gpu_util import rel_err
+    from tests.test_gpu_dp import _same_trajectory
+    rs = np.random.RandomState(22)
+    B = 8
+    its = _feeds(rs, B, 2, alg)
+    outs = []
+    for pool in (False, True):
+        monkeypatch.setattr(cm, "POOL_IN_TRUNK", pool)
+        m = _model(alg, dtype, B)
+        try:
+            g1 = {}
+            outs.append(_run_iterations(m, its, g1) + (g1,))
+        finally:
+            m.ctx.close()
+    (pa, la, sa, ga), (pb, lb, sb, gb) = outs
+    gmax = max(float(np.abs(v).max()) for v in ga.values())
+    for k in ga:
+        if float(np.abs(ga[k]).max()) > 1e-3 * gmax:
+            assert rel_err(gb[k], ga[k]) <= 1e-5, (k, rel_err(gb[k], ga[k]))
+    _same_trajectory(pa, pb)

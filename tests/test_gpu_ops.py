@@ -443,6 +443,61 @@ def test_d_trunk_equals_layerwise_blocks(dev, n):
         assert_close(a["y"], t, TOL[mode] * 3, "trunk output vs oracle")
 
 
+@pytest.mark.parametrize("n,kind_a,kind_b", [(16, "HINGE_REAL", "HINGE_FAKE"), (128, "HINGE_REAL", "HINGE_FAKE"), (6, "NEG_MEAN", None)])
+def test_d_trunk_pooled_boundary(dev, n, kind_a, kind_b):
+    """rcgan_dtrunk_pooled: the stage's launch leaves mean_hw(relu(y)) beside y and the backward launch forms its incoming gradient
+    from the features' gradient (ops.d_trunk(pool=ACT_RELU) -> act_meanhw_later -> proj_head) -- against the same stage followed by
+    the head that pools by itself (ops.PooledLater).  The features differ by fp32 summation order only; the hinge / mean losses'
+    logit gradients are piecewise constant, so everything behind them agrees to rounding."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    from tests.gpu_util import rel_err
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the fused stage runs on 16-bit activations")
+    rs = np.random.RandomState(n + 40)
+    d, v, ed = 128, 10, 128
+    x = _prep(rs.randn(n, 8, 8, 128), mode)
+    ws = [(rs.randn(3, 3, 128, 128) / np.sqrt(9 * 128) * 1.2).astype(np.float32) for _ in range(8)]
+    bs = [(0.1 * rs.randn(128)).astype(np.float32) for _ in range(8)]
+    w_out = (rs.randn(d, 1) * 0.3).astype(np.float32); b_out = rs.randn(1).astype(np.float32)
+    table = (rs.randn(v, ed) * 0.1).astype(np.float32)
+    w_e = (rs.randn(ed, d) * 0.2).astype(np.float32); b_e = (rs.randn(d) * 0.1).astype(np.float32)
+    kinds = {"HINGE_REAL": L.LOSS_HINGE_REAL, "HINGE_FAKE": L.LOSS_HINGE_FAKE, "NEG_MEAN": L.LOSS_NEG_MEAN}
+    rows_a = n // 2 if kind_b else n
+    labs = [rs.randint(v, size=r).astype(np.int32) for r in (rows_a, n - rows_a) if r]
+    res = {}
+    for pooled in (True, False):
+        ctx.new_step()
+        xd = ctx.upload(x); xd.req = True
+        pw, pb = [FakeParam(ctx, w) for w in ws], [FakeParam(ctx, b) for b in bs]
+        W = [O.Weight(ctx, p.t, ctx.upload(np.array([1.3], np.float32), L.F32)) for p in pw]
+        pw_out, pb_out, ptab, pw_e, pb_e = (FakeParam(ctx, a) for a in (w_out, b_out, table, w_e, b_e))
+        W_out = O.Weight(ctx, pw_out.t, ctx.upload(np.array([1.1], np.float32), L.F32))
+        W_e = O.Weight(ctx, pw_e.t, ctx.upload(np.array([0.9], np.float32), L.F32))
+        y = O.d_trunk(ctx, xd, [(W[2 * k], pb[2 * k].t, W[2 * k + 1], pb[2 * k + 1].t) for k in range(4)],
+                      pool=(L.ACT_RELU if pooled else None))
+        feat = O.act_meanhw_later(ctx, y, L.ACT_RELU)
+        assert isinstance(feat, O.PooledByProducer if pooled else O.PooledLater)
+        if pooled:
+            want = np.maximum(ctx.download(y).astype(np.float64), 0).mean(axis=(1, 2))
+            assert_close(ctx.download(feat.feat), want, 2e-6, "features out of the stage's launch")
+        parts = [(len(l), kinds[k], ctx.upload(l), None) for l, k in zip(labs, (kind_a, kind_b))]
+        loss = ctx.persistent((1,), L.F32, fill=0.0)
+        O.proj_head(ctx, feat, W_out, pb_out.t, ptab.t, W_e, pb_e.t, parts, 2.0, loss)
+        ctx.backward()
+        res[pooled] = dict(loss=ctx.download(loss), dx=ctx.download(xd.grad), dw=[ctx.download(w.dwbar) for w in W],
+                           db=[p.grad(ctx) for p in pb], dwo=ctx.download(W_out.dwbar), dwe=ctx.download(W_e.dwbar), dt=ptab.grad(ctx))
+    a, b = res[True], res[False]
+    assert_close(a["loss"], b["loss"], 1e-5, "loss")
+    assert rel_err(a["dx"], b["dx"]) < 1e-5, rel_err(a["dx"], b["dx"])
+    for i in range(8):
+        assert rel_err(a["dw"][i], b["dw"][i]) < 1e-5, (i, rel_err(a["dw"][i], b["dw"][i]))
+        assert rel_err(a["db"][i], b["db"][i]) < 1e-5, (i, rel_err(a["db"][i], b["db"][i]))
+    for k in ("dwo", "dwe", "dt"):
+        assert rel_err(a[k], b[k]) < 1e-5, (k, rel_err(a[k], b[k]))
+
+
 HEAD_CASES = [
     # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
     (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
