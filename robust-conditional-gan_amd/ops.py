@@ -888,7 +888,9 @@ def proj_head(ctx, feat, w_out, b_out, table, w_e, b_e, parts, weight, loss_acc,
     parts: one or two (rows, kind, labels, wts) tuples covering feat's rows in order -- labels: int32 DT [rows] (one-hot
     weighting) or wts: fp32 DT [rows, v] (may require a gradient).  Adds weight * (mean over each part's rows) to loss_acc.
     Like loss_term this computes its gradients in the forward launch: feat (and a wts that requires one) get their .grad
-    here, the parameter gradients are accumulated into the step's zeroed buffers."""
+    here; the parameter gradients are accumulated into the step's zeroed buffers by two launches that are DEFERRED (HEAD_RIDERS:
+    they ride in the 8x8 stage's backward launch and the grouped filter-gradient launch) -- complete after Context.flush_wgrads() /
+    backward(), which every consumer of those gradients (the spectral-norm backward, the optimiser) sits behind."""
     n, d = feat.shape
     v, e_dim = table.shape
     assert 1 <= len(parts) <= 2 and sum(p[0] for p in parts) == n, (parts, n)

@@ -245,6 +245,7 @@ class Context:
         self.check(self.lib.rcgan_head_flush(self.h))
 
     def new_step(self):
+        self.check(self.lib.rcgan_head_flush(self.h))      # (a head whose backward pass never ran: its buffers are still valid here)
         self.tape = []
         self.sn_partial = []
         self.pending_wgrads = []

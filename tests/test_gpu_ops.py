@@ -546,6 +546,7 @@ def test_proj_head(dev, case):
     loss = ctx.persistent((1,), L.F32, fill=0.0)
     logits = ctx.empty((n, v), L.F32)
     O.proj_head(ctx, fd, W_out, pb_out.t, ptab.t, W_e, pb_e.t, parts, weight, loss, logits=logits)
+    ctx.flush_wgrads()          # the head's parameter gradients are deferred (they ride in later launches of a step): here, on their own
     # float64 autograd restatement
     T = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
     tf, two, tbo, tt, twe, tbe = T(feat), T(w_out), T(b_out), T(table), T(w_e), T(b_e)
@@ -613,6 +614,7 @@ def test_proj_head_pools_features(dev, case):
     feat = O.act_meanhw_later(ctx, xd, L.ACT_RELU)
     assert isinstance(feat, O.PooledLater)
     O.proj_head(ctx, feat, W_out, pb_out.t, ptab.t, W_e, pb_e.t, parts, weight, loss)
+    ctx.flush_wgrads()
     T = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
     tx, two, tbo, tt, twe, tbe = T(x), T(w_out), T(b_out), T(table), T(w_e), T(b_e)
     tf = torch.relu(tx).mean(dim=(1, 2))
@@ -664,6 +666,7 @@ def test_label_embeddings_ride_in_filter_preparation(dev):
             assert_close(ctx.download(E), ref, 2e-5, "riding label embeddings")
         loss = ctx.persistent((1,), L.F32, fill=0.0)
         O.proj_head(ctx, fd, W_out, pb_out.t, ptab.t, W_e, pb_e.t, [(n, L.LOSS_HINGE_REAL, ctx.upload(lab), None)], 2.0, loss, E_pre=E)
+        ctx.flush_wgrads()
         out.append((ctx.download(loss).copy(), ctx.download(fd.grad).copy(), ctx.download(W_e.dwbar).copy(), ptab.grad(ctx).copy()))
     for a, b in zip(*out):
         assert np.array_equal(a, b), "head with riding embeddings differs from the head computing them itself"
