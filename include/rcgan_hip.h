@@ -380,6 +380,24 @@ int rcgan_dtrunk(rcgan_ctx* ctx, int n, int backward, const void* x0, const void
  * then runs on [n][128] features without touching the activations. */
 int rcgan_dtrunk_pooled(rcgan_ctx* ctx, int n, int backward, const void* x0, const void* frag, const float* const* bias,
                         const void* const* masks, void* const* outs, float* feat, const void* xlast, void* dy_out);
+
+/* ---- register-filter convolution (csrc/conv_rf.hip) -----------------------------------------------------------------------------
+ * One 3x3 stride-1 SAME layer on a small image grid (8x8, 16x16; 128 -> 128 channels), forward or data gradient, with the workgroup's
+ * filter slice in registers and its input patch resident in LDS: the same values as rcgan_conv2d_fwd(_residual) / rcgan_conv2d_bwd_data
+ * up to fp32 summation order (tf.nn.conv2d + bias_add, conv2d_backprop_input: cifar10/common/ops/conv2d.py:181-216 for D.Block.2.Conv1).
+ * rcgan_conv_rf_ok: 1 if the kernel takes d (flags within IN_RELU | ACCUMULATE).  rcgan_conv_rf_prepare: ONE launch re-lays n prepared
+ * filters (rcgan_conv_prepare layout) fragment-major into frags[i] (rcgan_conv_rf_fragment_bytes each; both directions).
+ * rcgan_conv2d_rf: backward = 0: y = conv(x) (+bias) (+residual), input ReLU under IN_RELU; backward = 1: x = dy, y = dx, masked by
+ * mask_x > 0 under IN_RELU, += under ACCUMULATE, + residual. */
+int rcgan_conv_rf_ok(const rcgan_conv_desc* d);
+size_t rcgan_conv_rf_fragment_bytes(const rcgan_conv_desc* d);
+int rcgan_conv_rf_prepare(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* prepared, void* const* frags);
+/* rcgan_dtrunk_prepare (trunk_prepared = the stage's eight prepared filters in forward order, or NULL) and rcgan_conv_rf_prepare (n <= 12)
+ * as ONE launch: every fragment-major copy a critic step needs. */
+int rcgan_fragments_prepare(rcgan_ctx* ctx, const void* const* trunk_prepared, void* trunk_frag, int n, const rcgan_conv_desc* descs,
+                            const void* const* prepared, void* const* frags);
+int rcgan_conv2d_rf(rcgan_ctx* ctx, const rcgan_conv_desc* d, int backward, const void* x, const void* frag, const float* bias,
+                    const void* mask_x, const void* residual, void* y);
 /* Fused projection head: pooled features -> psi (D.Output, SN linear d -> 1), label embeddings E = table @ W_e / sigma_e + b_e
  * (embedding.py:29-51 + D.Embedding_y, gan_resnet.py:414-421), logits psi + <feat, E[l]> (:588, :654-660), loss terms and ALL
  * gradients in one launch.  Rows [0, rows_a) form part a, rows [rows_a, n) part b (real | fake of the critic step, :604-606);

@@ -171,6 +171,11 @@ SIGNATURES = {
     "rcgan_dtrunk": (I, [P, I, I, P, P, P, P, P]),
     "rcgan_dtrunk_pooled": (I, [P, I, I, P, P, P, P, P, P, P, P]),
     "rcgan_dtrunk_prepare": (I, [P, P, P]),
+    "rcgan_conv_rf_ok": (I, [C.POINTER(ConvDesc)]),
+    "rcgan_conv_rf_fragment_bytes": (SZ, [C.POINTER(ConvDesc)]),
+    "rcgan_conv_rf_prepare": (I, [P, I, C.POINTER(ConvDesc), P, P]),
+    "rcgan_fragments_prepare": (I, [P, P, P, I, C.POINTER(ConvDesc), P, P]),
+    "rcgan_conv2d_rf": (I, [P, C.POINTER(ConvDesc), I, P, P, P, P, P, P]),
     "rcgan_dtrunk_fragment_bytes": (SZ, []),
     "rcgan_head_flush": (I, [P]),
     "rcgan_proj_head_fwd_bwd": (I, [P, C.POINTER(HeadDesc)] + [P] * 16 + [P, SZ]),

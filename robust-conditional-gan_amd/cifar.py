@@ -313,7 +313,7 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
                             ws.append(spectral_normed_weight(fname, update_collection=update_collection))
                         ws.append(g.param(scoped('Biases')))
                 blocks.append(tuple(ws))
-            x = O.d_trunk(ctx, x, blocks, pool=(L.ACT_RELU if POOL_IN_TRUNK else None))
+            x = O.d_trunk(ctx, x, blocks, pool=(L.ACT_RELU if POOL_IN_TRUNK else None), frag=getattr(g, "trunk_frag", None))
         else:
             for blk in (3, 4, 5, 6):          # identity shortcut (in==out, no resample)
                 h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.%d.Conv1' % blk, _in_relu=True, **kw)
@@ -607,6 +607,18 @@ class CifarRCGAN:
         rode = g.prepare_convs(names, self.ctx.act_dtype, embed=embed, inputs=inputs)
         if rode and embed is not None:
             g.head_E = embed[3]
+        # every fragment-major filter copy of the critic in one launch: the 8x8 stage's (ops.d_trunk) and the register-filter
+        # layers' (ops.conv2d -> rcgan_conv2d_rf: D.Block.2.Conv1, 16 x 16 x 128)
+        g.trunk_frag = None
+        if self.PD in which and self.ctx.act_dtype != L.F32 and (FUSED_TRUNK or O.RF_CONV):
+            sn = lambda n: g.sn["Discriminator/%s/Filters" % n][0]
+            trunk = [sn("D.Block.%d.%s" % (b, c)) for b in (3, 4, 5, 6) for c in ("Conv1", "Conv2")] if FUSED_TRUNK else None
+            rf = []
+            if O.RF_CONV:
+                d = L.ConvDesc(1, 16, 16, DIM_D, DIM_D, 3, 3, 1, self.ctx.act_dtype, L.CONV_IN_RELU)
+                if self.ctx.lib.rcgan_conv_rf_ok(C.byref(d)):
+                    rf.append((sn("D.Block.2.Conv1"), d))
+            g.trunk_frag = O.fragments_batch(self.ctx, trunk, rf)
         return rode
 
     def _refresh_generator_filters(self):

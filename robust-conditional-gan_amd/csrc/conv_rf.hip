@@ -1,0 +1,394 @@
+// Register-filter convolution: ONE 3x3 stride-1 SAME layer on a small image grid (8x8, 16x16), forward or data gradient, with the
+// workgroup's FILTERS IN REGISTERS and its input pixels resident in LDS.
+//
+// Why.  The tile-per-tap kernels (conv_mfma.hip) stream every K-tile of pixels AND filters through LDS rings; what a CU ingests that
+// way is (bytes of ring it can hold in flight) / (memory latency) -- 60-75 GB/s measured, whatever the stage count (the 160 KB of LDS
+// are the limit: more stages = fewer resident workgroups) -- and the 8x8 / 16x16 layers are bound by exactly that: 18.5 us for
+// D.Block.2.Conv1 (9.7 GFLOP at n = 128).  conv_trunk.hip showed the way out for the 8x8 stage: registers hold far more in flight
+// than LDS (one wavefront per SIMD owns 512 of them), and a load instruction that reads one contiguous KiB of a fragment-major filter
+// copy runs at the CU's full ingest rate (136 GB/s, scripts/probes/filter_fetch.hip).  Here, for a single layer:
+//   * a workgroup owns `rows` image rows (64 or 128 pixels) x 64*CB output channels; its input patch ((rows + 2) x (W + 2) pixels, all
+//     Cin channels, zero halo) arrives ONCE by LDS-DMA (16-byte slots XOR-swizzled with the pixel index on the source side);
+//   * the reduction (9 * Cin) is split over KW = Cin / 64 wavefronts, the output channels over CB = 4 / KW: every wavefront keeps a
+//     64-channel x 576-deep filter slice in registers (18 K-steps x 4 channel tiles x 16 bytes per lane = 288 registers: 256 AccVGPRs +
+//     32 VGPRs), loaded once by 72 asm-issued global_load_dwordx4 that the MFMAs consume in order as they land;
+//   * a pixel fragment read from LDS feeds FOUR MFMAs (the four channel tiles): the LDS port carries half of what the matrix pipe needs
+//     (the 8x8 stage, with two MFMAs per read, runs the two level);
+//   * per group of 64 pixels the KW partial tiles meet in LDS (fixed order), each wavefront finishes 64 / KW pixels x 64 channels
+//     through the shared epilogue (bias, ReLU mask, residual, accumulate: mfma_util.h).
+// Layouts: activations [n][H][W][C] 16-bit; filters fragment-major [channel block of 64][K slice][K-step 18][channel tile 4][lane][8]
+// (rf_fragments_kernel, from the rcgan_conv_prepare row-major copies: forward rows, then the rotated data-gradient rows).
+#include <type_traits>
+
+#include "conv_mfma.h"
+#include "mfma_util.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+#if RCGAN_HALF_FP16
+#define RF_MFMA "v_mfma_f32_16x16x32_f16"
+#else
+#define RF_MFMA "v_mfma_f32_16x16x32_bf16"
+#endif
+
+struct RfArgs {
+  const bf16_t* in;        // [n][H][W][Cin]: x (forward) / dy (data gradient)
+  const bf16_t* wfrag;     // this direction's fragment-major filters
+  const float* bias;
+  const bf16_t* mask;      // data gradient under IN_RELU: the forward input whose sign gates dx
+  const bf16_t* resid;
+  bf16_t* out;
+  const bf16_t* zero;      // >= 16 zero bytes (halo source)
+  int accumulate, relu_in;
+  int H, W, lbpi, Cout;
+  int res_lw, res_lh;
+  long M;
+  unsigned long long* stamps;   // diagnostics (rcgan_debug_stamps): 16 s_memtime stamps per workgroup, normally null
+};
+
+template <int OFF> __device__ __forceinline__ void rf_load_a(i32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void rf_load_v(i32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void rf_mfma_a(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
+  asm volatile(RF_MFMA " %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x) : "memory");
+}
+__device__ __forceinline__ void rf_mfma_v(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
+  asm volatile(RF_MFMA " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x) : "memory");
+}
+// first K-step of a group: C = 0 (an inline constant) -- a VALU zero-fill in front of an MFMA the compiler cannot see misses the wait
+// states "VALU write -> MFMA SrcC read" needs: the group's first accumulator came out wrong
+__device__ __forceinline__ void rf_mfma_a0(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
+  asm volatile(RF_MFMA " %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x) : "memory");
+}
+__device__ __forceinline__ void rf_lds_read(bf16x8_t& dst, unsigned lds_byte_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_byte_addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void rf_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void rf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int I, int N, typename F> __device__ __forceinline__ void rf_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); rf_for<I + 1, N>(f); }
+}
+
+constexpr int RF_ROWS = 8;              // image rows per workgroup
+constexpr int RF_UPFRONT = 4;           // K-steps whose filter loads go out before the K loop; K-step s then issues those of K-step s + 4
+constexpr int RF_ASTEPS = 16;           // K-steps whose fragments live in AccVGPRs (4 x 4 registers each: 256); the other 2 in VGPRs
+constexpr int RF_RED = 4 * 16 * 64 * 16;   // bytes of the partial-tile exchange: 4 wavefronts x 16 tiles x 64 lanes x float4
+
+// rows [R][K] (rcgan_conv_prepare layout) -> fragment-major [block of 16*ctn rows][slice][step][tile ctn][lane 64][8]: lane (r = l & 15,
+// kc = l >> 4) of (block b, slice sl, step s, tile ct) owns row b*16*ctn + ct*16 + r, elements (sl*ss + s)*32 + kc*8 ..+8.
+struct FragItem { const bf16_t* src; bf16_t* dst; int K, ctn, ss, nsl, chunks; };
+struct FragBatch { FragItem it[40]; };
+__global__ __launch_bounds__(256) void rf_fragments_kernel(FragBatch b) {
+  const FragItem it = b.it[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= it.chunks) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int ct = rest % it.ctn; rest /= it.ctn;
+  const int s = rest % it.ss; rest /= it.ss;
+  const int sl = rest % it.nsl, blk = rest / it.nsl;
+  const int r = lane & 15, kc = lane >> 4;
+  const uint4 v = *(const uint4*)(it.src + (long)(blk * 16 * it.ctn + ct * 16 + r) * it.K + (sl * it.ss + s) * 32 + kc * 8);
+  *(uint4*)(it.dst + (long)i * 8) = v;
+}
+
+template <int CIN, int W>
+__global__ __launch_bounds__(256) void conv_rf_kernel(RfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KW = CIN / 64, CB = 4 / KW, KPT = CIN / 32, ROWB = CIN * 2, CPP = CIN / 8, PPW = 4 / KW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = wave % KW, cb = wave / KW;
+  const int r = lane & 15, kc = lane >> 4;
+  constexpr int PW = W + 2, LW = W == 16 ? 4 : 3, rows = RF_ROWS;
+  constexpr int npp = (rows + 2) * PW;
+  constexpr int patch_bytes = (npp * ROWB + 1023) / 1024 * 1024;
+  const int n = (int)blockIdx.x >> a.lbpi, r0 = ((int)blockIdx.x & ((1 << a.lbpi) - 1)) * rows;     // H / rows = 2^lbpi blocks per image
+  const long m0 = ((long)n * a.H + r0) * W;              // first output pixel of the workgroup
+  const int cbg = (int)blockIdx.y * CB + cb;             // this wavefront's 64-channel block
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+
+  // ---- the filter slice: 72 loads of one contiguous KiB each, in consumption order -------------------------------------------------
+  i32x4_t WA[RF_ASTEPS][4], WV[18 - RF_ASTEPS][4];
+  const bf16_t* const wl = a.wfrag + ((long)(cbg * KW + kq) * 18) * (4 * 512) + lane * 8;
+
+  // ---- the input patch by LDS-DMA: instruction q of the workgroup deposits 64 consecutive 16-byte slots (64 / CPP pixels) ----------
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  constexpr int ninst = (npp * CPP + 63) / 64;
+  const bf16_t* const img = a.in + (long)n * a.H * W * CIN;
+#pragma unroll
+  for (int i = 0; i < (ninst + 3) / 4; ++i) {
+    const int q = i * 4 + wave;
+    if (q < ninst) {                             // (wavefront-uniform)
+      const int c = q * 64 + lane, pp = c / CPP, sp = c % CPP;
+      const int pr = pp / PW, pc = pp - pr * PW;
+      const int ih = r0 + pr - 1, iw = pc - 1;
+      const bool ok = pp < npp && ih >= 0 && ih < a.H && iw >= 0 && iw < W;
+      const int off = ((ih * W + iw) * CIN + ((sp ^ (pp & 15)) << 3)) * 2;
+      const char* src = ok ? (const char*)img + off : (const char*)a.zero;
+      glds16_asm(src, lds0 + q * 1024);
+    }
+  }
+  // (the CU's vector-memory path moves 64 bytes per clock: the four slices are 288 KB = 2.1 us of it.  Only the first RF_UPFRONT
+  // K-steps go out here; the first group's K loop issues the rest, one K-step's four loads per K-step, RF_UPFRONT steps ahead of
+  // their use -- the stream then runs under the MFMAs.  All 72 at once: 4.2 us before the first MFMA; 48 at once: 2.9 us.)
+  auto wload = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int s = decltype(ic)::value;
+    const bf16_t* const p = wl + s * (4 * 512);
+    if constexpr (s < RF_ASTEPS) {
+      rf_load_a<0>(WA[s][0], p); rf_load_a<1024>(WA[s][1], p); rf_load_a<2048>(WA[s][2], p); rf_load_a<3072>(WA[s][3], p);
+    } else {
+      rf_load_v<0>(WV[s - RF_ASTEPS][0], p); rf_load_v<1024>(WV[s - RF_ASTEPS][1], p);
+      rf_load_v<2048>(WV[s - RF_ASTEPS][2], p); rf_load_v<3072>(WV[s - RF_ASTEPS][3], p);
+    }
+  };
+  rf_for<0, RF_UPFRONT>(wload);
+  stamp(1);
+  rf_wait<4 * RF_UPFRONT>();     // only the filter loads outstanding: every (older) patch deposit of this wavefront has landed
+  rf_barrier();
+  if (a.relu_in) {               // the input ReLU once, in place (the DMA cannot apply it; on the fragments it would sit in the K loop)
+    for (int i = tid; i < npp * CPP; i += 256) {
+      uint4 v = *(uint4*)(smem + i * 16);
+      v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
+      *(uint4*)(smem + i * 16) = v;
+    }
+    rf_barrier();
+  }
+  stamp(2);
+
+  float4* const red = (float4*)(smem + patch_bytes);
+  constexpr int groups = rows * W / 64;
+  // (the first group is its own copy of the code: its K loop issues the late filter loads UNCONDITIONALLY -- a load under an `if`
+  // would make the compiler merge "loaded" and "kept" values of registers it believes are ready the moment the asm statement ends)
+  auto group = [&](const int g, auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const unsigned lds_base = lds0;
+    // this lane's pixel of tile pt: p = g*64 + pt*16 + r -> patch pixel (p / W) * PW + p % W (+ tap offset kh * PW + kw)
+    int ppl[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int p = g * 64 + pt * 16 + r;
+      ppl[pt] = (p >> LW) * PW + (p & (W - 1));
+      asm volatile("" : "+v"(ppl[pt]));          // (opaque: the 72 fragment addresses of a group must not be hoisted and spilled)
+    }
+    f32x4_t acc[4][4];                           // [pixel tile][channel tile]; written (not accumulated) by the first K-step
+    // Pixel fragments by hand-scheduled LDS reads (the compiler, left to itself, issues a K-step's four reads right behind the MFMAs
+    // that free their registers and then computes the next addresses in front of the next MFMA batch: ~150 cycles per K-step with
+    // the matrix pipe idle, 3.2 us per group against 2.0 of MFMAs).  Order per K-step s: the four reads of K-step s + 1 (addresses
+    // ready since the previous step), wait for the four of K-step s (LDS reads return in order: at most 4 outstanding), then four
+    // blocks of four MFMAs, each followed by the address of one tile for K-step s + 2 -- six VALU instructions in the shadow of an MFMA.
+    // (every asm statement of the loop carries a "memory" clobber: that is what keeps them in SOURCE order -- without it the
+    // scheduler moved the address arithmetic back in front of the MFMA batch)
+    auto xaddr = [&](int s, int pt, unsigned& out) __attribute__((always_inline)) {
+      const int gk = kq * 18 + s, tap = gk / KPT, cq = gk % KPT;
+      const int t3 = (tap * 11) >> 5;            // tap / 3 for tap < 9
+      const int stap = t3 * PW + (tap - 3 * t3);
+      const int slotk = cq * 4 + kc;
+      unsigned tmp;
+      // pp = ppl + tap offset;  out = lds0 + pp * ROWB + ((slotk ^ (pp & 15)) << 4)
+      asm volatile("v_add_u32 %0, %2, %3\n\tv_and_b32 %1, 15, %0\n\tv_xor_b32 %1, %1, %4\n\tv_lshl_add_u32 %1, %1, 4, %5\n\tv_lshl_add_u32 %0, %0, %6, %1"
+                   : "=&v"(out), "=&v"(tmp) : "s"(stap), "v"(ppl[pt]), "v"(slotk), "s"(lds_base), "n"(CIN == 128 ? 8 : 9) : "memory");
+    };
+    unsigned ad[4];
+    bf16x8_t xf[2][4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) xaddr(0, pt, ad[pt]);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) rf_lds_read(xf[0][pt], ad[pt]);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) xaddr(1, pt, ad[pt]);
+    rf_for<0, 18>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int s = decltype(ic)::value;
+      if constexpr (s + 1 < 18) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) rf_lds_read(xf[(s + 1) & 1][pt], ad[pt]);
+      }
+      // first group: K-step s issues the loads of K-step s + RF_UPFRONT; its own fragments have landed once at most the loads of
+      // the K-steps behind it (s + 1 .. min(s + RF_UPFRONT, 17)) are outstanding
+      if constexpr (FIRST && s + RF_UPFRONT < 18) wload(std::integral_constant<int, s + RF_UPFRONT>{});
+      rf_wait<4 * ((s + RF_UPFRONT < 18 ? s + RF_UPFRONT : 17) - s)>();
+      if constexpr (s + 1 < 18) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          if constexpr (s == 0) rf_mfma_a0(acc[pt][ct], WA[s][ct], xf[s & 1][pt]);
+          else if constexpr (s < RF_ASTEPS) rf_mfma_a(acc[pt][ct], WA[s][ct], xf[s & 1][pt]);
+          else rf_mfma_v(acc[pt][ct], WV[s - RF_ASTEPS][ct], xf[s & 1][pt]);
+        }
+        if constexpr (s + 2 < 18) xaddr(s + 2, ct, ad[ct]);      // five VALU instructions in the shadow of the block's last MFMA
+      }
+    });
+    // ---- the KW partial tiles meet in LDS: slice order, every wavefront finishes its PPW pixel tiles x 4 channel tiles -------------
+    stamp(3 + 3 * g);
+    // (MFMA results read by non-MFMA instructions: the asm MFMAs are invisible to the compiler's hazard recogniser)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        red[(wave * 16 + pt * 4 + ct) * 64 + lane] = make_float4(acc[pt][ct][0], acc[pt][ct][1], acc[pt][ct][2], acc[pt][ct][3]);
+    rf_barrier();
+    f32x4_t fin[4][PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int pt = kq * PPW + j;
+        float4 sum = red[((cb * KW) * 16 + pt * 4 + ct) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < KW; ++q) {
+          const float4 v = red[((cb * KW + q) * 16 + pt * 4 + ct) * 64 + lane];
+          sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        fin[ct][j] = (f32x4_t){sum.x, sum.y, sum.z, sum.w};
+      }
+    rf_barrier();                                // the exchange buffer is free for the next group
+    stamp(4 + 3 * g);
+    conv_epilogue<4, PPW>(fin, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + g * 64 + kq * PPW * 16, cbg * 64, lane,
+                          RowIdent(), a.res_lw, a.res_lh);
+    stamp(5 + 3 * g);
+  };
+  group(0, std::true_type{});
+#pragma unroll 1
+  for (int g = 1; g < groups; ++g) group(g, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CIN, int W>
+int rf_launch(rcgan_ctx* ctx, const RfArgs& a, int n_img) {
+  constexpr int npp = (RF_ROWS + 2) * (W + 2);
+  const size_t lds = (size_t)((npp * CIN * 2 + 1023) / 1024 * 1024) + RF_RED;
+  static size_t attr = 0;
+  if (lds > attr) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_rf_kernel<CIN, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  constexpr int CB = 4 / (CIN / 64);
+  dim3 grid(n_img * (a.H / RF_ROWS), a.Cout / (64 * CB));
+  hipLaunchKernelGGL((conv_rf_kernel<CIN, W>), grid, dim3(256), lds, ctx->stream, a);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+bool rf_takes(const rcgan_conv_desc* d) {
+  if (!d || d->dtype != RCGAN_H16 || d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
+  if (d->flags & ~(RCGAN_CONV_IN_RELU | RCGAN_CONV_ACCUMULATE)) return false;
+  if (!(d->cin == 128 && d->cout == 128)) return false;
+  if (!((d->w == 16 && d->h == 16) || (d->w == 8 && d->h == 8))) return false;
+  return (long)d->n * d->h * d->w * d->cin < (1L << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcgan_conv_rf_ok(const rcgan_conv_desc* d) { return rf_takes(d) ? 1 : 0; }
+
+// bytes of one filter's fragment-major copy: forward fragments, then the data gradient's
+size_t rcgan_conv_rf_fragment_bytes(const rcgan_conv_desc* d) {
+  return d ? (size_t)2 * d->kh * d->kw * d->cin * d->cout * sizeof(bf16_t) : 0;
+}
+
+// prepared[i]: filter i in the rcgan_conv_prepare layout of descs[i] (forward rows, then the rotated data-gradient rows).
+// ONE launch writes every frags[i].
+int rcgan_conv_rf_prepare(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* prepared, void* const* frags) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, n >= 0 && (n == 0 || (descs && prepared && frags)), "bad arguments");
+  for (int i0 = 0; i0 < n; i0 += 20) {
+    FragBatch b;
+    const int m = n - i0 < 20 ? n - i0 : 20;
+    int maxchunks = 0;
+    for (int i = 0; i < m; ++i) {
+      const rcgan_conv_desc* d = descs + i0 + i;
+      RC_REQUIRE(ctx, rf_takes(d) && prepared[i0 + i] && frags[i0 + i], "filter %d: not a register-filter shape / null pointer", i0 + i);
+      const long elems = 9L * d->cin * d->cout;
+      for (int dir = 0; dir < 2; ++dir) {
+        const int K = 9 * (dir ? d->cout : d->cin), nsl = (dir ? d->cout : d->cin) / 64;     // reduction length / slices of this direction
+        FragItem& it = b.it[2 * i + dir];
+        it.src = (const bf16_t*)prepared[i0 + i] + dir * elems;
+        it.dst = (bf16_t*)frags[i0 + i] + dir * elems;
+        it.K = K; it.ctn = 4; it.ss = 18; it.nsl = nsl; it.chunks = (int)(elems / 8);
+        if (it.chunks > maxchunks) maxchunks = it.chunks;
+      }
+    }
+    hipLaunchKernelGGL(rf_fragments_kernel, dim3(cdiv(maxchunks, 256), 2 * m), dim3(256), 0, ctx->stream, b);
+    RC_LAUNCH_CHECK(ctx);
+  }
+  return RCGAN_OK;
+}
+
+// The fragment-major copies of a critic step in ONE launch: the 8x8 stage's (what rcgan_dtrunk_prepare writes: trunk_prepared = its
+// eight prepared filters in forward order, or NULL) and n register-filter layers' (what rcgan_conv_rf_prepare writes).
+int rcgan_fragments_prepare(rcgan_ctx* ctx, const void* const* trunk_prepared, void* trunk_frag, int n, const rcgan_conv_desc* descs,
+                            const void* const* prepared, void* const* frags) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, n >= 0 && n <= 12 && (n == 0 || (descs && prepared && frags)) && (!trunk_prepared || trunk_frag), "bad arguments");
+  FragBatch b;
+  int m = 0, maxchunks = 0;
+  if (trunk_prepared) {
+    const long elems = 9L * 128 * 128;
+    for (int i = 0; i < 8; ++i) {
+      RC_REQUIRE(ctx, trunk_prepared[i], "stage layer %d: null pointer", i);
+      // forward pass: layers first to last; backward pass: last to first, the rotated rows (the layout conv_trunk.hip reads)
+      b.it[m++] = FragItem{(const bf16_t*)trunk_prepared[i], (bf16_t*)trunk_frag + i * elems, 1152, 2, 36, 1, (int)(elems / 8)};
+      b.it[m++] = FragItem{(const bf16_t*)trunk_prepared[7 - i] + elems, (bf16_t*)trunk_frag + (8 + i) * elems, 1152, 2, 36, 1, (int)(elems / 8)};
+    }
+    maxchunks = (int)(elems / 8);
+  }
+  for (int i = 0; i < n; ++i) {
+    const rcgan_conv_desc* d = descs + i;
+    RC_REQUIRE(ctx, rf_takes(d) && prepared[i] && frags[i], "filter %d: not a register-filter shape / null pointer", i);
+    const long elems = 9L * d->cin * d->cout;
+    for (int dir = 0; dir < 2; ++dir) {
+      const int kc = dir ? d->cout : d->cin;
+      b.it[m++] = FragItem{(const bf16_t*)prepared[i] + dir * elems, (bf16_t*)frags[i] + dir * elems, 9 * kc, 4, 18, kc / 64, (int)(elems / 8)};
+    }
+    if ((int)(elems / 8) > maxchunks) maxchunks = (int)(elems / 8);
+  }
+  if (m == 0) return RCGAN_OK;
+  hipLaunchKernelGGL(rf_fragments_kernel, dim3(cdiv(maxchunks, 256), m), dim3(256), 0, ctx->stream, b);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// backward = 0: y = conv2d_SAME(x)(+bias)(+residual), input ReLU under RCGAN_CONV_IN_RELU.
+// backward = 1: x = dy, y = dx (masked by mask_x > 0 under RCGAN_CONV_IN_RELU; += under RCGAN_CONV_ACCUMULATE; + residual).
+int rcgan_conv2d_rf(rcgan_ctx* ctx, const rcgan_conv_desc* d, int backward, const void* x, const void* frag, const float* bias,
+                    const void* mask_x, const void* residual, void* y) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, rf_takes(d), "not a register-filter shape (rcgan_conv_rf_ok)");
+  RC_REQUIRE(ctx, x && frag && y, "null argument");
+  const bool bwd = backward & 1;
+  RC_REQUIRE(ctx, !(bwd && (d->flags & RCGAN_CONV_IN_RELU)) || mask_x, "the data gradient under IN_RELU needs the forward input");
+  RfArgs a;
+  a.in = (const bf16_t*)x;
+  a.wfrag = (const bf16_t*)frag + (bwd ? (size_t)9 * d->cin * d->cout : 0);
+  a.bias = bwd ? nullptr : bias;
+  a.mask = (bwd && (d->flags & RCGAN_CONV_IN_RELU)) ? (const bf16_t*)mask_x : nullptr;
+  a.resid = (const bf16_t*)residual;
+  a.out = (bf16_t*)y;
+  a.zero = (const bf16_t*)ctx->zero_page;
+  a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  a.relu_in = (!bwd && (d->flags & RCGAN_CONV_IN_RELU)) ? 1 : 0;
+  a.H = d->h; a.W = d->w; a.lbpi = ilog2_exact(d->h / RF_ROWS); a.Cout = bwd ? d->cin : d->cout;
+  a.res_lw = -1; a.res_lh = 0;
+  a.M = (long)d->n * d->h * d->w;
+  a.stamps = (unsigned long long*)ctx->dbg_stamps;
+  const int cin_k = bwd ? d->cout : d->cin;          // channels of the tensor the launch reads
+  if (cin_k == 128 && d->w == 16) return rf_launch<128, 16>(ctx, a, d->n);
+  if (cin_k == 128 && d->w == 8) return rf_launch<128, 8>(ctx, a, d->n);
+  RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "register-filter kernel: %d input channels", cin_k);
+}
+
+}  // extern "C"

@@ -100,6 +100,11 @@ __device__ __forceinline__ void trw_load2_v(uint2& dst, const void* p) { asm vol
 __device__ __forceinline__ void trw_mfma_a(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
   asm volatile(TRW_MFMA " %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
 }
+// first K-step of a layer: C = 0 as an inline constant instead of a VALU zero-fill of the accumulators -- the compiler cannot see these
+// MFMAs, so it cannot insert the wait states "VALU write -> MFMA SrcC read" needs (conv_rf.hip lost a tile to exactly that)
+__device__ __forceinline__ void trw_mfma_a0(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
+  asm volatile(TRW_MFMA " %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+}
 __device__ __forceinline__ void trw_mfma_v(f32x4_t& acc, const i32x4_t& w, const bf16x8_t& x) {
   asm volatile(TRW_MFMA " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
 }
@@ -218,11 +223,7 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
     // the filters of the next layer replace this layer's as they are consumed (past the last layer: a harmless re-read of its own,
     // so that the count of operations in flight is the same in every layer)
     const bf16_t* const wnext = a.w[L + 1 < TR_LAYERS ? L + 1 : L] + wlane;
-    f32x4_t acc[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[2][4];                    // written (not accumulated) by the first K-step
     float4 b4[2];
     uint2 mk[2][4];
     if (!BWD) {
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) void conv_trunk_rw_kernel(TrunkArgs a) {
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-          if constexpr (s < TRW_ASTEPS) trw_mfma_a(acc[ct][pt], WA[s][ct], xf[s & 1][pt]);
+          if constexpr (s == 0) trw_mfma_a0(acc[ct][pt], WA[s][ct], xf[s & 1][pt]);
+          else if constexpr (s < TRW_ASTEPS) trw_mfma_a(acc[ct][pt], WA[s][ct], xf[s & 1][pt]);
           else trw_mfma_v(acc[ct][pt], WV[s - TRW_ASTEPS][ct], xf[s & 1][pt]);
         }
 #if !(TRW_ABLATE & 2)

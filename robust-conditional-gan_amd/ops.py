@@ -57,6 +57,7 @@ class Weight:
     def __init__(self, ctx, param, sigma=None):
         self.ctx, self.param, self.sigma = ctx, param, sigma
         self._prepared = {}
+        self.rf_frag = None        # fragment-major copy for the register-filter kernel (fragments_batch), this step's
         self.dwbar = None
 
     @property
@@ -134,6 +135,31 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
             return True
         ctx.check(ctx.lib.rcgan_conv_prepare_batch(ctx.h, arr, len(todo)))
     return False
+
+
+RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
+
+
+def fragments_batch(ctx, trunk, rf):
+    """ONE launch writes every fragment-major filter copy of a step (rcgan_fragments_prepare): trunk = the 8x8 stage's eight Weights in
+    forward order (or None) -> returns its fragment buffer (ops.d_trunk(frag=...)); rf = [(Weight, desc)] of the layers the
+    register-filter kernel takes -> each Weight gets .rf_frag.  All filters must be prepared already (prepare_batch)."""
+    tp = tf = None
+    if trunk:
+        tdesc = L.ConvDesc(1, 8, 8, 128, 128, 3, 3, 1, ctx.act_dtype, L.CONV_IN_RELU)
+        tp = (C.c_void_p * 8)(*[w.prepared(tdesc).ptr for w in trunk])
+        nb = ctx.lib.rcgan_dtrunk_fragment_bytes()
+        tf = DT(ctx.arena.alloc(nb), (nb,), "u8", ctx.arena.buf)
+    n = len(rf)
+    descs = (L.ConvDesc * max(n, 1))(*[d for _, d in rf])
+    preps = (C.c_void_p * max(n, 1))(*[w.prepared(d).ptr for w, d in rf])
+    frags = []
+    for w, d in rf:
+        nb = ctx.lib.rcgan_conv_rf_fragment_bytes(C.byref(d))
+        w.rf_frag = DT(ctx.arena.alloc(nb), (nb,), "u8", ctx.arena.buf)
+        frags.append(w.rf_frag.ptr)
+    ctx.check(ctx.lib.rcgan_fragments_prepare(ctx.h, tp, _p(tf), n, descs, preps, (C.c_void_p * max(n, 1))(*frags)))
+    return tf
 
 
 def spectral_norm_batch(ctx, entries):
@@ -231,6 +257,9 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     else:
         y = ctx.empty((n, oh, ow, cout), x.dtype)
         fdesc = desc
+    # the register-filter kernel (conv_rf.hip) for the small-grid 3x3 layers it takes, when this step's fragment-major copy exists
+    use_rf = (RF_CONV and weight.rf_frag is not None and residual is None and not in_up and not force_direct
+              and bool(ctx.lib.rcgan_conv_rf_ok(C.byref(fdesc))))
     sdesc = None
     if want_stats and FUSE_BN_STATS and accumulate_into is None and not in_relu and x.dtype != L.F32:
         sd = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_RESID_UPSAMPLE2X if (residual is not None and residual_up) else 0))
@@ -253,6 +282,8 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     elif residual is not None:
         assert residual.shape == (n, oh, ow, cout) and accumulate_into is None, (residual.shape, (n, oh, ow, cout))
         ctx.check(ctx.lib.rcgan_conv2d_fwd_residual(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(residual), _p(y)))
+    elif use_rf:
+        ctx.check(ctx.lib.rcgan_conv2d_rf(ctx.h, C.byref(fdesc), 0, _p(x), _p(weight.rf_frag), _p(bias), None, None, _p(y)))
     else:
         ctx.check(ctx.lib.rcgan_conv2d_fwd(ctx.h, C.byref(fdesc), _p(x), _p(prep), _p(bias), _p(y)))
     prev_req = y.req if accumulate_into is not None else False
@@ -295,8 +326,11 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
             elif xr:
                 dx, acc = grad_of(ctx, x)
                 d2 = L.ConvDesc(n, h, w, cin, cout, k, k, stride, x.dtype, flags | (L.CONV_ACCUMULATE if acc else 0))
-                ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
-                                                        _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                if use_rf and ctx.lib.rcgan_conv_rf_ok(C.byref(d2)):
+                    ctx.check(ctx.lib.rcgan_conv2d_rf(ctx.h, C.byref(d2), 1, _p(dy), _p(weight.rf_frag), None, _p(x) if in_relu else None, None, _p(dx)))
+                else:
+                    ctx.check(ctx.lib.rcgan_conv2d_bwd_data(ctx.h, C.byref(d2), _p(dy), _p(prep), _p(x) if in_relu else None,
+                                                            _p(dx), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
             if fork:
                 ctx.check(ctx.lib.rcgan_side_join(ctx.h))
             if residual is not None and residual.req and residual_up:
@@ -384,7 +418,7 @@ def d_trunk_ok(ctx, x):
     return x.dtype != L.F32 and tuple(x.shape[1:]) == (8, 8, 128)
 
 
-def d_trunk(ctx, x, blocks, pool=None):
+def d_trunk(ctx, x, blocks, pool=None, frag=None):
     """D.Block.3 .. D.Block.6 of the CIFAR discriminator -- four identity-shortcut residual blocks
     x' = x + Conv2(relu(Conv1(relu(x)))) (gan_resnet.py:275-328 with resample=None, :398-404) -- as ONE launch each way
     (rcgan_dtrunk): a workgroup carries one image through all eight 3x3 convolutions with the activations in LDS.
@@ -403,8 +437,9 @@ def d_trunk(ctx, x, blocks, pool=None):
     preps = [w.prepared(desc) for w, _ in flat]
     outs = [ctx.empty(x.shape, x.dtype) for _ in range(8)]
     # the stage's filters re-laid fragment-major, both directions, once per set of weights (the arena keeps it until the backward pass)
-    frag = DT(ctx.arena.alloc(ctx.lib.rcgan_dtrunk_fragment_bytes()), (ctx.lib.rcgan_dtrunk_fragment_bytes(),), "u8", ctx.arena.buf)
-    ctx.check(ctx.lib.rcgan_dtrunk_prepare(ctx.h, arr(preps), _p(frag)))
+    if frag is None:           # (the CIFAR step writes it with the other fragment copies: fragments_batch)
+        frag = DT(ctx.arena.alloc(ctx.lib.rcgan_dtrunk_fragment_bytes()), (ctx.lib.rcgan_dtrunk_fragment_bytes(),), "u8", ctx.arena.buf)
+        ctx.check(ctx.lib.rcgan_dtrunk_prepare(ctx.h, arr(preps), _p(frag)))
     feat = ctx.empty((n, 128), L.F32) if pool is not None else None
     ctx.check(ctx.lib.rcgan_dtrunk_pooled(ctx.h, n, 0, _p(x), _p(frag), arr([b for _, b in flat]), None, arr(outs), _p(feat), None, None))
     y = outs[7]

@@ -53,6 +53,7 @@ class Graph:
         # label embeddings): a later forward-only pass must not pick up a previous step's tensors
         self.image_pool = None
         self.head_E = None
+        self.trunk_frag = None
         # data-parallel steps: closures the model functions record on the tape where the LAST layers' gradients are complete in the
         # backward pass (Discriminator: in front of D.Block.3; Generator: in front of G.Block.2) -- they finish that bucket and hand it
         # to the all-reduce while the earlier layers' backward still runs (cifar.CifarRCGAN._dp_early)

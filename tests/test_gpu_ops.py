@@ -498,6 +498,54 @@ def test_d_trunk_pooled_boundary(dev, n, kind_a, kind_b):
         assert rel_err(a[k], b[k]) < 1e-5, (k, rel_err(a[k], b[k]))
 
 
+@pytest.mark.parametrize("n,hw,in_relu,second", [(3, 16, True, False), (128, 16, True, True), (5, 8, True, False), (4, 16, False, True)])
+def test_register_filter_conv_equals_tile_kernels(dev, n, hw, in_relu, second):
+    """rcgan_conv2d_rf (csrc/conv_rf.hip: filter slices in registers, input patch resident in LDS, K split over the wavefronts) through
+    ops.conv2d against the tile-per-tap kernels: forward (+bias, input ReLU), data gradient (ReLU mask; `second`: accumulated onto an
+    existing gradient) and the float64 oracle of the forward values.  Same 16-bit inputs and rounding points: fp32 summation order only."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    from tests.gpu_util import rel_err
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the register-filter kernel runs on 16-bit activations")
+    rs = np.random.RandomState(n + hw)
+    x = _prep(rs.randn(n, hw, hw, 128), mode)
+    wv = (rs.randn(3, 3, 128, 128) / np.sqrt(9 * 128) * 1.2).astype(np.float32)
+    bv = (0.1 * rs.randn(128)).astype(np.float32)
+    dy = _prep(rs.randn(n, hw, hw, 128), mode)
+    g0 = _prep(rs.randn(n, hw, hw, 128), mode)
+    res = {}
+    for rf in (True, False):
+        ctx.new_step()
+        xd = ctx.upload(x); xd.req = True
+        if second:
+            xd.grad = ctx.upload(g0)
+        pw, pb = FakeParam(ctx, wv), FakeParam(ctx, bv)
+        W = O.Weight(ctx, pw.t, ctx.upload(np.array([1.3], np.float32), L.F32))
+        desc = L.ConvDesc(n, hw, hw, 128, 128, 3, 3, 1, xd.dtype, L.CONV_IN_RELU if in_relu else 0)
+        W.prepared(desc)
+        if rf:
+            assert ctx.lib.rcgan_conv_rf_ok(C.byref(desc))
+            O.fragments_batch(ctx, None, [(W, desc)])
+            assert W.rf_frag is not None
+        y = O.conv2d(ctx, xd, W, pb.t, 3, in_relu=in_relu)
+        out = ctx.download(y)
+        y.grad = ctx.upload(dy)
+        ctx.backward()
+        res[rf] = dict(y=out, dx=ctx.download(xd.grad), dw=ctx.download(W.dwbar), db=pb.grad(ctx))
+    a, b = res[True], res[False]
+    assert_close(a["y"], b["y"], TOL[mode], "register-filter forward vs tile kernel")
+    assert rel_err(a["y"], b["y"]) < 2e-4, rel_err(a["y"], b["y"])
+    assert rel_err(a["dx"], b["dx"]) < 2e-4, rel_err(a["dx"], b["dx"])
+    assert np.array_equal(a["dw"], b["dw"]) and np.array_equal(a["db"], b["db"])          # same inputs, same filter-gradient kernel
+    if n <= 8:
+        q = lambda v: half_round(mode, v).astype(np.float64)
+        xin = np.maximum(x.astype(np.float64), 0) if in_relu else x.astype(np.float64)
+        ref = q(nn.conv2d_fwd(xin, q(wv / np.float32(1.3))) + bv)
+        assert_close(a["y"], ref, TOL[mode] * 3, "register-filter forward vs oracle")
+
+
 HEAD_CASES = [
     # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
     (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
