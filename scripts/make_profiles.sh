@@ -36,6 +36,7 @@ cd "$ROOT"
 python3 scripts/bench_conv.py > "$OUT/microbench_conv.txt" 2>&1
 python3 scripts/bench_bn.py 128 > "$OUT/microbench_bn.txt" 2>&1
 python3 scripts/bench_trunk.py 128 > "$OUT/microbench_trunk.txt" 2>&1
+STAMPS=1 python3 scripts/bench_rf.py 128 > "$OUT/microbench_rf.txt" 2>&1
 python3 scripts/exp_p8_fixed_cost.py > "$OUT/exp_p8_fixed_cost.txt" 2>&1
 python3 scripts/exp_p8_timeline.py 320 256 3 > "$OUT/exp_p8_timeline.txt" 2>&1
 python3 scripts/step_times.py > "$OUT/step_times.txt" 2>&1
@@ -49,7 +50,13 @@ python3 bench.py --no-cpu-baseline --algorithm rcgan-u > "$OUT/bench_rcganu.json
 python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8.json" 2> /dev/null
 RCGAN_DP_OVERLAP=1 python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8_overlap.json" 2> /dev/null
 RCGAN_FUSE_BN_STATS=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_fuse_bn_stats.json" 2> /dev/null
+RCGAN_HEAD_RIDERS=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_head_riders.json" 2> /dev/null
+RCGAN_POOL_IN_TRUNK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_pool_in_trunk.json" 2> /dev/null
+RCGAN_RF_CONV=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_rf_conv.json" 2> /dev/null
+RCGAN_FUSED_TRUNK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_fused_trunk.json" 2> /dev/null
 python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_smooth.txt" 2>&1
 RCGAN_BENCH_IMAGES=uniform python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_uniform.txt" 2>&1
 [ -x scripts/probes/_bin/epilogue_store ] && ./scripts/probes/_bin/epilogue_store > "$OUT/probe_epilogue_store.txt" 2>&1
+[ -x scripts/probes/_bin/filter_fetch ] && ./scripts/probes/_bin/filter_fetch > "$OUT/probe_filter_fetch.txt" 2>&1
+[ -x scripts/probes/_bin/lds_dma_fetch ] && ./scripts/probes/_bin/lds_dma_fetch > "$OUT/probe_lds_dma_fetch.txt" 2>&1
 ls -la "$OUT"

@@ -10,6 +10,8 @@ c $R/bench_n1_kernel_stats.csv ${P}_bench_n1_kernel_stats.csv
 c $R/exp_p8_fixed_cost.txt ${P}_exp_p8_fixed_cost.txt
 c $R/exp_p8_timeline.txt ${P}_exp_p8_timeline.txt
 c $R/probe_epilogue_store.txt ${P}_probe_epilogue_store.txt
+c $R/probe_filter_fetch.txt ${P}_probe_filter_fetch.txt
+c $R/probe_lds_dma_fetch.txt ${P}_probe_lds_dma_fetch.txt
 python3 scripts/pmc_traffic_json.py $R/pmc_FETCH_SIZE_conv_p8.txt $R/pmc_WRITE_SIZE_conv_p8.txt ${P}_pmc_traffic_conv_p8.json > /dev/null
 python3 scripts/pmc_busy_table.py $R/pmc_mfma_busy_raw.txt > ${P}_pmc_mfma_busy.txt
 F=${P}_microbench.txt
@@ -17,11 +19,12 @@ g() { if [ -f "$1" ]; then grep -v "amdgpu.ids" "$1"; else echo "(not collected 
 echo "# scripts/bench_conv.py 64  (HIP events, 20 launches each, eager; n = 2B = 128 unless noted; every layer as the reference poses it -- the up blocks' shortcuts at full resolution, D.Block.1/2.Conv2 without their pool)" > $F; g $R/microbench_conv.txt >> $F
 echo "# scripts/bench_bn.py 128  (conditional batch norm entry points, bf16: statistics / apply+ReLU / backward = 2 launches)" >> $F; g $R/microbench_bn.txt >> $F
 echo "# scripts/bench_trunk.py 128  (the fused 8x8 stage, RCGAN_FUSED_TRUNK, against its eight launches)" >> $F; g $R/microbench_trunk.txt >> $F
+echo "# STAMPS=1 scripts/bench_rf.py 128  (the register-filter convolution, rcgan_conv2d_rf, against the tile-per-tap kernels; per-workgroup s_memtime segments)" >> $F; g $R/microbench_rf.txt >> $F
 echo "# scripts/step_times.py  (HIP-graph replays, B = 64)" >> $F; g $R/step_times.txt >> $F
 echo "# scripts/bench_mnist.py 256 f32" >> $F; g $R/bench_mnist.txt >> $F
 echo "# scripts/bench_wgrad_group.py  (rcgan_conv2d_bwd_weight_group on the critic step's layer set as PLAIN 3x3 layers, n = 128; grouped launches + grouped reduction)" >> $F; g $R/wgrad_group.txt >> $F
 echo "# python bench.py --no-cpu-baseline --batch 512 --steps 8 | --dtype f16 | --algorithm rcgan-u   (ms per iteration, images/s, sustained TFLOP/s at the reference's FLOP count, dominant kernel: fraction of peak at the reference's count / executed)" >> $F
-for f in b512 f16 f16_b512 rcganu dpstub8 dpstub8_overlap fuse_bn_stats; do [ -s $R/bench_$f.json ] && python3 -c "
+for f in b512 f16 f16_b512 rcganu dpstub8 dpstub8_overlap fuse_bn_stats no_head_riders no_pool_in_trunk no_rf_conv no_fused_trunk; do [ -s $R/bench_$f.json ] && python3 -c "
 import json
 d=json.load(open('$R/bench_$f.json')); print('%-16s %8.3f ms %10.1f img/s %8.1f TFLOP/s   %.3f / %.3f' % ('$f', d['ms_per_step'], d['value'], d['config']['sustained_tflops'], d['roofline']['frac'], d['roofline']['executed_frac']))" >> $F; done
 echo "# scripts/exp_bench_data.py 60 32: d_loss / g_loss of the bench workload, smooth class-conditional images (default) vs uniform noise (rounds 1-2)" >> $F
@@ -33,7 +36,7 @@ its=24
 cat={}
 def c(n):
     if 'wgrad' in n or 'slab_reduce' in n: return 'filter gradients (+ slab reduction)'
-    if 'conv_mfma' in n: return 'MFMA convolutions fwd/dgrad'
+    if 'conv_mfma' in n or 'conv_trunk' in n or 'conv_rf' in n: return 'MFMA convolutions fwd/dgrad'
     if 'bn_' in n: return 'batch norm'
     if 'conv_img' in n: return 'image-end convolutions'
     if 'prepare' in n or n.startswith('sn_'): return 'spectral norm + filter preparation (+ riders)'
