@@ -15,7 +15,7 @@ for path in sys.argv[2:]:
                       (flt,)).fetchall()
     last = None
     for r in rows:
-        key = (re.sub(r"^void ", "", re.sub(r"\(.*", "", r[0]))[:60], r[1], r[2], r[3])
+        key = (re.sub(r"^void ", "", re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "")))[:60], r[1], r[2], r[3])
         if key != last:
             print("%s grid %s (%d dispatches)" % (key[0], key[1:], r[6]))
             last = key

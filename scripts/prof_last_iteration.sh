@@ -11,7 +11,7 @@ print(cols)
 gc = [c for c in cols if 'grid' in c.lower() or 'workgroup' in c.lower()]
 rows = db.execute("select name, start, end, %s from kernels order by start" % ",".join(gc)).fetchall()[-269:]
 for i, r in enumerate(rows):
-    n = re.sub(r"\(.*", "", r[0]); n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "")); n = re.sub(r"^void ", "", n)
     print(i, "%.1f" % ((r[2]-r[1])/1e3), n[:70], r[3:])
 PY
 rm -rf $R/gpurun_out/seq_kt

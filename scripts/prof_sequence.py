@@ -18,7 +18,7 @@ def main():
     t0 = rows[0][1]
     prev_end = t0
     for i, (name, s, e) in enumerate(rows):
-        n = re.sub(r"\(.*", "", name)
+        n = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
         n = re.sub(r"^void ", "", n)
         line = "%4d %9.1f us  dur %7.1f  gap %6.1f  %s" % (i, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, n[:90])
         if flt is None or flt in n:

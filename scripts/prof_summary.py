@@ -21,7 +21,7 @@ def main():
     print("total kernel time %.3f ms (%.3f ms / iteration), %d launches / iteration" %
           (tot / 1e6, tot / 1e6 / iters, sum(r[1] for r in rows) / iters))
     for r in rows:
-        n = re.sub(r"\(.*", "", r[0])
+        n = re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", ""))
         if out:
             out.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n, r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
         print("%-72s %7.1f /it %9.3f ms/it %8.1f us %5.1f%%" % (n[:72], r[1] / iters, r[2] / 1e6 / iters, r[3] / 1e3, 100 * r[2] / tot))

@@ -29,7 +29,7 @@ def main():
         if full:
             for prev, r in zip([None] + g[:-1], g):
                 gap = (r[1] - prev[2]) / 1e3 if prev else 0.0
-                print("      %-60s %8.1f us  gap %6.1f" % (re.sub(r"\(.*", "", r[0])[:60], (r[2] - r[1]) / 1e3, gap))
+                print("      %-60s %8.1f us  gap %6.1f" % (re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", ""))[:60], (r[2] - r[1]) / 1e3, gap))
 
 
 if __name__ == "__main__":
