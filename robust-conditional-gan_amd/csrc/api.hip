@@ -404,6 +404,7 @@ int rcgan_graph_abort(rcgan_ctx* ctx) {
   if (!ctx) return RCGAN_EINVALID_ARG;
   if (!ctx->capturing) return RCGAN_OK;
   ctx->capturing = false;
+  ctx->head_stage = 0;           // (deferred launches recorded into the dropped capture never ran; their buffers belong to the aborted step)
   hipGraph_t g = nullptr;
   (void)hipStreamEndCapture(ctx->stream, &g);
   if (g) (void)hipGraphDestroy(g);

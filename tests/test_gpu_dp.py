@@ -44,7 +44,7 @@ def _feeds(rs, B, n_iter, alg):
     return its
 
 
-def _run_iterations(m, its, grads_after_first=None):
+def _run_iterations(m, its, grads_after_first=None, losses_after_first=None):
     """The production loop (bench.py / train_cifar.py): prepare_critic_fakes + N_CRITIC critic steps + a generator step."""
     for it, (lra, ds, g) in enumerate(its):
         m.set_feed("gf", m.pack_feed("gf", labels_random_all=lra))
@@ -56,6 +56,8 @@ def _run_iterations(m, its, grads_after_first=None):
                 grads_after_first.update(m.get_grads(m.PD))
         m.set_feed("g", m.pack_feed("g", **g))
         m.g_step(iteration=it + 1)
+        if losses_after_first is not None and it == 0:
+            losses_after_first.append(m.losses())
     m.ctx.sync()
     return m.get_params(), m.losses(), m.get_state()
 
@@ -153,17 +155,19 @@ def test_stub_world_with_early_bucket_matches_single_rank(alg, dtype, monkeypatc
         m = _model(alg, dtype, B, world_size=w, comm=("stub" if w > 1 else None))
         try:
             assert m.dp_overlap == (w > 1)
-            g1 = {}
-            outs.append(_run_iterations(m, its, g1) + (g1,))
+            g1, l1 = {}, []
+            outs.append(_run_iterations(m, its, g1, l1) + (g1, l1[0]))
         finally:
             m.ctx.close()
-    (pa, la, sa, ga), (pb, lb, sb, gb) = outs
+    (pa, _, sa, ga, la), (pb, _, sb, gb, lb) = outs
     gmax = max(float(np.abs(v).max()) for v in ga.values())
     for k in ga:
         if float(np.abs(ga[k]).max()) > 1e-3 * gmax:
             assert rel_err(gb[k], ga[k]) <= 2e-5, ("gradient of the first critic step", k, rel_err(gb[k], ga[k]))
     _same_trajectory(pa, pb)
-    assert abs(la[0] - lb[0]) <= 2e-2 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) <= 2e-2 * max(1.0, abs(la[1])), (la, lb)
+    # losses after the FIRST iteration (six optimiser steps): at B = 8 the second iteration's losses of two bf16 runs that differ in
+    # summation order already sit 0.1-0.9 apart (rcgan-u, scripts/probes/dp_overlap_check.py), whichever kernels run
+    assert abs(la[0] - lb[0]) <= 5e-3 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) <= 5e-3 * max(1.0, abs(la[1])), (la, lb)
 
 
 @pytest.mark.parametrize("overlap", ["0", "1"])
