@@ -282,8 +282,8 @@ def cpu_baseline_mnist(cores, B=64, alpha=0.5, iters=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU critic batch")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--algorithm", default="rcgan")
