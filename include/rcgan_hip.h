@@ -179,6 +179,16 @@ int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, co
                      const float* bias /* or NULL */, void* y);
 /* y = conv2d_SAME(x, w) (+bias) + residual: the pre-activation residual sum `shortcut + output` of
  * gan_resnet.py:328 folded into the convolution's epilogue.  residual: [n, oh, ow, cout] or NULL, must not alias y. */
+/* y = conv2d_SAME(act(batch_norm(x))) (+bias) with the (conditional) batch norm + activation of cond_batchnorm / nonlinearity
+ * (normalization.py:27-59, gan_resnet.py:350-352) applied to the convolution's staged input instead of being written out and read back:
+ * for a forward-only pass (the critic steps' generator forwards) the normalised tensor never exists.  x: the batch norm's INPUT;
+ * mean / rstd [segments][cin] from rcgan_bn_fwd_segments(..., y = NULL) (statistics only) or rcgan_bn_stats; gamma / beta [n_labels][cin];
+ * labels [n] or NULL.  Same values as rcgan_bn_apply_* followed by rcgan_conv2d_fwd (the affine is evaluated in the same fp32
+ * sequence and rounded to 16 bits at the same point).  rcgan_conv_bn_in_ok: the small-output image-end layers (G.Output: 256 -> 3). */
+int rcgan_conv_bn_in_ok(const rcgan_conv_desc* d);
+int rcgan_conv2d_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
+                        int segments, const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        int act);
 int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
                               const float* bias /* or NULL */, const void* residual /* or NULL */, void* y);
 /* dx = d(conv)/dx.  With IN_RELU, dx is masked by x>0 (x = the pre-activation input).  With

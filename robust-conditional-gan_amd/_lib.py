@@ -118,6 +118,8 @@ SIGNATURES = {
     "rcgan_conv_prepare_batch_riders": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc), C.POINTER(StepInputsDesc)]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
+    "rcgan_conv_bn_in_ok": (I, [DP]),
+    "rcgan_conv2d_fwd_bn": (I, [P, DP, P, P, P, P, I, P, P, P, P, P, I]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),
     "rcgan_conv_resid_up_ok": (I, [DP]),
     "rcgan_conv_wgrad_pool_ok": (I, [DP]),

@@ -251,7 +251,10 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels, segments)
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels, segments)
         with variable_scope('G.OutputNorm'):
-            output = cond_batchnorm('G.OutputNorm', [0, 1, 2], output, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
+            # (forward-only passes -- the critic steps' generator forwards, sampling: the affine + ReLU are applied inside G.Output's
+            # launch, the normalised tensor is never written: ops.BnPending)
+            output = cond_batchnorm('G.OutputNorm', [0, 1, 2], output, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments,
+                                    _defer_apply=True)
         output = Conv2D(output, DIM_G * 2, IMG_DIM, 3, 1, 'G.Output', he_init=False)
         output = O.act(ctx, output, L.ACT_TANH, out=out.reshape(output.shape) if out is not None else None)
         return O.reshape(ctx, output, (-1, OUTPUT_DIM))

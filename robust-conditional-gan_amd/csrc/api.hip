@@ -670,6 +670,21 @@ int rcgan_bn_stats_from_tiles(rcgan_ctx* ctx, const rcgan_conv_desc* d, int nseg
   return bn_tile_stats_finish_launch(ctx, tile_sums, d->cout, nseg, (int)((long)(d->n / nseg) * px / 256), 1, 0, count, eps, mean, rstd);
 }
 
+int rcgan_conv_bn_in_ok(const rcgan_conv_desc* d) {
+  return (d && d->dtype == RCGAN_H16 && img_fwd_bn_ok(d)) ? 1 : 0;
+}
+
+int rcgan_conv2d_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
+                        int segments, const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        int act) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_REQUIRE(ctx, x && prepared && y, "null argument");
+  if (!rcgan_conv_bn_in_ok(d)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "rcgan_conv2d_fwd_bn takes the small-output image-end layers (rcgan_conv_bn_in_ok)");
+  return img_fwd_bn(ctx, d, x, prepared, bias, y, mean, rstd, gamma, beta, labels, segments, act);
+}
+
 int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
                               const void* residual, void* y) {
   int rc = check_desc(ctx, d);

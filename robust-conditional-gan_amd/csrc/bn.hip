@@ -1137,6 +1137,7 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
       char* ys = (char*)y + (size_t)sg * rows * c * esz;
       int rc = rcgan_bn_stats(ctx, (int)rows, c, dtype, xs, eps, mean + (size_t)sg * c, rstd + (size_t)sg * c, nullptr, nullptr, 0.f, ws, ws_bytes);
       if (rc) return rc;
+      if (!y) continue;
       rc = rcgan_bn_apply_fwd(ctx, n_per_seg, rows_per_sample, c, n_labels, dtype, xs, labels ? labels + (size_t)sg * n_per_seg : nullptr,
                               gamma, beta, mean + (size_t)sg * c, rstd + (size_t)sg * c, act, ys, ws, ws_bytes);
       if (rc) return rc;
@@ -1161,6 +1162,7 @@ int rcgan_bn_fwd_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_per_
     RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL((bn_fused_reduce_kernel<T, 0>), dim3(c / 64, ng, nseg), dim3(256), bn_fused_lds(0, 0), ctx->stream, a));
     RC_LAUNCH_CHECK(ctx);
   }
+  if (!y) return RCGAN_OK;             // statistics only: the consumer normalises on load (rcgan_conv2d_fwd_bn)
   const long nchunks = rows * c / 8;
   int gx = apply_grid_fused(nchunks, c);
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(bn_apply_fused_kernel<T>, dim3(gx, nseg), dim3(256), 0, ctx->stream,

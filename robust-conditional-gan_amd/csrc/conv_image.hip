@@ -147,7 +147,16 @@ struct ImgSArgs {
   bf16_t* out;           // [N][H][W][Cs]
   const bf16_t* zero;
   int N, H, W, lw, lh, Cb, Cs, relu_in, accumulate;
+  // optional: the (conditional) batch norm + activation in FRONT of the convolution applied to the staged pixels in LDS -- the
+  // normalised tensor is never written (rcgan_conv2d_fwd_bn).  mean / rstd: [segments][Cb]; gamma / beta: [n_labels][Cb]
+  const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
+  const int32_t* bn_labels;         // [N] or null (label 0)
+  int bn_seg_samples, bn_act;
 };
+
+// the batch-norm affine exactly as bn.hip applies it (bn_pre / bn_c0 there): inv = rstd*gamma, c0 = fma(-mean, inv, beta), pre = fma(x, inv, c0)
+__device__ __forceinline__ float img_bn_c0(float mean, float inv, float beta) { return __fmaf_rn(-mean, inv, beta); }
+__device__ __forceinline__ float img_bn_pre(float x, float inv, float c0) { return __fmaf_rn(x, inv, c0); }
 
 template <int TT>
 __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
@@ -181,6 +190,18 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
     woff[i] = wr < TT * 16 ? wr * a.Cb + (((lane & 7) ^ (wr & 7)) << 3) : -1;
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // staged-pixel transform (below): 0 = none, 1 = input ReLU, 2 = batch norm + activation.  Tables inv[Cb], c0[Cb] behind the stages.
+  const int xmode = a.bn_mean ? 2 : (a.relu_in ? 1 : 0);
+  float* const bn_s = (float*)(smem + 2 * STAGE);
+  if (xmode == 2) {
+    const int lab = a.bn_labels ? a.bn_labels[b] : 0, seg = b / a.bn_seg_samples;
+    for (int c = tid; c < a.Cb; c += 256) {
+      const float inv = a.bn_rstd[seg * a.Cb + c] * a.bn_gamma[lab * a.Cb + c];
+      bn_s[c] = inv;
+      bn_s[a.Cb + c] = img_bn_c0(a.bn_mean[seg * a.Cb + c], inv, a.bn_beta[lab * a.Cb + c]);
+    }
+    __syncthreads();
+  }
   auto issue = [&](int c0, int buf) {
     const unsigned stage = lds0 + buf * STAGE;
 #pragma unroll
@@ -197,7 +218,6 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
     const int p = wave * 64 + f * 16 + px;
     tr0[f] = ((p >> a.lw) + HALO) * cols + (p & (a.W - 1)) + HALO;
   }
-  const uint32_t relu_lb = a.relu_in ? 0u : 0x80008000u;
   f32x4_t acc[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) acc[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -207,6 +227,41 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (xmode) {
+      // The input ReLU / batch norm ONCE per staged element instead of once per tap on the fragments (nine taps read every pixel:
+      // 288 packed-max instructions per chunk and wavefront sat in the MFMA loop).  Every thread transforms exactly the slots its own
+      // DMA lanes deposited (landed: vmcnt(0) above): slot (lane & 7) of row tr holds source chunk (lane & 7) ^ (tr & 7), and
+      // tr & 7 = lane >> 3 for every deposit of this thread -- the same 8 channels each time.  Halo slots (zero page) stay zero.
+      unsigned char* const st = smem + buf * STAGE;
+      const int cch = ch * 64 + (((lane & 7) ^ (lane >> 3)) << 3);
+      float inv8[8], c08[8];
+      const float relu_floor = a.bn_act == RCGAN_ACT_RELU ? 0.f : -INFINITY;
+      if (xmode == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { inv8[j] = bn_s[cch + j]; c08[j] = bn_s[a.Cb + cch + j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        if (xoff[i] < 0) continue;
+        uint4* const slot = (uint4*)(st + (i * 4 + wave) * 1024 + lane * 16);
+        uint4 v = *slot;
+        if (xmode == 1) {
+          v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
+        } else {
+          uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // (ReLU or none -- img_fwd_bn refuses the rest: act_apply's run-time switch in here cost more than the pass it replaces)
+            float lo = img_bn_pre(h16_lo(w4[q]), inv8[2 * q], c08[2 * q]);
+            float hi = img_bn_pre(h16_hi(w4[q]), inv8[2 * q + 1], c08[2 * q + 1]);
+            lo = fmaxf(lo, relu_floor); hi = fmaxf(hi, relu_floor);
+            w4[q] = pack_h16x2(lo, hi);
+          }
+          v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *slot = v;
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ch + 1 < nch) issue((ch + 1) * 64, buf ^ 1);
     const unsigned char* xs = smem + buf * STAGE;
@@ -222,9 +277,7 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           const int tr = tr0[f] + dtr;
-          uint4 v = *(const uint4*)(xs + tr * 128 + ((kc ^ (tr & 7)) << 4));
-          v.x = pk_max_i16(v.x, relu_lb); v.y = pk_max_i16(v.y, relu_lb); v.z = pk_max_i16(v.z, relu_lb); v.w = pk_max_i16(v.w, relu_lb);
-          acc[f] = mfma16(wf, __builtin_bit_cast(bf16x8_t, v), acc[f]);
+          acc[f] = mfma16(wf, *(const bf16x8_t*)(xs + tr * 128 + ((kc ^ (tr & 7)) << 4)), acc[f]);
         }
       }
     }
@@ -318,12 +371,12 @@ static int launch_small_out(rcgan_ctx* ctx, const rcgan_conv_desc* d, ImgSArgs& 
   dim3 grid(d->n * (d->h / R));
   if (d->kh == 3) {
     static bool attr = false;
-    const size_t lds = (size_t)2 * (352 + 160) * 128;
+    const size_t lds = (size_t)2 * (352 + 160) * 128 + 2 * 256 * sizeof(float);
     if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     hipLaunchKernelGGL(conv_img_small_out_kernel<9>, grid, dim3(256), lds, ctx->stream, a);
   } else {
     static bool attr = false;
-    const size_t lds = (size_t)2 * (256 + 32) * 128;
+    const size_t lds = (size_t)2 * (256 + 32) * 128 + 2 * 256 * sizeof(float);
     if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     hipLaunchKernelGGL(conv_img_small_out_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
   }
@@ -342,9 +395,26 @@ int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void*
     a.wK = img_wk(d, prepared); a.bias = bias; a.out = (bf16_t*)y; a.Cb = d->cout; a.accumulate = acc;
     return launch_small_red(ctx, a);
   }
-  ImgSArgs a;
+  ImgSArgs a = {};
   a.in = (const bf16_t*)x; a.wS = img_ws(d, prepared); a.bias = bias; a.out = (bf16_t*)y;
   a.Cb = d->cin; a.Cs = d->cout; a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0; a.accumulate = acc;
+  return launch_small_out(ctx, d, a);
+}
+
+// y = conv(act(batch_norm(x))) with the normalisation applied to the staged pixels (ImgSArgs::bn_*): the small-output side only
+bool img_fwd_bn_ok(const rcgan_conv_desc* d) {
+  return img_side(d) == 2 && d->cin % 64 == 0 && d->cin <= 256 && (d->flags & ~RCGAN_CONV_ACCUMULATE) == 0;
+}
+int img_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
+               const float* mean, const float* rstd, const float* gamma, const float* beta, const int32_t* labels, int segments, int act) {
+  RC_REQUIRE(ctx, img_fwd_bn_ok(d), "not a small-output image-end shape");
+  RC_REQUIRE(ctx, mean && rstd && gamma && beta && segments >= 1 && d->n % segments == 0, "bad batch-norm arguments");
+  RC_REQUIRE(ctx, act == RCGAN_ACT_NONE || act == RCGAN_ACT_RELU, "activation %d: ReLU or none", act);
+  ImgSArgs a = {};
+  a.in = (const bf16_t*)x; a.wS = img_ws(d, prepared); a.bias = bias; a.out = (bf16_t*)y;
+  a.Cb = d->cin; a.Cs = d->cout; a.relu_in = 0; a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+  a.bn_mean = mean; a.bn_rstd = rstd; a.bn_gamma = gamma; a.bn_beta = beta; a.bn_labels = labels;
+  a.bn_seg_samples = d->n / segments; a.bn_act = act;
   return launch_small_out(ctx, d, a);
 }
 
@@ -362,7 +432,7 @@ int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const vo
     return launch_small_red(ctx, a);
   }
   if (pt != (d->kh == 3 ? 1 : 0) || pl != pt) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "asymmetric padding");
-  ImgSArgs a;                        // dX[m][Cin small] from dY[m][Cout big]
+  ImgSArgs a = {};                   // dX[m][Cin small] from dY[m][Cout big]
   a.in = (const bf16_t*)dy; a.wS = img_ws(d, prepared); a.bias = nullptr; a.out = (bf16_t*)dx;
   a.Cb = d->cout; a.Cs = d->cin; a.relu_in = 0; a.accumulate = accumulate;
   return launch_small_out(ctx, d, a);

@@ -102,6 +102,9 @@ size_t img_wgrad_ws_bytes(const rcgan_conv_desc* d);
 int img_prepare_launch(rcgan_ctx* ctx, const rcgan_conv_desc* d, const float* w, const float* sigma, void* prepared);
 int img_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y);
 int img_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const void* prepared, void* dx, int accumulate);
+bool img_fwd_bn_ok(const rcgan_conv_desc* d);
+int img_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
+               const float* mean, const float* rstd, const float* gamma, const float* beta, const int32_t* labels, int segments, int act);
 int img_wgrad_plan(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int target_wgs, ImgWArgs* a, int* cb, int* nwg);
 int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
               void* ws, size_t ws_bytes);

@@ -241,6 +241,18 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
     the upsample it commutes with); its gradient is the 2x2 sum of dy.
     want_stats: the caller will batch-normalise the result -- where the producing kernel can, the per-tile column sums of the stored
     output come out of its epilogue (rcgan_conv2d_fwd_stats) and are attached as ``y.tile_stats`` for batch_norm_act."""
+    if isinstance(x, BnPending):
+        pend = x
+        n, hs, ws_, cin = pend.shape
+        cout = weight.param.shape[-1]
+        bdesc = L.ConvDesc(n, hs, ws_, cin, cout, k, k, stride, pend.dtype, 0)
+        if (not in_up and not in_relu and accumulate_into is None and residual is None and not force_direct and not ctx.recording
+                and pend.act in (L.ACT_NONE, L.ACT_RELU) and ctx.lib.rcgan_conv_bn_in_ok(C.byref(bdesc))):
+            y = ctx.empty((n, hs, ws_, cout), pend.dtype)
+            ctx.check(ctx.lib.rcgan_conv2d_fwd_bn(ctx.h, C.byref(bdesc), _p(pend.x), _p(weight.prepared(bdesc)), _p(bias), _p(y), pend.segments,
+                                                  _p(pend.labels), _p(pend.gamma), _p(pend.beta), _p(pend.mean), _p(pend.rstd), pend.act))
+            return y
+        x = pend.materialize()
     n, hs, ws_, cin = x.shape
     h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
     cout = weight.param.shape[-1]
@@ -547,7 +559,35 @@ def _rows(x):
     return x.shape[0], 1, x.shape[1]
 
 
-def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1, moving=None, decay=0.9, eps=1e-5, segments=1):
+class BnPending:
+    """act(batch_norm(x)) whose statistics exist and whose affine has NOT been applied: ops.conv2d applies it to its staged input
+    (rcgan_conv2d_fwd_bn: the normalised tensor is never written) where the convolution can, else materialize() writes it.
+    Forward-only passes (batch_norm_act(defer_apply=True) without a tape)."""
+
+    def __init__(self, ctx, x, gamma, beta, labels, n_labels, mean, rstd, act, segments):
+        self.ctx, self.x, self.gamma, self.beta, self.labels, self.n_labels = ctx, x, gamma, beta, labels, n_labels
+        self.mean, self.rstd, self.act, self.segments = mean, rstd, act, segments
+        self.shape, self.dtype, self.req = x.shape, x.dtype, False
+
+    def materialize(self):
+        ctx, x = self.ctx, self.x
+        n, rps, c = _rows(x)
+        y = ctx.empty(x.shape, x.dtype)
+        if self.segments > 1:
+            ctx.check(ctx.lib.rcgan_bn_apply_segments(ctx.h, self.segments, n // self.segments, rps, c, self.n_labels, x.dtype, _p(x), _p(self.labels),
+                                                      _p(self.gamma), _p(self.beta), _p(self.mean), _p(self.rstd), self.act, _p(y),
+                                                      C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        else:
+            ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, n, rps, c, self.n_labels, x.dtype, _p(x), _p(self.labels), _p(self.gamma), _p(self.beta),
+                                                 _p(self.mean), _p(self.rstd), self.act, _p(y), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        return y
+
+
+BN_INTO_CONV = os.environ.get("RCGAN_BN_INTO_CONV", "1") != "0"
+
+
+def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1, moving=None, decay=0.9, eps=1e-5, segments=1,
+                   defer_apply=False):
     """Batch statistics + (conditional) affine + activation, one fused op.
     labels=None: tf.contrib.layers.batch_norm (mnist/ops.py:38-44), ``moving`` = (moving_mean, moving_var)
     DTs updated in place.  labels=int32 DT [n]: cond_batchnorm (cifar10/common/ops/normalization.py:27-59),
@@ -556,6 +596,18 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
     n, rps, c = _rows(x)
     rows = n * rps
     tile = getattr(x, "tile_stats", None) if moving is None else None      # statistics left by the producing convolution's epilogue
+    if (defer_apply and BN_INTO_CONV and not ctx.recording and moving is None and tile is None and x.dtype != L.F32
+            and n % max(segments, 1) == 0):
+        # forward-only pass: statistics now, the affine + activation inside the consuming convolution (BnPending)
+        mean = ctx.empty((max(segments, 1), c), L.F32)
+        rstd = ctx.empty((max(segments, 1), c), L.F32)
+        if segments > 1:
+            ctx.check(ctx.lib.rcgan_bn_fwd_segments(ctx.h, segments, n // segments, rps, c, n_labels, x.dtype, _p(x), _p(labels), _p(gamma),
+                                                    _p(beta), eps, act, _p(mean), _p(rstd), None, C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        else:
+            ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), None, None, decay,
+                                             C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+        return BnPending(ctx, x, gamma, beta, labels, n_labels, mean, rstd, act, max(segments, 1))
     if segments > 1:
         if (ctx.recording and (x.req or gamma.req or beta.req)) or moving is not None or n % segments:
             raise NotImplementedError("segmented batch norm is forward-only (no gradient, no moving statistics)")

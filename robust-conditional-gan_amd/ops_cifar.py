@@ -90,7 +90,7 @@ def Linear(inputs, input_dim, output_dim, name,
 
 
 def cond_batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update_moving_stats=True, fused=True,
-                   labels=None, n_labels=None, _act=L.ACT_NONE, _segments=1):
+                   labels=None, n_labels=None, _act=L.ACT_NONE, _segments=1, _defer_apply=False):
     """cifar10/common/ops/normalization.py:27-59: batch moments over (N,H,W), per-class scale/offset
     gathered by label, no moving averages.  ``_act`` fuses the following nonlinearity."""
     if axes != [0, 1, 2]:
@@ -99,7 +99,8 @@ def cond_batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update
     with variable_scope('CondBatchNorm'):
         offset_m = g.param(scoped('offset'))
         scale_m = g.param(scoped('scale'))
-    return O.batch_norm_act(g.ctx, inputs, scale_m, offset_m, act=_act, labels=labels, n_labels=n_labels, segments=_segments)
+    return O.batch_norm_act(g.ctx, inputs, scale_m, offset_m, act=_act, labels=labels, n_labels=n_labels, segments=_segments,
+                            defer_apply=_defer_apply)
 
 
 def embed_y(inputs, vocab_size=1000, embedding_dim=300, word2vec_file=None,

@@ -546,6 +546,44 @@ def test_register_filter_conv_equals_tile_kernels(dev, n, hw, in_relu, second):
         assert_close(a["y"], ref, TOL[mode] * 3, "register-filter forward vs oracle")
 
 
+@pytest.mark.parametrize("n,segments,hw", [(10, 5, 32), (6, 1, 32), (4, 2, 16)])
+def test_batch_norm_inside_the_image_end_convolution(dev, n, segments, hw):
+    """rcgan_conv2d_fwd_bn (forward-only passes: ops.BnPending): conditional batch norm + ReLU applied to G.Output's staged input inside
+    its launch, against the written-out batch_norm_act followed by conv2d.  The affine is the same fp32 sequence rounded to 16 bits at
+    the same point and the convolution is the same kernel on the same values: bit-identical outputs."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the image-end kernels run on 16-bit activations")
+    rs = np.random.RandomState(n + segments)
+    c, nl = 256, 10
+    x = _prep(rs.randn(n, hw, hw, c) * 1.5 + 0.3, mode)
+    gamma = (1.0 + 0.2 * rs.randn(nl, c)).astype(np.float32); beta = (0.2 * rs.randn(nl, c)).astype(np.float32)
+    lab = rs.randint(nl, size=n).astype(np.int32)
+    wv = (rs.randn(3, 3, c, 3) * 0.05).astype(np.float32); bv = (0.1 * rs.randn(3)).astype(np.float32)
+    outs = []
+    for defer in (True, False):
+        ctx.new_step()
+        rec, ctx.recording = ctx.recording, False
+        try:
+            xd = ctx.upload(x)
+            pg, pb2, pw, pbias = FakeParam(ctx, gamma), FakeParam(ctx, beta), FakeParam(ctx, wv), FakeParam(ctx, bv)
+            W = O.Weight(ctx, pw.t, None)
+            h = O.batch_norm_act(ctx, xd, pg.t, pb2.t, act=L.ACT_RELU, labels=ctx.upload(lab), n_labels=nl, segments=segments, defer_apply=defer)
+            assert isinstance(h, O.BnPending) == defer
+            y = O.conv2d(ctx, h, W, pbias.t, 3)
+            outs.append(ctx.download(y).copy())
+            if defer:                         # what materialize() writes is what the other branch convolves
+                hm = ctx.download(h.materialize()).copy()
+            else:
+                assert np.array_equal(ctx.download(h), hm)
+        finally:
+            ctx.recording = rec
+    assert outs[0].shape == (n, hw, hw, 3) and np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0], outs[1])
+
+
 HEAD_CASES = [
     # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
     (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
