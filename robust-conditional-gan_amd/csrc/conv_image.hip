@@ -158,7 +158,9 @@ struct ImgSArgs {
 __device__ __forceinline__ float img_bn_c0(float mean, float inv, float beta) { return __fmaf_rn(-mean, inv, beta); }
 __device__ __forceinline__ float img_bn_pre(float x, float inv, float c0) { return __fmaf_rn(x, inv, c0); }
 
-template <int TT>
+// NST: stages per workgroup.  2 = the next chunk's DMA runs under this chunk's MFMAs, one workgroup per CU (128 KB of LDS);
+// 1 = one stage, TWO workgroups per CU that cover each other's DMA round trips and in-LDS transforms.
+template <int TT, int NST = 2>
 __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALO = TT == 9 ? 1 : 0;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // staged-pixel transform (below): 0 = none, 1 = input ReLU, 2 = batch norm + activation.  Tables inv[Cb], c0[Cb] behind the stages.
   const int xmode = a.bn_mean ? 2 : (a.relu_in ? 1 : 0);
-  float* const bn_s = (float*)(smem + 2 * STAGE);
+  float* const bn_s = (float*)(smem + NST * STAGE);
   if (xmode == 2) {
     const int lab = a.bn_labels ? a.bn_labels[b] : 0, seg = b / a.bn_seg_samples;
     for (int c = tid; c < a.Cb; c += 256) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
   const int nch = a.Cb / 64;
   issue(0, 0);
   for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
+    const int buf = NST == 2 ? (ch & 1) : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (xmode) {
       // The input ReLU / batch norm ONCE per staged element instead of once per tap on the fragments (nine taps read every pixel:
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ch + 1 < nch) issue((ch + 1) * 64, buf ^ 1);
+    if (NST == 2 && ch + 1 < nch) issue((ch + 1) * 64, buf ^ 1);
     const unsigned char* xs = smem + buf * STAGE;
     const unsigned char* ws = xs + XROWS * 128;
 #pragma unroll
@@ -280,6 +282,10 @@ __global__ __launch_bounds__(256) void conv_img_small_out_kernel(ImgSArgs a) {
           acc[f] = mfma16(wf, *(const bf16x8_t*)(xs + tr * 128 + ((kc ^ (tr & 7)) << 4)), acc[f]);
         }
       }
+    }
+    if (NST == 1 && ch + 1 < nch) {        // one stage: everybody has read it before the next chunk lands in it
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue((ch + 1) * 64, 0);
     }
   }
   // D[row = n][col = pixel]: lanes 0..15 hold n = 0..3 of their pixel
@@ -369,7 +375,15 @@ static int launch_small_out(rcgan_ctx* ctx, const rcgan_conv_desc* d, ImgSArgs& 
   a.zero = (const bf16_t*)ctx->zero_page;
   const int R = 256 / d->w;
   dim3 grid(d->n * (d->h / R));
-  if (d->kh == 3) {
+  // one stage, two workgroups per CU (default): G.Output forward 30.7 -> 22.0 us, D.Block.1.Conv1's data gradient 17.8 -> 11.9 us at n = 128,
+  // the critic steps' generator forwards 1.301 -> 1.280 ms (profiles/r03_microbench.txt); RCGAN_IMG_OUT_STAGES=2: double-buffered, one per CU
+  static const int nst = [] { const char* e = getenv("RCGAN_IMG_OUT_STAGES"); return e ? atoi(e) : 1; }();
+  if (d->kh == 3 && nst == 1) {
+    static bool attr = false;
+    const size_t lds = (size_t)(352 + 160) * 128 + 2 * 256 * sizeof(float);
+    if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((conv_img_small_out_kernel<9, 1>), grid, dim3(256), lds, ctx->stream, a);
+  } else if (d->kh == 3) {
     static bool attr = false;
     const size_t lds = (size_t)2 * (352 + 160) * 128 + 2 * 256 * sizeof(float);
     if (!attr) { RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_img_small_out_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
