@@ -283,7 +283,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU critic batch")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--algorithm", default="rcgan")
