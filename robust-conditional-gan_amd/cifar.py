@@ -589,6 +589,8 @@ class CifarRCGAN:
                 if pool and n in ("Discriminator/D.Block.1.Conv2/Filters", "Discriminator/D.Block.2.Conv2/Filters"):
                     up = L.CONV_OUT_MEANPOOL2
                 names.append((n, shp[0], 1, IMG_SIZE if min(shp[2], shp[3]) <= 3 else 8, up))
+            elif n == "Generator/G.Input/W" and O.LINEAR_MFMA:
+                names.append((n, 1, 1, 1, 0))          # the dense input layer runs as a 1x1 convolution (ops.linear): its 16-bit filter
         return names
 
     def _prepare_all(self, which, head_update=False, inputs=None):

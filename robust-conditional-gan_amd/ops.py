@@ -59,6 +59,7 @@ class Weight:
         self._prepared = {}
         self.rf_frag = None        # fragment-major copy for the register-filter kernel (fragments_batch), this step's
         self.dwbar = None
+        self._conv1 = None         # this [k, n] matrix as the [1, 1, k, n] filter of a 1x1 convolution (as_conv1x1)
 
     @property
     def req(self):
@@ -82,6 +83,20 @@ class Weight:
             self._prepared[key] = buf
         return self._prepared[key]
 
+    def as_conv1x1(self):
+        """The same parameter memory viewed as an HWIO filter [1, 1, k, n] (ops.linear on the matrix cores): shares the gradient
+        buffer and the prepared-layout cache."""
+        if self._conv1 is None:
+            p = self.param
+            pv = DT(p.ptr, (1, 1) + tuple(p.shape), p.dtype, p.base, p.name)
+            pv.req, pv.group = p.req, p.group
+            if p.grad is not None:
+                pv.grad = p.grad.reshape((1, 1) + tuple(p.shape))
+            w4 = Weight(self.ctx, pv, self.sigma)
+            w4._prepared = self._prepared
+            self._conv1 = w4
+        return self._conv1
+
     def grad_target(self):
         """Where d/dW (or d/dW_bar for SN weights) is accumulated."""
         if self.sigma is None:
@@ -100,7 +115,7 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
                 with their optimiser step)."""
     todo = []
     for w, k, stride, hw, *rest in weights_and_shapes:
-        kk, _, cin, cout = w.param.shape
+        cin, cout = w.param.shape[-2:]          # HWIO filters, or a [k, n] matrix prepared as a 1x1 filter (ops.linear)
         # flags that change the prepared layout (CONV_IN_UPSAMPLE2X: the summed phase filters of the sub-pixel form ride along)
         desc = L.ConvDesc(1, hw, hw, cin, cout, k, k, stride, dtype, rest[0] if rest else 0)
         nbytes = ctx.lib.rcgan_conv_prepared_bytes(C.byref(desc))
@@ -138,6 +153,7 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
 
 
 RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
+LINEAR_MFMA = os.environ.get("RCGAN_LINEAR_MFMA", "1") != "0"
 
 
 def fragments_batch(ctx, trunk, rf):
@@ -530,6 +546,11 @@ def linear(ctx, x, weight, bias, out_dtype=None):
     m, kk = x.shape
     n = weight.param.shape[-1]
     assert weight.param.shape == (kk, n), (weight.param.shape, (kk, n))
+    if LINEAR_MFMA and x.dtype != L.F32 and weight.sigma is None and kk % 64 == 0 and n % 64 == 0 and n >= 1024 and out_dtype is None:
+        # a wide dense layer on 16-bit activations (G.Input: 128 -> 16384) as a 1x1 convolution on the bf16 / fp16 matrix cores with
+        # its prepared 16-bit filter -- the layout is the same ([m, 1, 1, k] / [1, 1, k, n]); the fp32 gather GEMM ran it at 45 TFLOP/s
+        y4 = conv2d(ctx, reshape(ctx, x, (m, 1, 1, kk)), weight.as_conv1x1(), bias, 1)
+        return reshape(ctx, y4, (m, n))
     y = ctx.empty((m, n), x.dtype)
     ctx.check(ctx.lib.rcgan_linear_fwd(ctx.h, m, kk, n, x.dtype, _p(x), _p(weight.param), _p(weight.sigma), _p(bias), _p(y)))
     if _track(ctx, y, x, weight.param, bias):

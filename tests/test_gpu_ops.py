@@ -584,6 +584,47 @@ def test_batch_norm_inside_the_image_end_convolution(dev, n, segments, hw):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("m,k,n", [(128, 128, 16384), (40, 64, 1024)])
+def test_wide_dense_layer_on_the_matrix_cores(dev, m, k, n, monkeypatch):
+    """ops.linear routes a wide dense layer on 16-bit activations (G.Input: 128 -> 16384) through the 1x1-convolution kernels with its
+    prepared 16-bit filter (RCGAN_LINEAR_MFMA): against the fp32 gather GEMM on the same inputs (which keeps the weights in fp32:
+    the difference is the 16-bit rounding of W) and the float64 product of the rounded operands."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    from tests.gpu_util import rel_err
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("fp32 activations keep the fp32 gather GEMM")
+    rs = np.random.RandomState(m + n)
+    x = _prep(rs.randn(m, k), mode)
+    wv = (rs.randn(k, n) / np.sqrt(k)).astype(np.float32); bv = (0.1 * rs.randn(n)).astype(np.float32)
+    dy = _prep(rs.randn(m, n), mode)
+    res = {}
+    for mfma in (True, False):
+        monkeypatch.setattr(O, "LINEAR_MFMA", mfma)
+        ctx.new_step()
+        xd = ctx.upload(x)
+        pw, pb = FakeParam(ctx, wv), FakeParam(ctx, bv)
+        W = O.Weight(ctx, pw.t, None)
+        y = O.linear(ctx, xd, W, pb.t)
+        assert y.shape == (m, n)
+        out = ctx.download(y)
+        if y.grad is not None:            # (a reshaped view of the convolution's output: its gradient buffer already exists)
+            ctx.upload(dy, out=y.grad)
+        else:
+            y.grad = ctx.upload(dy)
+        ctx.backward()
+        res[mfma] = dict(y=out, dw=pw.grad(ctx), db=pb.grad(ctx))
+    a, b = res[True], res[False]
+    q = lambda v: half_round(mode, v).astype(np.float64)
+    ref = q(x.astype(np.float64) @ q(wv) + bv)
+    assert_close(a["y"], ref, TOL[mode], "dense layer on the matrix cores vs float64 of the rounded operands")
+    assert rel_err(a["y"], b["y"]) < 6e-3, rel_err(a["y"], b["y"])                       # W rounded to 16 bits vs W in fp32
+    assert rel_err(a["dw"], b["dw"]) < 2e-3 and rel_err(a["db"], b["db"]) < 2e-3, (rel_err(a["dw"], b["dw"]), rel_err(a["db"], b["db"]))
+    dw_ref = x.astype(np.float64).T @ dy.astype(np.float64)
+    assert rel_err(a["dw"], dw_ref) < 2e-3
+
+
 HEAD_CASES = [
     # n, rows_a, kind_a, mode_a, kind_b, mode_b          mode: "lab" one-hot labels, "wts" explicit weight matrix (with gradient)
     (16, 8, "HINGE_REAL", "lab", "HINGE_FAKE", "lab"),        # rcgan / biased critic step (gan_resnet.py:585-606)
