@@ -55,6 +55,8 @@ RCGAN_POOL_IN_TRUNK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_pool_i
 RCGAN_RF_CONV=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_rf_conv.json" 2> /dev/null
 RCGAN_FUSED_TRUNK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_fused_trunk.json" 2> /dev/null
 RCGAN_BN_INTO_CONV=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_bn_into_conv.json" 2> /dev/null
+RCGAN_LINEAR_MFMA=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_linear_mfma.json" 2> /dev/null
+RCGAN_IMG_OUT_STAGES=2 python3 bench.py --no-cpu-baseline > "$OUT/bench_img_out_stages2.json" 2> /dev/null
 python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_smooth.txt" 2>&1
 RCGAN_BENCH_IMAGES=uniform python3 scripts/exp_bench_data.py 60 32 > "$OUT/bench_data_uniform.txt" 2>&1
 [ -x scripts/probes/_bin/epilogue_store ] && ./scripts/probes/_bin/epilogue_store > "$OUT/probe_epilogue_store.txt" 2>&1
