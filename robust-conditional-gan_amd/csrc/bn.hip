@@ -1240,8 +1240,10 @@ int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_label
       // fewer than 32 rows (the 4x4 stage) go nsub to a workgroup, which still writes one partial row per sample
       static long target = -1, maxg = -1;
       if (target < 0) {
-        const char* e = getenv("RCGAN_BN_BWD_WGS"); target = e ? atol(e) : 512;
-        const char* m = getenv("RCGAN_BN_BWD_MAXG"); maxg = m ? atol(m) : 512;
+        // (round 3, same box: 512 / 512 -> 5.827 ms per iteration, 1024 / 1024 -> 5.801, 2048 / 2048 -> 5.815: the 32 x 32 layers gain from more
+        // workgroups, the 8 x 8 / 16 x 16 ones lose to the longer finisher)
+        const char* e = getenv("RCGAN_BN_BWD_WGS"); target = e ? atol(e) : 1024;
+        const char* m = getenv("RCGAN_BN_BWD_MAXG"); maxg = m ? atol(m) : 1024;
       }
       rpg = rows_per_sample;
       if (rows_per_sample < 32 && 32 % rows_per_sample == 0 && n % (32 / rows_per_sample) == 0) { nsub = 32 / rows_per_sample; rpg = 32; }

@@ -1458,8 +1458,8 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
       b.inputs_row = b.rows++;
       // a few elements per thread: the image units, the fake half's pooled outputs and the fill share the workgroups
       const size_t work = (size_t)inputs->n * 3 * 16 * 8 + (inputs->pooled ? (size_t)inputs->n * 768 : 0) + inputs->fill4;
-      // (measured: 256 workgroups 6.37 ms, 512: 6.42, 2048: 6.48, 64: 6.39 per iteration)
-      static const int per = env_int("RCGAN_RIDE_PER_THREAD", 16), cap = env_int("RCGAN_RIDE_MAXWG", 256);
+      // (measured, round 2: 256 workgroups 6.37 ms, 512: 6.42, 2048: 6.48, 64: 6.39 per iteration; round 3: 128: 5.770, 256: 5.784, 512: 5.785)
+      static const int per = env_int("RCGAN_RIDE_PER_THREAD", 16), cap = env_int("RCGAN_RIDE_MAXWG", 128);
       size_t wgs = (work + 256 * per - 1) / (256 * per);
       if (wgs < 1) wgs = 1;
       if (wgs > (size_t)cap) wgs = cap;
