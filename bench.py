@@ -164,6 +164,21 @@ def kernel_roofline(m, pool, default_workload=True):
             "executed_tflops": round(fx.value / (ms.value * 1e-3) / 1e12, 2), "executed_frac": round(fx.value / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
 
+def comm_profile(m, pool):
+    """One eager iteration with every all-reduce group of the in-ABI communicator bracketed by HIP events on the stream it is issued
+    on: (groups per iteration, their summed duration in ms, bytes this rank hands over per iteration).  The duration of an all-reduce
+    includes waiting for the slowest rank to arrive."""
+    ctx = m.ctx
+    saved = m.use_graphs
+    m.use_graphs = False
+    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 6))       # RCGAN_PROF_ALLREDUCE
+    iteration(m, pool, 1, [0])
+    n, ms, by = C.c_int(0), C.c_double(0), C.c_double(0)
+    ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(by)))
+    m.use_graphs = saved
+    return n.value, ms.value, by.value
+
+
 def effective_cores():
     """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes report 256
     logical CPUs under a 16-CPU quota; 256 threads on 16 CPUs ran the same step 180x slower than 16 threads)."""
@@ -279,6 +294,30 @@ def cpu_baseline_mnist(cores, B=64, alpha=0.5, iters=5):
                                              "logging-only evals (model.py:374-398), mean %.2fs" % l}}
 
 
+def launcher_command(args, argv, env):
+    """The command that starts the ranks of ``--gpus N`` when this process is not one of them already (no WORLD_SIZE in the
+    environment): one process per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1.  None when this
+    process IS a rank (started by a launcher) or N = 1."""
+    if args.gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    rest, skip = [], False
+    for a in argv:                      # the ranks get the same flags minus the launcher's own
+        if skip:
+            skip = False
+        elif a == "--master-port":
+            skip = True
+        elif not a.startswith("--master-port=") and a != "--dry-run":
+            rest.append(a)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,16 +329,37 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-stub", type=int, default=0,
-                    help="single GPU only: run the world-size-N data-parallel step schedule (two gradient buckets per step, the first on the "
-                         "communication stream beside the backward pass, optimiser inside the captured graph) against the in-ABI test-double "
-                         "communicator -- measures what the schedule itself costs; no RCCL traffic")
+                    help="single GPU only: run the world-size-N data-parallel step schedule (one whole-slab gradient bucket per optimiser group and "
+                         "step, optimiser inside the captured graph) against the in-ABI test-double communicator -- measures what the schedule itself costs; no RCCL traffic")
+    ap.add_argument("--dp-stub-gbps", type=float, default=0.0,
+                    help="--dp-stub cost model: bus bandwidth in GB/s; every all-reduce of b bytes then occupies its stream for "
+                         "latency + 2(N-1)/N * b / bandwidth (0 = free: the schedule's own cost only)")
+    ap.add_argument("--dp-stub-lat-us", type=float, default=0.0, help="--dp-stub cost model: latency per all-reduce group in microseconds")
+    ap.add_argument("--bucket-dtype", default=None, choices=["f32", "bf16"],
+                    help="dtype the gradient buckets travel in (default f32, or RCGAN_DP_BUCKET_DTYPE)")
     ap.add_argument("--lr", type=float, default=2e-4, help="Adam learning rate (reference: 2e-4, gan_resnet.py:--lr)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks --gpus N starts (default: a free one)")
+    ap.add_argument("--dry-run", action="store_true", help="print the launcher command --gpus N would start, and exit")
     args = ap.parse_args()
     default_wl = args.batch == 64 and args.dtype == "bf16" and args.algorithm == "rcgan"
+
+    # --gpus N outside a launcher: start the N ranks as CHILD processes (this process has made no GPU call yet and never
+    # replaces itself) and relay their output; rank 0's JSON line is the last line of it
+    cmd = launcher_command(args, sys.argv[1:], os.environ)
+    if args.dry_run:
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return subprocess.run(cmd, env=env).returncode
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: the line would not describe the run" % (args.gpus, world))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -312,7 +372,16 @@ def main():
     alpha = 0.6
     m = CifarRCGAN(algorithm=args.algorithm, alpha=alpha, batch_size=args.batch, dtype=args.dtype, seed=0, lr=args.lr,
                    device=local, use_graphs=not args.no_graphs, device_rng=True,
-                   world_size=(args.dp_stub if args.dp_stub > 1 else world), rank=rank, comm=("stub" if args.dp_stub > 1 else None))
+                   world_size=(args.dp_stub if args.dp_stub > 1 else world), rank=rank, comm=("stub" if args.dp_stub > 1 else None),
+                   grad_bucket_dtype=args.bucket_dtype,
+                   stub_model=((args.dp_stub_gbps, args.dp_stub_lat_us) if args.dp_stub > 1 and (args.dp_stub_gbps or args.dp_stub_lat_us) else None))
+    ranks_reported = None
+    if m.dp_active:
+        rr = C.c_int(0)
+        m.ctx.check(m.ctx.lib.rcgan_comm_count(m.ctx.h, C.byref(rr)))
+        ranks_reported = rr.value
+        if ranks_reported != m.world:
+            raise SystemExit("bench.py: the communicator reports %d ranks, the run was started for %d" % (ranks_reported, m.world))
     pool = build_pool(m, rank, alpha)
     dcount = [0]
     warm = max(args.warmup, 2)      # iteration 0 has no G step; graphs are captured on first use
@@ -339,6 +408,7 @@ def main():
     d_loss, g_loss = m.losses()
     ok = np.isfinite(d_loss) and np.isfinite(g_loss)
 
+    comm = comm_profile(m, pool) if m.dp_active else None      # every rank: the extra iteration all-reduces
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -351,15 +421,22 @@ def main():
                                       % (args.algorithm.upper(), args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
                           "gradient_exchange": ("none (single rank)" if m.world == 1 else
-                                                "in-ABI %s all-reduce(sum) of the fp32 gradient slabs inside the step's graph, 2 buckets per step%s, optimiser %s"
+                                                "in-ABI %s all-reduce(sum) of the gradient slabs inside the step's graph, %s, optimiser %s"
                                                 % ("RCCL" if m.comm_kind == "rccl" else "TEST-DOUBLE (--dp-stub %d: schedule only, no traffic)" % args.dp_stub,
-                                                   " (first on the communication stream beside the backward pass)" if m.dp_overlap else "",
+                                                   "1 whole-slab %s bucket per optimiser group and step" % m.grad_bucket_dtype,
                                                    "in the graph" if m.dp_adam_in_graph else "after the graph")),
                           "critic_generator_forwards": ("one pass over N_CRITIC x B samples, batch-norm statistics per critic step"
                                                         if BATCH_CRITIC_FAKES else "inside every critic step"),
                           "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
                           "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
                           "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}
+        if comm is not None:
+            out["config"].update({"communicator_ranks": ranks_reported, "gradient_bucket_dtype": m.grad_bucket_dtype,
+                                  "allreduce_groups_per_iteration": comm[0], "allreduce_ms_per_iteration": round(comm[1], 4),
+                                  "allreduce_mbytes_per_iteration": round(comm[2] / 1e6, 3)})
+            if args.dp_stub > 1:
+                out["config"]["stub_link_model"] = ("none (all-reduce is free)" if not (args.dp_stub_gbps or args.dp_stub_lat_us) else
+                                                    "%.1f us + 2(N-1)/N * bytes / %.0f GB/s per all-reduce group" % (args.dp_stub_lat_us, args.dp_stub_gbps))
         out["roofline"] = kernel_roofline(m, pool, default_wl) if args.dtype in ("bf16", "f16") else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alpha, args.batch)
@@ -381,4 +458,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -83,6 +83,7 @@ int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* 
 #define RCGAN_PROF_WGRAD_MFMA 3      /* conv_mfma_wgrad_kernel */
 #define RCGAN_PROF_CONV_P8 4         /* conv_mfma_p8_kernel: 256 x 256 tile, 8 wavefronts (fwd + dgrad of the 256-channel layers) */
 #define RCGAN_PROF_CONV_P8N 5        /* conv_mfma_p8n_kernel: 256 x 128 tile */
+#define RCGAN_PROF_ALLREDUCE 6       /* every all-reduce group of comm.hip (eager launches only); "flops" = bytes exchanged per rank */
 int rcgan_prof_begin(rcgan_ctx* ctx, int which);
 int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);
 /* Flops the kernels of the last rcgan_prof_begin .. rcgan_prof_end section EXECUTED: equal to the algorithmic count except for
@@ -517,7 +518,16 @@ int rcgan_loss_scale_update(rcgan_ctx* ctx, float* ls_state, float* t_dev0, floa
  *   rcgan_allreduce_sum_buckets  the same for several buckets as ONE RCCL group
  *   rcgan_allreduce_sum_async  on the communication stream, ordered after everything queued on the context's stream so far: the bucket must
  *                              be final; later launches of the backward pass run beside it (xGMI transfers under compute)
- *   rcgan_allreduce_join       the context's stream waits for the asynchronous buckets (before the optimiser reads them) */
+ *   rcgan_allreduce_join       the context's stream waits for the asynchronous buckets (before the optimiser reads them)
+ *   rcgan_comm_count           the number of ranks the COMMUNICATOR reports (ncclCommCount; the test double: its world)
+ *   rcgan_allreduce_sum_bf16_buckets  the same sum with the buckets travelling as bfloat16 (half the bytes over xGMI): every bucket is
+ *                              rounded to bf16 (nearest even) into scratch16, summed there (ncclBfloat16) and widened back over the fp32 bucket,
+ *                              three launches + one RCCL group whatever n.  scratch16: device memory, 2 bytes per float of all buckets together
+ *                              (each bucket's part 256-byte aligned: rcgan_allreduce_bf16_scratch_bytes).  The sum of N bf16 values carries
+ *                              8 mantissa bits: a gradient-precision trade the caller opts into
+ *   rcgan_comm_stub_model      cost model of the test double: every all-reduce group then occupies its stream for
+ *                              latency_us + 2 (world - 1) / world * bytes / bus_gbps (a one-thread kernel that watches the wall clock), so a
+ *                              single GPU reports what a world-size-N step would take under a stated link model; 0, 0 = free */
 #define RCGAN_COMM_ID_BYTES 128
 int rcgan_comm_unique_id(void* id_out);
 int rcgan_comm_init(rcgan_ctx* ctx, const void* id, int world, int rank);
@@ -528,6 +538,12 @@ int rcgan_allreduce_sum(rcgan_ctx* ctx, float* buf, size_t count);
 int rcgan_allreduce_sum_buckets(rcgan_ctx* ctx, int n, float* const* bufs, const size_t* counts);
 int rcgan_allreduce_sum_async(rcgan_ctx* ctx, float* buf, size_t count);
 int rcgan_allreduce_join(rcgan_ctx* ctx);
+int rcgan_comm_count(rcgan_ctx* ctx, int* ranks);
+size_t rcgan_allreduce_bf16_scratch_bytes(int n, const size_t* counts);
+int rcgan_allreduce_sum_bf16_buckets(rcgan_ctx* ctx, int n, float* const* bufs, const size_t* counts, void* scratch16, size_t scratch_bytes);
+int rcgan_comm_stub_model(rcgan_ctx* ctx, double bus_gbps, double latency_us);
+/* why librccl could not be bound ("" when it was, or when nothing has tried yet) */
+const char* rcgan_comm_load_error(void);
 /* {a, b} -> p[0..1] by a one-thread launch on the stream: sets the DEVICE {lr, t} of rcgan_adam_tf in front of a replayed graph without a
  * host-to-device copy. */
 int rcgan_set2_f32(rcgan_ctx* ctx, float* p, float a, float b);

@@ -201,6 +201,11 @@ SIGNATURES = {
     "rcgan_allreduce_sum_buckets": (I, [P, I, P, P]),
     "rcgan_allreduce_sum_async": (I, [P, P, SZ]),
     "rcgan_allreduce_join": (I, [P]),
+    "rcgan_comm_count": (I, [P, P]),
+    "rcgan_allreduce_bf16_scratch_bytes": (SZ, [I, P]),
+    "rcgan_allreduce_sum_bf16_buckets": (I, [P, I, P, P, P, SZ]),
+    "rcgan_comm_stub_model": (I, [P, C.c_double, C.c_double]),
+    "rcgan_comm_load_error": (C.c_char_p, []),
     "rcgan_set2_f32": (I, [P, P, F, F]),
     "rcgan_set_grad_scale": (I, [P, F, P]),
     "rcgan_grad_finite_check": (I, [P, SZ, P, P]),

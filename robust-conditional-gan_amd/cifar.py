@@ -246,8 +246,6 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         output = Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = O.reshape(ctx, output, (-1, 4, 4, DIM_G * 8))
         output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels, segments)
-        if Graph.current.early_g is not None and output.req:
-            ctx.record(Graph.current.early_g)       # backward: G.Block.2 .. G.Output are done here -> their bucket leaves early
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels, segments)
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels, segments)
         with variable_scope('G.OutputNorm'):
@@ -302,8 +300,6 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
             h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
             t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
             x = O.meanpool2(ctx, t)
-        if Graph.current.early_d is not None and x.req:
-            ctx.record(Graph.current.early_d)       # backward: D.Block.3 .. the head are done here -> their bucket leaves early
         if FUSED_TRUNK and O.d_trunk_ok(ctx, x):
             # D.Block.3 .. D.Block.6 (identity shortcuts, 8 x 8 pixels): one launch for the eight convolutions (ops.d_trunk)
             g, blocks = Graph.current, []
@@ -386,7 +382,8 @@ class CifarRCGAN:
                  perm_classifier=False, perm_multiplier=1.0, perm_type="linear",
                  confuse_init=False, confuse_init_diag=0.2, confuse_multiplier=1.0, confuse_lr_decay=False,
                  device=0, use_graphs=True, device_rng=True, arena_bytes=None, world_size=1, rank=0,
-                 variables=None, loss_scale=None, dynamic_loss_scale=None, loss_scale_growth_interval=2000, comm=None):
+                 variables=None, loss_scale=None, dynamic_loss_scale=None, loss_scale_growth_interval=2000, comm=None,
+                 grad_bucket_dtype=None, stub_model=None):
         if algorithm not in ALGORITHMS:
             raise ValueError("Unknown algorithm %s" % algorithm)
         self.alg, self.alpha, self.B, self.lr = algorithm, alpha, int(batch_size), lr
@@ -431,9 +428,7 @@ class CifarRCGAN:
             self.state[k] = t
         self.graph = Graph(ctx, self.groups, self.state)
         # Data parallel (world_size > 1; gan_resnet.py:529-546,697,786): the gradient slabs are all-reduced INSIDE the C ABI
-        # (rcgan_allreduce_sum*, RCCL over xGMI) and inside the step's captured graph, in two buckets per step: the layers whose
-        # backward finishes first (D.Block.3 .. head | G.Block.2 .. G.Output) leave on the communication stream while the rest of the
-        # backward pass runs, the remainder follows on the step's stream; the optimiser launch is part of the same graph.
+        # (rcgan_allreduce_sum*, RCCL over xGMI) and inside the step's captured graph; the optimiser launch is part of the same graph.
         #   comm: None -> RCCL (one process per GPU, dp.init_comm);  "stub" -> the single-process test double (every rank holds what
         #   this rank holds), which lets ONE GPU run and verify the whole world > 1 schedule.
         #   "rccl-self" (world_size 1) -> a ONE-rank RCCL communicator under the same schedule: real ncclAllReduce calls, captured and
@@ -446,15 +441,21 @@ class CifarRCGAN:
             if self.comm_kind not in ("rccl", "stub", "rccl-self") or (self.comm_kind == "rccl-self" and self.world != 1):
                 raise ValueError("Unknown comm %s for world_size %d" % (comm, self.world))
             dp.init_comm(ctx, self.world, self.rank, stub=(self.comm_kind == "stub"))
-        # RCGAN_DP_OVERLAP=1: the early bucket (below).  Measured on one MI355X against the test-double communicator (bench.py --dp-stub 8,
-        # i.e. WITHOUT any traffic to hide): 6.73 -> 7.46 ms per iteration, ~0.12 ms per optimiser step for the second filter-gradient
-        # group + second spectral-norm backward + the fork / join -- more than the ~0.08 ms a 4.9 MB all-reduce takes over xGMI.
-        # The whole-slab exchange on the step's own stream costs 0.03 ms per iteration on the same measure, so that is the default.
-        self.dp_overlap = self.dp_active and os.environ.get("RCGAN_DP_OVERLAP", "0") == "1"
+            if stub_model is not None:
+                # (bus GB/s, latency us): the test double then occupies its stream like an all-reduce under that link model
+                ctx.check(ctx.lib.rcgan_comm_stub_model(ctx.h, float(stub_model[0]), float(stub_model[1])))
+        # gradient buckets travel as fp32 (default: the reference sums fp32 tower gradients) or as bf16 (half the xGMI bytes; the
+        # sum over the ranks then carries 8 mantissa bits -- an opt-in trade, RCGAN_DP_BUCKET_DTYPE=bf16)
+        self.grad_bucket_dtype = grad_bucket_dtype or os.environ.get("RCGAN_DP_BUCKET_DTYPE", "f32")
+        if self.grad_bucket_dtype not in ("f32", "bf16"):
+            raise ValueError("Unknown gradient bucket dtype %s" % self.grad_bucket_dtype)
+        self._bucket16 = None
+        # One whole-slab bucket per optimiser group and step, on the step's own stream.  An overlapped schedule (the last layers' bucket
+        # leaving on the communication stream in the middle of the backward pass) was built in round 3 and deleted in round 4: against
+        # the test double it cost 0.6-0.73 ms per iteration of extra launches (second filter-gradient group, second spectral-norm
+        # backward, fork / join) with nothing to hide, and under the link model of `bench.py --dp-stub 8 --dp-stub-gbps 200
+        # --dp-stub-lat-us 40` it still lost: 6.94 ms against 6.70 ms (fp32 buckets) and 6.42 ms (bf16 buckets) -- DESIGN 5.
         self.dp_adam_in_graph = self.dp_active and not self.dynamic_ls and os.environ.get("RCGAN_DP_GRAPH_ADAM", "1") == "1"
-        # first parameter of the early bucket of each group (everything from there to the end of the slab)
-        self._early_lo = {id(self.PD): self.PD.offsets["Discriminator/D.Block.3.Conv1/Filters"],
-                          id(self.PG): self.PG.offsets["Generator/G.Block.2.Shortcut/Filters"]}
         B = self.B
         f32, i32, act = L.F32, "i32", ctx.act_dtype
         P = ctx.persistent
@@ -648,7 +649,6 @@ class CifarRCGAN:
         self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
         g.begin_step({1})
-        g.early_d = self._dp_early(self.PD) if self.dp_overlap else None
         # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
         # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
         # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
@@ -734,7 +734,6 @@ class CifarRCGAN:
         self._refresh_generator_filters()
         ctx.new_step()
         g.begin_step({0, 2} if self.PC is not None else {0})
-        g.early_g = self._dp_early(self.PG) if self.dp_overlap else None
         self.PG.zero_grad()
         if self.PC is not None:
             self.PC.zero_grad()
@@ -794,6 +793,9 @@ class CifarRCGAN:
                 # the same software and takes the same branch, so the ranks stay in step)
                 warnings.warn("step %r: the all-reduce could not be captured (%s); running it uncaptured" % (key, e))
                 gid = None
+            except BaseException:
+                ctx.graph_abort()       # never leave the stream in capture mode (any later launch or sync would fail)
+                raise
             self._graphs[key] = gid
             return                      # the warm-up execution already did this step's work
         if self._graphs[key] is None:
@@ -802,38 +804,29 @@ class CifarRCGAN:
         ctx.graph_launch(self._graphs[key])
 
     # ---------------------------------------------------------------------------------- data parallel
-    def _dp_early(self, grp):
-        """Tape closure for the point of the backward pass where the group's LAST layers are done: flush their filter gradients,
-        run their spectral-norm backward, and start the all-reduce of slab[lo:] on the communication stream."""
-        ctx, lo = self.ctx, self._early_lo[id(grp)]
-        state = {"sent": False}
-        grp._dp_early_state = state
-
-        def fire():
-            ctx.flush_wgrads()
-            for bw in ctx.sn_partial:
-                bw(lambda name: name in grp.offsets and grp.offsets[name] >= lo)
-            ctx.check(ctx.lib.rcgan_allreduce_sum_async(ctx.h, C.c_void_p(grp.grad.data_ptr() + 4 * lo), grp.count - lo))
-            state["sent"] = True
-        return fire
-
     def _dp_finish(self, groups):
-        """End of a step's backward pass: all-reduce what has not left yet (ONE RCCL group), join the communication stream, and --
-        static loss scale -- run the optimiser inside the same captured graph."""
+        """End of a step's backward pass: all-reduce the gradient slabs of the step's optimiser groups (ONE RCCL group) and -- static
+        loss scale -- run the optimiser inside the same captured graph."""
         ctx = self.ctx
         if not self.dp_active or not ctx.recording:   # (forward-only evaluations -- eval_d_cost -- exchange and update nothing)
             return
         ptrs, counts = [], []
         for grp in groups:
-            st = getattr(grp, "_dp_early_state", None)
-            hi = self._early_lo[id(grp)] if (st is not None and st["sent"]) else grp.count
-            grp._dp_early_state = None
-            if hi > 0:
-                ptrs.append(grp.grad.data_ptr())
-                counts.append(hi)
+            ptrs.append(grp.grad.data_ptr())
+            counts.append(grp.count)
         n = len(ptrs)
-        ctx.check(ctx.lib.rcgan_allreduce_sum_buckets(ctx.h, n, (C.c_void_p * n)(*ptrs), (C.c_size_t * n)(*counts)))
-        ctx.check(ctx.lib.rcgan_allreduce_join(ctx.h))
+        if self.grad_bucket_dtype == "bf16":
+            cnt = (C.c_size_t * n)(*counts)
+            need = ctx.lib.rcgan_allreduce_bf16_scratch_bytes(n, cnt)
+            if self._bucket16 is None:           # persistent (captured graphs keep its address): sized for all groups together
+                allc = [g.count for g in self.groups]
+                self._bucket16 = torch.empty(ctx.lib.rcgan_allreduce_bf16_scratch_bytes(len(allc), (C.c_size_t * len(allc))(*allc)),
+                                             dtype=torch.uint8, device=ctx.device)
+            assert need <= self._bucket16.numel()
+            ctx.check(ctx.lib.rcgan_allreduce_sum_bf16_buckets(ctx.h, n, (C.c_void_p * n)(*ptrs), cnt, C.c_void_p(self._bucket16.data_ptr()),
+                                                               self._bucket16.numel()))
+        else:
+            ctx.check(ctx.lib.rcgan_allreduce_sum_buckets(ctx.h, n, (C.c_void_p * n)(*ptrs), (C.c_size_t * n)(*counts)))
         if self.dp_adam_in_graph:
             for grp in groups:
                 grp.adam_captured(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))

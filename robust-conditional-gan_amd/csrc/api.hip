@@ -266,6 +266,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->head_stage = 0;
   c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stub = false; c->comm_stream = nullptr;
   c->comm_fork = nullptr; c->comm_join = nullptr; c->comm_pending = false;
+  c->stub_bus_gbps = 0.0; c->stub_latency_us = 0.0; c->wall_clock_khz = 0;
   c->gscale_host = 1.f;
   c->gscale_dev = nullptr;
   c->zero_page = nullptr;
@@ -280,11 +281,13 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
 
 int rcgan_destroy(rcgan_ctx* ctx) {
   if (!ctx) return RCGAN_EINVALID_ARG;
+  (void)hipStreamSynchronize(ctx->stream);
+  // graphs first: captured ncclAllReduce nodes hold references to the communicator, which RCCL wants released before ncclCommDestroy
+  for (auto& g : ctx->graphs)
+    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
   (void)rcgan_comm_destroy(ctx);
   for (int i = 0; i < 64; ++i)
     if (ctx->event_made[i]) (void)hipEventDestroy(ctx->events[i]);
-  for (auto g : ctx->graphs)
-    if (g) (void)hipGraphExecDestroy(g);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
@@ -405,6 +408,7 @@ int rcgan_graph_abort(rcgan_ctx* ctx) {
   if (!ctx->capturing) return RCGAN_OK;
   ctx->capturing = false;
   ctx->head_stage = 0;           // (deferred launches recorded into the dropped capture never ran; their buffers belong to the aborted step)
+  ctx->comm_pending = false;     // (an asynchronous bucket's join event was recorded inside the dropped capture)
   hipGraph_t g = nullptr;
   (void)hipStreamEndCapture(ctx->stream, &g);
   if (g) (void)hipGraphDestroy(g);

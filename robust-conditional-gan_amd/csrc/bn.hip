@@ -1177,7 +1177,16 @@ int rcgan_bn_apply_segments(rcgan_ctx* ctx, int nseg, int n_per_seg, int rows_pe
                             void* y, void* ws, size_t ws_bytes) {
   RC_REQUIRE(ctx, nseg >= 1 && n_per_seg >= 1, "segments %d x %d", nseg, n_per_seg);
   if (nseg == 1) return rcgan_bn_apply_fwd(ctx, n_per_seg, rows_per_sample, c, n_labels, dtype, x, labels, gamma, beta, mean, rstd, act, y, ws, ws_bytes);
-  RC_REQUIRE(ctx, bn_fused_ok(c), "segmented apply needs the fused path (channels %d)", c);
+  if (!bn_fused_ok(c)) {           // channel counts the fused kernel does not take: segment by segment, as rcgan_bn_fwd_segments does
+    const size_t seg_elems = (size_t)n_per_seg * rows_per_sample * c;
+    for (int sg = 0; sg < nseg; ++sg) {
+      int rc = rcgan_bn_apply_fwd(ctx, n_per_seg, rows_per_sample, c, n_labels, dtype, (const char*)x + sg * seg_elems * dtype_size(dtype),
+                                  labels ? labels + (size_t)sg * n_per_seg : nullptr, gamma, beta, mean + (size_t)sg * c, rstd + (size_t)sg * c,
+                                  act, (char*)y + sg * seg_elems * dtype_size(dtype), ws, ws_bytes);
+      if (rc != RCGAN_OK) return rc;
+    }
+    return RCGAN_OK;
+  }
   const long rows = (long)n_per_seg * rows_per_sample;
   const long nchunks = rows * c / 8;
   const int gx = apply_grid_fused(nchunks, c);

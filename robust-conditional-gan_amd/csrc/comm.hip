@@ -16,13 +16,14 @@ namespace {
 // the few RCCL declarations this file needs (rccl.h: ncclUniqueId, ncclDataType_t, ncclRedOp_t)
 struct RcclUniqueId { char internal[RCGAN_COMM_ID_BYTES]; };
 typedef int rccl_result_t;                 // ncclSuccess == 0
-const int kRcclFloat32 = 7, kRcclSum = 0;  // ncclFloat32, ncclSum
+const int kRcclFloat32 = 7, kRcclBfloat16 = 9, kRcclSum = 0;  // ncclFloat32, ncclBfloat16, ncclSum
 
 struct RcclApi {
   void* lib = nullptr;
   rccl_result_t (*GetUniqueId)(RcclUniqueId*) = nullptr;
   rccl_result_t (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
   rccl_result_t (*CommDestroy)(void*) = nullptr;
+  rccl_result_t (*CommCount)(void*, int*) = nullptr;
   rccl_result_t (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   rccl_result_t (*GroupStart)() = nullptr;
   rccl_result_t (*GroupEnd)() = nullptr;
@@ -35,18 +36,26 @@ RcclApi* rccl_api() {
   static bool tried = false;
   if (tried) return &api;
   tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so"};
+  // RCGAN_RCCL_LIB names the library instead (a site build of RCCL; the tests point it at a file that does not exist)
+  const char* override_name = getenv("RCGAN_RCCL_LIB");
+  const char* names[] = {override_name && *override_name ? override_name : "librccl.so.1", "librccl.so"};
+  const int n_names = override_name && *override_name ? 1 : 2;
   for (int pass = 0; pass < 2 && !api.lib; ++pass)          // pass 0: an instance the process already carries
-    for (const char* n : names) {
-      api.lib = dlopen(n, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0));
+    for (int i = 0; i < n_names; ++i) {
+      api.lib = dlopen(names[i], RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0));
       if (api.lib) break;
     }
-  if (!api.lib) { api.why = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return &api; }
+  if (!api.lib) {
+    const char* e = dlerror();                               // one call: dlerror() clears the message it returns
+    api.why = std::string("dlopen(") + names[0] + "): " + (e ? e : "not found");
+    return &api;
+  }
   bool ok = true;
   auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p) { ok = false; api.why = std::string("missing symbol ") + n; } return p; };
   api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+  api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
   api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
   api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
   api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
@@ -74,29 +83,82 @@ int ensure_comm_stream(rcgan_ctx* ctx) {
   return RCGAN_OK;
 }
 
-int allreduce_on(rcgan_ctx* ctx, hipStream_t stream, float* const* bufs, const size_t* counts, int n) {
+// the test double's link model: one thread watches the constant-rate wall clock until `ticks` have passed
+__global__ void stub_wait_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// bf16 buckets: fp32 -> bf16 (nearest even; inf / nan kept) and back, all buckets of a group in one launch each (blockIdx.y = bucket)
+struct Bf16Buckets {
+  float* f32[8];
+  unsigned short* b16[8];
+  size_t count[8];
+};
+__global__ void buckets_to_bf16_kernel(Bf16Buckets b) {
+  const float* src = b.f32[blockIdx.y];
+  unsigned short* dst = b.b16[blockIdx.y];
+  const size_t n = b.count[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned u = __float_as_uint(src[i]);
+    dst[i] = (u & 0x7fffffffu) > 0x7f800000u ? (unsigned short)((u >> 16) | 0x40u)      // nan stays nan
+                                             : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+__global__ void buckets_from_bf16_kernel(Bf16Buckets b, float scale) {
+  float* dst = b.f32[blockIdx.y];
+  const unsigned short* src = b.b16[blockIdx.y];
+  const size_t n = b.count[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = __uint_as_float((unsigned)src[i] << 16) * scale;
+}
+
+int stub_wait(rcgan_ctx* ctx, hipStream_t stream, size_t bytes) {
+  if (ctx->stub_bus_gbps <= 0.0 && ctx->stub_latency_us <= 0.0) return RCGAN_OK;
+  if (ctx->wall_clock_khz == 0) {
+    int khz = 0;
+    RC_HIP(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    ctx->wall_clock_khz = khz > 0 ? khz : 100000;
+  }
+  const int N = ctx->comm_world;
+  double us = ctx->stub_latency_us;
+  if (ctx->stub_bus_gbps > 0.0 && N > 1) us += 2.0 * (N - 1) / N * (double)bytes / (ctx->stub_bus_gbps * 1e3);
+  hipLaunchKernelGGL(stub_wait_kernel, dim3(1), dim3(1), 0, stream, (long long)(us * 1e-3 * ctx->wall_clock_khz));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+// one all-reduce group on `stream`: fp32 buckets in place, or (b16 != nullptr) their bf16 images in b16[i]
+int allreduce_on(rcgan_ctx* ctx, hipStream_t stream, float* const* bufs, const size_t* counts, int n, unsigned short* const* b16 = nullptr) {
   RC_REQUIRE(ctx, ctx->comm != nullptr || ctx->comm_stub, "no communicator: call rcgan_comm_init first");
-  for (int i = 0; i < n; ++i) RC_REQUIRE(ctx, bufs[i] != nullptr || counts[i] == 0, "null bucket %d", i);
+  size_t bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    RC_REQUIRE(ctx, bufs[i] != nullptr || counts[i] == 0, "null bucket %d", i);
+    bytes += counts[i] * (b16 ? 2 : 4);
+  }
+  ProfScope ps(ctx, RCGAN_PROF_ALLREDUCE, (double)bytes, -1.0, stream);
   if (ctx->comm_stub) {
     // fault injection for the tests of the host side's fallback: a communicator whose all-reduce cannot be recorded into a graph
     if (ctx->capturing && getenv("RCGAN_COMM_STUB_FAIL_IN_CAPTURE")) RC_FAIL(ctx, RCGAN_ERCCL, "test double: all-reduce refused inside a capture");
-    for (int i = 0; i < n; ++i) {
-      if (counts[i] == 0) continue;
-      size_t blocks = (counts[i] + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(scale_inplace_kernel, dim3((int)blocks), dim3(256), 0, stream, counts[i], bufs[i], (float)ctx->comm_world);
-      RC_LAUNCH_CHECK(ctx);
-    }
-    return RCGAN_OK;
+    if (!b16)          // (bf16 buckets: the widening launch applies the factor -- world * x is what N ranks holding x sum to)
+      for (int i = 0; i < n; ++i) {
+        if (counts[i] == 0) continue;
+        size_t blocks = (counts[i] + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(scale_inplace_kernel, dim3((int)blocks), dim3(256), 0, stream, counts[i], bufs[i], (float)ctx->comm_world);
+        RC_LAUNCH_CHECK(ctx);
+      }
+    return stub_wait(ctx, stream, bytes);
   }
   RcclApi* api = rccl_api();
   if (n > 1) RC_RCCL(ctx, api, api->GroupStart());
   for (int i = 0; i < n; ++i) {
     if (counts[i] == 0) continue;
-    rccl_result_t r = api->AllReduce(bufs[i], bufs[i], counts[i], kRcclFloat32, kRcclSum, ctx->comm, stream);
+    void* p = b16 ? (void*)b16[i] : (void*)bufs[i];
+    rccl_result_t r = api->AllReduce(p, p, counts[i], b16 ? kRcclBfloat16 : kRcclFloat32, kRcclSum, ctx->comm, stream);
     if (r != 0) {
       if (n > 1) (void)api->GroupEnd();
-      RC_FAIL(ctx, RCGAN_ERCCL, "ncclAllReduce(bucket %d, %zu floats) -> %s", i, counts[i], api->GetErrorString(r));
+      RC_FAIL(ctx, RCGAN_ERCCL, "ncclAllReduce(bucket %d, %zu %s) -> %s", i, counts[i], b16 ? "bf16" : "floats", api->GetErrorString(r));
     }
   }
   if (n > 1) RC_RCCL(ctx, api, api->GroupEnd());
@@ -148,6 +210,7 @@ int rcgan_comm_destroy(rcgan_ctx* ctx) {
     ctx->comm = nullptr;
   }
   ctx->comm_stub = false; ctx->comm_world = 1; ctx->comm_rank = 0; ctx->comm_pending = false;
+  ctx->stub_bus_gbps = 0.0; ctx->stub_latency_us = 0.0;
   if (ctx->comm_fork) { (void)hipEventDestroy(ctx->comm_fork); ctx->comm_fork = nullptr; }
   if (ctx->comm_join) { (void)hipEventDestroy(ctx->comm_join); ctx->comm_join = nullptr; }
   if (ctx->comm_stream) { (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
@@ -155,6 +218,59 @@ int rcgan_comm_destroy(rcgan_ctx* ctx) {
 }
 
 int rcgan_comm_world(rcgan_ctx* ctx) { return ctx ? ctx->comm_world : 0; }
+
+const char* rcgan_comm_load_error(void) { return rccl_api()->why.c_str(); }
+
+int rcgan_comm_count(rcgan_ctx* ctx, int* ranks) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, ranks != nullptr, "null argument");
+  RC_REQUIRE(ctx, ctx->comm != nullptr || ctx->comm_stub, "no communicator: call rcgan_comm_init first");
+  if (ctx->comm_stub) { *ranks = ctx->comm_world; return RCGAN_OK; }
+  RcclApi* api = rccl_api();
+  RC_RCCL(ctx, api, api->CommCount(ctx->comm, ranks));
+  return RCGAN_OK;
+}
+
+int rcgan_comm_stub_model(rcgan_ctx* ctx, double bus_gbps, double latency_us) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, ctx->comm_stub, "the cost model belongs to the test double (rcgan_comm_init_stub)");
+  RC_REQUIRE(ctx, bus_gbps >= 0.0 && latency_us >= 0.0, "bus %g GB/s, latency %g us", bus_gbps, latency_us);
+  ctx->stub_bus_gbps = bus_gbps; ctx->stub_latency_us = latency_us;
+  return RCGAN_OK;
+}
+
+size_t rcgan_allreduce_bf16_scratch_bytes(int n, const size_t* counts) {
+  size_t b = 0;
+  for (int i = 0; i < n && counts; ++i) b += (counts[i] * 2 + 255) / 256 * 256;
+  return b;
+}
+
+int rcgan_allreduce_sum_bf16_buckets(rcgan_ctx* ctx, int n, float* const* bufs, const size_t* counts, void* scratch16, size_t scratch_bytes) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  RC_REQUIRE(ctx, n >= 0 && n <= 8 && (n == 0 || (bufs && counts && scratch16)), "bad bucket list (at most 8 buckets)");
+  RC_REQUIRE(ctx, ctx->comm != nullptr || ctx->comm_stub, "no communicator: call rcgan_comm_init first");
+  if (n == 0) return RCGAN_OK;
+  const size_t need = rcgan_allreduce_bf16_scratch_bytes(n, counts);
+  if (scratch_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, scratch_bytes);
+  Bf16Buckets b = {};
+  size_t off = 0, most = 0;
+  for (int i = 0; i < n; ++i) {
+    RC_REQUIRE(ctx, bufs[i] != nullptr || counts[i] == 0, "null bucket %d", i);
+    b.f32[i] = bufs[i]; b.b16[i] = (unsigned short*)((char*)scratch16 + off); b.count[i] = counts[i];
+    off += (counts[i] * 2 + 255) / 256 * 256;
+    if (counts[i] > most) most = counts[i];
+  }
+  if (most == 0) return RCGAN_OK;
+  size_t blocks = (most + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(buckets_to_bf16_kernel, dim3((int)blocks, n), dim3(256), 0, ctx->stream, b);
+  RC_LAUNCH_CHECK(ctx);
+  int rc = allreduce_on(ctx, ctx->stream, bufs, counts, n, b.b16);
+  if (rc != RCGAN_OK) return rc;
+  hipLaunchKernelGGL(buckets_from_bf16_kernel, dim3((int)blocks, n), dim3(256), 0, ctx->stream, b, ctx->comm_stub ? (float)ctx->comm_world : 1.0f);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
 
 int rcgan_allreduce_sum(rcgan_ctx* ctx, float* buf, size_t count) {
   if (!ctx) return RCGAN_EINVALID_ARG;

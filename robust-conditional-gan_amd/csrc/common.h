@@ -41,6 +41,10 @@ struct rcgan_ctx {
   hipStream_t comm_stream;
   hipEvent_t comm_fork, comm_join;
   bool comm_pending;   // an asynchronous bucket has not been joined yet
+  // cost model of the test double (rcgan_comm_stub_model): an all-reduce group of `bytes` occupies its stream for
+  // latency + 2 (world - 1) / world * bytes / bus bandwidth; 0 / 0 = free (the schedule's own cost only)
+  double stub_bus_gbps, stub_latency_us;
+  int wall_clock_khz;  // hipDeviceAttributeWallClockRate (the constant-rate counter the wait kernel reads)
   void* dbg_stamps;    // rcgan_debug_stamps
   // deferred parameter gradients of the projection head (head_rider.h): 0 = nothing pending, 1 = dE GEMM + parameter sums,
   // 2 = parameter sums; the argument block is loss.hip's
@@ -71,11 +75,13 @@ struct rcgan_ctx {
 // brackets one launch with events when profiling is armed for kernel id `which`
 struct ProfScope {
   rcgan_ctx* c; bool on;
-  ProfScope(rcgan_ctx* ctx, int which, double flops, double executed = -1.0) : c(ctx), on(ctx->prof_which == which) {
+  hipStream_t s;
+  ProfScope(rcgan_ctx* ctx, int which, double flops, double executed = -1.0, hipStream_t on_stream = nullptr)
+      : c(ctx), on(ctx->prof_which == which && !ctx->capturing), s(on_stream ? on_stream : ctx->stream) {
     if (!on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(e, c->stream);
+    (void)hipEventRecord(e, s);
     c->prof_ev.push_back(e);
     c->prof_flops += flops;
     c->prof_flops_exec += executed < 0.0 ? flops : executed;
@@ -84,7 +90,7 @@ struct ProfScope {
     if (!on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, c->stream);
+    (void)hipEventRecord(e, s);
     c->prof_ev.push_back(e);
   }
 };

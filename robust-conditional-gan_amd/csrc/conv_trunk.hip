@@ -379,7 +379,6 @@ int rcgan_dtrunk_pooled(rcgan_ctx* ctx, int n, int backward, const void* x0, con
   a.xlast = (const bf16_t*)xlast;
   a.dy_out = (bf16_t*)dy_out;
   a.gemm = SmallGemmArgs{};
-  const int riders = ((backward & 1) && head_take_gemm(ctx, &a.gemm)) ? cdiv(a.gemm.d, 16) : 0;
   const size_t elems = (size_t)9 * TR_C * TR_C;
   for (int i = 0; i < TR_LAYERS; ++i) {
     RC_REQUIRE(ctx, outs[i], "layer %d: null pointer", i);
@@ -395,6 +394,9 @@ int rcgan_dtrunk_pooled(rcgan_ctx* ctx, int n, int backward, const void* x0, con
     RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_trunk_rw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRW_LDS));
     attr_set = true;
   }
+  // the head's dE GEMM is taken (head_stage 1 -> 2) only here, behind every check that can fail: a rider marked as carried by a
+  // launch that never happened would leave the parameter sums reading a dE nobody wrote
+  const int riders = ((backward & 1) && head_take_gemm(ctx, &a.gemm)) ? cdiv(a.gemm.d, 16) : 0;
   if (backward & 1) hipLaunchKernelGGL((conv_trunk_rw_kernel<true>), dim3(n + riders), dim3(256), TRW_LDS, ctx->stream, a);
   else hipLaunchKernelGGL((conv_trunk_rw_kernel<false>), dim3(n), dim3(256), TRW_LDS, ctx->stream, a);
   RC_LAUNCH_CHECK(ctx);

@@ -298,8 +298,10 @@ class MnistRCGAN:
             ctx.graph_begin()
             try:
                 body()
-            finally:
-                self._graphs[key] = ctx.graph_end()
+            except BaseException:
+                ctx.graph_abort()       # never leave the stream in capture mode
+                raise
+            self._graphs[key] = ctx.graph_end()
             return
         ctx.graph_launch(self._graphs[key])
 
@@ -426,8 +428,10 @@ class MnistRCGAN:
             ctx.graph_begin()
             try:
                 body()
-            finally:
-                self._graphs[key] = ctx.graph_end()
+            except BaseException:
+                ctx.graph_abort()
+                raise
+            self._graphs[key] = ctx.graph_end()
         ctx.graph_launch(self._graphs[key])
 
     # ------------------------------------------------------------------------------------ io

@@ -170,10 +170,13 @@ def main(argv=None):
     def inception_score(n):
         # gan_resnet.py:836-845: 100 samples with uniformly random labels per Generator call, n / 100 calls
         from .inception_score import get_inception_score, samples_as_the_reference_feeds_them
-        all_samples = [m.sample(np.random.randint(10, size=100).astype('int32'), np.random.normal(size=(100, Z_DIM)).astype('float32'))
+        # the reference draws these labels and latents with TensorFlow's generators (gan_resnet.py:836-838): they must not advance
+        # the global numpy stream the data and label-noise draws come from -- a private stream
+        all_samples = [m.sample(is_rs.randint(10, size=100).astype('int32'), is_rs.normal(size=(100, Z_DIM)).astype('float32'))
                        for _ in range(int(n / 100))]
         return get_inception_score(samples_as_the_reference_feeds_them(np.concatenate(all_samples, axis=0)), inception_fn)
 
+    is_rs = np.random.RandomState(0x15c0 + rank)
     inception_score_max = 0.0                                                  # gan_resnet.py:917
     from .dp import mean_over_ranks
     pending = []                       # (iteration, ticket) of losses read back asynchronously

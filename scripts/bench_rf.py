@@ -32,6 +32,7 @@ def main():
     cases = [("D.Block.2.Conv1 16x16 128>128", 16, 128, 128), ("D.Block.3 8x8 128>128", 8, 128, 128),
              ("G.Block.1.Conv2 8x8 256>256", 8, 256, 256), ("G.Block.2.Conv2 16x16 256>256", 16, 256, 256)]
     print("%-34s %9s %9s %9s %9s   %s" % ("layer (n = %d)" % n, "fwd us", "rf fwd", "dgrad us", "rf dgrad", "norm-rel diff fwd / dgrad"))
+    bad = 0
     for name, hw, cin, cout in cases:
         desc = L.ConvDesc(n, hw, hw, cin, cout, 3, 3, 1, L.BF16, L.CONV_IN_RELU)
         if not lib.rcgan_conv_rf_ok(C.byref(desc)):
@@ -71,7 +72,13 @@ def main():
         ctx.sync()
         rel = lambda a, b: float(np.linalg.norm(ctx.download(a).astype(np.float64) - ctx.download(b)) / np.linalg.norm(ctx.download(b).astype(np.float64)))
         print("%-34s %9.1f %9.1f %9.1f %9.1f   %.2e / %.2e" % (name, t[0], t[1], t[2], t[3], rel(y1, y0), rel(dx1, dx0)))
+        # admission contract of rcgan_conv_rf_ok: whatever it admits runs within 1.2x of the tile kernels, both directions
+        verdict = "ok" if (t[1] <= 1.2 * t[0] and t[3] <= 1.2 * t[2]) else "FAIL"
+        print("   admitted shape within 1.2x of the tile kernel (fwd %.2fx, dgrad %.2fx): %s" % (t[1] / t[0], t[3] / t[2], verdict))
+        bad += verdict != "ok"
     ctx.close()
+    if bad:
+        sys.exit("bench_rf: %d admitted shape(s) slower than 1.2x the tile kernel" % bad)
 
 
 if __name__ == "__main__":

@@ -48,7 +48,9 @@ python3 bench.py --no-cpu-baseline --dtype f16 --batch 512 --steps 8 > "$OUT/ben
 python3 bench.py --no-cpu-baseline --algorithm rcgan-u > "$OUT/bench_rcganu.json" 2> /dev/null
 # the world-size-8 step schedule against the in-ABI test-double communicator (no traffic): what the schedule itself costs
 python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8.json" 2> /dev/null
-RCGAN_DP_OVERLAP=1 python3 bench.py --no-cpu-baseline --dp-stub 8 > "$OUT/bench_dpstub8_overlap.json" 2> /dev/null
+# ... and under a stated link model (40 us + 2(N-1)/N * bytes / 200 GB/s per all-reduce group): the predicted 8-rank iteration, fp32 / bf16 buckets
+python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 > "$OUT/bench_dpstub8_model_f32.json" 2> /dev/null
+python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 --bucket-dtype bf16 > "$OUT/bench_dpstub8_model_bf16.json" 2> /dev/null
 RCGAN_FUSE_BN_STATS=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_fuse_bn_stats.json" 2> /dev/null
 RCGAN_HEAD_RIDERS=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_head_riders.json" 2> /dev/null
 RCGAN_POOL_IN_TRUNK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_pool_in_trunk.json" 2> /dev/null

@@ -498,7 +498,25 @@ def test_d_trunk_pooled_boundary(dev, n, kind_a, kind_b):
         assert rel_err(a[k], b[k]) < 1e-5, (k, rel_err(a[k], b[k]))
 
 
-@pytest.mark.parametrize("n,hw,in_relu,second", [(3, 16, True, False), (128, 16, True, True), (5, 8, True, False), (4, 16, False, True)])
+def test_register_filter_conv_admits_only_shapes_it_runs_well(dev):
+    """rcgan_conv_rf_ok is the admission test of rcgan_conv2d_rf: 3x3 stride-1 128 -> 128 on 16x16 images, 16-bit.  8x8 images are
+    refused (their data gradient ran 250x slower than the tile kernel in round 3; the fused stage serves those layers)."""
+    from rcgan_amd import _lib as L
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("16-bit kernel")
+    ok = lambda *a: bool(ctx.lib.rcgan_conv_rf_ok(C.byref(L.ConvDesc(*a))))
+    dt = ctx.act_dtype
+    assert ok(128, 16, 16, 128, 128, 3, 3, 1, dt, L.CONV_IN_RELU)
+    assert not ok(128, 8, 8, 128, 128, 3, 3, 1, dt, L.CONV_IN_RELU)
+    assert not ok(128, 16, 16, 256, 256, 3, 3, 1, dt, 0)
+    assert not ok(128, 16, 16, 128, 128, 1, 1, 1, dt, 0)
+    assert not ok(128, 16, 16, 128, 128, 3, 3, 1, L.F32, 0)
+    d8 = L.ConvDesc(4, 8, 8, 128, 128, 3, 3, 1, dt, 0)
+    assert ctx.lib.rcgan_conv2d_rf(ctx.h, C.byref(d8), 0, None, None, None, None, None, None) == -1      # RCGAN_EINVALID_ARG
+
+
+@pytest.mark.parametrize("n,hw,in_relu,second", [(3, 16, True, False), (128, 16, True, True), (5, 16, True, False), (4, 16, False, True)])
 def test_register_filter_conv_equals_tile_kernels(dev, n, hw, in_relu, second):
     """rcgan_conv2d_rf (csrc/conv_rf.hip: filter slices in registers, input patch resident in LDS, K split over the wavefronts) through
     ops.conv2d against the tile-per-tap kernels: forward (+bias, input ReLU), data gradient (ReLU mask; `second`: accumulated onto an

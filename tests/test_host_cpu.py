@@ -188,3 +188,44 @@ def test_product_mnist_noise_schedule_matches_oracle():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     with pytest.raises(ValueError):
         DM.noise_schedule(0, 0.5, 0.95, 1, 2)
+
+
+def test_bench_gpus_n_starts_n_ranks(tmp_path):
+    """`python bench.py --gpus N` outside a launcher must start N ranks itself (round-3 verdict: it printed n_gpus: 1): --dry-run prints the
+    torch.distributed.run command; inside a launcher (WORLD_SIZE set) or at N = 1 there is none; a rank whose WORLD_SIZE disagrees with
+    --gpus refuses to run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    run = lambda args, e: subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
+    r = run(["--gpus", "2", "--steps", "3", "--master-port", "29777", "--dry-run"], env)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launcher"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29777"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "2", "--steps", "3"]                   # the ranks get the same flags, minus the launcher's own
+    assert json.loads(run(["--dry-run"], env).stdout.strip().splitlines()[-1])["launcher"] is None
+    assert json.loads(run(["--gpus", "2", "--dry-run"], dict(env, WORLD_SIZE="2")).stdout.strip().splitlines()[-1])["launcher"] is None
+    bad = run(["--gpus", "4", "--steps", "1"], dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_rccl_that_cannot_be_loaded_is_an_error_code_not_a_crash():
+    """comm.hip binds librccl at run time; when it cannot be loaded rcgan_comm_unique_id returns RCGAN_ERCCL and rcgan_comm_load_error says why
+    (round-3 advisor: the message was built from a second dlerror() call, i.e. from NULL).  RCGAN_RCCL_LIB points the loader at a file that does
+    not exist; a fresh process, because the binding is cached per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import rcgan_amd; from rcgan_amd import _lib as L; lib = L.load(); "
+            "buf = C.create_string_buffer(128); rc = lib.rcgan_comm_unique_id(buf); why = lib.rcgan_comm_load_error().decode(); "
+            "print(rc, '|', why)") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RCGAN_RCCL_LIB="/nonexistent/librccl_missing.so"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rc, why = r.stdout.strip().splitlines()[-1].split(" | ")
+    assert int(rc) == -5 and "librccl_missing.so" in why             # RCGAN_ERCCL
