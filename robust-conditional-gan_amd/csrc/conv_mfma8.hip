@@ -21,6 +21,12 @@
 #include "conv_mfma.h"
 #include "mfma_util.h"
 
+// timing-only ablations of the ping-pong K loop (scripts/build_p8_ablate.sh: results are wrong by construction):
+// 1 = no LDS-DMA issue, 2 = no fragment reads after the first K-tile, 4 = no MFMAs, 8 = no barriers, 16 = no pixel (X) LDS-DMA, filters only
+#ifndef P8_ABLATE
+#define P8_ABLATE 0
+#endif
+
 namespace {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -31,10 +37,17 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 }
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// without the LDS wait: fragment reads stay in flight across it (the compiler's counted lgkmcnt waits sit in front of the MFMAs)
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 }  // namespace
 
-template <bool RELU, bool XCDSWZ, bool STATS = false>
+// PP ("ping-pong", round 4): the two wavefronts of a SIMD (waves w and w + 4) run ONE BARRIER APART, and every phase gets a second
+// barrier between its fragment reads and its MFMAs -- while one group of four wavefronts (one per SIMD) multiplies, the other reads
+// its fragments and issues its bursts, instead of all eight reading at once and then queueing for the matrix pipe (the schedule of
+// the guide's 8-phase GEMM template).  The counted waits move in front of the phase's FIRST barrier: a burst is read one barrier
+// after the wait that retires it PLUS the one-barrier lag of the other group.
+template <bool RELU, bool XCDSWZ, bool STATS = false, bool PP = false>
 __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALF = 128 * 128;                 // bytes of one half-tile (128 rows x 128 B)
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
       if (which == 0 && pend) { use_tap(); pend = false; }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
+        if (!(P8_ABLATE & 16)) glds16_asm(rp[h * 2 + j] + i_c0 * rstep[h * 2 + j], base + XOFF + h * HALF + (wave * 2 + j) * 1024);
       if (which == 3) {
         if (a.cm) {
           // channel-major: the taps of one 64-channel chunk back to back.  They read the same 128-byte line of every
@@ -231,10 +244,52 @@ __global__ __launch_bounds__(512) void conv_mfma_p8_kernel(MfmaConvArgs a) {
 #pragma unroll
   for (int w = 0; w < 4; ++w) issue(w, 0);
   wait_vm<0>();
+  const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD
+  if (PP && grp) wg_barrier();                     // group 1 runs one barrier behind group 0 from here on
   wg_barrier();
   stamp(2);
 
-  for (int t = 0; t < KT; ++t) {
+  for (int t = 0; PP && t < KT; ++t) {
+    const unsigned char* bufp = smem + (t & 1) * BUF;
+    const int nb = (t + 1) & 1;
+    const bool more = t + 1 < KT;
+    // phase 1: (P0, C0)
+    if (!(P8_ABLATE & 2) || t == 0) { load_x(bufp, 0); load_w(bufp, 0); }
+    if (more && !(P8_ABLATE & 1)) issue(0, nb);
+    if (P8_ABLATE & 16) wait_vm<0>(); else
+    if (more) wait_vm<4>(); else wait_vm<2>();    // C1 of this tile has landed (newer: P1 [, P0 of the next tile]); read after b_1
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(P8_ABLATE & 8)) raw_barrier();                                 // a_1
+    if (!(P8_ABLATE & 4)) mma(0, 0);
+    if (!(P8_ABLATE & 8)) raw_barrier();                                 // b_1
+    // phase 2: (P0, C1)
+    if (!(P8_ABLATE & 2) || t == 0) load_w(bufp, 1);
+    if (more && !(P8_ABLATE & 1)) issue(1, nb);
+    if (P8_ABLATE & 16) {} else
+    if (more) wait_vm<4>(); else wait_vm<0>();    // P1 of this tile has landed; read after b_2
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+    if (!(P8_ABLATE & 4)) mma(0, 1);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+    // phase 3: (P1, C1)
+    if (!(P8_ABLATE & 2) || t == 0) load_x(bufp, 1);
+    if (more && !(P8_ABLATE & 1)) issue(2, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+    if (!(P8_ABLATE & 4)) mma(1, 1);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+    // phase 4: (P1, C0) -- both operands are still in registers
+    if (more && !(P8_ABLATE & 1)) issue(3, nb);
+    if (P8_ABLATE & 16) wait_vm<2>(); else
+    if (more) wait_vm<4>();                       // P0 and C0 of the next tile have landed (newer: its C1, P1); read after b_4
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+    if (!(P8_ABLATE & 4)) mma(1, 0);
+    if (!(P8_ABLATE & 8)) raw_barrier();
+  }
+  if (PP && !grp) wg_barrier();                    // group 0 waits for group 1's last barrier: equal counts, everything read
+
+  for (int t = 0; !PP && t < KT; ++t) {
     const unsigned char* bufp = smem + (t & 1) * BUF;
     const int nb = (t + 1) & 1;
     const bool more = t + 1 < KT;
@@ -716,19 +771,19 @@ __global__ __launch_bounds__(512) void conv_mfma_p8n_kernel(MfmaConvArgs a) {
                 RowPhase{phm ? 1 : 0, glw, glh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
 }
 
-template <bool RELU, bool XCDSWZ, bool STATS = false>
+template <bool RELU, bool XCDSWZ, bool STATS = false, bool PP = false>
 static int launch8(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 4 * 128 * 128 + 16 * 256 * sizeof(unsigned);     // tile buffers + tap-source table (<= 16 taps)
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_p8_kernel<RELU, XCDSWZ, STATS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * (a.phase == 2 ? 36 : a.KH * a.KW) * a.Cin * a.Cout,
                  2.0 * (double)a.M * (a.phase == 2 ? 16 : a.phase == 1 ? 4 : a.KH * a.KW) * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ, STATS>), grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_p8_kernel<RELU, XCDSWZ, STATS, PP>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -799,6 +854,11 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
     b.phase = a.phase ? a.phase : (phase ? 1 : 0);
     b.stamps = (unsigned long long*)ctx->dbg_stamps;
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
+    // plain 3x3 layers on 16- / 32-wide images: the pixel operand as a zero-padded patch in LDS, fetched once per 64-channel chunk
+    // instead of once per tap (conv_mfma8h.hip); RCGAN_P8_HALO=0 keeps the tile-per-tap kernel
+    static int halo = -1;
+    if (halo < 0) { const char* e = getenv("RCGAN_P8_HALO"); halo = e ? atoi(e) : 1; }
+    if (halo && !b.stats && mfma_conv8_halo_takes(b)) return mfma_conv8_halo_launch(ctx, b);
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
     if (persist && !b.phase && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
       return b.relu_in ? launch8p<true>(ctx, b, swz) : launch8p<false>(ctx, b, swz);
@@ -806,6 +866,9 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
       if (b.relu_in || b.Cout != 256 || b.M % 256 != 0 || b.accumulate || b.mask) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics: unsupported form");
       return swz ? launch8<false, true, true>(ctx, b) : launch8<false, false, true>(ctx, b);
     }
+    static int pp = -1;
+    if (pp < 0) { const char* e = getenv("RCGAN_P8_PP"); pp = e ? atoi(e) : 0; }
+    if (swz && pp) return b.relu_in ? launch8<true, true, false, true>(ctx, b) : launch8<false, true, false, true>(ctx, b);
     if (swz) return b.relu_in ? launch8<true, true>(ctx, b) : launch8<false, true>(ctx, b);
     return b.relu_in ? launch8<true, false>(ctx, b) : launch8<false, false>(ctx, b);
   }

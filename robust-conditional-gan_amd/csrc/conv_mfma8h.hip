@@ -1,0 +1,307 @@
+// 256 x 256-tile, 8-wavefront convolution with the PIXEL operand held as a zero-padded image patch in LDS (round 4).
+//
+// What round 4 measured on the tile-per-tap kernel (conv_mfma8.hip; scripts/build_p8_ablate.sh, profiles/r04_exp_p8_ablation.txt):
+// per K-tile 1.52 us as built, 0.98 us with MFMAs and barriers only (the matrix pipe at the clock the chip sustains under this
+// load), 1.02 us with the LDS-DMA stream and barriers only -- and 0.99 us when only the FILTER half of the stream is issued.  The
+// kernel is bound by the bytes it moves from L2 into LDS (64 KB per K-tile and CU: at the ~0.6 us such a burst takes to land,
+// the 2-3 half-tiles its LDS can keep in flight do not cover it), not by its matrix or LDS-read schedule.  Half of those bytes
+// are the pixel tile, fetched again for every one of the nine taps although the taps read the same pixels shifted by a row or a
+// column.  Here the pixels of a 64-channel chunk are fetched ONCE as a patch (the tile's TR image rows + one halo row above and
+// below, one halo column left and right: (TR + 2) x (W + 2) pixels x 128 B = 43 KB for W = 32), the nine taps are row offsets into
+// it, K runs chunk-major, and only the filter tiles stream per K-tile: 36.8 KB per K-tile instead of 64.  No tap-source table.
+//
+//   workgroup tile : 256 pixels (TR = 256 / W whole image rows, W = 16 or 32) x 256 output channels; K-tile = one tap x 64 channels
+//   wavefronts     : 8 = 2 (pixels, 128 each) x 4 (channels, 64 each); 4 x 8 accumulator tiles, the epilogue of the other kernels
+//   LDS            : 2 patches (chunk c, c + 1) + 2 filter K-tiles (t, t + 1 by parity) of 2 x 16 KiB halves (C0 / C1: the first /
+//                    second 32 channels of every wavefront column) = 2 x 43.0 + 64 KiB = 150 KiB
+//   LDS-DMA        : filters run 1.5 K-tiles ahead -- C0(t+2) is issued in phase 3 of tile t, C1(t+2) in phase 4 (their slots
+//                    were last read in phases 1 / 2 of tile t); the next chunk's patch rides one piece per wavefront and K-tile in
+//                    phase 2 of the chunk's first taps.  Counted waits: vmcnt(4) in front of phase 1's first barrier (C1 of this
+//                    tile has landed), vmcnt(6) in front of phase 4's (C0 of the next tile; a patch piece issued in between only
+//                    makes the count conservative).  Loads retire in order, so the patch of chunk c + 1 (issued by tap 5) has
+//                    landed when C0 of its first K-tile (issued at tap 7) has.
+//   schedule       : the ping-pong form of conv_mfma8.hip (PP): the wavefronts of a SIMD run one barrier apart, every phase has a
+//                    barrier between its fragment reads and its MFMAs; a burst is read one barrier after the wait + barrier that
+//                    retires it (the other group runs a barrier behind).
+//   fragment reads : pixel fragment f of tap (kh, kw) = 16 consecutive patch pixels from (tr + kh) * PC + tc + kw; the 16-byte
+//                    slots of a patch pixel P are XOR-swizzled with (P >> 1) & 7 (source side, as everywhere), so a window that
+//                    starts at a multiple of four pixels reads conflict-free and the others 2-way on a quarter of their banks.
+#include "conv_mfma.h"
+#include "mfma_util.h"
+
+// timing-only ablations (scripts/build_p8_ablate.sh h<k>; results are wrong by construction): 1 = every tap reads the patch at tap (0, 0)
+// (aligned, conflict-free windows), 2 = no patch LDS-DMA after the prologue, 4 = no filter LDS-DMA after the prologue, 8 = no pixel
+// fragment reads after the first K-tile, 16 = no MFMAs
+#ifndef H8_ABLATE
+#define H8_ABLATE 0
+#endif
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+constexpr int H8_HALF = 128 * 128;                   // one filter half-tile: 128 rows x 128 B
+constexpr int h8_patch_rows(int lw) { return (((256 >> lw) + 2) * ((1 << lw) + 2) + 7) / 8 * 8; }      // patch pixels, padded to whole DMA pieces
+constexpr int h8_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8_HALF; }      // [filter buffers 0, 1][patch 0][patch 1]
+
+}  // namespace
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the address of a burst needs no vector ALU
+// work in the loop (the tile-per-tap kernels add a 64-bit per-lane pointer per burst) -- every VALU instruction a "loading"
+// wavefront issues comes out of the matrix pipe's time of the wavefront it shares the SIMD with.
+__device__ __forceinline__ void glds16_sbase(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_byte_addr /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+// 16 bytes from an absolute LDS byte address + a compile-time offset (the ds_read immediate): no `smem +` pointer arithmetic, which
+// costs a vector add per read (the dynamic-LDS base is a relocation the compiler does not fold)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));     // (a native vector: HIP's uint4 struct is loaded as two 8-byte halves -> ds_read2_b64)
+__device__ __forceinline__ u32x4_t lds_read16(int byte_addr, int imm) {
+  typedef __attribute__((address_space(3))) const unsigned char* lds_bytes;
+  // (LLVM folds a DS offset only onto a base it knows to be non-negative, and splits a 16-byte read it cannot prove aligned into ds_read2_b64)
+  __builtin_assume(byte_addr >= 0 && byte_addr < (1 << 18) && (byte_addr & 15) == 0);
+  return *(__attribute__((address_space(3))) const u32x4_t*)((lds_bytes)(size_t)(unsigned)byte_addr + imm);
+}
+
+// x ^ 64 where it is used: a loop-invariant the compiler would otherwise hoist into a register of its own (sixteen of them: spills)
+__device__ __forceinline__ int xor64(int x) {
+  int y;
+  asm volatile("v_xor_b32 %0, 64, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
+template <int LW, bool RELU>
+__global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W = 1 << LW, TR = 256 >> LW;        // image width, image rows per tile
+  constexpr int PC = W + 2, PR = TR + 2;            // patch columns / rows
+  constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;      // patch pixels, padded rows, DMA pieces (8 rows each)
+  constexpr int PATCH = NROWS * 128;
+  constexpr int WBUF = 2 * H8_HALF;
+  // LDS: [filter K-tile buffers 0, 1][patch 0][patch 1]; the filter buffers differ in address bit 15 only (toggled by XOR)
+  constexpr int WOFF = 0, P0OFF = 2 * WBUF, P1OFF = 2 * WBUF + PATCH;
+  static_assert(WBUF == 32768, "the filter buffers are toggled with ^ 0x8000");
+  constexpr int MAXP = (NP + 7) / 8;                // patch pieces per wavefront
+  static_assert(MAXP <= 6, "a wavefront issues its patch pieces during the first six taps of a chunk");
+  static_assert((PR - 1) * PC * 128 + PC * 128 < 65536, "tap offsets are ds_read immediates");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;          // pixel half / channel quarter of this wavefront
+  const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: the two ping-pong groups
+  unsigned mt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // a contiguous run of tiles per XCD
+  const long m0 = (long)mt * 256;
+  const int co0 = blockIdx.y * 256;
+  const int K = 9 * a.Cin;
+  const int lrow = lane >> 3, pos = lane & 7;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+
+  // ---- patch sources: piece i = wave + 8 j covers patch pixels 8 i .. 8 i + 7; this lane deposits pixel q = 8 i + lrow, slot pos.
+  // Halo slots (SAME padding, the padding rows behind the patch) are zeroed once, here, in both buffers, and never written again:
+  // their lanes are masked out of every burst.
+  const unsigned n_img = (unsigned)(m0 >> (LW + a.lh));
+  const int oh0 = (int)((m0 >> LW) & (unsigned)(a.H - 1));
+  unsigned poff[MAXP];                              // BYTE offset into a.in (without the chunk's channel offset), ~0u = halo
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int piece = wave + 8 * j;
+    const int q = piece * 8 + lrow;
+    const int pr = q / PC, pc = q - pr * PC;
+    const int ih = oh0 - 1 + pr, iw = pc - 1;
+    const bool ok = piece < NP && q < NPX && ih >= 0 && ih < a.H && iw >= 0 && iw < W;
+    poff[j] = ok ? 2u * (((n_img * (unsigned)a.H + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8)) : ~0u;
+    if (!ok && piece < NP) {
+      *(uint4*)(smem + P0OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(smem + P1OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+
+  // ---- filter sources: per half-tile this wavefront deposits rows (wave*2 + j)*8 + lrow, j = 0,1; row r of half h = channel (r>>5)*64 + h*32 + (r&31)
+  unsigned woff[2];                                 // BYTE offset into a.wt of half 0 (without the K-tile's column offset); half 1 = + 32 rows, uniform
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + lrow;
+    const int co = co0 + (r >> 5) * 64 + (r & 31);
+    woff[j] = 2u * ((unsigned)co * (unsigned)K + (unsigned)((pos ^ ((r >> 1) & 7)) * 8));
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto issue_patch = [&](int j, int cnext) __attribute__((always_inline)) {      // piece j of this wavefront, patch of chunk cnext
+    const bf16_t* base = a.in + cnext * 64;
+    const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
+    if (poff[j] != ~0u) glds16_sbase(base, poff[j], dst);
+  };
+  // K-tile (chunk c, tap): filter columns tap * Cin + c * 64; LDS buffer = parity of t = 9 c + tap
+  auto issue_w = [&](int h, int c, int tap) __attribute__((always_inline)) {
+    const bf16_t* base = a.wt + (tap * a.Cin + c * 64) + (long)h * 32 * K;
+    const unsigned dst = lds0 + WOFF + ((c + tap) & 1) * WBUF + h * H8_HALF + wave * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_sbase(base, woff[j], dst + j * 1024);
+  };
+
+  f32x4_t acc[4][8];       // [co fragment = c-half*2 + g][px fragment = p-half*4 + f]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  // filter fragments: byte address inside the CURRENT K-tile buffer, toggled between the two buffers after every K-tile
+  if (lds0 != 0) __builtin_trap();                  // (the fragment addresses below are absolute: the dynamic array is the kernel's only LDS)
+  int wad = WOFF + wn * 32 * 128 + frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);
+  // pixel fragments: patch pixel = pw0 + immP with immP = kh * PC + kw + (first tile pixel of the fragment as a patch offset), a
+  // compile-time number once the taps are unrolled; the swizzle key of the slot depends on (pw0 + immP) & 15 only, so sixteen
+  // per-lane bases AD[immP & 15] (those that occur stay live) + the immediate immP * 128 address every fragment without any
+  // vector ALU work in the loop.  The second K-step's slot is the first's ^ 4: byte address ^ 64.
+  const int pw0 = ((wm * 128) >> LW) * PC + frow;
+  int AD[16];
+#pragma unroll
+  for (int sx = 0; sx < 16; ++sx) AD[sx] = P0OFF + pw0 * 128 + ((kc ^ (((pw0 + sx) & 15) >> 1)) << 4);
+
+  bf16x8_t xf[2][4], wfc[2][2][2];                  // [ks][fragment] of the current pixel half; [channel half][ks][fragment]
+  auto load_x = [&](int kh, int kw, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int p = h * 64 + f * 16;                // first tile pixel of the fragment inside the wavefront's 128
+      const int immP = (H8_ABLATE & 1) ? 0 : kh * PC + kw + (p >> LW) * PC + (p & (W - 1));
+      const int ad = AD[immP & 15];
+      const int ad1 = xor64(ad);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t v = lds_read16(ks ? ad1 : ad, immP * 128);
+        if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+        xf[ks][f] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+  };
+  auto load_w = [&](int h) __attribute__((always_inline)) {
+    const int wad1 = xor64(wad);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) wfc[h][ks][g] = __builtin_bit_cast(bf16x8_t, lds_read16(ks ? wad1 : wad, h * H8_HALF + g * 16 * 128));
+  };
+  auto mma = [&](int ph, int ch) __attribute__((always_inline)) {
+    if (H8_ABLATE & 16) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          acc[ch * 2 + g][ph * 4 + f] = mfma16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
+  const int nchunks = a.Cin >> 6;
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) issue_patch(j, 0);
+  issue_w(0, 0, 0); issue_w(1, 0, 0);
+  issue_w(0, 0, 1); issue_w(1, 0, 1);
+  wait_vm<4>();
+  if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
+  wg_barrier();
+  stamp(2);
+
+  for (int c = 0; c < nchunks; ++c) {
+    const bool next_chunk = c + 1 < nchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      // K-tiles t + 1, t + 2 exist?  (t = 9 c + tap)
+      const bool more1 = tap < 8 || next_chunk, more2 = tap < 7 || next_chunk;
+      const int c2 = tap < 7 ? c : c + 1, tap2 = tap < 7 ? tap + 2 : tap - 7;      // (chunk, tap) of K-tile t + 2
+      // phase 1: (P0, C0)
+      if (!(H8_ABLATE & 8) || (c == 0 && tap == 0)) load_x(kh, kw, 0);
+      load_w(0);
+      if (more1) wait_vm<4>(); else wait_vm<0>();   // C1 of this tile has landed (newer: a patch piece at most, C0 and C1 of the next tile); read after b_1
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();                                 // a_1
+      mma(0, 0);
+      raw_barrier();                                 // b_1
+      // phase 2: (P0, C1); one piece of the next chunk's patch
+      load_w(1);
+      if (tap < MAXP && next_chunk && !(H8_ABLATE & 2)) issue_patch(tap, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();
+      mma(0, 1);
+      raw_barrier();
+      // phase 3: (P1, C1); C0 of tile t + 2 (its slot was last read in phase 1)
+      if (!(H8_ABLATE & 8) || (c == 0 && tap == 0)) load_x(kh, kw, 1);
+      if (more2 && !(H8_ABLATE & 4)) issue_w(0, c2, tap2);
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();
+      mma(1, 1);
+      raw_barrier();
+      // phase 4: (P1, C0) -- both operands are still in registers; C1 of tile t + 2 (slot last read in phase 2)
+      if (more2 && !(H8_ABLATE & 4)) issue_w(1, c2, tap2);
+      if (H8_ABLATE & 4) wait_vm<0>(); else
+      if (more2) wait_vm<6>(); else if (more1) wait_vm<2>();   // C0 of the next tile has landed (newer: its C1 [, C0 and C1 of the one after]); read after b_4
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();
+      mma(1, 0);
+      raw_barrier();
+      wad ^= WBUF;                                  // the other filter buffer
+    }
+    const int pdelta = (c & 1) ? -PATCH : PATCH;    // the patches alternate (a select of two constants: the addresses stay provably 16-byte aligned)
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) AD[sx] += pdelta;
+  }
+  if (!grp) wg_barrier();                           // group 0 waits for group 1's last barrier: equal counts, everything read
+
+  stamp(3);
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
+                RowIdent(), a.resid_up ? a.lw : -1, a.lh);
+  if (a.stamps) {
+    stamp(4);
+    wait_vm<0>();
+    stamp(5);
+  }
+}
+
+// plain 3x3 stride-1 SAME convolution (forward, or the data gradient with the rotated filters) on 16- or 32-pixel-wide power-of-two
+// images whose 256-pixel tiles are whole image rows
+bool mfma_conv8_halo_takes(const MfmaConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.PT == 1 && a.PL == 1 && !a.up && a.phase == 0 && !a.stats && (a.lw == 4 || a.lw == 5) && a.lh >= 0 &&
+         (a.H << a.lw) % 256 == 0 && a.M % 256 == 0 && a.Cin % 64 == 0 && a.Cout % 256 == 0 && (long)a.N * a.H * a.W * a.Cin < (1L << 31) && (long)a.Cout * 9 * a.Cin < (1L << 31);     // 32-bit byte offsets
+}
+
+template <int LW, bool RELU>
+static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  const size_t lds = h8_lds_bytes(LW);
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8_kernel<LW, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, 256), a.Cout / 256);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * 9 * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU>), grid, dim3(512), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  MfmaConvArgs b = a;
+  b.stamps = (unsigned long long*)ctx->dbg_stamps;
+  if (a.lw == 5) return a.relu_in ? launch8h<5, true>(ctx, b) : launch8h<5, false>(ctx, b);
+  return a.relu_in ? launch8h<4, true>(ctx, b) : launch8h<4, false>(ctx, b);
+}

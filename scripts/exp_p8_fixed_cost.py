@@ -3,7 +3,7 @@
 function of the K-tile count (Cin x taps / 64) and of the number of rounds (n = 64: 256 tiles = one round of 256 CUs).
 time = rounds x (fixed + per_ktile x KT): `fixed` is what a round pays outside its K loop (launch, tap table, first
 K-tile's round trip, epilogue stores).  HIP events on the launch stream.
-usage: python scripts/exp_p8_fixed_cost.py"""
+usage: python scripts/exp_p8_fixed_cost.py [quick]"""
 import ctypes as C
 import os
 import sys
@@ -21,8 +21,10 @@ def main():
     lib, h = ctx.lib, ctx.h
     reps = 30
     rows = []
-    for n in (64, 128, 320):
-        for k, cin in ((1, 256), (1, 512), (1, 1024), (3, 64), (3, 128), (3, 256), (3, 512)):
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"      # three 3x3 layers at n = 320: the per-K-tile slope only
+    ns = (320,) if quick else (64, 128, 320)
+    for n in ns:
+        for k, cin in (((3, 128), (3, 256), (3, 512)) if quick else ((1, 256), (1, 512), (1, 1024), (3, 64), (3, 128), (3, 256), (3, 512))):
             ctx.new_step()
             x = ctx.empty((n, 32, 32, cin))
             y = ctx.empty((n, 32, 32, 256))
@@ -44,7 +46,7 @@ def main():
             fl = 2.0 * n * 1024 * k * k * cin * 256
             rows.append((n, k, cin, kt, tiles, us, fl / us / 1e6))
             print("n=%3d k=%d cin=%4d  KT=%3d tiles=%4d  %8.1f us  %7.0f TFLOP/s" % rows[-1], flush=True)
-    for n in (64, 128, 320):
+    for n in ns:
         r = [x for x in rows if x[0] == n]
         A = np.array([[1.0, x[3]] for x in r])
         b = np.array([x[5] for x in r])

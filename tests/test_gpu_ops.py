@@ -64,6 +64,8 @@ CONV_CASES = [
     (5, 16, 32, 128, 2, 3, 1, False, True),     # 2 output channels, folded input ReLU
     (52, 32, 32, 64, 256, 3, 1, False, True),   # 208 workgroups of 256x256: the 8-wavefront four-phase kernel (fwd; dgrad stays 64->...)
     (50, 32, 32, 256, 256, 1, 1, False, False), # four-phase kernel forward AND data gradient (Cin = Cout = 256), M tail (51200 = 200 tiles)
+    (52, 32, 32, 256, 256, 3, 1, False, True),  # 208 tiles: the halo-patch 256x256 kernel (conv_mfma8h.hip), forward AND data gradient, four 64-channel chunks
+    (200, 16, 16, 128, 256, 3, 1, False, False),# ... its 16-pixel-wide form (a tile = one whole image), two chunks; dgrad on the 128-channel path
 ]
 
 
