@@ -15,11 +15,12 @@
 //   LDS            : 2 patches (chunk c, c + 1) + 2 filter K-tiles (t, t + 1 by parity) of 2 x 16 KiB halves (C0 / C1: the first /
 //                    second 32 channels of every wavefront column) = 2 x 43.0 + 64 KiB = 150 KiB
 //   LDS-DMA        : filters run 1.5 K-tiles ahead -- C0(t+2) is issued in phase 3 of tile t, C1(t+2) in phase 4 (their slots
-//                    were last read in phases 1 / 2 of tile t); the next chunk's patch rides one piece per wavefront and K-tile in
-//                    phase 2 of the chunk's first taps.  Counted waits: vmcnt(4) in front of phase 1's first barrier (C1 of this
-//                    tile has landed), vmcnt(6) in front of phase 4's (C0 of the next tile; a patch piece issued in between only
-//                    makes the count conservative).  Loads retire in order, so the patch of chunk c + 1 (issued by tap 5) has
-//                    landed when C0 of its first K-tile (issued at tap 7) has.
+//                    were last read in phases 1 / 2 of tile t); the next chunk's patch rides one piece per wavefront and K-tile
+//                    behind C1 in phase 4 of the chunk's first taps.  Counted waits: vmcnt(4 + patch pieces issued since) in front of
+//                    phase 1's first barrier (C1 of this tile has landed), vmcnt(6 + ...) in front of phase 4's (C0 of the next tile).
+//                    Loads retire in order, so the patch of chunk c + 1 (issued by tap 5) has landed when C0 of its first K-tile
+//                    (issued at tap 7) has; the counts are exact (a per-wavefront mask of the pieces that have lanes to fetch): a
+//                    conservative count made every wait stall on a filter burst issued two phases earlier (0.15 us per K-tile).
 //   schedule       : the ping-pong form of conv_mfma8.hip (PP): the wavefronts of a SIMD run one barrier apart, every phase has a
 //                    barrier between its fragment reads and its MFMAs; a burst is read one barrier after the wait + barrier that
 //                    retires it (the other group runs a barrier behind).
@@ -42,8 +43,15 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else static_assert(N == 0, "unsupported vmcnt immediate");
+}
+// vmcnt(BASE + extra), extra in {0, 1, 2} wave-uniform: the patch pieces that were really issued behind the burst waited for
+template <int BASE> __device__ __forceinline__ void wait_vm_plus(int extra) {
+  if (extra == 0) wait_vm<BASE>(); else if (extra == 1) wait_vm<BASE + 1>(); else wait_vm<BASE + 2>();
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -130,6 +138,12 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     }
   }
 
+  // bit j: piece j of this wavefront has at least one lane to fetch (wave-uniform: the counted waits below count issued bursts)
+  unsigned pmask = 0;
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) pmask |= (__builtin_amdgcn_ballot_w64(poff[j] != ~0u) != 0 ? 1u : 0u) << j;
+  pmask = __builtin_amdgcn_readfirstlane(pmask);
+
   // ---- filter sources: per half-tile this wavefront deposits rows (wave*2 + j)*8 + lrow, j = 0,1; row r of half h = channel (r>>5)*64 + h*32 + (r&31)
   unsigned woff[2];                                 // BYTE offset into a.wt of half 0 (without the K-tile's column offset); half 1 = + 32 rows, uniform
 #pragma unroll
@@ -211,7 +225,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
   const int nchunks = a.Cin >> 6;
 #pragma unroll
-  for (int j = 0; j < MAXP; ++j) issue_patch(j, 0);
+  for (int j = 0; j < MAXP; ++j)
+    if ((pmask >> j) & 1) issue_patch(j, 0);
   issue_w(0, 0, 0); issue_w(1, 0, 0);
   issue_w(0, 0, 1); issue_w(1, 0, 1);
   wait_vm<4>();
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 
   for (int c = 0; c < nchunks; ++c) {
     const bool next_chunk = c + 1 < nchunks;
+    const unsigned pmask_c = (next_chunk && !(H8_ABLATE & 2)) ? pmask : 0u;        // the pieces this chunk issues (the next chunk's patch)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - 3 * kh;
@@ -230,14 +246,16 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       // phase 1: (P0, C0)
       if (!(H8_ABLATE & 8) || (c == 0 && tap == 0)) load_x(kh, kw, 0);
       load_w(0);
-      if (more1) wait_vm<4>(); else wait_vm<0>();   // C1 of this tile has landed (newer: a patch piece at most, C0 and C1 of the next tile); read after b_1
+      // C1 of this tile has landed (newer: C0 and C1 of the next tile and the patch pieces issued behind this tile's and the next
+      // tile's C1, i.e. in phase 4 of the previous two K-tiles: taps tap - 2 and tap - 1 of this chunk); read after b_1
+      if (more1) wait_vm_plus<4>((tap >= 2 && tap - 2 < MAXP ? (int)((pmask_c >> (tap - 2)) & 1) : 0) + (tap >= 1 && tap - 1 < MAXP ? (int)((pmask_c >> (tap - 1)) & 1) : 0));
+      else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();                                 // a_1
       mma(0, 0);
       raw_barrier();                                 // b_1
-      // phase 2: (P0, C1); one piece of the next chunk's patch
+      // phase 2: (P0, C1)
       load_w(1);
-      if (tap < MAXP && next_chunk && !(H8_ABLATE & 2)) issue_patch(tap, c + 1);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
       mma(0, 1);
@@ -251,8 +269,14 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       raw_barrier();
       // phase 4: (P1, C0) -- both operands are still in registers; C1 of tile t + 2 (slot last read in phase 2)
       if (more2 && !(H8_ABLATE & 4)) issue_w(1, c2, tap2);
+      // ... and one piece of the next chunk's patch, BEHIND the filter bursts: loads retire in order, and a pixel burst comes from
+      // HBM / the Infinity Cache, not from L2 like the filters -- as the newest operation it is never what a counted wait below
+      // waits for until two K-tiles later (in front of the filters it stalled every wait of the next K-tile: 0.15 us per K-tile)
+      if (tap < MAXP && ((pmask_c >> tap) & 1)) issue_patch(tap, c + 1);
+      // C0 of the next tile has landed (newer: its C1 [, C0 and C1 of the one after], the patch pieces of this and the previous tap); read after b_4
       if (H8_ABLATE & 4) wait_vm<0>(); else
-      if (more2) wait_vm<6>(); else if (more1) wait_vm<2>();   // C0 of the next tile has landed (newer: its C1 [, C0 and C1 of the one after]); read after b_4
+      if (more2) wait_vm_plus<6>((tap < MAXP ? (int)((pmask_c >> tap) & 1) : 0) + (tap >= 1 && tap - 1 < MAXP ? (int)((pmask_c >> (tap - 1)) & 1) : 0));
+      else if (more1) wait_vm<2>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
       mma(1, 0);

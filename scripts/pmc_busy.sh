@@ -15,4 +15,4 @@ DB=$(find "$OUT/pmc_$TAG" -name "*.db" | head -1)
 python3 "$ROOT/scripts/pmc_summary.py" conv_ "$DB" > "$OUT/${TAG}_pmc_raw.txt"
 python3 "$ROOT/scripts/pmc_busy_table.py" "$OUT/${TAG}_pmc_raw.txt" > "$OUT/${TAG}_pmc_mfma_busy.txt"
 rm -rf "$OUT/pmc_$TAG"
-grep -E "p8|wgrad3_group|trunk|kernel  " "$OUT/${TAG}_pmc_mfma_busy.txt"
+grep -E "p8|h8|wgrad3_group|trunk|kernel  " "$OUT/${TAG}_pmc_mfma_busy.txt"
