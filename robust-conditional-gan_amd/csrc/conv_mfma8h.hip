@@ -47,11 +47,21 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N == 0, "unsupported vmcnt immediate");
 }
-// vmcnt(BASE + extra), extra in {0, 1, 2} wave-uniform: the patch pieces that were really issued behind the burst waited for
-template <int BASE> __device__ __forceinline__ void wait_vm_plus(int extra) {
-  if (extra == 0) wait_vm<BASE>(); else if (extra == 1) wait_vm<BASE + 1>(); else wait_vm<BASE + 2>();
+// vmcnt(BASE + extra), extra in 0 .. MAXX wave-uniform: the patch pieces that were really issued behind the burst waited for
+template <int BASE, int MAXX> __device__ __forceinline__ void wait_vm_plus(int extra) {
+  if (extra == 0) wait_vm<BASE>();
+  else if (MAXX < 2 || extra == 1) wait_vm<BASE + 1>();
+  else if (MAXX < 3 || extra == 2) wait_vm<BASE + 2>();
+  else if (MAXX < 4 || extra == 3) wait_vm<BASE + 3>();
+  else if (MAXX < 5 || extra == 4) wait_vm<BASE + 4>();
+  else if (MAXX < 6 || extra == 5) wait_vm<BASE + 5>();
+  else wait_vm<BASE + 6>();
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -88,10 +98,17 @@ __device__ __forceinline__ int xor64(int x) {
   return y;
 }
 
-template <int LW, bool RELU>
+// PHM: the sub-pixel form of a 3x3 convolution behind the nearest 2x upsample (MfmaConvArgs::wph, conv_mfma8.hip): a tile is 256
+// pixels of ONE phase (ph, pw) over the LOW-resolution grid (W = its width), the reduction runs over the 2 x 2 taps (a, b) that read
+// low-resolution pixel (i + a - 1 + ph, j + b - 1 + pw) with the phase's summed filters -- patch rows / columns (a + ph, b + pw), so the
+// one (TR + 2) x (W + 2) patch serves every phase; the epilogue scatters the rows to output pixel (2 i + ph, 2 j + pw).  Four K-tiles per
+// chunk instead of nine: the patch pieces go out behind the filter bursts of the chunk's first two taps.
+template <int LW, bool RELU, bool PHM>
 __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int W = 1 << LW, TR = 256 >> LW;        // image width, image rows per tile
+  constexpr int W = 1 << LW, TR = 256 >> LW;        // (low-resolution) image width, image rows per tile
+  constexpr int NT = PHM ? 4 : 9;                   // taps = K-tiles per 64-channel chunk
+  constexpr int NTI = PHM ? 2 : 6;                  // ... of which the first NTI carry patch pieces (landed two K-tiles later: NTI <= NT - 2)
   constexpr int PC = W + 2, PR = TR + 2;            // patch columns / rows
   constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;      // patch pixels, padded rows, DMA pieces (8 rows each)
   constexpr int PATCH = NROWS * 128;
@@ -100,7 +117,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   constexpr int WOFF = 0, P0OFF = 2 * WBUF, P1OFF = 2 * WBUF + PATCH;
   static_assert(WBUF == 32768, "the filter buffers are toggled with ^ 0x8000");
   constexpr int MAXP = (NP + 7) / 8;                // patch pieces per wavefront
-  static_assert(MAXP <= 6, "a wavefront issues its patch pieces during the first six taps of a chunk");
+  constexpr int PPT = (MAXP + NTI - 1) / NTI;       // patch pieces per wavefront behind one K-tile's filter bursts
+  static_assert(MAXP <= 6 && NTI <= NT - 2, "a wavefront issues its patch pieces during the first taps of a chunk");
   static_assert((PR - 1) * PC * 128 + PC * 128 < 65536, "tap offsets are ds_read immediates");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,8 +129,15 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   if ((gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // a contiguous run of tiles per XCD
   const long m0 = (long)mt * 256;
   const int co0 = blockIdx.y * 256;
-  const int K = 9 * a.Cin;
+  const int K = NT * a.Cin;
   const int lrow = lane >> 3, pos = lane & 7;
+  // image grid the patch is cut from, and the tile's place in it
+  const int HI = PHM ? (a.H >> 1) : a.H, lhi = PHM ? a.lh - 1 : a.lh;
+  const long Mph = a.M >> 2;
+  const int tph = PHM ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;
+  const long mbase = PHM ? (long)tph * Mph : 0;
+  const unsigned ms0 = (unsigned)(m0 - mbase);
+  const bf16_t* const wbase = PHM ? a.wph + (long)tph * a.Cout * K : a.wt;
   auto stamp = [&](int k) __attribute__((always_inline)) {
     if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
   };
@@ -121,8 +146,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   // ---- patch sources: piece i = wave + 8 j covers patch pixels 8 i .. 8 i + 7; this lane deposits pixel q = 8 i + lrow, slot pos.
   // Halo slots (SAME padding, the padding rows behind the patch) are zeroed once, here, in both buffers, and never written again:
   // their lanes are masked out of every burst.
-  const unsigned n_img = (unsigned)(m0 >> (LW + a.lh));
-  const int oh0 = (int)((m0 >> LW) & (unsigned)(a.H - 1));
+  const unsigned n_img = ms0 >> (LW + lhi);
+  const int oh0 = (int)((ms0 >> LW) & (unsigned)(HI - 1));
   unsigned poff[MAXP];                              // BYTE offset into a.in (without the chunk's channel offset), ~0u = halo
 #pragma unroll
   for (int j = 0; j < MAXP; ++j) {
@@ -130,8 +155,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     const int q = piece * 8 + lrow;
     const int pr = q / PC, pc = q - pr * PC;
     const int ih = oh0 - 1 + pr, iw = pc - 1;
-    const bool ok = piece < NP && q < NPX && ih >= 0 && ih < a.H && iw >= 0 && iw < W;
-    poff[j] = ok ? 2u * (((n_img * (unsigned)a.H + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8)) : ~0u;
+    const bool ok = piece < NP && q < NPX && ih >= 0 && ih < HI && iw >= 0 && iw < W;
+    poff[j] = ok ? 2u * (((n_img * (unsigned)HI + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8)) : ~0u;
     if (!ok && piece < NP) {
       *(uint4*)(smem + P0OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
       *(uint4*)(smem + P1OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
@@ -159,10 +184,10 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
     if (poff[j] != ~0u) glds16_sbase(base, poff[j], dst);
   };
-  // K-tile (chunk c, tap): filter columns tap * Cin + c * 64; LDS buffer = parity of t = 9 c + tap
+  // K-tile (chunk c, tap): filter columns tap * Cin + c * 64; LDS buffer = parity of t = NT c + tap
   auto issue_w = [&](int h, int c, int tap) __attribute__((always_inline)) {
-    const bf16_t* base = a.wt + (tap * a.Cin + c * 64) + (long)h * 32 * K;
-    const unsigned dst = lds0 + WOFF + ((c + tap) & 1) * WBUF + h * H8_HALF + wave * 2048;
+    const bf16_t* base = wbase + (tap * a.Cin + c * 64) + (long)h * 32 * K;
+    const unsigned dst = lds0 + WOFF + ((NT * c + tap) & 1) * WBUF + h * H8_HALF + wave * 2048;
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16_sbase(base, woff[j], dst + j * 1024);
   };
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   // compile-time number once the taps are unrolled; the swizzle key of the slot depends on (pw0 + immP) & 15 only, so sixteen
   // per-lane bases AD[immP & 15] (those that occur stay live) + the immediate immP * 128 address every fragment without any
   // vector ALU work in the loop.  The second K-step's slot is the first's ^ 4: byte address ^ 64.
-  const int pw0 = ((wm * 128) >> LW) * PC + frow;
+  const int pw0 = ((wm * 128) >> LW) * PC + frow + (PHM ? ph * PC + pw : 0);
   int AD[16];
 #pragma unroll
   for (int sx = 0; sx < 16; ++sx) AD[sx] = P0OFF + pw0 * 128 + ((kc ^ (((pw0 + sx) & 15) >> 1)) << 4);
@@ -237,18 +262,28 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     const bool next_chunk = c + 1 < nchunks;
     const unsigned pmask_c = (next_chunk && !(H8_ABLATE & 2)) ? pmask : 0u;        // the pieces this chunk issues (the next chunk's patch)
+    // patch pieces issued behind the filter bursts of tap tp of this chunk: pieces j = tp, tp + NTI, ...
+    auto pieces_at = [&](int tp) __attribute__((always_inline)) -> int {
+      int n = 0;
+      if (tp >= 0 && tp < NTI) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap - 3 * kh;
-      // K-tiles t + 1, t + 2 exist?  (t = 9 c + tap)
-      const bool more1 = tap < 8 || next_chunk, more2 = tap < 7 || next_chunk;
-      const int c2 = tap < 7 ? c : c + 1, tap2 = tap < 7 ? tap + 2 : tap - 7;      // (chunk, tap) of K-tile t + 2
+        for (int j = tp; j < MAXP; j += NTI) n += (int)((pmask_c >> j) & 1);
+      }
+      return n;
+    };
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      const int kh = PHM ? (tap >> 1) : tap / 3, kw = PHM ? (tap & 1) : tap - 3 * (tap / 3);     // (+ the phase's (ph, pw): in pw0)
+      // K-tiles t + 1, t + 2 exist?  (t = NT c + tap)
+      const bool more1 = tap < NT - 1 || next_chunk, more2 = tap < NT - 2 || next_chunk;
+      const int c2 = tap < NT - 2 ? c : c + 1, tap2 = tap < NT - 2 ? tap + 2 : tap + 2 - NT;      // (chunk, tap) of K-tile t + 2
       // phase 1: (P0, C0)
       if (!(H8_ABLATE & 8) || (c == 0 && tap == 0)) load_x(kh, kw, 0);
       load_w(0);
       // C1 of this tile has landed (newer: C0 and C1 of the next tile and the patch pieces issued behind this tile's and the next
       // tile's C1, i.e. in phase 4 of the previous two K-tiles: taps tap - 2 and tap - 1 of this chunk); read after b_1
-      if (more1) wait_vm_plus<4>((tap >= 2 && tap - 2 < MAXP ? (int)((pmask_c >> (tap - 2)) & 1) : 0) + (tap >= 1 && tap - 1 < MAXP ? (int)((pmask_c >> (tap - 1)) & 1) : 0));
+      // (the previous chunk's last two taps carry none: NTI <= NT - 2)
+      if (more1) wait_vm_plus<4, 2 * PPT>(pieces_at(tap - 2) + pieces_at(tap - 1));
       else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();                                 // a_1
@@ -272,10 +307,14 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       // ... and one piece of the next chunk's patch, BEHIND the filter bursts: loads retire in order, and a pixel burst comes from
       // HBM / the Infinity Cache, not from L2 like the filters -- as the newest operation it is never what a counted wait below
       // waits for until two K-tiles later (in front of the filters it stalled every wait of the next K-tile: 0.15 us per K-tile)
-      if (tap < MAXP && ((pmask_c >> tap) & 1)) issue_patch(tap, c + 1);
+      if (tap < NTI) {
+#pragma unroll
+        for (int j = tap; j < MAXP; j += NTI)
+          if ((pmask_c >> j) & 1) issue_patch(j, c + 1);
+      }
       // C0 of the next tile has landed (newer: its C1 [, C0 and C1 of the one after], the patch pieces of this and the previous tap); read after b_4
       if (H8_ABLATE & 4) wait_vm<0>(); else
-      if (more2) wait_vm_plus<6>((tap < MAXP ? (int)((pmask_c >> tap) & 1) : 0) + (tap >= 1 && tap - 1 < MAXP ? (int)((pmask_c >> (tap - 1)) & 1) : 0));
+      if (more2) wait_vm_plus<6, 2 * PPT>(pieces_at(tap) + pieces_at(tap - 1));
       else if (more1) wait_vm<2>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
@@ -291,7 +330,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 
   stamp(3);
   conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 128, co0 + wn * 64, lane,
-                RowIdent(), a.resid_up ? a.lw : -1, a.lh);
+                RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
   if (a.stamps) {
     stamp(4);
     wait_vm<0>();
@@ -300,24 +339,28 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 }
 
 // plain 3x3 stride-1 SAME convolution (forward, or the data gradient with the rotated filters) on 16- or 32-pixel-wide power-of-two
-// images whose 256-pixel tiles are whole image rows
+// images whose 256-pixel tiles are whole image rows -- or (phase == 1) the sub-pixel form of an upsample-3x3 convolution whose
+// LOW-resolution grid is such an image
 bool mfma_conv8_halo_takes(const MfmaConvArgs& a) {
-  return a.KH == 3 && a.KW == 3 && a.PT == 1 && a.PL == 1 && !a.up && a.phase == 0 && !a.stats && (a.lw == 4 || a.lw == 5) && a.lh >= 0 &&
-         (a.H << a.lw) % 256 == 0 && a.M % 256 == 0 && a.Cin % 64 == 0 && a.Cout % 256 == 0 && (long)a.N * a.H * a.W * a.Cin < (1L << 31) && (long)a.Cout * 9 * a.Cin < (1L << 31);     // 32-bit byte offsets
+  if (a.KH != 3 || a.KW != 3 || a.stats || a.lw < 0 || a.lh < 0 || a.M % 256 || a.Cin % 64 || a.Cout % 256) return false;
+  if ((long)a.N * a.H * a.W * a.Cin >= (1L << 31) || (long)a.Cout * 9 * a.Cin >= (1L << 31)) return false;      // 32-bit byte offsets
+  if (a.phase == 0) return a.PT == 1 && a.PL == 1 && !a.up && (a.lw == 4 || a.lw == 5) && (a.H << a.lw) % 256 == 0;
+  if (a.phase == 1) return a.up && a.wph != nullptr && (a.lw == 5 || a.lw == 6) && a.lh >= 1 && ((a.H >> 1) << (a.lw - 1)) % 256 == 0 && (a.M >> 2) % 256 == 0;
+  return false;
 }
 
-template <int LW, bool RELU>
+template <int LW, bool RELU, bool PHM>
 static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = h8_lds_bytes(LW);
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8_kernel<LW, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8_kernel<LW, RELU, PHM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * 9 * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU>), grid, dim3(512), lds, ctx->stream, a);
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU, PHM>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -326,6 +369,10 @@ static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   MfmaConvArgs b = a;
   b.stamps = (unsigned long long*)ctx->dbg_stamps;
-  if (a.lw == 5) return a.relu_in ? launch8h<5, true>(ctx, b) : launch8h<5, false>(ctx, b);
-  return a.relu_in ? launch8h<4, true>(ctx, b) : launch8h<4, false>(ctx, b);
+  if (a.phase == 1) {
+    if (a.lw == 6) return a.relu_in ? launch8h<5, true, true>(ctx, b) : launch8h<5, false, true>(ctx, b);
+    return a.relu_in ? launch8h<4, true, true>(ctx, b) : launch8h<4, false, true>(ctx, b);
+  }
+  if (a.lw == 5) return a.relu_in ? launch8h<5, true, false>(ctx, b) : launch8h<5, false, false>(ctx, b);
+  return a.relu_in ? launch8h<4, true, false>(ctx, b) : launch8h<4, false, false>(ctx, b);
 }

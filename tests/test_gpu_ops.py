@@ -66,6 +66,8 @@ CONV_CASES = [
     (50, 32, 32, 256, 256, 1, 1, False, False), # four-phase kernel forward AND data gradient (Cin = Cout = 256), M tail (51200 = 200 tiles)
     (52, 32, 32, 256, 256, 3, 1, False, True),  # 208 tiles: the halo-patch 256x256 kernel (conv_mfma8h.hip), forward AND data gradient, four 64-channel chunks
     (200, 16, 16, 128, 256, 3, 1, False, False),# ... its 16-pixel-wide form (a tile = one whole image), two chunks; dgrad on the 128-channel path
+    (52, 32, 32, 256, 256, 3, 1, True, True),   # ... the sub-pixel form of an upsample-3x3 layer on it (G.Block.3.Conv1): 16 x 16 low-resolution images, four taps per chunk
+    (13, 64, 64, 64, 256, 3, 1, True, False),   # ... and on 32-wide low-resolution images (one chunk: no patch hand-over)
 ]
 
 
