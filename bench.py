@@ -164,6 +164,30 @@ def kernel_roofline(m, pool, default_workload=True):
             "executed_tflops": round(fx.value / (ms.value * 1e-3) / 1e12, 2), "executed_frac": round(fx.value / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
 
+PEAK_F32_TFLOPS = 157.3       # dense fp32 MFMA (v_mfma_f32_32x32x2_f32) peak, MI355X_MICROARCH.md
+
+
+def kernel_roofline_f32(m, pool):
+    """--dtype f32 (the reference's own precision): the dominant kernel is the fp32 gather GEMM (gemm_gather_kernel, conv_direct.hip) --
+    every convolution and dense layer, forward, data and filter gradient, on v_mfma_f32_32x32x2_f32.  One eager iteration with each
+    of its launches bracketed by HIP events; priced against the dense fp32 matrix peak."""
+    ctx = m.ctx
+    saved = m.use_graphs
+    m.use_graphs = False
+    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 7))       # RCGAN_PROF_GATHER_F32
+    iteration(m, pool, 1, [0])
+    n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
+    ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(fl)))
+    m.use_graphs = saved
+    if n.value == 0 or ms.value <= 0:
+        return None
+    achieved = fl.value / (ms.value * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4),
+            "traffic": None, "kernel": "gemm_gather_kernel (fp32 matrix cores)", "launches_per_iteration": n.value,
+            "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "flops_per_launch_avg": fl.value / n.value,
+            "time_in_kernel_ms_per_iteration": round(ms.value, 3)}
+
+
 def comm_profile(m, pool):
     """One eager iteration with every all-reduce group of the in-ABI communicator bracketed by HIP events on the stream it is issued
     on: (groups per iteration, their summed duration in ms, bytes this rank hands over per iteration).  The duration of an all-reduce
@@ -324,7 +348,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU critic batch")
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="activation dtype: bf16 (BASELINE configs[2], default), f16 (configs[4]) or f32 (the reference's own precision: every "
+                         "layer on the fp32 matrix cores; its roofline object prices the gather GEMM against the 157 TFLOP/s fp32 peak)")
     ap.add_argument("--algorithm", default="rcgan")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -437,12 +463,14 @@ def main():
             if args.dp_stub > 1:
                 out["config"]["stub_link_model"] = ("none (all-reduce is free)" if not (args.dp_stub_gbps or args.dp_stub_lat_us) else
                                                     "%.1f us + 2(N-1)/N * bytes / %.0f GB/s per all-reduce group" % (args.dp_stub_lat_us, args.dp_stub_gbps))
-        out["roofline"] = kernel_roofline(m, pool, default_wl) if args.dtype in ("bf16", "f16") else None
+        out["roofline"] = kernel_roofline(m, pool, default_wl) if args.dtype in ("bf16", "f16") else kernel_roofline_f32(m, pool)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alpha, args.batch)
     else:
         if args.dtype in ("bf16", "f16"):
             kernel_roofline(m, pool, default_wl)      # keep ranks in lock-step through the extra (all-reducing) iteration
+        else:
+            kernel_roofline_f32(m, pool)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

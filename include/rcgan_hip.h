@@ -83,6 +83,7 @@ int rcgan_event_elapsed_ms(rcgan_ctx* ctx, int slot_start, int slot_end, float* 
 #define RCGAN_PROF_WGRAD_MFMA 3      /* conv_mfma_wgrad_kernel */
 #define RCGAN_PROF_CONV_P8 4         /* conv_mfma_p8_kernel: 256 x 256 tile, 8 wavefronts (fwd + dgrad of the 256-channel layers) */
 #define RCGAN_PROF_CONV_P8N 5        /* conv_mfma_p8n_kernel: 256 x 128 tile */
+#define RCGAN_PROF_GATHER_F32 7      /* gemm_gather_kernel (conv_direct.hip): the fp32 path's gather GEMM on the fp32 matrix cores */
 #define RCGAN_PROF_ALLREDUCE 6       /* every all-reduce group of comm.hip (eager launches only); "flops" = bytes exchanged per rank */
 int rcgan_prof_begin(rcgan_ctx* ctx, int which);
 int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* total_flops);

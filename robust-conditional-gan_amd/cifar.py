@@ -395,7 +395,9 @@ class CifarRCGAN:
         self.fused_head = os.environ.get("RCGAN_FUSED_HEAD", "1") == "1" and 2 * int(batch_size) <= O.HEAD_MAX_N
         self.ride_inputs = os.environ.get("RCGAN_RIDE_INPUTS", "1") == "1"
         if arena_bytes is None:
-            arena_bytes = int(2.5e6 * 4 * self.B * 2) + (1 << 30)      # ~20 MB/sample fp32-equivalent + slack
+            # ~20 MB/sample with 16-bit activations (the five-step generator pass at 5B samples is the high-water mark), twice
+            # that in fp32, + slack
+            arena_bytes = int(2.5e6 * 4 * self.B * (4 if dtype == "f32" else 2)) + (1 << 30)
         self.ctx = Context(device, dtype, arena_bytes=arena_bytes)
         ctx = self.ctx
         # Static loss scaling for fp16 activations (5 exponent bits: activation gradients of ~1e-5 and below would go

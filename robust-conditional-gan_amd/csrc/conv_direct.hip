@@ -916,7 +916,13 @@ static int launch_gemm_ks(rcgan_ctx* ctx, Op& op, dim3 grid, const typename Op::
     RC_HIP(ctx, hipFuncSetAttribute((const void*)gemm_gather_kernel<Op, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_gather_kernel<Op, KS>), grid, dim3(256 * KS), lds, ctx->stream, op, aux);
+  {
+    // multiply-adds the launch performs: M x N outputs over the whole reduction (grid.z splits R), or -- ops that use grid.z for the
+    // parity classes of a stride-2 data gradient -- over every class's share
+    const double fl = 2.0 * (double)op.M * (double)op.N * (double)op.R * (has_select<Op>::value ? (double)grid.z : 1.0);
+    ProfScope ps(ctx, RCGAN_PROF_GATHER_F32, fl);
+    hipLaunchKernelGGL((gemm_gather_kernel<Op, KS>), grid, dim3(256 * KS), lds, ctx->stream, op, aux);
+  }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
