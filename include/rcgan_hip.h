@@ -224,6 +224,11 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
 int rcgan_deconv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const float* w,
                        const float* bias, void* y);
 int rcgan_deconv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx);
+/* ... only the first n_cols input channels of it, dense ([n, h', w', n_cols]; RCGAN_CONV_ACCUMULATE in d.flags adds onto dx): the input of
+ * the generator's transposed convolutions is conv_cond_concat(x, y) (mnist/ops.py:46-51, model.py:716-726) and the label channels need no
+ * gradient -- the x part lands straight in x's gradient, a third of the column tiles (138 -> 128 channels) and the split kernel go away.
+ * n_cols = 0: all of them. */
+int rcgan_deconv2d_bwd_data_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx, int n_cols);
 int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
                               float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
 

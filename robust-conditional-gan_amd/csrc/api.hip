@@ -7,7 +7,7 @@
 // ---- provided by the other translation units ------------------------------------------------------
 
 size_t direct_wgrad_ws_bytes(const rcgan_conv_desc* d);
-template <typename T> int direct_fwd(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, T*);
+template <typename T> int direct_fwd(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, T*, int n_cols = 0);
 template <typename T> int direct_dgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, const T*, T*, int);
 template <typename T> int direct_wgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, float*, float*, int, void*, size_t);
 template <typename T> int colsum_launch(rcgan_ctx*, const T*, long, int, float*, int, float*);
@@ -1081,9 +1081,14 @@ int rcgan_deconv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, 
 }
 
 int rcgan_deconv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx) {
+  return rcgan_deconv2d_bwd_data_cols(ctx, d, dy, w, dx, 0);
+}
+
+int rcgan_deconv2d_bwd_data_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx, int n_cols) {
   int rc = check_desc(ctx, d);
   if (rc) return rc;
-  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_fwd<T>(ctx, d, (const T*)dy, w, nullptr, nullptr, (T*)dx));
+  RC_REQUIRE(ctx, n_cols >= 0 && n_cols <= d->cout, "n_cols %d of %d input channels", n_cols, d->cout);
+  RC_DISPATCH_DTYPE(ctx, d->dtype, return direct_fwd<T>(ctx, d, (const T*)dy, w, nullptr, nullptr, (T*)dx, n_cols));
   return RCGAN_OK;
 }
 

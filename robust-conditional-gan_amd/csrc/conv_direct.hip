@@ -154,6 +154,7 @@ template <typename T> struct FwdOp {
   const float* wscale;   // optional device scalar: filter is divided by it (spectral norm sigma)
   long M, N, R, r_chunk;
   int avec, bvec;
+  int ldy;               // elements between two output pixels: g.Cout, or N when only the first N output channels are produced
   const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   struct Row { int n, ih0, iw0, ok; };
   __device__ __forceinline__ Row row(long i) const {
@@ -207,7 +208,7 @@ template <typename T> struct FwdOp {
   }
   __device__ __forceinline__ void store(long i, long j, float v, int) const {
     if (bias) v += bias[j];
-    T* p = y + i * g.Cout + j;
+    T* p = y + i * ldy + j;
     if (accumulate) v += Elem<T>::ld(p);
     Elem<T>::st(p, v);
   }
@@ -1188,17 +1189,20 @@ int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy
 template int linear_wgrad<float>(rcgan_ctx*, long, long, long, const float*, const float*, float*, float*, int, void*, size_t);
 template int linear_wgrad<bf16_t>(rcgan_ctx*, long, long, long, const bf16_t*, const bf16_t*, float*, float*, int, void*, size_t);
 
+// n_cols > 0: only the first n_cols output channels are produced, densely ([pixels][n_cols]) -- the data gradient of a transposed
+// convolution whose input was a channel concatenation x || labels needs the x part only (mnist/ops.py:46-51: the labels are data)
 template <typename T>
-int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float* w, const float* wscale, const float* bias, T* y) {
+int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float* w, const float* wscale, const float* bias, T* y, int n_cols) {
   FwdOp<T> op;
   op.g = make_geom(d); op.x = x; op.w = w; op.wscale = wscale; op.bias = bias; op.y = y;
   op.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
-  op.M = (long)op.g.N * op.g.OH * op.g.OW; op.N = op.g.Cout; op.R = (long)op.g.KH * op.g.KW * op.g.Cin; op.r_chunk = op.R;
+  op.M = (long)op.g.N * op.g.OH * op.g.OW; op.N = n_cols > 0 ? n_cols : op.g.Cout; op.R = (long)op.g.KH * op.g.KW * op.g.Cin; op.r_chunk = op.R;
+  op.ldy = (int)op.N;
   op.avec = vec_of(x, op.g.Cin); op.bvec = vec_of(w, op.g.Cout);
   return launch_gemm(ctx, op, 1);
 }
-template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*);
-template int direct_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const float*, const float*, const float*, bf16_t*);
+template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*, int);
+template int direct_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const float*, const float*, const float*, bf16_t*, int);
 
 // dgrad at the LOGICAL input resolution (no upsample folding here; the caller pools afterwards).
 template <typename T>

@@ -127,6 +127,10 @@ class MnistRCGAN:
         self.inp = dict(images=P((B, 28, 28, 1), act), z=P((B, Z_DIM), act), y_real=P((B, Y_DIM), f32), y_fake=P((B, Y_DIM), f32),
                         y_gen=P((B, Y_DIM), f32), y_real_weights=P((B, Y_DIM), f32), lab_real=P((B,), i32), lab_gen=P((B,), i32),
                         eye=P((Y_DIM, Y_DIM), f32), C_const=P((Y_DIM, Y_DIM), f32))
+        # the critic step's one-pass input [images ; G(z)] and its label rows [y_real ; y_fake] / [y_real ; y_gen] (set_inputs fills the
+        # real halves; the generator writes the fake half of x_all)
+        self.inp.update(x_all=P((2 * B, 28, 28, 1), act, fill=0.0), y_all_fake=P((2 * B, Y_DIM), f32, fill=0.0), y_all_gen=P((2 * B, Y_DIM), f32, fill=0.0))
+        self.merge_critic = os.environ.get("RCGAN_MNIST_MERGE_CRITIC", "1") == "1"
         ctx.view(self.inp["eye"]).copy_(torch.eye(Y_DIM))
         if confusion_matrix is None:
             confusion_matrix = ((1 - alpha) / 9.0) * np.ones((10, 10)) + (alpha - (1 - alpha) / 9.0) * np.eye(10)
@@ -148,7 +152,7 @@ class MnistRCGAN:
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------ model
-    def generator(self, z, y, train=True):
+    def generator(self, z, y, train=True, out=None):
         ctx = self.ctx
         B = z.shape[0]
         with variable_scope("generator"):
@@ -160,10 +164,11 @@ class MnistRCGAN:
             h1 = conv_cond_concat(h1, y)
             h2 = self.g_bn2(deconv2d(h1, [B, 14, 14, GF_DIM * 2], name='g_h2'), train=train, _act=L.ACT_RELU)
             h2 = conv_cond_concat(h2, y)
-            return O.act(ctx, deconv2d(h2, [B, 28, 28, 1], name='g_h3'), L.ACT_SIGMOID)
+            return O.act(ctx, deconv2d(h2, [B, 28, 28, 1], name='g_h3'), L.ACT_SIGMOID, out=out)
 
-    def _features(self, image, y):
-        """projection D up to the pooled features h3 [B,64] and h4 [B] (model.py:649-681)."""
+    def _features(self, image, y, segments=1):
+        """projection D up to the pooled features h3 [B,64] and h4 [B] (model.py:649-681).  segments: that many batches back to
+        back, each with its own batch-norm statistics (consecutive discriminator() calls of the reference as one pass)."""
         ctx = self.ctx
         x = image
         bns = (None, self.d_bn1, self.d_bn2, self.d_bn3)
@@ -171,18 +176,18 @@ class MnistRCGAN:
             if (i + 1) in self.layers:
                 x = conv_cond_concat(x, y)
             x = conv2d(x, DF_DIM, spectral_norm=self.sn, name='d_h%d_conv' % i)
-            x = lrelu(x) if i == 0 else bns[i](x, _act=L.ACT_LRELU)
+            x = lrelu(x) if i == 0 else bns[i](x, _act=L.ACT_LRELU, _segments=segments)
         h3 = O.act_meanhw(ctx, x, L.ACT_NONE)
         h4 = O.reshape(ctx, linear(h3, 1, 'd_h4_lin', max_norm=self.max_norm), (-1,))
         return h3, h4
 
-    def discriminator(self, image, y):
+    def discriminator(self, image, y, segments=1):
         """-> logits [B] (h6 / h4 of model.py:685,701)."""
         ctx = self.ctx
         B = image.shape[0]
         with variable_scope("discriminator"):
             if self.disc_type == "projection":
-                h3, h4 = self._features(image, y)
+                h3, h4 = self._features(image, y, segments)
                 h5 = linear(y, DF_DIM, 'd_h5_y_lin', max_norm=self.max_norm)
                 return O.proj_logit(ctx, h3, h4, h5)
             x = conv_cond_concat(image, y)
@@ -253,6 +258,22 @@ class MnistRCGAN:
             else:
                 O.loss_term(ctx, kg, logits, 1.0, self.loss["g_loss"])
 
+    def _merged_critic(self):
+        """The critic step's D(real) and D(fake) as ONE pass over [images ; G(z)] (2B samples): the discriminator's convolutions and
+        dense layers are per-sample, its batch norms take their statistics (and moving-average updates, real first) per half -- the
+        values of two consecutive discriminator() calls (model.py:131-135,179-183).  Taken where both halves go through the plain
+        discriminator(): projection D without label concatenation, one label per sample on both sides."""
+        return (self.merge_critic and self.disc_type == "projection" and not self.layers and self.alg in ("biased", "rcgan", "ambient")
+                and not (self.alg in ("rcgan", "ambient") and self.est))
+
+    def _critic_losses_merged(self, G):
+        """d_loss_real + d_loss_fake from the one pass; G = the fake half of inp['x_all'] (the generator wrote it there)."""
+        ctx, inp, B = self.ctx, self.inp, self.B
+        kr, kf, kg = self._kinds()
+        logits = self.discriminator(inp["x_all"], inp["y_all_fake" if self.alg in ("rcgan", "ambient") else "y_all_gen"], segments=2)
+        O.loss_term(ctx, kr, O.rows(ctx, logits, 0, B), 1.0, self.loss["d_loss_real"])
+        O.loss_term(ctx, kf, O.rows(ctx, logits, B, 2 * B), 1.0, self.loss["d_loss_fake"])
+
     def _d_body(self):
         ctx, g, inp = self.ctx, self.graph, self.inp
         ctx.new_step()
@@ -261,13 +282,17 @@ class MnistRCGAN:
         self._zero_losses(("d_loss_real", "d_loss_fake", "class_loss_real"))
         self._sn_prefetch()
         kr, kf, kg = self._kinds()
-        G = self.generator(inp["z"], inp["y_gen"])                                   # model.py:126
-        if self.alg in ("biased", "rcgan", "ambient"):
+        merged = self._merged_critic()
+        G = self.generator(inp["z"], inp["y_gen"], out=inp["x_all"].rows(self.B, 2 * self.B) if merged else None)      # model.py:126
+        if merged:
+            self._critic_losses_merged(G)
+        elif self.alg in ("biased", "rcgan", "ambient"):
             O.loss_term(ctx, kr, self.discriminator(inp["images"], inp["y_real"]), 1.0, self.loss["d_loss_real"])
         else:                                                                        # unbiased (:152-174)
             logits = self.discriminator_all_labels(inp["images"])
             O.loss_term(ctx, kr, logits, 1.0, self.loss["d_loss_real"], wts=inp["y_real_weights"])
-        self._fake_branch(G, True)
+        if not merged:
+            self._fake_branch(G, True)
         if self.perm:
             O.bce_onehot_term(ctx, self.classifier(inp["images"]), inp["lab_real"], 1.0, self.loss["class_loss_real"])
         ctx.backward()
@@ -356,8 +381,9 @@ class MnistRCGAN:
         keep = [b.momentum for b in bns]
         for b in bns:
             b.momentum = b.momentum * b.momentum
+        merged = self._merged_critic()
         try:
-            G = self.generator(inp["z"], inp["y_gen"])                               # taped: generator parameters are trainable
+            G = self.generator(inp["z"], inp["y_gen"], out=inp["x_all"].rows(self.B, 2 * self.B) if merged else None)   # taped: generator parameters are trainable
         finally:
             for b, m0 in zip(bns, keep):
                 b.momentum = m0
@@ -367,12 +393,15 @@ class MnistRCGAN:
         self._zero_losses(("d_loss_real", "d_loss_fake", "class_loss_real"))
         self._sn_prefetch()
         kr, kf, kg = self._kinds()
-        if self.alg in ("biased", "rcgan", "ambient"):
+        if merged:
+            self._critic_losses_merged(G)
+        elif self.alg in ("biased", "rcgan", "ambient"):
             O.loss_term(ctx, kr, self.discriminator(inp["images"], inp["y_real"]), 1.0, self.loss["d_loss_real"])
         else:
             logits = self.discriminator_all_labels(inp["images"])
             O.loss_term(ctx, kr, logits, 1.0, self.loss["d_loss_real"], wts=inp["y_real_weights"])
-        self._fake_branch(G, True)
+        if not merged:
+            self._fake_branch(G, True)
         if self.perm:
             O.bce_onehot_term(ctx, self.classifier(inp["images"]), inp["lab_real"], 1.0, self.loss["class_loss_real"])
         self._kept = (G, list(ctx.tape[:n_gen]))
@@ -450,6 +479,17 @@ class MnistRCGAN:
                 src = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
                 # pinned staging + asynchronous copy (a pageable copy waits for all queued device work)
                 dst.copy_(src.reshape(dst.shape).to(dst.dtype).pin_memory(), non_blocking=True)
+                # the halves of the critic step's one-pass inputs this array belongs to (device-to-device, same stream)
+                B = self.B
+                if k == "images":
+                    ctx.view(self.inp["x_all"])[:B].copy_(dst, non_blocking=True)
+                elif k == "y_real":
+                    ctx.view(self.inp["y_all_fake"])[:B].copy_(dst, non_blocking=True)
+                    ctx.view(self.inp["y_all_gen"])[:B].copy_(dst, non_blocking=True)
+                elif k == "y_fake":
+                    ctx.view(self.inp["y_all_fake"])[B:].copy_(dst, non_blocking=True)
+                elif k == "y_gen":
+                    ctx.view(self.inp["y_all_gen"])[B:].copy_(dst, non_blocking=True)
 
     def losses(self):
         out = {k: float(self.ctx.download(v)[0]) for k, v in self.loss.items()}

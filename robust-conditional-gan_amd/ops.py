@@ -153,6 +153,8 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
 
 
 RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
+# the data gradient of a layer fed by conv_cond_concat(x, labels) computed for the x channels only, straight into x's gradient
+CONCAT_DIRECT = os.environ.get("RCGAN_CONCAT_DIRECT", "1") != "0"
 LINEAR_MFMA = os.environ.get("RCGAN_LINEAR_MFMA", "1") != "0"
 
 
@@ -522,7 +524,16 @@ def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
             dy = y.grad
             if dy is None:
                 return
-            if x.req:
+            src = getattr(x, "concat_src", None)
+            if x.req and src is not None and CONCAT_DIRECT:
+                # x = conv_cond_concat(xs, labels): only the xs channels need a gradient -- produced straight into xs's gradient
+                # (x.grad stays None: the concatenation's own backward then has nothing to split)
+                xs, c1 = src
+                dxs, acc = grad_of(ctx, xs)
+                dsc = L.ConvDesc(desc.n, desc.h, desc.w, desc.cin, desc.cout, desc.kh, desc.kw, desc.stride, desc.dtype,
+                                 desc.flags | (L.CONV_ACCUMULATE if acc else 0))
+                ctx.check(ctx.lib.rcgan_deconv2d_bwd_data_cols(ctx.h, C.byref(dsc), _p(dy), _p(w), _p(dxs), c1))
+            elif x.req:
                 dx, acc = grad_of(ctx, x)
                 if not acc:
                     ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(dx)))
@@ -558,7 +569,13 @@ def linear(ctx, x, weight, bias, out_dtype=None):
             dy = y.grad
             if dy is None:
                 return
-            if xr:
+            src = getattr(x, "concat_src", None)
+            if xr and src is not None and CONCAT_DIRECT:
+                # x = concat(xs, labels) (model.py:710-714): the first c1 rows of W give xs's gradient, written straight into it
+                xs, c1 = src
+                dxs, acc = grad_of(ctx, xs)
+                ctx.check(ctx.lib.rcgan_linear_bwd_data(ctx.h, m, c1, n, x.dtype, _p(dy), _p(weight.param), _p(weight.sigma), _p(dxs), acc))
+            elif xr:
                 dx, acc = grad_of(ctx, x)
                 ctx.check(ctx.lib.rcgan_linear_bwd_data(ctx.h, m, kk, n, x.dtype, _p(dy), _p(weight.param), _p(weight.sigma), _p(dx), acc))
             if wr:
@@ -627,9 +644,40 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
             ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, rows, c, x.dtype, _p(x), eps, _p(mean), _p(rstd), None, None, decay,
                                              C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         return BnPending(ctx, x, gamma, beta, labels, n_labels, mean, rstd, act, max(segments, 1))
+    if segments > 1 and labels is None and n % segments == 0 and ((ctx.recording and (x.req or gamma.req or beta.req)) or moving is not None):
+        # Several independent batches back to back THROUGH the tape (the MNIST critic step: D(real) and D(fake) as one pass of 2B
+        # images, model.py:131-179): every segment gets its own statistics, its own moving-average update -- in segment order, as the
+        # reference's consecutive discriminator() calls apply them -- and its own backward reduction; the convolutions around it run
+        # once on all of them.
+        ns = n // segments
+        y = ctx.empty(x.shape, x.dtype)
+        mm, mv = moving if moving is not None else (None, None)
+        stats = []
+        for sg in range(segments):
+            xs, ys = x.rows(sg * ns, (sg + 1) * ns), y.rows(sg * ns, (sg + 1) * ns)
+            mean, rstd = ctx.empty((c,), L.F32), ctx.empty((c,), L.F32)
+            ctx.check(ctx.lib.rcgan_bn_stats(ctx.h, ns * rps, c, x.dtype, _p(xs), eps, _p(mean), _p(rstd), _p(mm), _p(mv), decay,
+                                             C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            ctx.check(ctx.lib.rcgan_bn_apply_fwd(ctx.h, ns, rps, c, n_labels, x.dtype, _p(xs), None, _p(gamma), _p(beta), _p(mean), _p(rstd),
+                                                 act, _p(ys), C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            stats.append((mean, rstd))
+        if _track(ctx, y, x, gamma, beta):
+            def bw_seg():
+                dy = y.grad
+                if dy is None:
+                    return
+                dx, acc_dx = grad_of(ctx, x)
+                dg, db = (gamma.grad, beta.grad) if gamma.req else (zeros_like_grad(ctx, gamma), zeros_like_grad(ctx, beta))
+                for sg, (mean, rstd) in enumerate(stats):
+                    lo, hi = sg * ns, (sg + 1) * ns
+                    ctx.check(ctx.lib.rcgan_bn_bwd2(ctx.h, ns, rps, c, n_labels, x.dtype, _p(x.rows(lo, hi)), _p(y.rows(lo, hi)), _p(dy.rows(lo, hi)),
+                                                    None, _p(gamma), _p(beta), _p(mean), _p(rstd), act, _p(dx.rows(lo, hi)), acc_dx, _p(dg), _p(db), 1,
+                                                    C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+            ctx.record(bw_seg)
+        return y
     if segments > 1:
         if (ctx.recording and (x.req or gamma.req or beta.req)) or moving is not None or n % segments:
-            raise NotImplementedError("segmented batch norm is forward-only (no gradient, no moving statistics)")
+            raise NotImplementedError("segmented conditional batch norm is forward-only (no gradient, no moving statistics)")
         mean = ctx.empty((segments, c), L.F32)
         rstd = ctx.empty((segments, c), L.F32)
         y = ctx.empty(x.shape, x.dtype)
@@ -797,6 +845,7 @@ def concat_channels(ctx, x, yb):
     c2 = yb.shape[1]
     y = ctx.empty(oshape, x.dtype)
     ctx.check(ctx.lib.rcgan_concat_channels_fwd(ctx.h, n, hw, c1, c2, x.dtype, _p(x), _p(yb), _p(y)))
+    y.concat_src = (x, c1)       # a consumer whose data gradient can be limited to the x channels bypasses the split below
     if _track(ctx, y, x):
         def bw():
             if y.grad is None:

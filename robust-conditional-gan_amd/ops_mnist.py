@@ -20,13 +20,15 @@ class batch_norm(object):
     def __init__(self, epsilon=1e-5, momentum=0.9, name="batch_norm"):
         self.epsilon, self.momentum, self.name = epsilon, momentum, name
 
-    def __call__(self, x, train=True, _act=L.ACT_NONE):
+    def __call__(self, x, train=True, _act=L.ACT_NONE, _segments=1):
+        """_segments > 1: x holds that many batches back to back (consecutive calls of the reference on each of them, in that order)."""
         g = _graph()
         with variable_scope(self.name):
             gamma, beta = g.param(scoped("gamma")), g.param(scoped("beta"))
             mm, mv = g.state[scoped("moving_mean")], g.state[scoped("moving_variance")]
         if train:
-            return O.batch_norm_act(g.ctx, x, gamma, beta, act=_act, moving=(mm, mv), decay=self.momentum, eps=self.epsilon)
+            return O.batch_norm_act(g.ctx, x, gamma, beta, act=_act, moving=(mm, mv), decay=self.momentum, eps=self.epsilon, segments=_segments)
+        assert _segments == 1
         return O.batch_norm_infer(g.ctx, x, gamma, beta, mm, mv, act=_act, eps=self.epsilon)
 
 

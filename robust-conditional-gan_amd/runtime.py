@@ -31,7 +31,7 @@ def _np_dtype(code):
 
 class DT:
     """A device tensor: raw pointer + shape + dtype code.  ``base`` keeps the owning torch storage alive."""
-    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen", "group", "tile_stats", "pooled", "pool_grad")
+    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen", "group", "tile_stats", "pooled", "pool_grad", "concat_src")
 
     def __init__(self, ptr, shape, dtype, base=None, name=None):
         self.ptr = int(ptr)
@@ -46,6 +46,7 @@ class DT:
         self.tile_stats = None     # (conv desc, per-tile column sums) left by the producing convolution (ops.conv2d(want_stats=True))
         self.pooled = None         # (features, activation kind) the producer left beside the tensor (ops.d_trunk(pool=...))
         self.pool_grad = None      # gradient of those features, handed back by their consumer (ops.proj_head)
+        self.concat_src = None     # (x, channels of x) when this tensor is conv_cond_concat(x, labels) (ops.concat_channels)
 
     @property
     def size(self):
