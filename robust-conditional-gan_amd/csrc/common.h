@@ -45,6 +45,10 @@ struct rcgan_ctx {
   // latency + 2 (world - 1) / world * bytes / bus bandwidth; 0 / 0 = free (the schedule's own cost only)
   double stub_bus_gbps, stub_latency_us;
   int wall_clock_khz;  // hipDeviceAttributeWallClockRate (the constant-rate counter the wait kernel reads)
+  // grow-only device scratch of the two-step narrow data gradient (conv_direct.hip: per-pixel tap products, then col2im); (re)allocated
+  // outside graph capture only -- the first call of every step is eager
+  void* narrow_ws;
+  size_t narrow_ws_bytes;
   void* dbg_stamps;    // rcgan_debug_stamps
   // deferred parameter gradients of the projection head (head_rider.h): 0 = nothing pending, 1 = dE GEMM + parameter sums,
   // 2 = parameter sums; the argument block is loss.hip's

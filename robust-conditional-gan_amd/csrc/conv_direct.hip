@@ -1204,6 +1204,40 @@ int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float
 template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*, int);
 template int direct_fwd<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const float*, const float*, const float*, bf16_t*, int);
 
+// ---- narrow stride-2 data gradient / transposed convolution in two steps (fp32) ------------------------------------------------
+// The MNIST generator's image layer (g_h3: 138 -> 1 channel, 14x14 -> 28x28, model.py:726) and the data gradient of the critic's first
+// convolution (1 <- 64 channels) produce ONE channel per pixel: as a gather GEMM a 64-column tile is 1/64 occupied, and the
+// 16-lanes-per-pixel kernel above spends its time on tap arithmetic (118 us for 0.35 GFLOP at B = 256).  Because the output is narrow
+// the products can be formed per SOURCE pixel instead: P[m][(kh, kw, ci)] = sum_co dy[m][co] * w[kh][kw][ci][co] is a dense
+// [N*OH*OW, Cout] x [Cout, KH*KW*Cin] GEMM on the matrix cores (linear_dgrad: 25 columns for one output channel), and the transposed
+// convolution is then a col2im: every output pixel adds the <= ceil(K/2)^2 products that land on it (+ bias).
+__global__ __launch_bounds__(256) void col2im_s2_kernel(long total, ConvGeom g, const float* P, const float* bias, float* dx, int accumulate) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int ci = (int)(e % g.Cin);
+  long t = e / g.Cin;
+  const int iw = (int)(t % g.W); t /= g.W;
+  const int ih = (int)(t % g.H);
+  const int n = (int)(t / g.H);
+  const int ntap = g.KH * g.KW * g.Cin;
+  float v = bias ? bias[ci] : 0.f;
+  for (int kh = (ih + g.PT) % g.S; kh < g.KH; kh += g.S) {
+    const int oh = (ih + g.PT - kh) / g.S;
+    if (ih + g.PT - kh < 0 || oh >= g.OH) continue;
+    for (int kw = (iw + g.PL) % g.S; kw < g.KW; kw += g.S) {
+      const int ow = (iw + g.PL - kw) / g.S;
+      if (iw + g.PL - kw < 0 || ow >= g.OW) continue;
+      v += P[(((long)n * g.OH + oh) * g.OW + ow) * ntap + (kh * g.KW + kw) * g.Cin + ci];
+    }
+  }
+  dx[e] = accumulate ? dx[e] + v : v;
+}
+
+static int narrow_two_step_enabled() {
+  static const int v = gg_env_int("RCGAN_NARROW_TWO_STEP", 1);
+  return v;
+}
+
 // dgrad at the LOGICAL input resolution (no upsample folding here; the caller pools afterwards).
 template <typename T>
 int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const float* w, const float* wscale, const float* bias,
@@ -1240,6 +1274,26 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
       op.M = maxM; op.R = maxR; op.r_chunk = maxR;
       { const auto& c = tab.cls[0]; op.ph = c.ph; op.pw = c.pw; op.Hp = c.Hp; op.Wp = c.Wp; op.kh0 = c.kh0; op.kw0 = c.kw0;
         op.nkh = c.nkh; op.nkw = c.nkw; op.dh = c.dh; op.dwc = c.dwc; op.dnkw = c.dnkw; }
+      if constexpr (std::is_same<T, float>::value) {
+        // one or two output channels, fp32, no ReLU mask: products per source pixel on the matrix cores + col2im (above)
+        const long m = (long)g.N * g.OH * g.OW, kcols = (long)g.KH * g.KW * g.Cin;
+        const size_t need = (size_t)m * kcols * sizeof(float);
+        if (narrow_two_step_enabled() && op.N <= 2 && xmask == nullptr && g.Cout >= 32 && need <= ((size_t)1 << 30)) {
+          if (ctx->narrow_ws_bytes < need) {
+            if (ctx->capturing) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "narrow data gradient: scratch of %zu bytes must be allocated outside a capture", need);
+            if (ctx->narrow_ws) { RC_HIP(ctx, hipStreamSynchronize(ctx->stream)); RC_HIP(ctx, hipFree(ctx->narrow_ws)); ctx->narrow_ws = nullptr; ctx->narrow_ws_bytes = 0; }
+            RC_HIP(ctx, hipMalloc(&ctx->narrow_ws, need));
+            ctx->narrow_ws_bytes = need;
+          }
+          int rc = linear_dgrad<float>(ctx, m, kcols, g.Cout, (const float*)dy, w, wscale, (float*)ctx->narrow_ws, 0);
+          if (rc != RCGAN_OK) return rc;
+          const long total = (long)g.N * g.H * g.W * g.Cin;
+          hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, ctx->stream, total, g, (const float*)ctx->narrow_ws, bias,
+                             (float*)dx, accumulate);
+          RC_LAUNCH_CHECK(ctx);
+          return RCGAN_OK;
+        }
+      }
       if (op.N <= 4 && maxR > 0 && (size_t)maxR * op.N * sizeof(float) <= 48 * 1024) return launch_dgrad_s2_narrow(ctx, op, tab, ncls, maxM, maxR);
       return launch_gemm(ctx, op, ncls, tab);
     }
