@@ -267,7 +267,7 @@ int rcgan_create(rcgan_ctx** out, int device, void* stream) {
   c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stub = false; c->comm_stream = nullptr;
   c->comm_fork = nullptr; c->comm_join = nullptr; c->comm_pending = false;
   c->stub_bus_gbps = 0.0; c->stub_latency_us = 0.0; c->wall_clock_khz = 0;
-  c->narrow_ws = nullptr; c->narrow_ws_bytes = 0;
+  c->narrow_ws = nullptr; c->narrow_ws_bytes = 0; c->splitr_ws = nullptr; c->splitr_ws_bytes = 0;
   c->gscale_host = 1.f;
   c->gscale_dev = nullptr;
   c->zero_page = nullptr;
@@ -291,6 +291,8 @@ int rcgan_destroy(rcgan_ctx* ctx) {
     if (ctx->event_made[i]) (void)hipEventDestroy(ctx->events[i]);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->narrow_ws) (void)hipFree(ctx->narrow_ws);
+  if (ctx->splitr_ws) (void)hipFree(ctx->splitr_ws);
+  for (void* p : ctx->retired_ws) (void)hipFree(p);
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

@@ -49,6 +49,9 @@ struct rcgan_ctx {
   // outside graph capture only -- the first call of every step is eager
   void* narrow_ws;
   size_t narrow_ws_bytes;
+  void* splitr_ws;     // ... and of the split-reduction forward / data-gradient GEMMs (partial tiles)
+  size_t splitr_ws_bytes;
+  std::vector<void*> retired_ws;   // outgrown scratch buffers: captured graphs may still address them, freed with the context
   void* dbg_stamps;    // rcgan_debug_stamps
   // deferred parameter gradients of the projection head (head_rider.h): 0 = nothing pending, 1 = dE GEMM + parameter sums,
   // 2 = parameter sums; the argument block is loss.hip's
@@ -75,6 +78,19 @@ struct rcgan_ctx {
 #define RC_COUNTER_HEAD 500    // loss partials of the fused projection head
 #define RC_COUNTER_INPUTS 501  // the step-input rider of the filter preparation (step_inputs.h)
 #define RC_COUNTER_BNSEG 512   // [512,768): segmented forward batch norm, one per (segment, 64-channel column block)
+
+// grow-only scratch (*buf, *cap) of at least `need` bytes; never inside a capture, and an outgrown buffer stays allocated (a graph
+// captured earlier replays launches that address it)
+static inline hipError_t ctx_grow_scratch(rcgan_ctx* c, void** buf, size_t* cap, size_t need) {
+  if (*cap >= need) return hipSuccess;
+  if (c->capturing) return hipErrorStreamCaptureUnsupported;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, need);
+  if (e != hipSuccess) return e;
+  if (*buf) c->retired_ws.push_back(*buf);
+  *buf = p; *cap = need;
+  return hipSuccess;
+}
 
 // brackets one launch with events when profiling is armed for kernel id `which`
 struct ProfScope {

