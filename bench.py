@@ -10,9 +10,11 @@ slabs.  Inputs are synthetic and resident in HBM before the timed re
 dequantisation noise are drawn on the device inside the captured step graphs.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (conv_mfma_p8_kernel: fwd + dgrad of the 256-channel convs, 256x256 tiles): algorithmic flops
-               of its launches in one iteration / their summed duration measured with HIP events on the
-               launch stream, against the dense bf16 MFMA peak.
+  roofline     dominant kernel (conv_mfma_h8_kernel: fwd + dgrad of the 256-channel 32x32 convs, 256x256 tiles, pixel operand as an
+               LDS patch): algorithmic flops of its launches in one iteration / their summed duration measured with HIP events on
+               the launch stream, against the dense bf16 MFMA peak; mfma_busy = the matrix pipe's busy fraction by the hardware
+               counter and traffic = HBM bytes per launch, both from committed rocprofv3 --pmc passes of this same command on this
+               same build of the kernels (null otherwise).
   cpu_baseline the PyTorch-CPU restatement of the reference graph (oracle/torch_port.py; kind "port": TensorFlow 1.5 is not
                installable) on all host cores for a bounded sample at the same batch, rank 0 at N=1 only.
 """
@@ -127,8 +129,9 @@ def iteration(m, pool, it, dcount):
 
 
 def kernel_roofline(m, pool, default_workload=True):
-    """One eager (un-captured) iteration with every conv_mfma_p8_kernel launch (the dominant kernel: forward and data
-    gradient of the 256-channel 3x3 / 1x1 convolutions, 256 x 256 tiles) bracketed by HIP events on the launch stream."""
+    """One eager (un-captured) iteration with every launch of the dominant kernel (conv_mfma_h8_kernel: forward and data
+    gradient of the 256-channel 3x3 convolutions at 32x32, 256 x 256 tiles; a layer it does not take runs on conv_mfma_p8_kernel
+    under the same profiling id) bracketed by HIP events on the launch stream."""
     from rcgan_amd import _lib as L
     ctx = m.ctx
     saved = m.use_graphs
@@ -147,16 +150,27 @@ def kernel_roofline(m, pool, default_workload=True):
     # WRITE_SIZE cannot share a pass; corrections as MI355X_MICROARCH.md prescribes) and committed with the profile
     traffic = None
     import glob
-    tfs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_conv_p8.json")))
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    tfs = sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic_conv_p8.json")) + glob.glob(os.path.join(pdir, "r*_pmc_traffic_conv_h8.json")),
+                 key=os.path.basename)
+    mfma_busy = None
     if default_workload and tfs:                         # the counters were collected on the default workload only; newest round
         with open(tfs[-1]) as f:
             tj = json.load(f)
         # ... and only a measurement of THIS build of the kernels counts (the profile records the hash of the sources it ran)
         if tj.get("source_sha16") == L.source_hash():
             traffic = float(tj["traffic_bytes_per_launch"])
+    # the matrix pipe's busy fraction by the hardware counter (SQ_VALU_MFMA_BUSY_CYCLES / 4 x SQ_BUSY_CU_CYCLES), collected in its own
+    # rocprofv3 --pmc pass of this command and committed with the profile; same gate
+    bfs = sorted(glob.glob(os.path.join(pdir, "r*_pmc_mfma_busy.json")), key=os.path.basename)
+    if default_workload and bfs:
+        with open(bfs[-1]) as f:
+            bj = json.load(f)
+        if bj.get("source_sha16") == L.source_hash():
+            mfma_busy = round(float(bj["mfma_busy"]), 4)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "kernel": "conv_mfma_p8_kernel", "launches_per_iteration": n.value,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy": mfma_busy,
+            "kernel": "conv_mfma_h8_kernel", "launches_per_iteration": n.value,
             "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
             "flops_per_launch_avg": fl.value / n.value,
             # algorithmic = the reference's formulation; the upsample-3x3 layers run in their sub-pixel form (four 2x2

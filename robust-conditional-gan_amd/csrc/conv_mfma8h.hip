@@ -67,7 +67,10 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 constexpr int H8_HALF = 128 * 128;                   // one filter half-tile: 128 rows x 128 B
-constexpr int h8_patch_rows(int lw) { return (((256 >> lw) + 2) * ((1 << lw) + 2) + 7) / 8 * 8; }      // patch pixels, padded to whole DMA pieces
+#ifndef H8_PC_EXTRA
+#define H8_PC_EXTRA 2      /* patch columns beyond the image width: 2 = the halo; 4 = two more (idle) columns, row pitch = 2 mod 4 pixels */
+#endif
+constexpr int h8_patch_rows(int lw) { return (((256 >> lw) + 2) * ((1 << lw) + H8_PC_EXTRA) + 7) / 8 * 8; }      // patch pixels, padded to whole DMA pieces
 constexpr int h8_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8_HALF; }      // [filter buffers 0, 1][patch 0][patch 1]
 
 }  // namespace
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   constexpr int W = 1 << LW, TR = 256 >> LW;        // (low-resolution) image width, image rows per tile
   constexpr int NT = PHM ? 4 : 9;                   // taps = K-tiles per 64-channel chunk
   constexpr int NTI = PHM ? 2 : 6;                  // ... of which the first NTI carry patch pieces (landed two K-tiles later: NTI <= NT - 2)
-  constexpr int PC = W + 2, PR = TR + 2;            // patch columns / rows
+  constexpr int PC = W + H8_PC_EXTRA, PR = TR + 2;  // patch columns / rows
   constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;      // patch pixels, padded rows, DMA pieces (8 rows each)
   constexpr int PATCH = NROWS * 128;
   constexpr int WBUF = 2 * H8_HALF;
@@ -142,6 +145,10 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     if (a.stamps && tid == 0) a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  if (a.stamps && tid == 0) {
+    a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+    a.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+  }
 
   // ---- patch sources: piece i = wave + 8 j covers patch pixels 8 i .. 8 i + 7; this lane deposits pixel q = 8 i + lrow, slot pos.
   // Halo slots (SAME padding, the padding rows behind the patch) are zeroed once, here, in both buffers, and never written again:
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  stamp(1);        // (scripts/exp_p8_timeline.py: segment 0 = patch sources, filter sources, fragment addresses)
   // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
   const int nchunks = a.Cin >> 6;
 #pragma unroll

@@ -53,7 +53,7 @@ def main():
     for xc in np.unique(xcc):
         t[xcc == xc] -= t[xcc == xc, 0].min()
     seg = np.diff(t, axis=1)
-    names = ["tap table", "first K-tile (load latency)", "K loop (%d K-tiles)" % (k * k * cin // 64), "epilogue issue", "store drain"]
+    names = ["setup (tap table / patch sources)", "first K-tile (load latency)", "K loop (%d K-tiles)" % (k * k * cin // 64), "epilogue issue", "store drain"]
     ctx.event_record(0)
     for _ in range(10):
         call()
@@ -63,9 +63,9 @@ def main():
     print("n=%d cin=%d k=%d: %d tiles; kernel %.1f us per launch (events, back to back); longest XCD span %.0f ticks" % (n, cin, k, tiles, us, span))
     tick = 1.0 / 2270.0       # us per tick if the counter runs at ~2.27 GHz (K loop of 36 K-tiles = 58 us = 132k ticks)
     for i, nm in enumerate(names):
-        print("  %-30s mean %8.0f ticks (%6.2f us @2.27GHz)   min %8.0f   max %8.0f" % (nm, seg[:, i].mean(), seg[:, i].mean() * tick, seg[:, i].min(), seg[:, i].max()))
+        print("  %-34s mean %8.0f ticks (%6.2f us @2.27GHz)   min %8.0f   max %8.0f" % (nm, seg[:, i].mean(), seg[:, i].mean() * tick, seg[:, i].min(), seg[:, i].max()))
     tot = t[:, 5] - t[:, 0]
-    print("  %-30s mean %8.0f ticks (%6.2f us)   min %8.0f   max %8.0f" % ("workgroup total", tot.mean(), tot.mean() * tick, tot.min(), tot.max()))
+    print("  %-34s mean %8.0f ticks (%6.2f us)   min %8.0f   max %8.0f" % ("workgroup total", tot.mean(), tot.mean() * tick, tot.min(), tot.max()))
     cu = xcc * 65536 + ((s[:, 6] >> 8) & 0xffff)               # XCC + (CU, SH, SE) bits of HW_ID
     gaps, per_cu = [], []
     for c in np.unique(cu):

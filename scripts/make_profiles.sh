@@ -22,7 +22,7 @@ rm -rf "$OUT/prof_kt"
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace -d "$OUT/pmc_$CTR" -o pmc -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$CTR.err"
   DB=$(find "$OUT/pmc_$CTR" -name "*.db" | head -1)
-  python3 "$ROOT/scripts/pmc_summary.py" conv_mfma_p8_kernel "$DB" > "$OUT/pmc_${CTR}_conv_p8.txt"
+  python3 "$ROOT/scripts/pmc_summary.py" conv_mfma_h8_kernel "$DB" > "$OUT/pmc_${CTR}_conv_h8.txt"
   rm -rf "$OUT/pmc_$CTR"
 done
 
@@ -41,6 +41,24 @@ python3 scripts/exp_p8_fixed_cost.py > "$OUT/exp_p8_fixed_cost.txt" 2>&1
 python3 scripts/exp_p8_timeline.py 320 256 3 > "$OUT/exp_p8_timeline.txt" 2>&1
 python3 scripts/step_times.py > "$OUT/step_times.txt" 2>&1
 python3 scripts/bench_mnist.py 256 f32 > "$OUT/bench_mnist.txt" 2>&1
+# MNIST cfg2 under the profiler: per-kernel summary (55 iterations) and launches per iteration
+( cd /tmp && rocprofv3 --kernel-trace -d "$OUT/prof_mnist" -o kt -- python3 "$ROOT/scripts/bench_mnist.py" 256 f32 > /dev/null 2>&1 )
+DBM=$(find "$OUT/prof_mnist" -name "*.db" | head -1)
+python3 scripts/prof_summary.py "$DBM" 55 --csv "$OUT/mnist_b256_f32_kernel_stats.csv" > "$OUT/mnist_b256_f32_kernel_stats.txt"
+python3 scripts/prof_summary.py "$DBM" 55 --by-grid > "$OUT/mnist_b256_f32_kernel_stats_by_grid.txt"
+rm -rf "$OUT/prof_mnist"
+# the reference's own precision: every layer on the fp32 matrix cores
+python3 bench.py --no-cpu-baseline --dtype f32 --steps 20 > "$OUT/bench_f32.json" 2> /dev/null
+# what bounds the 256 x 256 kernels (timing-only ablation builds; scripts/build_p8_ablate.sh ran before the snapshot)
+{ echo "# per K-tile cost of the tile-per-tap 256x256 kernel (conv_mfma_p8_kernel, ping-pong schedule) and of the halo-patch kernel (conv_mfma_h8_kernel):"
+  echo "# scripts/exp_p8_fixed_cost.py quick (n = 320, 3x3, Cin 128 / 256 / 512: fit time = fixed + per-K-tile x KT); ablation builds are wrong by construction"
+  echo "halo-patch kernel as built:                 $(python3 scripts/exp_p8_fixed_cost.py quick 2>/dev/null | tail -1)"
+  echo "tile-per-tap kernel (RCGAN_P8_HALO=0):      $(RCGAN_P8_HALO=0 python3 scripts/exp_p8_fixed_cost.py quick 2>/dev/null | tail -1)"
+  echo "tile-per-tap, ping-pong (RCGAN_P8_PP=1):    $(RCGAN_P8_HALO=0 RCGAN_P8_PP=1 python3 scripts/exp_p8_fixed_cost.py quick 2>/dev/null | tail -1)"
+  for k in 1 2 4 3 16 h1 h2 h4 h6 h8 h16; do
+    L=scripts/probes/_bin/librcgan_abl$k.so
+    [ -f $L ] && echo "ablation $k: $(RCGAN_LIB_PATH=$PWD/$L RCGAN_P8_PP=1 RCGAN_P8_HALO=$([ "${k#h}" != "$k" ] && echo 1 || echo 0) python3 scripts/exp_p8_fixed_cost.py quick 2>/dev/null | tail -1)"
+  done; } > "$OUT/exp_p8_ablation.txt"
 python3 scripts/bench_wgrad_group.py > "$OUT/wgrad_group.txt" 2>&1
 python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512.json" 2> /dev/null
 python3 bench.py --no-cpu-baseline --dtype f16 > "$OUT/bench_f16.json" 2> /dev/null

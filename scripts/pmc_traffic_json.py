@@ -2,7 +2,7 @@
 """HBM traffic per launch of the dominant kernel from the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 summarised by scripts/pmc_summary.py  ->  the JSON that bench.py reports as roofline.traffic.
 
-usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_p8.txt> <pmc_WRITE_SIZE_conv_p8.txt> <out.json>
+usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_h8.txt> <pmc_WRITE_SIZE_conv_h8.txt> <out.json>
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KB and counts the 128-byte requests of a wide
 coalesced stream at 64 bytes on gfx950 -> x2; WRITE_SIZE (KB) as reported."""
@@ -15,7 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def parse(path):
-    out, cur = {}, None
+    # (several template instances of the kernel may share a grid -- the plain and the sub-pixel form at 1280 / 512 workgroups: merged,
+    # dispatch-weighted)
+    acc, cur = {}, None
     for line in open(path):
         m = re.match(r"(\S.*) grid \((\d+), (\d+), (\d+)\) \((\d+) dispatches\)", line)
         if m:
@@ -23,8 +25,9 @@ def parse(path):
             continue
         m = re.match(r"\s+(\w+)\s+([\d.]+)", line)
         if m and cur:
-            out[cur[0]] = (cur[1], float(m.group(2)))
-    return out
+            n0, s0 = acc.get(cur[0], (0, 0.0))
+            acc[cur[0]] = (n0 + cur[1], s0 + cur[1] * float(m.group(2)))
+    return {g: (n, s / n) for g, (n, s) in acc.items()}
 
 
 def main():
@@ -48,7 +51,7 @@ def main():
     from rcgan_amd import _lib
     out = {
         "source_sha16": _lib.source_hash(),      # bench.py attaches the figure to a run only on the same build of the kernels
-        "kernel": "conv_mfma_p8_kernel<false, true> (channel-major K order, shared epilogue with paired 16-byte stores; upsample-3x3 layers in sub-pixel form, shortcuts before the upsample)",
+        "kernel": "conv_mfma_h8_kernel (256 x 256 tile, pixel operand as an LDS patch fetched once per 64-channel chunk; the upsample-3x3 layers in sub-pixel form, shortcuts before the upsample)",
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes; scripts/make_profiles.sh)",
         "fetch_size_kb_avg": f_avg, "write_size_kb_avg": w_avg, "launches": n,
         "per_grid": {str(g): {"launches": fetch[g][0], "fetch_kb": fetch[g][1], "write_kb": write[g][1], "algorithmic_bytes": alg[g]} for g in sorted(fetch)},
