@@ -801,14 +801,31 @@ static int launch_dgrad_s2_narrow(rcgan_ctx* ctx, DgradS2Op<T>& op, const S2Tabl
   return RCGAN_OK;
 }
 
-// out[i] (= or +=) sum_z slab[z][i]
-__global__ void slab_reduce_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += slab[(long)z * count + i];
-  if (accumulate) s += out[i];
-  out[i] = s;
+// out[i] (= or +=) sum_z slab[z][i].  A block owns 64 outputs; its four wavefronts take the slabs z = w, w + 4, ... (four
+// independent loads in flight each) and meet in LDS in a fixed order: the narrow layers' filter gradients come as up to 256 slabs of a
+// few thousand outputs (g_h3: 3450 outputs x 256 slabs), where one thread per output was a chain of 256 dependent loads (48 us).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, float* out, long count, int nz, int accumulate) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int z = w;
+    for (; z + 12 < nz; z += 16) {
+      s0 += slab[(long)z * count + i];
+      s1 += slab[(long)(z + 4) * count + i];
+      s2 += slab[(long)(z + 8) * count + i];
+      s3 += slab[(long)(z + 12) * count + i];
+    }
+    for (; z < nz; z += 4) s0 += slab[(long)z * count + i];
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && i < count) {
+    float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (accumulate) s += out[i];
+    out[i] = s;
+  }
 }
 
 // out[i] (= or +=) bias[i % n] + sum_z slab[z][i]  (the epilogue of a split-reduction forward / data-gradient GEMM)
@@ -1227,7 +1244,7 @@ int linear_wgrad(rcgan_ctx* ctx, long m, long k, long n, const T* x, const T* dy
     int rc = launch_gemm(ctx, op, nz);
     if (rc) return rc;
     long cnt = k * n;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)op.out, dw, cnt, nz, accumulate);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 64)), dim3(256), 0, ctx->stream, (const float*)op.out, dw, cnt, nz, accumulate);
     RC_LAUNCH_CHECK(ctx);
   }
   if (dbias) {
@@ -1373,7 +1390,7 @@ int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* 
   int rc = launch_gemm(ctx, op, nz);
   if (rc) return rc;
   long cnt = K * op.g.Cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)op.slab, dw, cnt, nz, accumulate);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(cnt, 64)), dim3(256), 0, ctx->stream, (const float*)op.slab, dw, cnt, nz, accumulate);
   RC_LAUNCH_CHECK(ctx);
   if (dbias) {
     float* part = (float*)((char*)ws + (size_t)wgrad_splits(K, op.g.Cout, M) * K * op.g.Cout * sizeof(float));
