@@ -919,9 +919,13 @@ static inline int apply_grid_fused(long nchunks, int c) {
   return (int)b;
 }
 
-static inline long stats_group_rows(long rows) {
+static inline long stats_group_rows(long rows, int c = 0, int dtype = -1) {
   long g = 512;
   while (rows / g > 2048) g *= 2;
+  // fp32 path (MNIST: 64-channel critic layers of 1024 .. 25088 rows): 512 rows per workgroup are 128 dependent rounds of loads in 2 .. 49
+  // workgroups -- a latency chain of 17-20 us for a few hundred KB.  Shorter groups until ~256 workgroups exist (the finisher reads <= 256 partials)
+  if (dtype == RCGAN_F32 && c > 0)
+    while (g > 32 && (rows / g) * (c / 64 > 0 ? c / 64 : 1) < 256) g /= 2;
   return g;
 }
 
@@ -1056,7 +1060,7 @@ size_t rcgan_bn_workspace_bytes(int rows, int c) {
 
 int rcgan_bn_stats(rcgan_ctx* ctx, int rows, int c, int dtype, const void* x, float eps, float* mean, float* rstd,
                    float* mm, float* mv, float decay, void* ws, size_t ws_bytes) {
-  long rpg = stats_group_rows(rows);
+  long rpg = stats_group_rows(rows, c, dtype);
   int ng = cdiv(rows, rpg);
   size_t need = (size_t)ng * 2 * c * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
@@ -1259,7 +1263,7 @@ int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_label
       else while ((long)n * gps * (c / 64) < target && rpg % 2 == 0 && rpg / 2 >= 32 && (long)n * gps * 2 <= maxg) { gps *= 2; rpg /= 2; }
       ng = n * gps;
     } else {
-      rpg = stats_group_rows(rows); ng = cdiv(rows, rpg);
+      rpg = stats_group_rows(rows, c, dtype); ng = cdiv(rows, rpg);
     }
     const int nwg = ng / nsub;
     size_t need = ((size_t)ng * 2 * c + 2 * (size_t)c) * sizeof(float);
@@ -1283,7 +1287,7 @@ int rcgan_bn_bwd2(rcgan_ctx* ctx, int n, int rows_per_sample, int c, int n_label
     return RCGAN_OK;
   }
   if (labels) { rpg = rows_per_sample; ng = n; }          // one group per sample: group label = sample label
-  else { rpg = stats_group_rows(rows); ng = cdiv(rows, rpg); }
+  else { rpg = stats_group_rows(rows, c, dtype); ng = cdiv(rows, rpg); }
   size_t need = ((size_t)ng * 2 * c + 2 * (size_t)c) * sizeof(float);
   if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
   float* partial = (float*)ws;
