@@ -934,7 +934,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   std::vector<MfmaWgradArgs> cand(n);
   std::vector<char> takes(n, 0);
   // pass 1: which layers the grouped kernel takes, and the pixels per workgroup that gives ~target_blocks workgroups in all
-  double work = 0;
+  double work = 0, work9 = 0;        // (work9: the plain 3x3 layers of the nine-tap kernel, one 768-thread workgroup per CU)
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
     int rc = check_desc(ctx, d);
@@ -946,7 +946,10 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     wgrad_args_from_desc(ctx, d, xs[i], dys[i], dbiases[i] != nullptr, a);
     if ((d->flags & RCGAN_CONV_OUT_MEANPOOL2) && a.sub != 2)
       RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "filter gradient from the pooled dy needs the sub-pixel three-tap kernel (rcgan_conv_wgrad_pool_ok)");
-    if (mfma_wgrad3_takes(a)) {
+    if (mfma_wgrad9_takes(a)) {
+      takes[i] = 2;
+      work9 += (double)a.M * (a.Cin / 64) * (a.Cout / 128);
+    } else if (mfma_wgrad3_takes(a)) {
       takes[i] = 1;
       // workgroup-passes over a pixel: 3 filter rows of three taps, or 8 (parity, row shift) tiles of two taps
       work += (double)a.M * (a.sub == 3 ? 1.0 / 3.0 : (a.sub ? 8 * 2.0 / 3.0 : a.KH)) * (a.Cin / 64) * (a.Cout / 128);
@@ -957,6 +960,11 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   px = (px + 63) / 64 * 64;
   if (px < 256) px = 256;
   if (px > px_max) px = px_max;      // big groups (the generator step): more workgroups rather than ever longer ones
+  static const int target9 = [] { const char* e = getenv("RCGAN_WGRAD9_BLOCKS"); return e ? atoi(e) : 256; }();
+  long px9 = ((long)(work9 / target9) + 63) / 64 * 64;
+  if (px9 < 512) px9 = 512;
+  std::vector<MfmaWgradArgs> args9[2];           // nine-tap kernel without / with input ReLU
+  std::vector<unsigned> gxs9[2], gys9[2];
   // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
   std::vector<MfmaWgradArgs> args[3];            // three-tap kernel without / with input ReLU, per-tap kernel
   std::vector<MfmaWgradArgs> late;               // small 1x1 layers on the two-tap body: join one of the first two
@@ -970,7 +978,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   for (int q = 0; q <= IMG_GROUP_MAX; ++q) img.first[q] = 0;
   static const int img_group = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_IMG"); return e ? atoi(e) : 1; }();
   bool any_group = false;
-  for (int i = 0; i < n && img_group; ++i) any_group = any_group || takes[i];
+  for (int i = 0; i < n && img_group; ++i) any_group = any_group || takes[i] == 1;
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
     bool grouped = false;
@@ -1005,15 +1013,17 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       MfmaWgradArgs a = cand[i];
       const int nz = a.sub ? mfma_wgrad_sub_splits(d, a.M) : mfma_wgrad_splits(d, a.M);
       unsigned gx = 0, gy = 0;
-      const bool three = takes[i] && mfma_wgrad3_plan(a, nz, &gx, &gy, px);
+      const bool nine = takes[i] == 2 && mfma_wgrad9_plan(a, nz, &gx, &gy, px9);
+      const bool three = !nine && takes[i] && mfma_wgrad3_plan(a, nz, &gx, &gy, px);
       if (a.sub && !three) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
-      if (three || mfma_wgrad_tap_plan(a, nz, &gx, &gy)) {
+      if (nine || three || mfma_wgrad_tap_plan(a, nz, &gx, &gy)) {
         const size_t need = ((size_t)gy * a.slab_stride * sizeof(float) + 255) / 256 * 256;
         if (used + need <= ws_bytes / 2) {
           a.slab = (float*)((char*)ws + used);
           used += need;
           const int f = three ? (a.relu_in ? 1 : 0) : 2;
-          if (three && a.sub == 3 && !a.relu_in) { late.push_back(a); late_gx.push_back(gx); late_gy.push_back(gy); }   // placed below
+          if (nine) { const int f9 = a.relu_in ? 1 : 0; args9[f9].push_back(a); gxs9[f9].push_back(gx); gys9[f9].push_back(gy); }
+          else if (three && a.sub == 3 && !a.relu_in) { late.push_back(a); late_gx.push_back(gx); late_gy.push_back(gy); }   // placed below
           else { args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy); }
           red.push_back(wgrad_reduce_item(d, a, dws[i], dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate));
           grouped = true;
@@ -1058,6 +1068,11 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       }
     }
   }
+  for (int f = 0; f < 2; ++f)
+    if (!args9[f].empty()) {
+      int rc = mfma_wgrad9_group_launch(ctx, (int)args9[f].size(), args9[f].data(), gxs9[f].data(), gys9[f].data());
+      if (rc) return rc;
+    }
   for (int f = 0; f < 3; ++f)
     if (!args[f].empty()) {
       int rc = mfma_wgrad3_group_launch(ctx, (int)args[f].size(), args[f].data(), gxs[f].data(), gys[f].data(), f == 2 ? 1 : 0,

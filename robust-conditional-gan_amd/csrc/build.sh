@@ -5,7 +5,7 @@
 # usage: build.sh [bf16|f16|all]   (default all)
 set -e
 cd "$(dirname "$0")"
-SRCS="api.hip comm.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_mfma8.hip conv_mfma8h.hip conv_trunk.hip conv_rf.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
+SRCS="api.hip comm.hip conv_direct.hip conv_small.hip conv_mfma.hip conv_mfma8.hip conv_mfma8h.hip conv_wgrad9.hip conv_trunk.hip conv_rf.hip conv_image.hip elementwise.hip bn.hip sn.hip loss.hip"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 WHAT=${1:-all}
 

@@ -89,6 +89,11 @@ int mfma_wgrad_sub_splits(const rcgan_conv_desc* d, long M);
 int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy, int family,
                              const ImgWGroup* img, bool carry_head = false);
 bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);
+// conv_wgrad9.hip: all nine taps of a plain 3x3 layer in one workgroup (dy and x staged once for the three filter rows)
+#define WGRAD9_GROUP_MAX 12
+bool mfma_wgrad9_takes(const MfmaWgradArgs& a);
+bool mfma_wgrad9_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
+int mfma_wgrad9_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy);
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);

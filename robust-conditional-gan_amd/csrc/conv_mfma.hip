@@ -907,6 +907,12 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
   }
 }
 
+// timing-only ablations of the three-tap body (scripts/build_p8_ablate.sh w<k>; results are wrong by construction): 1 = no LDS-DMA after the
+// prologue, 2 = no MFMAs, 4 = fragment reads of the first stage only, 8 = no ReLU / edge masks on the pixel fragments
+#ifndef WG3_ABLATE
+#define WG3_ABLATE 0
+#endif
+
 // SUB: the sub-pixel form (MfmaWgradArgs::sub != 0, checked by the caller): two column taps per workgroup (dw = tb, tb + 1 with
 // tb = -1 or 0 by the column parity) instead of three -- 16 accumulators, the tap rows and the edge mask chosen once per workgroup
 template <int NS, bool RELU, bool SUB>
@@ -1050,8 +1056,8 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
           wait_vmcnt_any<0>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + NS - 1 < KT) issue((sidx + NS - 1) % NS);
-        const unsigned char* sb = smem + sidx * STAGE;
+        if (kt + NS - 1 < KT && !(WG3_ABLATE & 1)) issue((sidx + NS - 1) % NS);
+        const unsigned char* sb = smem + ((WG3_ABLATE & 4) ? 0 : sidx) * STAGE;
         bf16x8_t yf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) yf[i] = tr_pair(sb + offy[i], 16 * 256);
@@ -1062,10 +1068,19 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             uint4 v = __builtin_bit_cast(uint4, tr_pair(sb + offx[t][j], 16 * 128));
+            if (!(WG3_ABLATE & 8)) {
             if (SUB ? relu_on : RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
             if (t == 0) { v.x &= maskl[0]; v.y &= maskl[1]; v.z &= maskl[2]; v.w &= maskl[3]; }
             if (t == NT - 1) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
+            }
             xf[j] = __builtin_bit_cast(bf16x8_t, v);
+          }
+          if (WG3_ABLATE & 2) {       // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(xf[j]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(yf[i]));
+            continue;
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -1784,6 +1799,14 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
 int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done) {
   *bias_done = false;
   if (a.sub && !mfma_wgrad3_takes(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
+  {
+    unsigned gx9 = 0, gy9 = 0;
+    if (mfma_wgrad9_plan(a, nz, &gx9, &gy9, 0)) {
+      int rc = mfma_wgrad9_group_launch(ctx, 1, &a, &gx9, &gy9);
+      *bias_done = a.want_bias != 0;
+      return rc ? -1 : (int)gy9;
+    }
+  }
   if (wgrad3_enabled() && a.use_tr && a.zero != nullptr && wgrad3_geom(a)) {
     long tiles3 = (long)wgrad3_rows(a) * (a.Cin / 64) * (a.Cout / 128);
     int want = (int)wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, a.M);

@@ -28,7 +28,14 @@ def main():
         "critic step (+ image-end layers)": [(n, 32, 32, 3, 128, 3, 0), (n, 16, 16, 3, 128, 1, 0), (n, 32, 32, 128, 128, 3, R), (n, 16, 16, 128, 128, 3, R),
                                              (n, 16, 16, 128, 128, 3, R), (n, 16, 16, 128, 128, 1, 0)] + [(n, 8, 8, 128, 128, 3, R)] * 8,
         "image-end layers alone": [(n, 32, 32, 3, 128, 3, 0), (n, 16, 16, 3, 128, 1, 0)],
+        # the generator step's 256-channel layers as plain 3x3 layers (the up blocks' Conv1 at their output resolution)
+        "generator 256-ch: 32x32 alone": [(n, 32, 32, 256, 256, 3, R)],
+        "generator 256-ch: 32x32 x2, 16x16 x2, 8x8 x2": [(n, 32, 32, 256, 256, 3, R)] * 2 + [(n, 16, 16, 256, 256, 3, R)] * 2 + [(n, 8, 8, 256, 256, 3, R)] * 2,
+        "critic 128-ch: 32x32 alone": [(n, 32, 32, 128, 128, 3, R)],
     }
+    only = os.environ.get("WGRAD_SETS")
+    if only:
+        sets = {k: v for k, v in sets.items() if any(o in k for o in only.split(","))}
     reps = 20
     for name, shapes in sets.items():
         ctx.new_step()
@@ -50,7 +57,9 @@ def main():
         for _ in range(reps):
             call()
         ctx.event_record(1)
-        print("%-36s %8.1f us" % (name, ctx.event_elapsed_ms(0, 1) * 1e3 / reps))
+        us = ctx.event_elapsed_ms(0, 1) * 1e3 / reps
+        gf = sum(2.0 * nn * hh * ww * cin * cout * k * k for (nn, hh, ww, cin, cout, k, fl) in shapes) / 1e9
+        print("%-48s %8.1f us  %7.1f GFLOP  %6.1f TFLOP/s" % (name, us, gf, gf / us * 1e3))
     ctx.close()
 
 

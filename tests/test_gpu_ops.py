@@ -68,6 +68,12 @@ CONV_CASES = [
     (200, 16, 16, 128, 256, 3, 1, False, False),# ... its 16-pixel-wide form (a tile = one whole image), two chunks; dgrad on the 128-channel path
     (52, 32, 32, 256, 256, 3, 1, True, True),   # ... the sub-pixel form of an upsample-3x3 layer on it (G.Block.3.Conv1): 16 x 16 low-resolution images, four taps per chunk
     (13, 64, 64, 64, 256, 3, 1, True, False),   # ... and on 32-wide low-resolution images (one chunk: no patch hand-over)
+    # the nine-tap filter gradient (conv_wgrad9.hip; the 16- and 32-wide cases above take it too): 8-pixel-wide images (four image rows per K-step),
+    (6, 8, 8, 64, 128, 3, 1, False, True),
+    (3, 16, 8, 128, 128, 3, 1, False, False),   # ... H != W
+    (8, 4, 8, 64, 128, 3, 1, False, False),     # ... an image = one K-step (its first and its last row in the same step)
+    (4, 2, 16, 64, 256, 3, 1, False, True),     # ... two-row images, 16 wide
+    (40, 8, 8, 128, 128, 3, 1, False, True),    # ... several ring revolutions per chunk (D.Block.3/4)
 ]
 
 
