@@ -49,6 +49,7 @@ struct SlabReduceGroup {
     int orient, Cb, Cs;     // orient 1: transposed image-end mapping
     int sub;                // 1 / 2: the slab holds the 16 cells of the sub-pixel form (MfmaWgradArgs::sub), folded into the 9 taps here
     long cc;                // Cin * Cout (sub only)
+    int bias_parts;         // 2: two bias partials per slab, nbias floats apart (the nine-tap kernel's upsample form); 0 / 1: one
   } it[REDUCE_GROUP_MAX];
 };
 __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
@@ -98,6 +99,10 @@ __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
     }
 #pragma unroll 4
     for (; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si];
+    if (i >= r.count && r.bias_parts == 2) {
+#pragma unroll 4
+      for (z = 0; z < r.nz; ++z) s += r.slab[(long)z * r.stride + si + r.nbias];
+    }
   }
   float* o;
   if (i >= r.count) o = r.bias_out + (i - r.count);
@@ -872,6 +877,7 @@ static SlabReduceGroup::Item wgrad_reduce_item(const rcgan_conv_desc* d, const M
   it.bias_out = dbias; it.nbias = nbias; it.nz = nz; it.accumulate = accumulate;
   it.bias_off = (long)a.cells * d->cin * d->cout;
   it.sub = a.sub == 3 ? 0 : a.sub; it.cc = (long)d->cin * d->cout;
+  it.bias_parts = a.slab_stride == it.bias_off + 2L * d->cout ? 2 : 1;       // (mfma_wgrad9_plan's upsample form)
   return it;
 }
 
@@ -933,8 +939,23 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 384; }();      // (512 before the sub-pixel forms: 6.67 -> 6.64 ms)
   std::vector<MfmaWgradArgs> cand(n);
   std::vector<char> takes(n, 0);
+  // The nine-tap kernel (conv_wgrad9.hip) takes the group's 3x3 layers when they are big: its one workgroup per CU writes a slab of ALL nine
+  // (sixteen) cells, and the riders of the three-tap launch (image-end layers, 1x1 shortcuts, the head) lose the workgroups they hid under.
+  // Measured on the bench iteration: the critic step's layers (n = 128, 128 channels: 1152 pixels per workgroup) 120 -> 172 us with it, the
+  // generator step's (256 channels: 12032 / 2560 pixels per workgroup) 478 -> 425 us.
+  static const long w9_minwork = [] { const char* e = getenv("RCGAN_WGRAD9_GROUP_MINWORK"); return e ? atol(e) : 1500000L; }();
+  bool wgrad9_group_on = false;
+  {
+    double w9 = 0;
+    for (int i = 0; i < n; ++i) {
+      const rcgan_conv_desc* d = descs + i;
+      if (check_desc(ctx, d) || !mfma_wgrad_eligible(d) || d->kh != 3) continue;
+      w9 += (double)d->n * d->h * d->w * (d->cin / 64) * (d->cout / 128);       // (full-resolution pixels x channel tiles)
+    }
+    wgrad9_group_on = w9 >= (double)w9_minwork;
+  }
   // pass 1: which layers the grouped kernel takes, and the pixels per workgroup that gives ~target_blocks workgroups in all
-  double work = 0, work9 = 0;        // (work9: the plain 3x3 layers of the nine-tap kernel, one 768-thread workgroup per CU)
+  double work = 0, work9[2] = {0, 0};        // (work9: the nine-tap kernel's plain / sub-pixel layers, one workgroup per CU each)
   for (int i = 0; i < n; ++i) {
     const rcgan_conv_desc* d = descs + i;
     int rc = check_desc(ctx, d);
@@ -946,9 +967,9 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     wgrad_args_from_desc(ctx, d, xs[i], dys[i], dbiases[i] != nullptr, a);
     if ((d->flags & RCGAN_CONV_OUT_MEANPOOL2) && a.sub != 2)
       RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "filter gradient from the pooled dy needs the sub-pixel three-tap kernel (rcgan_conv_wgrad_pool_ok)");
-    if (mfma_wgrad9_takes(a)) {
-      takes[i] = 2;
-      work9 += (double)a.M * (a.Cin / 64) * (a.Cout / 128);
+    if (mfma_wgrad9_takes(a) && wgrad9_group_on) {
+      takes[i] = a.sub ? 3 : 2;
+      work9[a.sub ? 1 : 0] += (double)a.M * (a.Cin / 64) * (a.Cout / 128) * (a.sub ? 2 : 1);
     } else if (mfma_wgrad3_takes(a)) {
       takes[i] = 1;
       // workgroup-passes over a pixel: 3 filter rows of three taps, or 8 (parity, row shift) tiles of two taps
@@ -961,10 +982,25 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   if (px < 256) px = 256;
   if (px > px_max) px = px_max;      // big groups (the generator step): more workgroups rather than ever longer ones
   static const int target9 = [] { const char* e = getenv("RCGAN_WGRAD9_BLOCKS"); return e ? atoi(e) : 256; }();
-  long px9 = ((long)(work9 / target9) + 63) / 64 * 64;
-  if (px9 < 512) px9 = 512;
-  std::vector<MfmaWgradArgs> args9[2];           // nine-tap kernel without / with input ReLU
-  std::vector<unsigned> gxs9[2], gys9[2];
+  // one workgroup per CU and equal pixels per workgroup: the smallest chunk with which the layers' tiles x chunks fit ONE round of target9
+  // workgroups (a 257th workgroup would double the launch's time); the plain and the sub-pixel layers are a launch each
+  long px9[2] = {0, 0};
+  for (int f = 0; f < 2; ++f) {
+    px9[f] = ((long)(work9[f] / target9) + 127) / 128 * 128;
+    if (px9[f] < 512) px9[f] = 512;
+    for (int it = 0; it < 4096 && work9[f] > 0; ++it, px9[f] += 128) {
+      long tot = 0;
+      for (int i = 0; i < n; ++i)
+        if (takes[i] == 2 + f) {
+          MfmaWgradArgs b = cand[i];
+          unsigned bgx = 0, bgy = 0;
+          if (mfma_wgrad9_plan(b, 1 << 20, &bgx, &bgy, px9[f])) tot += (long)bgx * bgy;
+        }
+      if (tot <= target9) break;
+    }
+  }
+  std::vector<MfmaWgradArgs> args9[4];           // nine-tap kernel: plain without / with input ReLU, sub-pixel forms without / with
+  std::vector<unsigned> gxs9[4], gys9[4];
   // pass 2: slabs, grouped launches per input-ReLU flavour, everything else on its own
   std::vector<MfmaWgradArgs> args[3];            // three-tap kernel without / with input ReLU, per-tap kernel
   std::vector<MfmaWgradArgs> late;               // small 1x1 layers on the two-tap body: join one of the first two
@@ -1013,16 +1049,17 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       MfmaWgradArgs a = cand[i];
       const int nz = a.sub ? mfma_wgrad_sub_splits(d, a.M) : mfma_wgrad_splits(d, a.M);
       unsigned gx = 0, gy = 0;
-      const bool nine = takes[i] == 2 && mfma_wgrad9_plan(a, nz, &gx, &gy, px9);
+      // (the grouped slabs are fitted into the workspace below: no a-priori bound on the nine-tap kernel's pixel chunks)
+      const bool nine = takes[i] >= 2 && mfma_wgrad9_plan(a, 1 << 20, &gx, &gy, px9[takes[i] - 2]);
       const bool three = !nine && takes[i] && mfma_wgrad3_plan(a, nz, &gx, &gy, px);
-      if (a.sub && !three) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
+      if (a.sub && !three && !nine) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
       if (nine || three || mfma_wgrad_tap_plan(a, nz, &gx, &gy)) {
         const size_t need = ((size_t)gy * a.slab_stride * sizeof(float) + 255) / 256 * 256;
         if (used + need <= ws_bytes / 2) {
           a.slab = (float*)((char*)ws + used);
           used += need;
           const int f = three ? (a.relu_in ? 1 : 0) : 2;
-          if (nine) { const int f9 = a.relu_in ? 1 : 0; args9[f9].push_back(a); gxs9[f9].push_back(gx); gys9[f9].push_back(gy); }
+          if (nine) { const int f9 = (a.sub ? 2 : 0) + (a.relu_in ? 1 : 0); args9[f9].push_back(a); gxs9[f9].push_back(gx); gys9[f9].push_back(gy); }
           else if (three && a.sub == 3 && !a.relu_in) { late.push_back(a); late_gx.push_back(gx); late_gy.push_back(gy); }   // placed below
           else { args[f].push_back(a); gxs[f].push_back(gx); gys[f].push_back(gy); }
           red.push_back(wgrad_reduce_item(d, a, dws[i], dbiases[i], dbiases[i] ? d->cout : 0, (int)gy, accumulate));
@@ -1068,7 +1105,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
       }
     }
   }
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < 4; ++f)
     if (!args9[f].empty()) {
       int rc = mfma_wgrad9_group_launch(ctx, (int)args9[f].size(), args9[f].data(), gxs9[f].data(), gys9[f].data());
       if (rc) return rc;

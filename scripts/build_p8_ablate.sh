@@ -6,7 +6,11 @@ cd "$(dirname "$0")/../robust-conditional-gan_amd/csrc"
 OUT=../../scripts/probes/_bin
 mkdir -p $OUT _obj_probe
 for k in "$@"; do
-  if [ "${k#w}" != "$k" ]; then      # w<k>: the three-tap filter-gradient kernel (conv_mfma.hip, -DWG3_ABLATE)
+  if [ "${k#n}" != "$k" ]; then      # n<k>: the nine-tap filter-gradient kernel (conv_wgrad9.hip, -DWG9_ABLATE: 1 = no LDS-DMA after the prologue, 2 = no MFMAs)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWG9_ABLATE=${k#n} -c conv_wgrad9.hip -o _obj_probe/conv_wgrad9_abl$k.o
+    objs=$(ls _obj/*.o | grep -v "conv_wgrad9.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs _obj_probe/conv_wgrad9_abl$k.o -o $OUT/librcgan_abl$k.so
+  elif [ "${k#w}" != "$k" ]; then      # w<k>: the three-tap filter-gradient kernel (conv_mfma.hip, -DWG3_ABLATE)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWG3_ABLATE=${k#w} -c conv_mfma.hip -o _obj_probe/conv_mfma_abl$k.o
     objs=$(ls _obj/*.o | grep -v "conv_mfma.o")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs _obj_probe/conv_mfma_abl$k.o -o $OUT/librcgan_abl$k.so

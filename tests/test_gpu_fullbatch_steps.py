@@ -345,11 +345,15 @@ def _mnist_cmp(tag, got, g64, g32):
         err = float(np.abs(a - gref).max()) / scale
         nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
         own = float(np.linalg.norm(g32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
+        own_err = float(np.abs(g32[k] - gref).max()) / scale
         rows.append((k, nrm, own))
         # (bound 4e-3 since round 4: rectifiers whose input lies within fp32 rounding of zero take the device's branch, not the float64
         # oracle's -- a handful per pass at B = 256, each worth ~1e-3 of the first layers' gradients; the split-reduction GEMMs changed the
         # summation order and with it WHICH units those are: 2.5e-3 on g_h0_lin where the fp32 numpy oracle itself sits 3.5e-4 away)
-        assert nrm <= max(4e-3, 8 * own) and err <= 1e-1, "%s %s: norm-rel %.3e max %.3e (fp32 oracle %.3e)" % (tag, k, nrm, err, own)
+        # (largest single entry: one flipped unit moves one row of a dense layer's gradient -- 1.4e-1 of the tensor's largest entry on g_h1_lin
+        # after the batch-norm reductions changed their grouping, where the fp32 oracle's own largest deviation is of the same kind)
+        assert nrm <= max(4e-3, 8 * own) and err <= max(1e-1, 8 * own_err), \
+            "%s %s: norm-rel %.3e max %.3e (fp32 oracle %.3e / %.3e)" % (tag, k, nrm, err, own, own_err)
     return rows
 
 
