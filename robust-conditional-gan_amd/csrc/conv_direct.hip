@@ -969,7 +969,15 @@ static int launch_gemm(rcgan_ctx* ctx, Op& op, int nz, const typename Op::Aux& a
   static const int ks_force = gg_env_int("RCGAN_GG_KS", 0);
   if (ks_force == 2) return launch_gemm_ks<Op, 2>(ctx, op, grid, aux);
   if (ks_force == 1) return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
-  if (steps >= ks_min_steps) return launch_gemm_ks<Op, 4>(ctx, op, grid, aux);
+  if (steps >= ks_min_steps) {
+    // four K-slices per workgroup = 1024 threads = ONE workgroup per CU: a grid of more workgroups than CUs runs in whole rounds (392
+    // workgroups: two, the second half empty).  Two slices = two workgroups per CU, the same K-steps per wavefront pair -- measured on the
+    // MNIST iteration (B = 256), per launch: 1568 workgroups 214 -> 177 us, 1666 111 -> 84, 392 170 -> 161; but 196 workgroups 46 -> 53,
+    // 128 44 -> 51 (fewer workgroups than CUs: the four slices are the parallelism).
+    static const long ks2_min_wgs = gg_env_int("RCGAN_GG_KS2_MINWGS", 256);
+    if ((long)grid.x * grid.y * grid.z >= ks2_min_wgs) return launch_gemm_ks<Op, 2>(ctx, op, grid, aux);
+    return launch_gemm_ks<Op, 4>(ctx, op, grid, aux);
+  }
   return launch_gemm_ks<Op, 1>(ctx, op, grid, aux);
 }
 
