@@ -674,7 +674,11 @@ __global__ __launch_bounds__(256 * KS) void gemm_gather_kernel(Op op_in, typenam
   const long nsteps = (r_end - r_begin + 31) / 32;
   const long T = (nsteps + KS - 1) / KS;          // per-group steps (same for every group: the barriers are block-wide)
   auto step_r = [&](long t) { return r_begin + 32 * (kg + KS * t); };
+  // a wavefront whose 32 x 32 block lies wholly past M or N (the 10 label columns of a 138- / 74- / 1034-wide operand fill a sixth of their
+  // tile) stages operands and keeps the barriers but leaves the matrix pipe and the LDS reads to the others
+  const bool block_live = i0 + wr * 32 < op.M && j0 + wc * 32 < op.N;
   auto mfma_step = [&](int buf) {
+    if (!block_live) return;
     float av[16], bv[16];
     get(lds + buf * GG_XBUF, Op::A_KMAJOR, wr * 32, av);
     get(lds + (2 + buf) * GG_XBUF, Op::B_KMAJOR, wc * 32, bv);

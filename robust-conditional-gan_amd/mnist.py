@@ -14,7 +14,7 @@ import torch
 from . import _lib as L
 from . import ops as O
 from .ops_mnist import batch_norm, conv2d, conv_cond_concat, deconv2d, linear, lrelu
-from .runtime import Context, ParamGroup
+from .runtime import DT, Context, ParamGroup
 from .variables import Graph, variable_scope
 
 Y_DIM, Z_DIM, GF_DIM, DF_DIM, GFC_DIM, DFC_DIM = 10, 100, 64, 64, 1024, 1024
@@ -136,7 +136,10 @@ class MnistRCGAN:
             confusion_matrix = ((1 - alpha) / 9.0) * np.ones((10, 10)) + (alpha - (1 - alpha) / 9.0) * np.eye(10)
         self.confusion_matrix_actual = np.asarray(confusion_matrix)
         ctx.view(self.inp["C_const"]).copy_(torch.from_numpy(self.confusion_matrix_actual.astype(np.float32)))
-        self.loss = {k: P((1,), f32, fill=0.0) for k in ("d_loss_real", "d_loss_fake", "g_loss", "class_loss_real", "class_loss_fake")}
+        # one block, a 256-byte slot per term, the critic step's three in front of the generator step's two: a step clears ITS terms with one fill
+        self._loss_block = P((5 * 64,), f32, fill=0.0)
+        self._loss_order = ("d_loss_real", "d_loss_fake", "class_loss_real", "g_loss", "class_loss_fake")
+        self.loss = {k: DT(self._loss_block.ptr + 256 * i, (1,), f32, self._loss_block.base) for i, k in enumerate(self._loss_order)}
         # bn objects as in DCGAN.__init__ (model.py:68-81)
         self.d_bn1, self.d_bn2, self.d_bn3 = batch_norm(name='d_bn1'), batch_norm(name='d_bn2'), batch_norm(name='d_bn3')
         self.g_bn0, self.g_bn1, self.g_bn2 = batch_norm(name='g_bn0'), batch_norm(name='g_bn1'), batch_norm(name='g_bn2')
@@ -230,8 +233,9 @@ class MnistRCGAN:
 
     def _zero_losses(self, keys):
         ctx = self.ctx
-        for k in keys:
-            ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 1, self.loss[k].ptr, 0.0))
+        idx = sorted(self._loss_order.index(k) for k in keys)
+        assert idx == list(range(idx[0], idx[-1] + 1)), keys            # (a step's terms are neighbours in the block)
+        ctx.check(ctx.lib.rcgan_fill_f32(ctx.h, 64 * (idx[-1] - idx[0]) + 1, self._loss_block.ptr + 256 * idx[0], 0.0))
 
     def _sn_prefetch(self):
         if not self.sn:

@@ -667,12 +667,13 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
                 if dy is None:
                     return
                 dx, acc_dx = grad_of(ctx, x)
-                dg, db = (gamma.grad, beta.grad) if gamma.req else (zeros_like_grad(ctx, gamma), zeros_like_grad(ctx, beta))
+                # (frozen parameters: a scratch nobody reads -- the first segment overwrites it, no fill)
+                dg, db = (gamma.grad, beta.grad) if gamma.req else (ctx.empty(gamma.shape, gamma.dtype), ctx.empty(beta.shape, beta.dtype))
                 for sg, (mean, rstd) in enumerate(stats):
                     lo, hi = sg * ns, (sg + 1) * ns
                     ctx.check(ctx.lib.rcgan_bn_bwd2(ctx.h, ns, rps, c, n_labels, x.dtype, _p(x.rows(lo, hi)), _p(y.rows(lo, hi)), _p(dy.rows(lo, hi)),
-                                                    None, _p(gamma), _p(beta), _p(mean), _p(rstd), act, _p(dx.rows(lo, hi)), acc_dx, _p(dg), _p(db), 1,
-                                                    C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                                                    None, _p(gamma), _p(beta), _p(mean), _p(rstd), act, _p(dx.rows(lo, hi)), acc_dx, _p(dg), _p(db),
+                                                    1 if (gamma.req or sg) else 0, C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
             ctx.record(bw_seg)
         return y
     if segments > 1:
@@ -706,15 +707,15 @@ def batch_norm_act(ctx, x, gamma, beta, act=L.ACT_NONE, labels=None, n_labels=1,
             if dy is None:
                 return
             dx, acc_dx = grad_of(ctx, x)
-            # parameter gradients always accumulate into the (zeroed) slab; frozen params get a scratch
+            # parameter gradients accumulate into the (zeroed) slab; frozen params get a scratch that is overwritten (no fill)
             if gamma.req:
                 dg, db = gamma.grad, beta.grad
             else:
-                dg = zeros_like_grad(ctx, gamma)
-                db = zeros_like_grad(ctx, beta)
+                dg = ctx.empty(gamma.shape, gamma.dtype)
+                db = ctx.empty(beta.shape, beta.dtype)
             # beta lets the fused kernels recompute the ReLU mask from x (the forward's exact arithmetic) instead of reading y
             ctx.check(ctx.lib.rcgan_bn_bwd2(ctx.h, n, rps, c, n_labels, x.dtype, _p(x), _p(y), _p(dy), _p(labels), _p(gamma), _p(beta),
-                                            _p(mean), _p(rstd), act, _p(dx), acc_dx, _p(dg), _p(db), 1,
+                                            _p(mean), _p(rstd), act, _p(dx), acc_dx, _p(dg), _p(db), 1 if gamma.req else 0,
                                             C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         ctx.record(bw)
     return y
