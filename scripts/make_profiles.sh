@@ -60,6 +60,14 @@ python3 bench.py --no-cpu-baseline --dtype f32 --steps 20 > "$OUT/bench_f32.json
     [ -f $L ] && echo "ablation $k: $(RCGAN_LIB_PATH=$PWD/$L RCGAN_P8_PP=1 RCGAN_P8_HALO=$([ "${k#h}" != "$k" ] && echo 1 || echo 0) python3 scripts/exp_p8_fixed_cost.py quick 2>/dev/null | tail -1)"
   done; } > "$OUT/exp_p8_ablation.txt"
 python3 scripts/bench_wgrad_group.py > "$OUT/wgrad_group.txt" 2>&1
+# what bounds the filter-gradient kernels (scripts/build_p8_ablate.sh w1 w2 w4 w8 w3 w6 n1 n2 n3 ran before the snapshot)
+{ echo "# rcgan_conv2d_bwd_weight_group on plain 3x3 layers at n = 128 (HIP events, launch + slab reduction), the kernel as built and with one part of its loop removed"
+  echo "# (timing-only builds, wrong by construction).  THREE-TAP kernel (conv_mfma_wgrad3_group_kernel, RCGAN_WGRAD9=0):"
+  RCGAN_WGRAD9=0 bash scripts/exp_wgrad_ablation.sh
+  echo "# NINE-TAP kernel (conv_wgrad9_group_kernel; RCGAN_WGRAD9_GROUP_MINWORK=0: the grouped entry point takes it whatever the size):"
+  RCGAN_WGRAD9_GROUP_MINWORK=0 bash scripts/exp_wgrad9_ablation.sh; } > "$OUT/exp_wgrad_ablation.txt" 2>&1
+RCGAN_WGRAD9=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_wgrad9.json" 2> /dev/null
+RCGAN_WGRAD9_GROUP_MINWORK=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_wgrad9_everywhere.json" 2> /dev/null
 python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512.json" 2> /dev/null
 python3 bench.py --no-cpu-baseline --dtype f16 > "$OUT/bench_f16.json" 2> /dev/null
 python3 bench.py --no-cpu-baseline --dtype f16 --batch 512 --steps 8 > "$OUT/bench_f16_b512.json" 2> /dev/null
