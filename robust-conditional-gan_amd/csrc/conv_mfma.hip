@@ -1130,6 +1130,7 @@ static_assert(WGRAD_GROUP_MAX == WGRAD_GROUP_MAX_HOST, "group size");
 // more slabs), 32 per layer +0.38 ms (they outlast the launch).
 struct WgradGroup {
   int n;
+  int xcd_runs;             // consecutive three-tap workgroups (a pixel chunk's tiles) on one XCD
   unsigned first[WGRAD_GROUP_MAX + 1];
   unsigned gx[WGRAD_GROUP_MAX];
   MfmaWgradArgs a[WGRAD_GROUP_MAX];
@@ -1142,13 +1143,20 @@ template <int NS, bool RELU>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad3_group_kernel(WgradGroup g) {
   // (the branch is marked unlikely so that its code is laid out BEHIND the three-tap body: with the image-end code in front the
   // same, instruction-for-instruction identical hot loop ran 40 % slower -- 198 vs 141 us for the critic step's eleven layers)
-  const unsigned b = blockIdx.x;
+  unsigned b = blockIdx.x;
   if (__builtin_expect(b >= g.first[g.n], 0)) {         // the image-end workgroups trail the grid, the head's trail them
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_img[];
     const unsigned bb = b - g.first[g.n];
     if (bb >= g.img.first[IMG_GROUP_MAX]) head_wgrad_body(g.head.a, g.head.dEg, (int)(bb - g.img.first[IMG_GROUP_MAX]), (float*)smem_img);
     else img_wgrad_group_body(g.img, bb, smem_img);
     return;
+  }
+  // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  The workgroups of one pixel chunk (consecutive indices: the filter rows and
+  // channel tiles of a layer) read the same dy and x pixels: run them on ONE XCD, through one L2 (round 4; RCGAN_WGRAD3_XCD=0 restores the
+  // dealt order) -- dealt out, every XCD fetched every chunk: 1.3 GB from beyond L2 per launch of a 256-channel layer at ~6.7 TB/s
+  if (g.xcd_runs) {
+    const unsigned t8 = g.first[g.n] >> 3;
+    if (b < t8 * 8) b = (b & 7) * t8 + (b >> 3);
   }
   int p = 0;
 #pragma unroll
@@ -1927,6 +1935,8 @@ int mfma_wgrad3_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, c
   static_assert((HEAD_MAX_V + 1) * HEAD_MAX_D * 4 <= 4 * (40 * 128 + 32 * 256), "head body needs more LDS than the three-tap kernel");
   for (int i0 = 0; i0 < n; i0 += WGRAD_GROUP_MAX) {
     WgradGroup g;
+    static const int xcd_runs = env_int("RCGAN_WGRAD3_XCD", 1);
+    g.xcd_runs = xcd_runs;
     g.head.blocks = 0;
     if (carry_head && family != 1 && i0 == 0) (void)head_take_wgrad(ctx, &g.head);
     if (img && i0 == 0) g.img = *img;
