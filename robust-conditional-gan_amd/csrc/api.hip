@@ -943,7 +943,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   // (sixteen) cells, and the riders of the three-tap launch (image-end layers, 1x1 shortcuts, the head) lose the workgroups they hid under.
   // Measured on the bench iteration: the critic step's layers (n = 128, 128 channels: 1152 pixels per workgroup) 120 -> 172 us with it, the
   // generator step's (256 channels: 12032 / 2560 pixels per workgroup) 478 -> 425 us.
-  static const long w9_minwork = [] { const char* e = getenv("RCGAN_WGRAD9_GROUP_MINWORK"); return e ? atol(e) : 1500000L; }();
+  const long w9_minwork = [] { const char* e = getenv("RCGAN_WGRAD9_GROUP_MINWORK"); return e ? atol(e) : 1500000L; }();      // (per call: the tests force it)
   bool wgrad9_group_on = false;
   {
     double w9 = 0;

@@ -1808,8 +1808,13 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
   *bias_done = false;
   if (a.sub && !mfma_wgrad3_takes(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
   {
+    // the nine-tap kernel where a workgroup's share of the pixels amortises its nine-cell slab (scripts/bench_conv.py, n = 128, layers alone:
+    // 32x32 256-channel 175 -> 142 us, 32x32 128-channel 72 -> 67, 16x16 256-channel 60 -> 60; but 8x8 256-channel 32 -> 37, 8x8 128-channel
+    // 21 -> 28, the sub-pixel forms 43 -> 83 / 122 -> 128: those stay on the three-tap kernel)
+    const long min_work = env_int("RCGAN_WGRAD9_MINWORK", 200000);        // (read per call: the tests force the kernel on small shapes)
+    const long work9 = a.M * (long)(a.Cin / 64) * (a.Cout / 128);
     unsigned gx9 = 0, gy9 = 0;
-    if (mfma_wgrad9_plan(a, nz, &gx9, &gy9, 0)) {
+    if ((a.sub ? min_work <= 0 : work9 >= min_work) && mfma_wgrad9_plan(a, nz, &gx9, &gy9, 0)) {
       int rc = mfma_wgrad9_group_launch(ctx, 1, &a, &gx9, &gy9);
       *bias_done = a.want_bias != 0;
       return rc ? -1 : (int)gy9;

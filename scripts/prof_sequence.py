@@ -1,30 +1,19 @@
 #!/usr/bin/env python3
-"""Launch sequence of the LAST iteration of a bench run from a rocprofv3 rocpd database: start offset, duration, gap to the
-previous kernel's end, kernel name (an iteration starts at the rng_fill / first kernel after the longest gaps).
+"""Launch order of the last `n` kernels of a rocprofv3 rocpd database (short names, grid, start gap to the previous kernel's end).
 
-usage: python scripts/prof_sequence.py <results.db> <launches per iteration> [name filter]
+usage: python scripts/prof_sequence.py <results.db> [n = 300] [name filter: only print launches whose neighbourhood (+-2) contains it]
 """
 import re
 import sqlite3
 import sys
 
-
-def main():
-    db = sqlite3.connect(sys.argv[1])
-    per = int(sys.argv[2])
-    flt = sys.argv[3] if len(sys.argv) > 3 else None
-    rows = db.execute("select name, start, end from kernels order by start").fetchall()
-    rows = rows[-per:]
-    t0 = rows[0][1]
-    prev_end = t0
-    for i, (name, s, e) in enumerate(rows):
-        n = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
-        n = re.sub(r"^void ", "", n)
-        line = "%4d %9.1f us  dur %7.1f  gap %6.1f  %s" % (i, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, n[:90])
-        if flt is None or flt in n:
-            print(line)
-        prev_end = e
-
-
-if __name__ == "__main__":
-    main()
+db = sqlite3.connect(sys.argv[1])
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+flt = sys.argv[3] if len(sys.argv) > 3 else None
+rows = db.execute("select name, grid_x / workgroup_x, grid_y / workgroup_y, start, end from kernels order by start").fetchall()[-n:]
+short = [re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "").replace("void ", ""))[:48] for r in rows]
+for i, r in enumerate(rows):
+    if flt and not any(flt in short[j] for j in range(max(0, i - 2), min(len(rows), i + 3))):
+        continue
+    gap = (r[3] - rows[i - 1][4]) / 1e3 if i else 0.0
+    print("%4d %-48s (%d,%d) %7.1f us  gap %6.1f" % (i, short[i], r[1], r[2], (r[4] - r[3]) / 1e3, gap))

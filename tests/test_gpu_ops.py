@@ -97,6 +97,29 @@ def _random_conv_cases(count=36, seed=2024):
     return cases
 
 
+# shapes of CONV_CASES the nine-tap filter-gradient kernel (conv_wgrad9.hip) can take: by default only big layers go to it (a size rule in
+# the one-layer entry point and in the grouped one), so these run a second time with the rule switched off -- plain 8 / 16 / 32-wide layers,
+# the upsample form over 8x8 and 16x16 low-resolution grids, with and without input ReLU, bias gradients included
+WGRAD9_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and c[3] % 64 == 0 and c[4] % 128 == 0 and
+                (c[1] // (2 if c[7] else 1)) * (c[2] // (2 if c[7] else 1)) * c[0] % 128 == 0 and (c[2] // (2 if c[7] else 1)) in (8, 16, 32)]
+assert len(WGRAD9_CASES) >= 10
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("case", WGRAD9_CASES)
+def test_conv2d_fwd_bwd_nine_tap_forced(dev, case, grouped, monkeypatch):
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the nine-tap kernel is a 16-bit matrix-core kernel")
+    monkeypatch.setenv("RCGAN_WGRAD9_MINWORK", "0")
+    monkeypatch.setenv("RCGAN_WGRAD9_GROUP_MINWORK", "0")
+    keep, ctx.group_wgrads = ctx.group_wgrads, grouped
+    try:
+        test_conv2d_fwd_bwd(dev, case)
+    finally:
+        ctx.group_wgrads = keep
+
+
 @pytest.mark.parametrize("case", CONV_CASES + _random_conv_cases())
 def test_conv2d_fwd_bwd(dev, case):
     from rcgan_amd import _lib as L
@@ -318,7 +341,8 @@ def test_conv_persistent_tiles(dev, case):
                                   (8, 16, 16, 64, 64, False, False),
                                   (128, 32, 32, 128, 128, True, False),    # D.Block.1.Conv2 at the bench batch: 256 x 128 kernel for dx
                                   (128, 16, 16, 128, 128, True, True)])    # D.Block.2.Conv2
-def test_conv2d_meanpool(dev, case):
+@pytest.mark.parametrize("force9", [False, True])      # True: the filter gradient on the nine-tap kernel's pooled form whatever the size
+def test_conv2d_meanpool(dev, case, force9, monkeypatch):
     """ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution with summed filters forward, the
     sub-pixel form for the data gradient, the ordinary grouped filter gradient on the spread dy) against conv -> mean pool."""
     import torch.nn.functional as F
@@ -326,6 +350,9 @@ def test_conv2d_meanpool(dev, case):
     ctx, mode = dev
     if mode == "f32":
         pytest.skip("the folded pool runs on the 16-bit matrix-core path")
+    if force9:
+        monkeypatch.setenv("RCGAN_WGRAD9_MINWORK", "0")
+        monkeypatch.setenv("RCGAN_WGRAD9_GROUP_MINWORK", "0")
     n, h, w, cin, cout, relu, acc = case
     rs = np.random.RandomState(n * 7 + cin)
     x = _prep(rs.randn(n, h, w, cin).astype(np.float32), mode)
