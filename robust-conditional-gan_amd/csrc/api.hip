@@ -936,7 +936,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
 int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* descs, const void* const* xs, const void* const* dys,
                                   float* const* dws, float* const* dbiases, int accumulate, void* ws, size_t ws_bytes) {
   RC_REQUIRE(ctx, n >= 0 && (n == 0 || (descs && xs && dys && dws && dbiases)), "null argument");
-  static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 384; }();      // (512 before the sub-pixel forms: 6.67 -> 6.64 ms)
+  static const int target_blocks = [] { const char* e = getenv("RCGAN_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 448; }();      // (512 before the sub-pixel forms: 6.67 -> 6.64 ms with 384; round 4, the critic step's launch with its chunks' workgroups on one XCD and the generator step's big layers gone to the nine-tap kernel, same box: 384 5.65 ms, 448 5.59, 512 5.60, 576 5.75)
   std::vector<MfmaWgradArgs> cand(n);
   std::vector<char> takes(n, 0);
   // The nine-tap kernel (conv_wgrad9.hip) takes the group's 3x3 layers when they are big: its one workgroup per CU writes a slab of ALL nine

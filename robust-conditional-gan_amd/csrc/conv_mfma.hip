@@ -1758,6 +1758,12 @@ int mfma_wgrad_splits(const rcgan_conv_desc* d, long M) {
     long tiles3 = (long)d->kh * (d->cin / 64) * (d->cout / 128);
     long want3 = wgrad_clamp_splits((512 + tiles3 - 1) / tiles3, M);
     if (want3 > want) want = want3;
+    // ... or the nine-tap kernel: one round of 256 workgroups (a 256-channel layer: 8 tiles x 32 chunks, not the 22 of the rule above)
+    if (d->cin % 64 == 0 && d->cout % 128 == 0) {
+      long tiles9 = (long)(d->cin / 64) * (d->cout / 128);
+      long want9 = wgrad_clamp_splits((256 + tiles9 - 1) / tiles9, M);
+      if (want9 > want) want = want9;
+    }
   }
   return (int)want;
 }
