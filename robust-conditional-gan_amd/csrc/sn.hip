@@ -49,8 +49,10 @@ __device__ __forceinline__ float block_sum_nt(float v, float* red /* >= SN_NW fl
   return r;
 }
 
-struct SnBatch { rcgan_sn_item it[SN_BATCH]; };
+struct SnBatch { rcgan_sn_item it[SN_BATCH]; unsigned* arrive; /* one self-resetting arrival counter per weight, a 128-byte line apart; NULL: two launches */ };
 struct SnBwdBatch { rcgan_sn_bwd_item it[SN_BATCH]; };
+
+template <bool AGENT> __device__ __forceinline__ void sn_fwd_finish(const rcgan_sn_item& it, float* red);
 
 // forward 1/2: a = W u for the chunk's rows, and the chunk's share of a W (= |a| * b)
 __global__ __launch_bounds__(SN_NT) void sn_fwd_rows_kernel(SnBatch batch) {
@@ -77,35 +79,55 @@ __global__ __launch_bounds__(SN_NT) void sn_fwd_rows_kernel(SnBatch batch) {
   for (int i = 0; i < SN_RB / SN_NW; ++i) {
     const int r = wave + i * SN_NW;
     const float s = wave_sum(part[i]);
-    if (lane == 0 && r < rows) { a_s[r] = s; L.a[r0 + r] = s; }
+    // (agent-scope stores: written through to the memory side, visible to the finishing workgroup on whatever XCD it runs)
+    if (lane == 0 && r < rows) { a_s[r] = s; __hip_atomic_store(L.a + r0 + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
   __syncthreads();
   for (int j = tid; j < c; j += SN_NT) {
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < rows; ++r) s += a_s[r] * w[(long)r * c + j];
-    L.pb[(long)blockIdx.x * c + j] = s;
+    __hip_atomic_store(L.pb + (long)blockIdx.x * c + j, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (batch.arrive == nullptr) return;
+  // ---- the LAST workgroup of a weight to arrive finishes it (round 4: sn_fwd_finish_kernel was a launch of its own, 6.4 us of pure
+  //      dependency in front of every critic step's filter preparation).  u is only rewritten here, after every workgroup has read it.
+  __shared__ int is_last;
+  __shared__ float red[SN_NW];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores are performed ...
+  __syncthreads();                                       // ... and every wavefront's, before the workgroup signals
+  if (tid == 0) {
+    unsigned* ctr = batch.arrive + blockIdx.y * 32;
+    const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == (unsigned)L.chunks - 1u ? 1 : 0;
+    if (is_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  sn_fwd_finish<true>(it, red);
 }
 
-// forward 2/2 (one workgroup per weight): norms, v, b, u', sigma, u update
-__global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
-  __shared__ float red[SN_NW];
-  const rcgan_sn_item it = batch.it[blockIdx.x];
+// forward 2/2 (one workgroup per weight): norms, v, b, u', sigma, u update.  AGENT: a and pb were written by OTHER workgroups of the SAME
+// launch (the fused form below): read them with agent-scope loads, served from the memory side, never from a stale cache line
+template <bool AGENT>
+__device__ __forceinline__ void sn_fwd_finish(const rcgan_sn_item& it, float* red) {
   const int k = it.k, c = it.c;
   const SnLayout L = sn_layout(it.save, k, c);
   const int tid = threadIdx.x;
+  auto ld = [&](const float* p) __attribute__((always_inline)) -> float {
+    return AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+  };
   float na2 = 0.f;
-  for (int r = tid; r < k; r += SN_NT) { float a = L.a[r]; na2 += a * a; }
+  for (int r = tid; r < k; r += SN_NT) { float a = ld(L.a + r); na2 += a * a; }
   na2 = block_sum_nt(na2, red);
   const float na = sqrtf(na2);
   const float inv_na = 1.f / (na + SN_EPS);
-  for (int r = tid; r < k; r += SN_NT) L.v[r] = L.a[r] * inv_na;
+  for (int r = tid; r < k; r += SN_NT) L.v[r] = ld(L.a + r) * inv_na;
   float nb2 = 0.f;
   for (int j = tid; j < c; j += SN_NT) {
     float s = 0.f;
 #pragma unroll 12
-    for (int q = 0; q < L.chunks; ++q) s += L.pb[(long)q * c + j];      // (independent loads, requested a dozen at a time)
+    for (int q = 0; q < L.chunks; ++q) s += ld(L.pb + (long)q * c + j);      // (independent loads, requested a dozen at a time)
     s *= inv_na;
     L.b[j] = s;
     nb2 += s * s;
@@ -127,6 +149,10 @@ __global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
     L.s[0] = na; L.s[1] = nb; L.s[2] = sg; L.s[3] = 0.f;
     *it.sigma = sg;
   }
+}
+__global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
+  __shared__ float red[SN_NW];
+  sn_fwd_finish<false>(batch.it[blockIdx.x], red);
 }
 
 // backward 1/3: the chunk's share of <dW_bar, W>
@@ -281,10 +307,14 @@ int rcgan_sn_power_iter(rcgan_ctx* ctx, const rcgan_sn_item* items, int n_items)
         RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sn weight [%d,%d]", b.it[i].k, b.it[i].c);
       if (b.it[i].k > maxk) maxk = b.it[i].k;
     }
+    static const int fused = [] { const char* e = getenv("RCGAN_SN_FUSED_FINISH"); return e ? atoi(e) : 1; }();
+    b.arrive = fused ? ctx->tree_counters() : nullptr;       // (SN_BATCH lines of the otherwise unused counter block)
     hipLaunchKernelGGL(sn_fwd_rows_kernel, dim3(sn_chunks(maxk), n), dim3(SN_NT), 0, ctx->stream, b);
     RC_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sn_fwd_finish_kernel, dim3(n), dim3(SN_NT), 0, ctx->stream, b);
-    RC_LAUNCH_CHECK(ctx);
+    if (!fused) {
+      hipLaunchKernelGGL(sn_fwd_finish_kernel, dim3(n), dim3(SN_NT), 0, ctx->stream, b);
+      RC_LAUNCH_CHECK(ctx);
+    }
   }
   return RCGAN_OK;
 }
