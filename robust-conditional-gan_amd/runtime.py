@@ -372,7 +372,12 @@ class ParamGroup:
         in front of the step's graph -- no host-to-device copy, and a replayed graph reads fresh values."""
         c = self.ctx
         if self.hyper is None:
-            self.hyper = torch.zeros(2, dtype=torch.float32, device=c.device)
+            # (no fill: the launch below writes both words.  A torch.zeros here ran its fill on torch's CURRENT stream, unordered against the
+            # context's stream -- when the fill lost the race against the first rcgan_set2_f32 the group's first captured-form Adam read
+            # {lr, t} = {0, 0} and divided 0 by 0: the generator's parameters became NaN in ~3 % of the data-parallel runs that reach that
+            # Adam launch by launch, found through tests/test_gpu_dp.py's capture-fallback case, round 4)
+            with torch.cuda.stream(c.stream):
+                self.hyper = torch.empty(2, dtype=torch.float32, device=c.device)
         if float(t) >= float(1 << 24):
             raise OverflowError("Adam step counter %d is not exactly representable as fp32" % int(t))
         c.check(c.lib.rcgan_set2_f32(c.h, self.hyper.data_ptr(), float(lr), float(t)))
@@ -388,7 +393,8 @@ class ParamGroup:
         """Raise ls_state's non-finite flag if this group's gradient slab holds an inf / nan (rcgan_grad_finite_check)."""
         c = self.ctx
         if self.t_dev is None:
-            self.t_dev = torch.full((1,), float(max(self.t - 1, 0)), dtype=torch.float32, device=c.device)
+            with torch.cuda.stream(c.stream):       # (the fill on the stream that reads it)
+                self.t_dev = torch.full((1,), float(max(self.t - 1, 0)), dtype=torch.float32, device=c.device)
         c.check(c.lib.rcgan_grad_finite_check(c.h, self.count, self.grad.data_ptr(), ls_state.data_ptr()))
 
     def adam_dyn(self, ls_state, beta1, beta2, eps=1e-8, clip=0.0, grad_scale=1.0):
