@@ -50,11 +50,65 @@ struct SlabReduceGroup {
     int sub;                // 1 / 2: the slab holds the 16 cells of the sub-pixel form (MfmaWgradArgs::sub), folded into the 9 taps here
     long cc;                // Cin * Cout (sub only)
     int bias_parts;         // 2: two bias partials per slab, nbias floats apart (the nine-tap kernel's upsample form); 0 / 1: one
+    int vec4;               // a thread sums FOUR consecutive filter elements with 16-byte loads (count, cc, stride multiples of 4, orient 0)
   } it[REDUCE_GROUP_MAX];
 };
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __global__ void slab_reduce2_group_kernel(SlabReduceGroup g) {
   const SlabReduceGroup::Item& r = g.it[blockIdx.y];
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r.vec4) {
+    // threads [0, count / 4): four elements each, the same per-element order of additions as the scalar form below (bit-identical sums);
+    // threads behind them: the bias tail, one element each, through the scalar form
+    const long nv = r.count >> 2;
+    if (i < nv) {
+      const long e = i << 2;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r.sub) {
+        const int tap = (int)(e / r.cc), kh = tap / 3, kw = tap - kh * 3;
+        const long rem = e - (long)tap * r.cc;
+        long c4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pa = q >> 1, pb = q & 1;
+          const int sa = ((r.sub == 1) == (pa == 0)) ? (kh >= 1) : (kh >= 2);
+          const int sb = ((r.sub == 1) == (pb == 0)) ? (kw >= 1) : (kw >= 2);
+          c4[q] = (long)(q * 4 + sa * 2 + sb) * r.cc + rem;
+        }
+        int z = 0;
+        for (; z + 2 <= r.nz; z += 2) {
+          float4 v[2][4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = *(const float4*)(r.slab + (long)(z + u) * r.stride + c4[q]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) s = f4add(s, f4add(f4add(v[u][0], v[u][1]), f4add(v[u][2], v[u][3])));
+        }
+        for (; z < r.nz; ++z) {
+          const float* sl = r.slab + (long)z * r.stride;
+          s = f4add(s, f4add(f4add(*(const float4*)(sl + c4[0]), *(const float4*)(sl + c4[1])), f4add(*(const float4*)(sl + c4[2]), *(const float4*)(sl + c4[3]))));
+        }
+        if (r.sub == 2) { s.x *= 0.25f; s.y *= 0.25f; s.z *= 0.25f; s.w *= 0.25f; }
+      } else {
+        int z = 0;
+        for (; z + 8 <= r.nz; z += 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(r.slab + (long)(z + u) * r.stride + e);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s = f4add(s, v[u]);
+        }
+#pragma unroll 4
+        for (; z < r.nz; ++z) s = f4add(s, *(const float4*)(r.slab + (long)z * r.stride + e));
+      }
+      float4* o = (float4*)(r.out + e);
+      if (r.accumulate) s = f4add(s, *o);
+      *o = s;
+      return;
+    }
+    i = r.count + (i - nv);       // a bias element (or past the end)
+  }
   if (i >= r.count + r.nbias) return;
   const long si = i < r.count ? i : r.bias_off + (i - r.count);
   float s = 0.f;
@@ -878,6 +932,8 @@ static SlabReduceGroup::Item wgrad_reduce_item(const rcgan_conv_desc* d, const M
   it.bias_off = (long)a.cells * d->cin * d->cout;
   it.sub = a.sub == 3 ? 0 : a.sub; it.cc = (long)d->cin * d->cout;
   it.bias_parts = a.slab_stride == it.bias_off + 2L * d->cout ? 2 : 1;       // (mfma_wgrad9_plan's upsample form)
+  static const int vec4_on = [] { const char* e = getenv("RCGAN_SLAB_REDUCE_VEC4"); return e ? atoi(e) : 1; }();
+  it.vec4 = vec4_on && it.count % 4 == 0 && it.cc % 4 == 0 && a.slab_stride % 4 == 0 && ((size_t)a.slab & 15) == 0 && ((size_t)dw & 15) == 0;
   return it;
 }
 
@@ -943,7 +999,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
   // (sixteen) cells, and the riders of the three-tap launch (image-end layers, 1x1 shortcuts, the head) lose the workgroups they hid under.
   // Measured on the bench iteration: the critic step's layers (n = 128, 128 channels: 1152 pixels per workgroup) 120 -> 172 us with it, the
   // generator step's (256 channels: 12032 / 2560 pixels per workgroup) 478 -> 425 us.
-  const long w9_minwork = [] { const char* e = getenv("RCGAN_WGRAD9_GROUP_MINWORK"); return e ? atol(e) : 1500000L; }();      // (per call: the tests force it)
+  const long w9_minwork = [] { const char* e = getenv("RCGAN_WGRAD9_GROUP_MINWORK"); return e ? atol(e) : 1000000L; }();      // (per call: the tests force it; the critic step's group is 0.52 M, the generator step's 2.75 M, one 256-channel 32x32 layer 1.05 M)
   bool wgrad9_group_on = false;
   {
     double w9 = 0;
@@ -1120,7 +1176,11 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     SlabReduceGroup g;
     const int m = (int)((red.size() - i0 < REDUCE_GROUP_MAX) ? red.size() - i0 : REDUCE_GROUP_MAX);
     long maxc = 0;
-    for (int q = 0; q < m; ++q) { g.it[q] = red[i0 + q]; if (g.it[q].count + g.it[q].nbias > maxc) maxc = g.it[q].count + g.it[q].nbias; }
+    for (int q = 0; q < m; ++q) {
+      g.it[q] = red[i0 + q];
+      const long threads = (g.it[q].vec4 ? g.it[q].count / 4 : g.it[q].count) + g.it[q].nbias;
+      if (threads > maxc) maxc = threads;
+    }
     for (int q = m; q < REDUCE_GROUP_MAX; ++q) g.it[q] = red[i0];
     hipLaunchKernelGGL(slab_reduce2_group_kernel, dim3(cdiv(maxc, 256), m), dim3(256), 0, ctx->stream, g);
     RC_LAUNCH_CHECK(ctx);

@@ -344,8 +344,6 @@ struct Wgrad9Group {
 };
 static_assert(sizeof(Wgrad9Group) <= 4096, "kernel argument block");
 
-template <bool RELU, bool SUBK> struct W9Launch { static constexpr int THREADS = SUBK ? 512 : 768; };
-
 // SUBK: the sub-pixel forms (8 wavefronts with 128 accumulator registers each: a kernel of its own, the plain form's 12 wavefronts have 170
 // registers to live in)
 template <bool RELU, bool SUBK>
