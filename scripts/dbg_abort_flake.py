@@ -17,7 +17,7 @@ its = T._feeds(rs, B, 2, "rcgan")
 m = T._model("rcgan", "bf16", B, world_size=1, comm=None)
 ref = T._run_iterations(m, its)
 m.ctx.close()
-if not (os.environ.get("DBG_EAGER1") or os.environ.get("DBG_EAGER2")):
+if not (os.environ.get("DBG_EAGER1") or os.environ.get("DBG_EAGER2") or os.environ.get("DBG_GRAPH2")):      # DBG_GRAPH2: the captured data-parallel steps, nothing injected
     os.environ["RCGAN_COMM_STUB_FAIL_IN_CAPTURE"] = "1"
 bad = 0
 for r in range(runs):
