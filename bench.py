@@ -49,22 +49,8 @@ def synthetic_images(rs, labels, kind=None):
     n = len(labels)
     if kind == "uniform":
         return rs.randint(0, 256, size=(n, 3072))
-    trs = np.random.RandomState(4242)
-    yy, xx = np.mgrid[0:32, 0:32] / 32.0
-    tmpl = np.zeros((10, 3, 32, 32))
-    for c in range(10):
-        for ch in range(3):
-            for _ in range(3):
-                fx, fy = trs.randint(0, 3, size=2)
-                px, py = trs.uniform(0, 2 * np.pi, size=2)
-                tmpl[c, ch] += trs.uniform(0.3, 1.0) * np.cos(2 * np.pi * fx * xx + px) * np.cos(2 * np.pi * fy * yy + py)
-    noise = rs.randn(n, 3, 32, 32)
-    for _ in range(4):          # separable [1 2 1]/4 blur, wrap-around: sigma ~ 1.4 pixels
-        noise = (np.roll(noise, 1, 2) + 2 * noise + np.roll(noise, -1, 2)) / 4
-        noise = (np.roll(noise, 1, 3) + 2 * noise + np.roll(noise, -1, 3)) / 4
-    noise /= noise.std()
-    img = np.tanh(0.6 * tmpl[np.asarray(labels)] + 0.6 * noise)
-    return np.clip(np.floor((img * 0.5 + 0.5) * 256.0), 0, 255).astype(np.int64).reshape(n, 3072)
+    from rcgan_amd import data as D
+    return D.template_images(rs, labels)
 
 
 def build_pool(m, rank, alpha):
@@ -448,6 +434,18 @@ def main():
     d_loss, g_loss = m.losses()
     ok = np.isfinite(d_loss) and np.isfinite(g_loss)
 
+    # replicated state must stay bit-identical across ranks (same kernels on the same all-reduced gradients): every rank hashes its
+    # parameters after the timed iterations, rank 0 reports whether all hashes agree
+    weights_identical = None
+    if world > 1:
+        import hashlib
+        hsh = hashlib.sha256()
+        for k, v in sorted(m.get_params().items()):
+            hsh.update(k.encode()), hsh.update(np.ascontiguousarray(v).tobytes())
+        hashes = [None] * world
+        dist.all_gather_object(hashes, hsh.hexdigest()[:16])
+        weights_identical = len(set(hashes)) == 1
+
     comm = comm_profile(m, pool) if m.dp_active else None      # every rank: the extra iteration all-reduces
     out = None
     if rank == 0:
@@ -471,6 +469,8 @@ def main():
                           "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
                           "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}
         if comm is not None:
+            if weights_identical is not None:
+                out["config"]["rank_weights_bit_identical"] = bool(weights_identical)
             out["config"].update({"communicator_ranks": ranks_reported, "gradient_bucket_dtype": m.grad_bucket_dtype,
                                   "allreduce_groups_per_iteration": comm[0], "allreduce_ms_per_iteration": round(comm[1], 4),
                                   "allreduce_mbytes_per_iteration": round(comm[2] / 1e6, 3)})

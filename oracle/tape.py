@@ -30,6 +30,35 @@ def _acc(var, g):
     var.g = g if var.g is None else var.g + g
 
 
+class Kinks:
+    """Rectifier inputs within rounding of zero.  A float32 device and this float64 restatement can land on different sides of
+    max(x, 0) / max(x, 0.2 x) when |x| is of the order of the fp32 summation error; the value does not care, the derivative
+    does, and at batch 8 one such unit moves whole gradient tensors by a few per cent.  With ``eps`` set, every rectifier call
+    lists its inputs with |x| <= eps * max(1, max|x|) in ``found`` (in call order) and those whose ordinal is in ``flip`` take
+    the OTHER branch's derivative -- so a test can ask "is the device's gradient the oracle's gradient for SOME assignment of the
+    undecidable units" instead of widening its tolerance for every tensor.  Off (eps None) everywhere else."""
+    eps = None
+    flip = frozenset()
+    found = []
+
+    @classmethod
+    def reset(cls, eps=None, flip=()):
+        cls.eps, cls.flip, cls.found = eps, frozenset(flip), []
+
+    @classmethod
+    def mask(cls, v):
+        on = v > 0
+        if cls.eps is not None:
+            near = np.flatnonzero(np.abs(v) <= cls.eps * max(1.0, float(np.abs(v).max())))
+            if near.size:
+                on = on.copy()
+                for i in near:
+                    if len(cls.found) in cls.flip:
+                        on.flat[i] = not on.flat[i]
+                    cls.found.append((v.shape, int(i), float(v.flat[i])))
+        return on
+
+
 class Tape:
     def __init__(self):
         self.ops = []
@@ -106,12 +135,14 @@ class Tape:
         return self.rec(out, bw, x)
 
     def relu(self, x):
-        return self._unary(x, np.maximum(x.v, 0), lambda g: g * (x.v > 0))
+        on = Kinks.mask(x.v)
+        return self._unary(x, np.maximum(x.v, 0), lambda g: g * on)
 
     def lrelu(self, x, leak=0.2):
         # tf.maximum(x, leak*x): mnist/ops.py:94-95
         lk = x.v.dtype.type(leak)
-        return self._unary(x, np.maximum(x.v, lk * x.v), lambda g: g * np.where(x.v > 0, x.v.dtype.type(1), lk))
+        on = Kinks.mask(x.v)
+        return self._unary(x, np.maximum(x.v, lk * x.v), lambda g: g * np.where(on, x.v.dtype.type(1), lk))
 
     def tanh(self, x):
         y = np.tanh(x.v)

@@ -116,6 +116,8 @@ int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const voi
 int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts
 bool mfma_conv8_halo_takes(const MfmaConvArgs& a);                             // conv_mfma8h.hip: 256 x 256 tile, pixel operand as an LDS patch
 int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
+bool mfma_conv8n_halo_takes(const MfmaConvArgs& a);                            // ... its 256 x 128-tile sibling (Cout % 128 == 0)
+int mfma_conv8n_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 struct SmallGemmArgs;
 struct StepInputsArgs;
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm = nullptr,

@@ -875,5 +875,13 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   if (a.stats) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel");
   MfmaConvArgs b = a;
   b.phase = a.phase ? a.phase : (phase ? 1 : 0);
+  // plain 3x3 layers / their sub-pixel forms on 16- / 32-wide (low-resolution) images: the patch kernel's 256 x 128 sibling
+  // (conv_mfma8h.hip); RCGAN_P8N_HALO=0 keeps the tile-per-tap kernel
+  static int halo_n = -1;
+  if (halo_n < 0) { const char* e = getenv("RCGAN_P8N_HALO"); halo_n = e ? atoi(e) : 1; }
+  if (halo_n && mfma_conv8n_halo_takes(b)) {
+    b.stamps = (unsigned long long*)ctx->dbg_stamps;
+    return mfma_conv8n_halo_launch(ctx, b);
+  }
   return b.relu_in ? launch8n<true>(ctx, b) : launch8n<false>(ctx, b);
 }

@@ -41,7 +41,9 @@ namespace {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -346,6 +348,206 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 x 128-tile sibling (round 5): the same patch design for layers with Cout % 128 == 0 whose 256 x 256 grid would leave the
+// chip half empty or whose Cout is 128 -- G.Block.2.Conv2 forward / data gradient (16 x 16, 256 -> 256: 128 pixel tiles at n = 128)
+// and the four-phase data gradient of D.Block.1.Conv2 + mean pool (low-resolution 16 x 16, 128 -> 128).  The tile-per-tap kernel
+// these ran on (conv_mfma_p8n_kernel) re-fetches the pixel tile for every tap: 21-36 % MFMA busy (profiles/r04_pmc_mfma_busy.txt).
+//
+//   wavefronts : 8 = 4 (pixels, 64 each) x 2 (channels, 64 each); 4 x 4 accumulator tiles; the channel half IS the ping-pong group
+//   K-tile     : one tap x 64 channels = two phases of 16 MFMAs, split along K (the first / second 32 reduction elements: bytes 0-63 /
+//                64-127 of every staged row), so both phases read 4 pixel + 4 filter fragments and run the same 16 accumulators
+//   LDS        : ring of 4 filter K-tiles (128 rows x 128 B = 16 KiB each) + 2 patches = 64 + 2 x 43 KiB = 150 KiB
+//   LDS-DMA    : the filters of K-tile t + 2 (two pieces per wavefront) go out in phase B of tile t, one piece of the next chunk's
+//                patch per wavefront behind them during the chunk's first taps; ONE counted wait per K-tile in front of phase B's
+//                first barrier: vmcnt(2 + patch pieces issued behind the filters of tiles t + 1 and t + 2) = tile t + 1 has landed
+//                (read two barriers later: the other group runs one barrier behind).  A patch piece issued in tap s has landed by
+//                the wait of tap s + 2 and is read from tap s + 3 on: the pieces ride in taps 0 .. NT - 3.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int H8N_WTILE = 128 * 128;                 // one filter K-tile
+constexpr int h8n_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8N_WTILE; }
+}  // namespace
+
+template <int LW, bool RELU, bool PHM>
+__global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W = 1 << LW, TR = 256 >> LW;
+  constexpr int NT = PHM ? 4 : 9;
+  constexpr int NTI = PHM ? 2 : 6;                  // taps of a chunk that carry patch pieces (<= NT - 2)
+  constexpr int PC = W + H8_PC_EXTRA, PR = TR + 2;
+  constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;
+  constexpr int PATCH = NROWS * 128;
+  constexpr int WOFF = 0, P0OFF = 4 * H8N_WTILE, P1OFF = 4 * H8N_WTILE + PATCH;
+  constexpr int MAXP = (NP + 7) / 8;
+  constexpr int PPT = (MAXP + NTI - 1) / NTI;
+  static_assert(MAXP <= 6 && NTI <= NT - 2, "a wavefront issues its patch pieces during the first taps of a chunk");
+  static_assert((PR - 1) * PC * 128 + PC * 128 < 65536, "tap offsets are ds_read immediates");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;          // pixel quarter / channel half
+  const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD
+  unsigned mt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long m0 = (long)mt * 256;
+  const int co0 = blockIdx.y * 128;
+  const int K = NT * a.Cin;
+  const int lrow = lane >> 3, pos = lane & 7;
+  const int HI = PHM ? (a.H >> 1) : a.H, lhi = PHM ? a.lh - 1 : a.lh;
+  const long Mph = a.M >> 2;
+  const int tph = PHM ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;
+  const long mbase = PHM ? (long)tph * Mph : 0;
+  const unsigned ms0 = (unsigned)(m0 - mbase);
+  const bf16_t* const wbase = PHM ? a.wph + (long)tph * a.Cout * K : a.wt;
+
+  // ---- patch sources (as in conv_mfma_h8_kernel)
+  const unsigned n_img = ms0 >> (LW + lhi);
+  const int oh0 = (int)((ms0 >> LW) & (unsigned)(HI - 1));
+  unsigned poff[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int piece = wave + 8 * j;
+    const int q = piece * 8 + lrow;
+    const int pr = q / PC, pc = q - pr * PC;
+    const int ih = oh0 - 1 + pr, iw = pc - 1;
+    const bool ok = piece < NP && q < NPX && ih >= 0 && ih < HI && iw >= 0 && iw < W;
+    poff[j] = ok ? 2u * (((n_img * (unsigned)HI + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8)) : ~0u;
+    if (!ok && piece < NP) {
+      *(uint4*)(smem + P0OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(smem + P1OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  unsigned pmask = 0;
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) pmask |= (__builtin_amdgcn_ballot_w64(poff[j] != ~0u) != 0 ? 1u : 0u) << j;
+  pmask = __builtin_amdgcn_readfirstlane(pmask);
+
+  // ---- filter sources: K-tile row r = channel co0 + r; this wavefront deposits pieces wave and wave + 8 (rows (wave + 8 j) * 8 + lrow)
+  unsigned woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave + 8 * j) * 8 + lrow;
+    woff[j] = 2u * ((unsigned)(co0 + r) * (unsigned)K + (unsigned)((pos ^ ((r >> 1) & 7)) * 8));
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto issue_patch = [&](int j, int cnext) __attribute__((always_inline)) {
+    const bf16_t* base = a.in + cnext * 64;
+    const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
+    if (poff[j] != ~0u) glds16_sbase(base, poff[j], dst);
+  };
+  auto issue_w = [&](int c, int tap) __attribute__((always_inline)) {      // K-tile t = NT c + tap -> ring slot t & 3
+    const bf16_t* base = wbase + (tap * a.Cin + c * 64);
+    const unsigned dst = lds0 + WOFF + ((NT * c + tap) & 3) * H8N_WTILE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_sbase(base, woff[j], dst + j * 8192);
+  };
+
+  f32x4_t acc[4][4];       // [co fragment][px fragment]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, kc = lane >> 4;
+  if (lds0 != 0) __builtin_trap();
+  const int wad = WOFF + wn * 64 * 128 + frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);      // + ring slot * H8N_WTILE
+  const int pw0 = ((wm * 64) >> LW) * PC + frow + (PHM ? ph * PC + pw : 0);
+  int AD[16];
+#pragma unroll
+  for (int sx = 0; sx < 16; ++sx) AD[sx] = P0OFF + pw0 * 128 + ((kc ^ (((pw0 + sx) & 15) >> 1)) << 4);
+
+  bf16x8_t xf[4], wf[4];
+  auto load_x = [&](int kh, int kw, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int p = f * 16;
+      const int immP = kh * PC + kw + (p >> LW) * PC + (p & (W - 1));
+      const int ad = AD[immP & 15];
+      u32x4_t v = lds_read16(ks ? xor64(ad) : ad, immP * 128);
+      if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+      xf[f] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  };
+  auto load_w = [&](int wcur, int ks) __attribute__((always_inline)) {
+    const int ad = ks ? xor64(wcur) : wcur;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wf[g] = __builtin_bit_cast(bf16x8_t, lds_read16(ad, g * 16 * 128));
+  };
+  auto mma = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[g][f] = mfma16(wf[g], xf[f], acc[g][f]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
+  const int nchunks = a.Cin >> 6;
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j)
+    if ((pmask >> j) & 1) issue_patch(j, 0);
+  issue_w(0, 0);
+  issue_w(0, 1);
+  wait_vm<2>();                                     // the patch and K-tile 0
+  if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
+  wg_barrier();
+
+  int slot = 0;                                     // ring slot of the current K-tile (wave-uniform)
+  for (int c = 0; c < nchunks; ++c) {
+    const bool next_chunk = c + 1 < nchunks;
+    const unsigned pmask_c = next_chunk ? pmask : 0u;
+    auto pieces_at = [&](int tp) __attribute__((always_inline)) -> int {
+      int n = 0;
+      if (tp >= 0 && tp < NTI) {
+#pragma unroll
+        for (int j = tp; j < MAXP; j += NTI) n += (int)((pmask_c >> j) & 1);
+      }
+      return n;
+    };
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      const int kh = PHM ? (tap >> 1) : tap / 3, kw = PHM ? (tap & 1) : tap - 3 * (tap / 3);
+      const bool more1 = tap < NT - 1 || next_chunk, more2 = tap < NT - 2 || next_chunk;
+      const int c2 = tap < NT - 2 ? c : c + 1, tap2 = tap < NT - 2 ? tap + 2 : tap + 2 - NT;
+      const int wcur = wad + slot * H8N_WTILE;
+      // phase A: the first 32 reduction elements
+      load_x(kh, kw, 0);
+      load_w(wcur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();
+      mma();
+      raw_barrier();
+      // phase B: the second 32; the filters of K-tile t + 2 (its slot was last read in K-tile t - 2) and one patch piece behind them
+      load_x(kh, kw, 1);
+      load_w(wcur, 1);
+      if (more2) issue_w(c2, tap2);
+      if (tap < NTI) {
+#pragma unroll
+        for (int j = tap; j < MAXP; j += NTI)
+          if ((pmask_c >> j) & 1) issue_patch(j, c + 1);
+      }
+      // K-tile t + 1 has landed (newer: the patch pieces issued behind it, K-tile t + 2 and the patch pieces behind that)
+      if (more2) wait_vm_plus<2, 2 * PPT>(pieces_at(tap - 1) + pieces_at(tap));
+      else if (more1) wait_vm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      raw_barrier();
+      mma();
+      raw_barrier();
+      slot = (slot + 1) & 3;
+    }
+    const int pdelta = (c & 1) ? -PATCH : PATCH;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) AD[sx] += pdelta;
+  }
+  if (!grp) wg_barrier();
+
+  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane,
+                RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+}
+
 // plain 3x3 stride-1 SAME convolution (forward, or the data gradient with the rotated filters) on 16- or 32-pixel-wide power-of-two
 // images whose 256-pixel tiles are whole image rows -- or (phase == 1) the sub-pixel form of an upsample-3x3 convolution whose
 // LOW-resolution grid is such an image
@@ -383,4 +585,39 @@ int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   }
   if (a.lw == 5) return a.relu_in ? launch8h<5, true, false>(ctx, b) : launch8h<5, false, false>(ctx, b);
   return a.relu_in ? launch8h<4, true, false>(ctx, b) : launch8h<4, false, false>(ctx, b);
+}
+
+// the 256 x 128 sibling: the same shapes at Cout % 128 == 0
+bool mfma_conv8n_halo_takes(const MfmaConvArgs& a) {
+  if (a.KH != 3 || a.KW != 3 || a.stats || a.lw < 0 || a.lh < 0 || a.M % 256 || a.Cin % 64 || a.Cout % 128) return false;
+  if ((long)a.N * a.H * a.W * a.Cin >= (1L << 31) || (long)a.Cout * 9 * a.Cin >= (1L << 31)) return false;
+  if (a.phase == 0) return a.PT == 1 && a.PL == 1 && !a.up && (a.lw == 4 || a.lw == 5) && (a.H << a.lw) % 256 == 0;
+  if (a.phase == 1) return a.up && a.wph != nullptr && (a.lw == 5 || a.lw == 6) && a.lh >= 1 && ((a.H >> 1) << (a.lw - 1)) % 256 == 0 && (a.M >> 2) % 256 == 0;
+  return false;
+}
+
+template <int LW, bool RELU, bool PHM>
+static int launch8hn(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  static bool attr_set = false;
+  const size_t lds = h8n_lds_bytes(LW);
+  if (!attr_set) {
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8n_kernel<LW, RELU, PHM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, 256), a.Cout / 128);
+  {
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM>), grid, dim3(512), lds, ctx->stream, a);
+  }
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int mfma_conv8n_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  if (a.phase == 1) {
+    if (a.lw == 6) return a.relu_in ? launch8hn<5, true, true>(ctx, a) : launch8hn<5, false, true>(ctx, a);
+    return a.relu_in ? launch8hn<4, true, true>(ctx, a) : launch8hn<4, false, true>(ctx, a);
+  }
+  if (a.lw == 5) return a.relu_in ? launch8hn<5, true, false>(ctx, a) : launch8hn<5, false, false>(ctx, a);
+  return a.relu_in ? launch8hn<4, true, false>(ctx, a) : launch8hn<4, false, false>(ctx, a);
 }

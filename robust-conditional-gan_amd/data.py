@@ -62,10 +62,47 @@ def load(batch_size, data_dir, C, rng=np.random):
     return cifar_generator(tx, ty, batch_size, C, rng), cifar_generator(vx, vy, batch_size, C, rng)
 
 
-def synthetic_cifar(n=50000, seed=1234):
-    """SURVEY 8(d) synthetic inputs: uint8 images U{0..255} [n,3072] (CHW) and clean labels U{0..9}."""
+def class_templates():
+    """Ten fixed low-frequency colour patterns [10,3,32,32] (sums of three separable cosines per channel, frequencies 0..2):
+    the class-carrying part of the "templates" synthetic images.  Not reference data -- a stand-in for CIFAR-10 (no dataset and
+    no network here) on which a generated image's class can be read off exactly (eval_cifar.TemplateClassifier)."""
+    trs = np.random.RandomState(4242)
+    yy, xx = np.mgrid[0:32, 0:32] / 32.0
+    tmpl = np.zeros((10, 3, 32, 32))
+    for c in range(10):
+        for ch in range(3):
+            for _ in range(3):
+                fx, fy = trs.randint(0, 3, size=2)
+                px, py = trs.uniform(0, 2 * np.pi, size=2)
+                tmpl[c, ch] += trs.uniform(0.3, 1.0) * np.cos(2 * np.pi * fx * xx + px) * np.cos(2 * np.pi * fy * yy + py)
+    return tmpl
+
+
+def template_images(rs, labels):
+    """uint8-valued CHW rows [n,3072]: tanh(0.6 template[label] + 0.6 low-pass noise) mapped to 0..255 -- natural-image-like
+    second-order statistics that carry the label (per-image noise sigma ~ 1.4 pixels, as strong as the class pattern)."""
+    n = len(labels)
+    noise = rs.randn(n, 3, 32, 32)
+    for _ in range(4):          # separable [1 2 1]/4 blur, wrap-around
+        noise = (np.roll(noise, 1, 2) + 2 * noise + np.roll(noise, -1, 2)) / 4
+        noise = (np.roll(noise, 1, 3) + 2 * noise + np.roll(noise, -1, 3)) / 4
+    noise /= noise.std()
+    img = np.tanh(0.6 * class_templates()[np.asarray(labels)] + 0.6 * noise)
+    return np.clip(np.floor((img * 0.5 + 0.5) * 256.0), 0, 255).astype(np.int64).reshape(n, 3072)
+
+
+def synthetic_cifar(n=50000, seed=1234, kind="uniform"):
+    """Synthetic stand-ins for the CIFAR-10 arrays.  kind "uniform" (SURVEY 8(d)): uint8 images U{0..255} [n,3072] (CHW) and
+    clean labels U{0..9} -- timing / plumbing only, the images carry no label.  kind "templates": ``template_images`` of the
+    clean labels -- a learnable conditional distribution for end-to-end training runs."""
     rs = np.random.RandomState(seed)
-    return rs.randint(0, 256, size=(n, 3072), dtype=np.uint8), rs.randint(10, size=n)
+    if kind == "uniform":
+        return rs.randint(0, 256, size=(n, 3072), dtype=np.uint8), rs.randint(10, size=n)
+    if kind != "templates":
+        raise ValueError("unknown synthetic kind %r" % (kind,))
+    labels = rs.randint(10, size=n)
+    images = np.concatenate([template_images(rs, labels[i:i + 5000]) for i in range(0, n, 5000)]).astype(np.uint8)
+    return images, labels
 
 
 def inf_train_gen(train_gen):

@@ -53,6 +53,8 @@ def define_flags():
     # this build's additions (absent flags keep the reference behaviour)
     f.DEFINE_string("dtype", 'bf16', "activation dtype [bf16, f16 (static loss scale 1024), f32]")
     f.DEFINE_boolean("synthetic", False, "train on the SURVEY 8(d) synthetic data instead of ../data/cifar10")
+    f.DEFINE_string("synthetic_kind", 'uniform', "with --synthetic: [uniform] SURVEY 8(d) label-free noise images, [templates] "
+                    "class-pattern images (data.template_images) scored by eval_cifar.TemplateClassifier instead of the CIFAR ResNet")
     f.DEFINE_integer("seed", 0, "variable-initialisation seed")
     f.DEFINE_string("data_dir", DATA_DIR, "CIFAR-10 python batches")
     f.DEFINE_integer("sample_every", 0, "if > 0: overrides --sample_freq (dev cost + sample grid period)")
@@ -121,8 +123,8 @@ def main(argv=None):
 
     # data: label noise drawn from the global numpy stream exactly as the reference does (unseeded there)
     if FLAGS.synthetic:
-        tx, ty = D.synthetic_cifar(50000, 1234)
-        vx, vy = D.synthetic_cifar(10000, 1235)
+        tx, ty = D.synthetic_cifar(50000, 1234, FLAGS.synthetic_kind)
+        vx, vy = D.synthetic_cifar(10000, 1235, FLAGS.synthetic_kind)
         train_gen = D.cifar_generator(tx, ty, BATCH_SIZE, C_ALPHA)
         dev_gen = D.cifar_generator(vx, vy, BATCH_SIZE, C_ALPHA)
     else:
@@ -154,14 +156,17 @@ def main(argv=None):
     acc_state = {"clf": None, "max": 0.0}
 
     def save_samples(n):
-        all_samples = [m.sample(label_100_list, np.random.normal(size=(100, Z_DIM)).astype('float32')) for _ in range(int(n / 100))]
+        # the reference draws these latents with TensorFlow's generator (Generator(noise=None), gan_resnet.py:847-861): a private
+        # stream, so that evaluating does not shift the numpy stream the data and label noise come from
+        all_samples = [m.sample(label_100_list, is_rs.normal(size=(100, Z_DIM)).astype('float32')) for _ in range(int(n / 100))]
         all_samples = ((np.concatenate(all_samples, axis=0) + 1.) * (255.99 / 2)).astype('int32')     # gan_resnet.py:858
         return all_samples.reshape((-1, 32, 32, 3)), np.concatenate([label_100_list] * int(n / 100), axis=0)
 
     def label_accuracy(confusion_matrix=None):
-        from .eval_cifar import LabelClassifier, generated_label_accuracy
+        from .eval_cifar import LabelClassifier, TemplateClassifier, generated_label_accuracy
         if acc_state["clf"] is None:
-            acc_state["clf"] = LabelClassifier(local)
+            templates = FLAGS.synthetic and FLAGS.synthetic_kind == 'templates'
+            acc_state["clf"] = TemplateClassifier() if templates else LabelClassifier(local)
         samples, labels = save_samples(1000)
         acc = generated_label_accuracy(samples, labels, confusion_matrix=confusion_matrix, classifier=acc_state["clf"])
         logging.info('generated label accuracy: {}'.format(acc))

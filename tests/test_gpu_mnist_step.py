@@ -21,12 +21,14 @@ def _batch(rs, B, alpha=0.3):
                    y_real_weights=np.linalg.inv(C)[yr].astype(np.float32))
 
 
-def _cmp(tag, got, grads, grads32):
-    """HIP fp32 vs the float64 oracle, per tensor: norm-relative error <= 1e-2 (or 4x the float32 oracle's own
-    distance from float64) and max error <= 1e-1 of the tensor's scale.  The max-error bound is loose on purpose:
-    a ReLU / leaky-ReLU input within ~1e-7 of zero can take the other branch under a different fp32 summation
-    order, which moves the few gradient entries fed by that one activation by ~1e-2 of the scale while leaving
-    the rest at 1e-6 (observed: tests/tools/debug_mnist.py)."""
+KINK_EPS = 4e-6      # |rectifier input| <= this x the tensor's scale: the branch is decided by fp32 rounding
+
+
+def _misfits(got, grads, grads32):
+    """Tensors of the device's gradient that are not the oracle's: norm-relative error > 1e-2 (or 4x the float32 oracle's own
+    distance from float64), largest entry off by > 1e-1 of the tensor's scale, or -- for tensors that are not noise-floor small --
+    a projection <got, ref> / <ref, ref> more than 1.5e-2 from 1 (a dropped or mis-scaled term).  -> [(name, message)]"""
+    bad = []
     gmax = max(float(np.abs(g).max()) for g in grads.values())
     for k, gref in grads.items():
         a = got[k]
@@ -35,18 +37,39 @@ def _cmp(tag, got, grads, grads32):
         err = float(np.abs(a - gref).max()) / scale
         nrm = float(np.linalg.norm(a - gref)) / max(float(np.linalg.norm(gref)), scale)
         own = float(np.linalg.norm(grads32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
-        # (round 4) At B = 8 ONE rectifier whose input sits within fp32 rounding of zero takes the other branch on the device than in
-        # the float64 oracle and moves a whole generator tensor by a few per cent -- scripts/probes/dbg_mnist_split.py: the case
-        # "unbiased", second generator run, showed 3.1e-2 on g_h0_lin / g_h1_lin with the split-reduction GEMMs on AND off at the same
-        # weights, while the run before it agreed to 2.5e-6.  Such a tensor still points the same way: beyond 1e-2 the error must stay
-        # under 6e-2 with a cosine >= 0.998 (a dropped or mis-scaled term does neither).
-        ok = nrm <= max(1e-2, 4 * own)
-        if not ok and nrm <= 6e-2:
-            a64 = a.astype(np.float64)
-            cos = float((a64 * gref).sum() / (np.linalg.norm(a64) * np.linalg.norm(gref) + 1e-300))
-            ok = cos >= 0.998
-        assert ok and err <= 1e-1, \
-            "%s %s: norm-rel %.3e max %.3e of scale %.3e (fp32 oracle norm-rel %.3e)" % (tag, k, nrm, err, scale, own)
+        rr = float((gref.astype(np.float64) ** 2).sum())
+        proj = float((a.astype(np.float64) * gref).sum()) / rr if rr > 0 and float(np.abs(gref).max()) >= 1e-3 * gmax else 1.0
+        if not (nrm <= max(1e-2, 4 * own) and err <= 1e-1 and abs(proj - 1.0) <= max(1.5e-2, 4 * own)):
+            bad.append((k, "%s: norm-rel %.3e max %.3e of scale %.3e, projection %.4f (fp32 oracle norm-rel %.3e)" % (k, nrm, err, scale, proj, own)))
+    return bad
+
+
+def _cmp(tag, got, oracle, grads32):
+    """HIP fp32 vs the float64 oracle, per tensor (``_misfits``).  ``oracle()`` evaluates the float64 gradients under the current
+    ``oracle.tape.Kinks`` policy.  A rectifier input within fp32 rounding of zero takes the device's branch, not the float64
+    oracle's, and at B = 8 ONE such unit moves whole tensors by a few per cent (round 4: "unbiased", second generator run, 3.1e-2
+    on g_h0_lin / g_h1_lin with the split-reduction GEMMs on AND off).  Instead of a wider bound for every tensor (round 4 accepted
+    6e-2 anywhere), the oracle lists its undecidable units (|input| <= KINK_EPS of the tensor's scale) and the device's gradient has to
+    be the oracle's for SOME assignment of them -- every tensor of the run at the strict bound under ONE assignment, found greedily."""
+    from oracle.tape import Kinks
+    try:
+        Kinks.reset(eps=KINK_EPS)
+        bad = _misfits(got, oracle(), grads32)
+        found = list(Kinks.found)
+        flips = []
+        if bad:
+            assert 0 < len(found) <= 12, "%s: %s and %d undecidable rectifier inputs" % (tag, bad[0][1], len(found))
+            for i in range(len(found)):
+                Kinks.reset(eps=KINK_EPS, flip=flips + [i])
+                trial = _misfits(got, oracle(), grads32)
+                if len(trial) < len(bad):
+                    flips, bad = flips + [i], trial
+                if not bad:
+                    break
+        assert not bad, "%s (undecidable units %s, flipped %s): %s" % (tag, found, flips, "; ".join(m for _, m in bad))
+        return flips
+    finally:
+        Kinks.reset()
 
 
 CASES = [("rcgan", "projection", False, "hinge", False), ("rcgan", "projection", True, "hinge", False),
@@ -90,13 +113,14 @@ def test_mnist_iteration_parity_fp32(alg, disc, est, loss, concat):
                    confuse_multiplier=10.0)
         m.set_inputs(**b)
         # ---- D run
-        L64, g64 = om.d_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+        d64 = lambda: om.d_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+        L64, _ = d64()
         _, g32 = om.d_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float32)
         m.d_step()
         got = m.losses()
         for k in ("d_loss_real", "d_loss_fake", "class_loss_real"):
             assert abs(got[k] - L64[k]) <= 2e-5 * max(1.0, abs(L64[k])), (k, got[k], L64[k])
-        _cmp("D grad", m.get_grads(m.PD), g64, g32)
+        _cmp("D grad", m.get_grads(m.PD), lambda: d64()[1], g32)
         tr = om.Trainer(P, So, Uo, cfg)
         tr.d_step(b)
         st = m.get_state()
@@ -118,7 +142,8 @@ def test_mnist_iteration_parity_fp32(alg, disc, est, loss, concat):
                 So[k] = st[k].copy()
             for k in Uo:
                 Uo[k] = st[k].copy()
-            L64, g64 = om.g_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+            g64f = lambda: om.g_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float64)
+            L64, _ = g64f()
             _, g32 = om.g_grads(P, {k: v.copy() for k, v in So.items()}, dict(Uo), cfg, b, dtype=np.float32)
             m.g_step()
             got = m.losses()
@@ -127,7 +152,7 @@ def test_mnist_iteration_parity_fp32(alg, disc, est, loss, concat):
             gg = m.get_grads(m.PG)
             if m.PC is not None:
                 gg.update(m.get_grads(m.PC))
-            _cmp("G grad run %d" % run, gg, g64, g32)
+            _cmp("G grad run %d" % run, gg, lambda: g64f()[1], g32)
     finally:
         m.ctx.close()
 

@@ -68,6 +68,11 @@ CONV_CASES = [
     (200, 16, 16, 128, 256, 3, 1, False, False),# ... its 16-pixel-wide form (a tile = one whole image), two chunks; dgrad on the 128-channel path
     (52, 32, 32, 256, 256, 3, 1, True, True),   # ... the sub-pixel form of an upsample-3x3 layer on it (G.Block.3.Conv1): 16 x 16 low-resolution images, four taps per chunk
     (13, 64, 64, 64, 256, 3, 1, True, False),   # ... and on 32-wide low-resolution images (one chunk: no patch hand-over)
+    # the 256 x 128-tile sibling of the halo-patch kernel (conv_mfma_h8n_kernel, round 5; the dgrad of the 16-wide case above takes it too):
+    (100, 16, 16, 256, 256, 3, 1, False, False),# ... 100 pixel tiles x 2 channel halves (G.Block.2.Conv2's shape), four chunks, forward AND data gradient
+    (50, 32, 32, 128, 128, 3, 1, False, True),  # ... 32-wide, Cout = 128, input ReLU, two chunks, both directions
+    (48, 32, 32, 128, 128, 3, 1, True, True),   # ... sub-pixel form over 16 x 16 low-resolution images (the shape of D.Block.1.Conv2's pooled data gradient)
+    (13, 64, 64, 64, 128, 3, 1, True, False),   # ... over 32-wide low-resolution images, one chunk
     # the nine-tap filter gradient (conv_wgrad9.hip; the 16- and 32-wide cases above take it too): 8-pixel-wide images (four image rows per K-step),
     (6, 8, 8, 64, 128, 3, 1, False, True),
     (3, 16, 8, 128, 128, 3, 1, False, False),   # ... H != W

@@ -229,3 +229,59 @@ def test_rccl_that_cannot_be_loaded_is_an_error_code_not_a_crash():
     assert r.returncode == 0, r.stderr
     rc, why = r.stdout.strip().splitlines()[-1].split(" | ")
     assert int(rc) == -5 and "librccl_missing.so" in why             # RCGAN_ERCCL
+
+
+def test_oracle_kink_policy_lists_and_flips_undecidable_rectifier_inputs():
+    """oracle.tape.Kinks (test infrastructure of the MNIST step-parity tests): inputs within eps of zero are listed in call order,
+    a flipped one takes the other branch's derivative, values are untouched, and the policy is off by default."""
+    from oracle.tape import Kinks, Tape, Var
+    x = np.array([[1.0, -2.0, 3e-9, -1e-9]])
+    def grad(leaky):
+        t = Tape()
+        v = Var(x.copy(), req=True)
+        y = t.lrelu(v) if leaky else t.relu(v)
+        t.backward(t.sum_axis(y, 1), np.ones(1))
+        return y.v, v.g
+    try:
+        Kinks.reset()
+        y0, g0 = grad(False)
+        assert Kinks.found == [] and np.array_equal(g0, [[1, 0, 1, 0]])
+        Kinks.reset(eps=1e-6)
+        y1, g1 = grad(False)
+        assert [f[1] for f in Kinks.found] == [2, 3] and np.array_equal(g1, g0) and np.array_equal(y1, y0)
+        Kinks.reset(eps=1e-6, flip=[1])
+        y2, g2 = grad(False)
+        assert np.array_equal(g2, [[1, 0, 1, 1]]) and np.array_equal(y2, y0)
+        Kinks.reset(eps=1e-6, flip=[0])
+        _, g3 = grad(True)
+        assert np.allclose(g3, [[1, 0.2, 0.2, 0.2]])
+    finally:
+        Kinks.reset()
+
+
+def test_template_images_carry_their_label_and_the_stand_in_classifier_reads_it():
+    """data.synthetic_cifar(kind="templates") + eval_cifar.TemplateClassifier: the synthetic stand-in of the end-to-end training runs
+    (scripts/train_synthetic.py, profiles/r05_train_*.json).  The classifier is >= 99.5 % correct on the real synthetic images
+    and at chance on label-free uniform images; bench.py's images are these."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import data as D
+    from rcgan_amd.eval_cifar import TemplateClassifier, generated_label_accuracy
+    x, y = D.synthetic_cifar(2000, 7, "templates")
+    assert x.dtype == np.uint8 and x.shape == (2000, 3072)
+    imgs = x.reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    clf = TemplateClassifier()
+    assert generated_label_accuracy(imgs, y, classifier=clf) >= 0.995
+    xu, yu = D.synthetic_cifar(2000, 7)
+    acc = generated_label_accuracy(xu.reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1), yu, classifier=clf)
+    assert 0.05 <= acc <= 0.15
+    import bench
+    rs = np.random.RandomState(3)
+    lab = rs.randint(10, size=16)
+    a = bench.synthetic_images(rs, lab)
+    assert np.array_equal(a, D.template_images(_rs_after_labels(3, 16), lab))
+
+
+def _rs_after_labels(seed, n):
+    rs = np.random.RandomState(seed)
+    rs.randint(10, size=n)
+    return rs
