@@ -13,8 +13,10 @@ Extra objects on the JSON line:
   roofline     dominant kernel (conv_mfma_h8_kernel: fwd + dgrad of the 256-channel 32x32 convs, 256x256 tiles, pixel operand as an
                LDS patch): algorithmic flops of its launches in one iteration / their summed duration measured with HIP events on
                the launch stream, against the dense bf16 MFMA peak; mfma_busy = the matrix pipe's busy fraction by the hardware
-               counter and traffic = HBM bytes per launch, both from committed rocprofv3 --pmc passes of this same command on this
-               same build of the kernels (null otherwise).
+               counter (its grids weighted by time), time_share = the kernel's part of the iteration's kernel time,
+               conv_mfma_busy_time_weighted = the same counter over EVERY convolution kernel weighted by time (conv2d as a whole) and
+               traffic = HBM bytes per launch, all from committed rocprofv3 --pmc / --kernel-trace passes of this same command on
+               this same build of the kernels (null / absent otherwise).
   cpu_baseline the PyTorch-CPU restatement of the reference graph (oracle/torch_port.py; kind "port": TensorFlow 1.5 is not
                installable) on all host cores for a bounded sample at the same batch, rank 0 at N=1 only.
 """
@@ -139,7 +141,7 @@ def kernel_roofline(m, pool, default_workload=True):
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     tfs = sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic_conv_p8.json")) + glob.glob(os.path.join(pdir, "r*_pmc_traffic_conv_h8.json")),
                  key=os.path.basename)
-    mfma_busy = None
+    mfma_busy, busy_extra = None, {}
     if default_workload and tfs:                         # the counters were collected on the default workload only; newest round
         with open(tfs[-1]) as f:
             tj = json.load(f)
@@ -154,6 +156,11 @@ def kernel_roofline(m, pool, default_workload=True):
             bj = json.load(f)
         if bj.get("source_sha16") == L.source_hash():
             mfma_busy = round(float(bj["mfma_busy"]), 4)
+            # utilisation of conv2d as a WHOLE, not of its best kernel: every convolution kernel that issues MFMAs, weighted by
+            # the time it takes in the kernel-trace pass of the same profile run (scripts/pmc_busy_table.py)
+            for k in ("mfma_busy_weighting", "time_share", "conv_mfma_busy_time_weighted", "conv_time_share"):
+                if k in bj:
+                    busy_extra[k] = round(bj[k], 4) if isinstance(bj[k], float) else bj[k]
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "mfma_busy": mfma_busy,
             "kernel": "conv_mfma_h8_kernel", "launches_per_iteration": n.value,
@@ -161,7 +168,8 @@ def kernel_roofline(m, pool, default_workload=True):
             "flops_per_launch_avg": fl.value / n.value,
             # algorithmic = the reference's formulation; the upsample-3x3 layers run in their sub-pixel form (four 2x2
             # convolutions with summed filters): the matrix cores execute 4/9 of those layers' multiply-adds
-            "executed_tflops": round(fx.value / (ms.value * 1e-3) / 1e12, 2), "executed_frac": round(fx.value / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            "executed_tflops": round(fx.value / (ms.value * 1e-3) / 1e12, 2), "executed_frac": round(fx.value / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            **busy_extra}
 
 
 PEAK_F32_TFLOPS = 157.3       # dense fp32 MFMA (v_mfma_f32_32x32x2_f32) peak, MI355X_MICROARCH.md

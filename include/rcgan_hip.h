@@ -98,6 +98,17 @@ int rcgan_debug_stamps(rcgan_ctx* ctx, void* stamps);
  * Replaces the per-step sess.run dispatch (gan_resnet.py:931,938; mnist/model.py:347-372). */
 int rcgan_graph_begin(rcgan_ctx* ctx);
 int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id);
+/* Capture contract of the entry points that take NO workspace argument.  The fp32 path of rcgan_conv2d_fwd, rcgan_deconv2d_bwd_data[_cols],
+ * rcgan_linear_bwd_data and the narrow (<= 2 output channels) data gradient keep partial tiles / per-source-pixel products in two scratch
+ * buffers hidden in the context that grow on demand with hipMalloc.  An allocation cannot be captured: inside rcgan_graph_begin .. end a call
+ * that would have to grow a buffer returns RCGAN_EHIP (hipErrorStreamCaptureUnsupported) and the capture has to be dropped with
+ * rcgan_graph_abort.  So before capturing either run every shape of the captured body once eagerly, or reserve the scratch up front:
+ * rcgan_reserve_scratch grows BOTH buffers to at least `bytes` each (never inside a capture; buffers only grow; an outgrown buffer stays
+ * alive until rcgan_destroy because earlier graphs address it).  Upper bounds: split reduction 8 x 4 bytes x the output elements of the
+ * largest GEMM with < 128 output tiles of 64 x 64 (<= 16 MiB); narrow data gradient 4 bytes x n x oh x ow x kh x kw x cin of the layer.
+ * rcgan_scratch_bytes reports the current sizes (either pointer may be null). */
+int rcgan_reserve_scratch(rcgan_ctx* ctx, size_t bytes);
+int rcgan_scratch_bytes(rcgan_ctx* ctx, size_t* split_reduction_bytes, size_t* narrow_bytes);
 /* Leave a capture that a failed launch has made impossible to finish; what was recorded is dropped (nothing of it ran). */
 int rcgan_graph_abort(rcgan_ctx* ctx);
 int rcgan_graph_launch(rcgan_ctx* ctx, int graph_id);

@@ -107,6 +107,8 @@ SIGNATURES = {
     "rcgan_prof_end": (I, [P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rcgan_prof_executed_flops": (I, [P, C.POINTER(C.c_double)]),
     "rcgan_graph_begin": (I, [P]),
+    "rcgan_reserve_scratch": (I, [P, C.c_size_t]),
+    "rcgan_scratch_bytes": (I, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rcgan_graph_end": (I, [P, C.POINTER(I)]),
     "rcgan_graph_abort": (I, [P]),
     "rcgan_graph_launch": (I, [P, I]),

@@ -451,6 +451,19 @@ int rcgan_graph_begin(rcgan_ctx* ctx) {
   return RCGAN_OK;
 }
 
+int rcgan_reserve_scratch(rcgan_ctx* ctx, size_t bytes) {
+  RC_REQUIRE(ctx, !ctx->capturing, "scratch cannot grow inside a capture");
+  RC_HIP(ctx, ctx_grow_scratch(ctx, &ctx->splitr_ws, &ctx->splitr_ws_bytes, bytes));
+  RC_HIP(ctx, ctx_grow_scratch(ctx, &ctx->narrow_ws, &ctx->narrow_ws_bytes, bytes));
+  return RCGAN_OK;
+}
+
+int rcgan_scratch_bytes(rcgan_ctx* ctx, size_t* split_reduction_bytes, size_t* narrow_bytes) {
+  if (split_reduction_bytes) *split_reduction_bytes = ctx->splitr_ws_bytes;
+  if (narrow_bytes) *narrow_bytes = ctx->narrow_ws_bytes;
+  return RCGAN_OK;
+}
+
 int rcgan_graph_end(rcgan_ctx* ctx, int* graph_id) {
   RC_REQUIRE(ctx, ctx->capturing, "not capturing");
   hipGraph_t g = nullptr;
@@ -959,7 +972,7 @@ int rcgan_conv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
     size_t need = (size_t)nz * a.slab_stride * sizeof(float) + (size_t)(cdiv(a.M, 2048) + 1024) * d->cout * sizeof(float);
     if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
     bool bias_done = false;
-    int nzz = mfma_wgrad_launch(ctx, a, nz, &bias_done);
+    int nzz = mfma_wgrad_launch(ctx, a, nz, &bias_done, ws_bytes);
     if (nzz < 0) return nzz;
     const int nb = bias_done ? d->cout : 0;
     if (a.sub == 1 || a.sub == 2) {

@@ -94,7 +94,7 @@ bool mfma_wgrad_tap_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy);
 bool mfma_wgrad9_takes(const MfmaWgradArgs& a);
 bool mfma_wgrad9_plan(MfmaWgradArgs& a, int nz, unsigned* gx, unsigned* gy, long px_per_block);
 int mfma_wgrad9_group_launch(rcgan_ctx* ctx, int n, const MfmaWgradArgs* args, const unsigned* gx, const unsigned* gy);
-int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done);
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done, size_t ws_bytes);
 int mfma_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, bf16_t* wt, bf16_t* wd, int T, int Cin, int Cout);
 int direct_prepare_launch(rcgan_ctx* ctx, const float* w, const float* sigma, float* out, long total);
 int mfma_selftest(rcgan_ctx* ctx, int* host_result);

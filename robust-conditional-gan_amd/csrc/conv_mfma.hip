@@ -1810,7 +1810,7 @@ static int launch_wgrad3(rcgan_ctx* ctx, MfmaWgradArgs& a, dim3 grid) {
   return RCGAN_OK;
 }
 
-int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done) {
+int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done, size_t ws_bytes) {
   *bias_done = false;
   if (a.sub && !mfma_wgrad3_takes(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "sub-pixel filter gradient needs the three-tap kernel");
   {
@@ -1820,7 +1820,12 @@ int mfma_wgrad_launch(rcgan_ctx* ctx, MfmaWgradArgs& a, int nz, bool* bias_done)
     const long min_work = env_int("RCGAN_WGRAD9_MINWORK", 200000);        // (read per call: the tests force the kernel on small shapes)
     const long work9 = a.M * (long)(a.Cin / 64) * (a.Cout / 128);
     unsigned gx9 = 0, gy9 = 0;
-    if ((a.sub ? min_work <= 0 : work9 >= min_work) && mfma_wgrad9_plan(a, nz, &gx9, &gy9, 0)) {
+    // (planned on a copy: the plan rewrites slab_stride -- the upsample form carries two bias tails per slab -- AFTER the caller sized
+    // the workspace for the stride it knew; the nine-tap kernel only runs if its slabs fit what the caller really handed over)
+    MfmaWgradArgs a9 = a;
+    if ((a.sub ? min_work <= 0 : work9 >= min_work) && mfma_wgrad9_plan(a9, nz, &gx9, &gy9, 0) &&
+        (size_t)gy9 * (size_t)a9.slab_stride * sizeof(float) <= ws_bytes) {
+      a = a9;
       int rc = mfma_wgrad9_group_launch(ctx, 1, &a, &gx9, &gy9);
       *bias_done = a.want_bias != 0;
       return rc ? -1 : (int)gy9;

@@ -462,6 +462,9 @@ class MnistRCGAN:
             body()
             return
         if key not in self._graphs:
+            # no eager rehearsal here: the hidden scratch of the fp32 entry points is sized up front (the capture contract of
+            # include/rcgan_hip.h) -- split reductions <= 16 MiB, narrow data gradient 4 B x batch x 14 x 14 x 25 x channels
+            ctx.reserve_scratch(max(16 << 20, 4 * self.B * 14 * 14 * 25 * 4))
             ctx.graph_begin()
             try:
                 body()

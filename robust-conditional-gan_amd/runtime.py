@@ -252,6 +252,11 @@ class Context:
         self.epoch += 1
 
     # ------------------------------------------------------------------ graphs
+    def reserve_scratch(self, nbytes):
+        """Grow the context's hidden scratch (split reductions, narrow data gradients of the fp32 path) BEFORE a capture: inside one an
+        entry point that has to grow it fails (include/rcgan_hip.h, capture contract)."""
+        self.check(self.lib.rcgan_reserve_scratch(self.h, C.c_size_t(int(nbytes))))
+
     def graph_begin(self):
         self.check(self.lib.rcgan_graph_begin(self.h))
         self.capturing = True

@@ -11,11 +11,16 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
 
+# the hash of the kernel sources THIS run measures (bench.py attaches the committed counters to a build by it): recorded here, at
+# measurement time -- scripts/publish_profiles.sh refuses to publish counters whose hash is not the tree's
+( cd "$ROOT" && python3 -c "import rcgan_amd; from rcgan_amd import _lib; print(_lib.source_hash())" ) > "$OUT/source_sha16.txt"
 python3 "$B" > "$OUT/bench_n1_default.json" 2> "$OUT/bench_n1_default.err"
 
 rocprofv3 --kernel-trace -d "$OUT/prof_kt" -o kt -- python3 "$B" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_n1_under_rocprof.json" 2> "$OUT/prof_kt.err"
 DB=$(find "$OUT/prof_kt" -name "*.db" | head -1)
 python3 "$ROOT/scripts/prof_summary.py" "$DB" 24 --csv "$OUT/bench_n1_kernel_stats.csv" > "$OUT/bench_n1_kernel_stats.txt"
+python3 "$ROOT/scripts/prof_summary.py" "$DB" 24 --by-grid --csv "$OUT/bench_n1_kernel_stats_by_grid.csv" > "$OUT/bench_n1_kernel_stats_by_grid.txt"
+python3 "$ROOT/scripts/prof_sequence.py" "$DB" 300 > "$OUT/bench_n1_last_iteration_sequence.txt"
 python3 "$ROOT/scripts/prof_timeline.py" "$DB" > "$OUT/bench_n1_timeline_groups.txt"
 rm -rf "$OUT/prof_kt"
 

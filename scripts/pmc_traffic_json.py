@@ -2,7 +2,8 @@
 """HBM traffic per launch of the dominant kernel from the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 summarised by scripts/pmc_summary.py  ->  the JSON that bench.py reports as roofline.traffic.
 
-usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_h8.txt> <pmc_WRITE_SIZE_conv_h8.txt> <out.json>
+usage: python scripts/pmc_traffic_json.py <pmc_FETCH_SIZE_conv_h8.txt> <pmc_WRITE_SIZE_conv_h8.txt> <out.json> [<source_sha16.txt>]
+source_sha16.txt: the hash scripts/make_profiles.sh recorded WHEN IT MEASURED; refused if it is not the current tree's.
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KB and counts the 128-byte requests of a wide
 coalesced stream at 64 bytes on gfx950 -> x2; WRITE_SIZE (KB) as reported."""
@@ -49,6 +50,10 @@ def main():
     alg_avg = sum(fetch[g][0] * alg[g] for g in fetch) / n
     import rcgan_amd  # noqa: F401
     from rcgan_amd import _lib
+    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        measured = open(sys.argv[4]).read().strip()
+        if measured != _lib.source_hash():
+            raise SystemExit("pmc_traffic_json.py: the counters were measured on sources %s, the tree is %s: not published" % (measured, _lib.source_hash()))
     out = {
         "source_sha16": _lib.source_hash(),      # bench.py attaches the figure to a run only on the same build of the kernels
         "kernel": "conv_mfma_h8_kernel (256 x 256 tile, pixel operand as an LDS patch fetched once per 64-channel chunk; the upsample-3x3 layers in sub-pixel form, shortcuts before the upsample)",

@@ -30,7 +30,7 @@ def main():
         n = r[0].replace("(anonymous namespace)::", "")
         n = re.sub(r"\(MfmaConvArgs\)|\(MfmaWgradArgs[^)]*\)|\([A-Za-z_][^)]*\)(?= grid|$)", "", n) if "--by-grid" in sys.argv else re.sub(r"\(.*", "", n)
         if out:
-            out.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n, r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
+            out.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n.replace("void ", "") if "--by-grid" in sys.argv else n, r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
         print("%-72s %7.1f /it %9.3f ms/it %8.1f us %5.1f%%" % (n[:72], r[1] / iters, r[2] / 1e6 / iters, r[3] / 1e3, 100 * r[2] / tot))
 
 

@@ -7,6 +7,8 @@ c() { if [ -f "$1" ]; then cp "$1" "$2"; else echo "(missing: $1)"; fi; }       
 c $R/bench_n1_default.json ${P}_bench_n1_default.json
 c $R/bench_n1_under_rocprof.json ${P}_bench_n1_under_rocprof.json
 c $R/bench_n1_kernel_stats.csv ${P}_bench_n1_kernel_stats.csv
+c $R/bench_n1_kernel_stats_by_grid.csv ${P}_bench_n1_kernel_stats_by_grid.csv
+c $R/bench_n1_last_iteration_sequence.txt ${P}_bench_n1_last_iteration_sequence.txt
 c $R/exp_p8_fixed_cost.txt ${P}_exp_p8_fixed_cost.txt
 c $R/exp_p8_timeline.txt ${P}_exp_p8_timeline.txt
 c $R/probe_epilogue_store.txt ${P}_probe_epilogue_store.txt
@@ -19,8 +21,10 @@ c $R/mnist_b256_f32_kernel_stats_by_grid.txt ${P}_mnist_b256_f32_kernel_stats_by
 c $R/bench_f32.json ${P}_bench_n1_f32.json
 c $R/bench_dpstub8_model_f32.json ${P}_bench_dpstub8_model_f32.json
 c $R/bench_dpstub8_model_bf16.json ${P}_bench_dpstub8_model_bf16.json
-python3 scripts/pmc_traffic_json.py $R/pmc_FETCH_SIZE_conv_h8.txt $R/pmc_WRITE_SIZE_conv_h8.txt ${P}_pmc_traffic_conv_h8.json > /dev/null
-python3 scripts/pmc_busy_table.py $R/pmc_mfma_busy_raw.txt ${P}_pmc_mfma_busy.json > ${P}_pmc_mfma_busy.txt
+# counters are attached to a build by the hash make_profiles.sh recorded when it measured (source_sha16.txt): both scripts refuse a
+# run whose hash is not the tree's
+python3 scripts/pmc_traffic_json.py $R/pmc_FETCH_SIZE_conv_h8.txt $R/pmc_WRITE_SIZE_conv_h8.txt ${P}_pmc_traffic_conv_h8.json $R/source_sha16.txt > /dev/null
+python3 scripts/pmc_busy_table.py $R/pmc_mfma_busy_raw.txt ${P}_pmc_mfma_busy.json $R/bench_n1_kernel_stats_by_grid.csv $R/source_sha16.txt > ${P}_pmc_mfma_busy.txt
 F=${P}_microbench.txt
 g() { if [ -f "$1" ]; then grep -v "amdgpu.ids" "$1"; else echo "(not collected in this run)"; fi; }
 echo "# scripts/bench_conv.py 64  (HIP events, 20 launches each, eager; n = 2B = 128 unless noted; every layer as the reference poses it -- the up blocks' shortcuts at full resolution, D.Block.1/2.Conv2 without their pool)" > $F; g $R/microbench_conv.txt >> $F

@@ -1,0 +1,36 @@
+"""The engine LEARNS: a short end-to-end training run of the production path (captured graphs, device random stream, host
+feeds) on the class-pattern synthetic images, scored by the nearest-pattern classifier (scripts/train_synthetic.py; the
+long runs behind DESIGN's training section are profiles/r05_train_*.json).  A synthetic stand-in for the reference's
+generated-label-accuracy curve (gan_resnet.py:424-455, 995-1005; README.md:75-80), NOT that curve."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+
+def test_generator_learns_the_conditional_distribution_in_bf16():
+    """3000 iterations (1 G + 5 D updates each) of rcgan at alpha = 1 (clean labels: the conditional GAN itself), bf16: the
+    generated-label accuracy leaves chance (0.1; the committed seeds reach 0.62-0.72 here and 0.9 by 4500 iterations), every
+    loss stays finite, and the critic's cost stays in the hinge's range.  ~20 s."""
+    import train_synthetic as TS
+    res = TS.run(algorithm="rcgan", dtype="bf16", iters=3000, eval_every=1000, alpha=1.0, batch=64, seed=0)
+    assert res["losses_finite"]
+    accs = [c["gen_label_acc"] for c in res["curve"]]
+    assert accs[-1] >= 0.25, accs
+    assert accs[-1] > accs[0], accs
+    assert all(0.0 <= c["d_cost"] <= 2.5 for c in res["curve"]), res["curve"]
+
+
+def test_noisy_labels_first_steps_are_finite_and_move_the_losses():
+    """300 iterations at the bench's noise level (alpha = 0.6), rcgan and biased: finite losses, critic cost below its
+    initial 2.0 (it has started to separate real from fake), generator cost finite -- the cheap guard that runs every round."""
+    import train_synthetic as TS
+    for alg in ("rcgan", "biased"):
+        res = TS.run(algorithm=alg, dtype="bf16", iters=300, eval_every=150, alpha=0.6, batch=64, seed=0, n_train=50000)
+        assert res["losses_finite"], alg
+        assert res["curve"][-1]["d_cost"] < 1.95, (alg, res["curve"])
+        assert np.isfinite(res["curve"][-1]["g_cost"])
