@@ -197,11 +197,19 @@ int rcgan_conv2d_fwd(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, co
  * for a forward-only pass (the critic steps' generator forwards) the normalised tensor never exists.  x: the batch norm's INPUT;
  * mean / rstd [segments][cin] from rcgan_bn_fwd_segments(..., y = NULL) (statistics only) or rcgan_bn_stats; gamma / beta [n_labels][cin];
  * labels [n] or NULL.  Same values as rcgan_bn_apply_* followed by rcgan_conv2d_fwd (the affine is evaluated in the same fp32
- * sequence and rounded to 16 bits at the same point).  rcgan_conv_bn_in_ok: the small-output image-end layers (G.Output: 256 -> 3). */
+ * sequence and rounded to 16 bits at the same point).  rcgan_conv_bn_in_ok: the small-output image-end layers (G.Output: 256 -> 3) and
+ * (round 5) the 3x3 / upsample-3x3 layers the halo-patch kernels take (conv_mfma8h.hip: 16- / 32-wide (low-resolution) images, enough
+ * 256-pixel tiles to fill the chip -- G.Block.2.Conv2, G.Block.3.Conv1 / Conv2 at the bench batches); d->flags may carry
+ * RCGAN_CONV_IN_UPSAMPLE2X (the norm sits in front of the upsample, as in UpsampleConv) and, for the _residual form,
+ * RCGAN_CONV_RESID_UPSAMPLE2X; not IN_RELU (the norm's own activation is `act`: RCGAN_ACT_NONE or RCGAN_ACT_RELU), ACCUMULATE, OUT_MEANPOOL2. */
 int rcgan_conv_bn_in_ok(const rcgan_conv_desc* d);
 int rcgan_conv2d_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
                         int segments, const int32_t* labels, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int act);
+/* ... + residual in the epilogue (rcgan_conv2d_fwd_residual's forms; halo-patch kernels only when residual != NULL). */
+int rcgan_conv2d_fwd_bn_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,
+                                 const void* residual, void* y, int segments, const int32_t* labels, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, int act);
 int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared,
                               const float* bias /* or NULL */, const void* residual /* or NULL */, void* y);
 /* dx = d(conv)/dx.  With IN_RELU, dx is masked by x>0 (x = the pre-activation input).  With

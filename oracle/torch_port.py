@@ -101,13 +101,14 @@ class _RoundBoth(torch.autograd.Function):
     way back (the product stores the gradient of a stored activation in the same format)."""
 
     @staticmethod
-    def forward(ctx, x, st):
-        ctx.st = st
+    def forward(ctx, x, st, gscale=1.0):
+        ctx.st, ctx.gscale = st, gscale
         return x.to(st).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(ctx.st).to(g.dtype), None
+        # (fp16: the product stores loss-scaled gradients -- unscaled, most of them would be fp16 denormals or zero)
+        return (g * ctx.gscale).to(ctx.st).to(g.dtype) / ctx.gscale, None, None
 
 
 class _RoundFwd(torch.autograd.Function):
@@ -132,8 +133,9 @@ class CifarTorch:
     those tensors rounded on the way back -- a storage-matched comparison for the 16-bit step tests: what is left between it and the
     device is fp32 summation order, not 45 layers of independent rounding noise."""
 
-    def __init__(self, P, U, dtype=torch.float64, storage=None):
+    def __init__(self, P, U, dtype=torch.float64, storage=None, grad_scale=1.0):
         self.storage = _STORAGE[storage] if storage else None
+        self.grad_scale = float(grad_scale)      # the product's loss scale (fp16 storage): stored gradients are rounded at that scale
         self.P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in P.items()}
         self.U = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in U.items()}
         self.U_new = {}
@@ -152,7 +154,7 @@ class CifarTorch:
         return F.relu(t)
 
     def q(self, x):
-        return _RoundBoth.apply(x, self.storage) if self.storage is not None else x
+        return _RoundBoth.apply(x, self.storage, self.grad_scale) if self.storage is not None else x
 
     def qw(self, w):
         return _RoundFwd.apply(w, self.storage) if self.storage is not None else w

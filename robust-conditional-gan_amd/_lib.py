@@ -122,6 +122,7 @@ SIGNATURES = {
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_bn_in_ok": (I, [DP]),
     "rcgan_conv2d_fwd_bn": (I, [P, DP, P, P, P, P, I, P, P, P, P, P, I]),
+    "rcgan_conv2d_fwd_bn_residual": (I, [P, DP, P, P, P, P, P, I, P, P, P, P, P, I]),
     "rcgan_conv_fused_pool_ok": (I, [DP]),
     "rcgan_conv_resid_up_ok": (I, [DP]),
     "rcgan_conv_wgrad_pool_ok": (I, [DP]),

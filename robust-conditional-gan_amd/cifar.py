@@ -227,11 +227,13 @@ def G_ResidualBlock(inputs, input_dim, output_dim, filter_size, name, labels, se
     else:
         shortcut = UpsampleConv(inputs, output_dim, 1, name + '.Shortcut', he_init=False)
     with variable_scope(name + '.N1'):
-        out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
+        # (_defer_apply: in forward-only passes the affine + ReLU go into the consuming convolution's staged input where its kernel can
+        # -- ops.BnPending: the halo-patch kernels and G.Output's; elsewhere, and under the tape, the norm is applied as before)
+        out = cond_batchnorm(name + '.N1', [0, 1, 2], inputs, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments, _defer_apply=True)
     # (_bn_next: a batch norm follows -- on the big grids its statistics come out of this convolution's epilogue, ops.conv2d)
     out = UpsampleConv(out, output_dim, filter_size, name + '.Conv1', _bn_next=True)
     with variable_scope(name + '.N2'):
-        out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments)
+        out = cond_batchnorm(name + '.N2', [0, 1, 2], out, labels=labels, n_labels=10, _act=L.ACT_RELU, _segments=segments, _defer_apply=True)
     if low:
         return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _residual=shortcut, _residual_up=True, _bn_next=True)
     return Conv2D(out, output_dim, output_dim, filter_size, 1, name + '.Conv2', _accumulate_into=shortcut)
@@ -458,6 +460,13 @@ class CifarRCGAN:
         # backward, fork / join) with nothing to hide, and under the link model of `bench.py --dp-stub 8 --dp-stub-gbps 200
         # --dp-stub-lat-us 40` it still lost: 6.94 ms against 6.70 ms (fp32 buckets) and 6.42 ms (bf16 buckets) -- DESIGN 5.
         self.dp_adam_in_graph = self.dp_active and not self.dynamic_ls and os.environ.get("RCGAN_DP_GRAPH_ADAM", "1") == "1"
+        # (round 5, measured and left off) single rank: the optimiser launch at the end of the step's captured graph too ({lr, t} from
+        # device memory, the rcgan_adam_tf launch the data-parallel steps capture).  As an eager launch BEHIND the graph it starts ~8 us
+        # after the graph's last kernel (the only gap of a critic step in the launch sequence), six times per iteration -- but the
+        # one-thread launch that writes {lr, t} in front of every graph costs more than the gap: same-box 5.50 / 5.52 / 5.52 ms eager
+        # against 5.55 / 5.56 / 5.55 captured.  RCGAN_GRAPH_ADAM=1 turns it on.
+        self.graph_adam = self.dp_adam_in_graph or (not self.dp_active and not self.dynamic_ls and
+                                                    os.environ.get("RCGAN_GRAPH_ADAM", "0") == "1")
         B = self.B
         f32, i32, act = L.F32, "i32", ctx.act_dtype
         P = ctx.persistent
@@ -810,7 +819,12 @@ class CifarRCGAN:
         """End of a step's backward pass: all-reduce the gradient slabs of the step's optimiser groups (ONE RCCL group) and -- static
         loss scale -- run the optimiser inside the same captured graph."""
         ctx = self.ctx
-        if not self.dp_active or not ctx.recording:   # (forward-only evaluations -- eval_d_cost -- exchange and update nothing)
+        if not ctx.recording:                         # (forward-only evaluations -- eval_d_cost -- exchange and update nothing)
+            return
+        if not self.dp_active:
+            if self.graph_adam:
+                for grp in groups:
+                    grp.adam_captured(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))
             return
         ptrs, counts = [], []
         for grp in groups:
@@ -835,7 +849,7 @@ class CifarRCGAN:
 
     def _optimise_or_publish(self, steps):
         """After a step's launch: the optimiser (eager) -- or, when it ran inside the step's graph, only its host-side bookkeeping."""
-        if self.dp_adam_in_graph:
+        if self.graph_adam:
             for grp, _ in steps:
                 grp.version += 1
             return
@@ -843,7 +857,7 @@ class CifarRCGAN:
 
     def _pre_step(self, steps):
         """In front of a step's launch: {lr, t} of the optimiser launches the step's graph contains."""
-        if self.dp_adam_in_graph:
+        if self.graph_adam:
             for grp, lr in steps:
                 grp.t += 1
                 grp.set_hyper_device(lr, grp.t)

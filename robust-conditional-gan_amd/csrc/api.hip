@@ -750,8 +750,38 @@ int rcgan_bn_stats_from_tiles(rcgan_ctx* ctx, const rcgan_conv_desc* d, int nseg
   return bn_tile_stats_finish_launch(ctx, tile_sums, d->cout, nseg, (int)((long)(d->n / nseg) * px / 256), 1, 0, count, eps, mean, rstd);
 }
 
+// the MfmaConvArgs of an ordinary forward launch (no pool fold), as rcgan_conv2d_fwd_residual builds them
+static void mfma_fwd_args(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, const void* residual,
+                          void* y, MfmaConvArgs& a) {
+  fill_mfma_args(d, a);
+  a.in = (const bf16_t*)x; a.wt = (const bf16_t*)prepared; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)y;
+  if (mfma_phase_filters(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
+  a.resid = (const bf16_t*)residual;
+  a.resid_up = (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X)) ? 1 : 0;
+  a.zero = ctx ? (const bf16_t*)ctx->zero_page : (const bf16_t*)d;       // (routing queries without a context: any non-null value)
+  a.Cin = d->cin; a.Cout = d->cout;
+  a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
+  a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
+  a.accumulate = (d->flags & RCGAN_CONV_ACCUMULATE) ? 1 : 0;
+}
+
+// the convolutions that can apply the batch norm in front of them to their staged input: the small-output image-end layers (G.Output)
+// and (round 5) whatever the routing hands to a halo-patch kernel -- plain 3x3 / upsample-3x3 layers on 16- / 32-wide (low-resolution)
+// images with enough tiles to fill the chip (G.Block.2.Conv2, G.Block.3.Conv1 / Conv2 at the bench batches)
+static int mfma_bn_in_route(const rcgan_conv_desc* d) {
+  if (!d || d->dtype != RCGAN_H16 || !mfma_eligible(d) || (d->flags & (RCGAN_CONV_OUT_MEANPOOL2 | RCGAN_CONV_IN_RELU | RCGAN_CONV_ACCUMULATE | RCGAN_CONV_FORCE_DIRECT)))
+    return 0;
+  if ((long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) >= (1L << 31)) return 0;
+  static const int on = [] { const char* e = getenv("RCGAN_BN_INTO_PATCH"); return e ? atoi(e) : 1; }();
+  if (!on) return 0;
+  MfmaConvArgs a;
+  // (the summed sub-pixel filters exist whenever mfma_phase_filters(d): a non-null stand-in is enough for the routing question)
+  mfma_fwd_args(nullptr, d, nullptr, d, nullptr, nullptr, nullptr, a);
+  return mfma_conv_bn_route(a);
+}
+
 int rcgan_conv_bn_in_ok(const rcgan_conv_desc* d) {
-  return (d && d->dtype == RCGAN_H16 && img_fwd_bn_ok(d)) ? 1 : 0;
+  return (d && d->dtype == RCGAN_H16 && (img_fwd_bn_ok(d) || mfma_bn_in_route(d))) ? 1 : 0;
 }
 
 int rcgan_conv2d_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, void* y,
@@ -761,8 +791,29 @@ int rcgan_conv2d_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x,
   int rc = check_desc(ctx, d);
   if (rc) return rc;
   RC_REQUIRE(ctx, x && prepared && y, "null argument");
-  if (!rcgan_conv_bn_in_ok(d)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "rcgan_conv2d_fwd_bn takes the small-output image-end layers (rcgan_conv_bn_in_ok)");
-  return img_fwd_bn(ctx, d, x, prepared, bias, y, mean, rstd, gamma, beta, labels, segments, act);
+  return rcgan_conv2d_fwd_bn_residual(ctx, d, x, prepared, bias, nullptr, y, segments, labels, gamma, beta, mean, rstd, act);
+}
+
+int rcgan_conv2d_fwd_bn_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias, const void* residual,
+                                 void* y, int segments, const int32_t* labels, const float* gamma, const float* beta, const float* mean,
+                                 const float* rstd, int act) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_REQUIRE(ctx, x && prepared && y && mean && rstd && gamma && beta, "null argument");
+  RC_REQUIRE(ctx, segments >= 1 && d->n % segments == 0, "segments must divide the batch");
+  if (!rcgan_conv_bn_in_ok(d)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "no kernel applies a batch norm to this convolution's staged input (rcgan_conv_bn_in_ok)");
+  if (residual == nullptr && img_fwd_bn_ok(d)) return img_fwd_bn(ctx, d, x, prepared, bias, y, mean, rstd, gamma, beta, labels, segments, act);
+  RC_REQUIRE(ctx, mfma_bn_in_route(d), "residual form needs a halo-patch kernel");
+  if (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X))
+    RC_REQUIRE(ctx, rcgan_conv_resid_up_ok(d), "half-resolution residual not available for this convolution (rcgan_conv_resid_up_ok)");
+  rc = ensure_selftest(ctx);
+  if (rc) return rc;
+  MfmaConvArgs a;
+  mfma_fwd_args(ctx, d, x, prepared, bias, residual, y, a);
+  a.bn_mean = mean; a.bn_rstd = rstd; a.bn_gamma = gamma; a.bn_beta = beta; a.bn_labels = labels;
+  a.bn_seg_samples = d->n / segments; a.bn_act = act;
+  return mfma_conv_launch(ctx, a);
 }
 
 int rcgan_conv2d_fwd_residual(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* prepared, const float* bias,

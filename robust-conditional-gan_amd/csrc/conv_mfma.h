@@ -30,6 +30,16 @@ struct MfmaConvArgs {
   // eight-wave 256 x 256 kernel only: per-tile column sums of the stored output and of its squares, [pixel tile][Cout][2] fp32 --
   // the batch-norm statistics of the layer behind this convolution come out of its epilogue (bn.hip: bn_tile_stats_finish_kernel)
   float* stats;
+  // halo-patch kernels (conv_mfma8h.hip) only: the input is act(cond_batch_norm(in)) -- the affine + ReLU of the batch norm IN FRONT of
+  // this convolution applied to the staged patch in LDS, once per staged element, the normalised tensor never written (forward-only
+  // passes: rcgan_conv2d_fwd_bn_residual).  mean / rstd [segments][Cin], gamma / beta [labels][Cin], labels [N] or null, bn_seg_samples
+  // images per segment; bn_act RCGAN_ACT_NONE or RCGAN_ACT_RELU.  bn_mean == nullptr: off.
+  const float* bn_mean = nullptr;
+  const float* bn_rstd = nullptr;
+  const float* bn_gamma = nullptr;
+  const float* bn_beta = nullptr;
+  const int32_t* bn_labels = nullptr;
+  int bn_seg_samples = 1, bn_act = 0;
 };
 
 struct MfmaWgradArgs {
@@ -118,6 +128,7 @@ bool mfma_conv8_halo_takes(const MfmaConvArgs& a);                             /
 int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 bool mfma_conv8n_halo_takes(const MfmaConvArgs& a);                            // ... its 256 x 128-tile sibling (Cout % 128 == 0)
 int mfma_conv8n_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
+int mfma_conv_bn_route(const MfmaConvArgs& a);                                 // would mfma_conv_launch run it on a halo-patch kernel?  1: 256 x 256, 2: 256 x 128, 0: no
 struct SmallGemmArgs;
 struct StepInputsArgs;
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm = nullptr,

@@ -1685,10 +1685,26 @@ bool mfma_conv_is_p8(const MfmaConvArgs& a) {
   return off32 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
 }
 
+// Would mfma_conv_launch run this (phase 0 on entry) forward launch on one of the halo-patch kernels -- the ones that can apply a
+// batch norm to their staged input (MfmaConvArgs::bn_*)?  1: 256 x 256 tile, 2: 256 x 128 tile, 0: no.  Mirrors the routing below.
+int mfma_conv_bn_route(const MfmaConvArgs& a) {
+  if (a.phase != 0 || a.Cin % 64 || a.zero == nullptr || a.stats || a.relu_in || a.Cin > 1024) return 0;
+  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200), p8n_min = env_int("RCGAN_P8N_MINBLK", 190);
+  static const int halo = env_int("RCGAN_P8_HALO", 1), halo_n = env_int("RCGAN_P8N_HALO", 1);
+  MfmaConvArgs b = a;
+  b.phase = mfma_conv8_phase_form(a) ? 1 : 0;
+  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);
+  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
+  if (a.Cout % 256 == 0 && off32 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return (halo && mfma_conv8_halo_takes(b)) ? 1 : 0;
+  if (a.Cout % 128 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 128) >= p8n_min) return (halo_n && mfma_conv8n_halo_takes(b)) ? 2 : 0;
+  return 0;
+}
+
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
   MfmaConvArgs a = a_in;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
+  if (a.bn_mean && !mfma_conv_bn_route(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "batch norm on the staged input needs a halo-patch kernel (rcgan_conv_bn_in_ok)");
   if (a.stats && !mfma_conv_is_p8(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel (rcgan_conv_stats_ok)");
   if (a.phase == 1) {
     // forced sub-pixel form (the data gradient of a ConvMeanPool: a.wt is not a usable fallback): same routing as below

@@ -103,17 +103,65 @@ __device__ __forceinline__ int xor64(int x) {
   return y;
 }
 
+// ---- batch norm + activation applied to the staged patch (MfmaConvArgs::bn_*; the forward-only generator passes) -------------------
+// Every thread transforms exactly the 16-byte slots its own LDS-DMA lanes deposited (once it knows they have landed): slot `pos` of
+// patch pixel q holds source channels ((pos ^ ((q >> 1) & 7)) * 8 .. + 7 of the chunk, and (q >> 1) & 7 = (wave & 1) * 4 + (lrow >> 1) for
+// every piece (wave + 8 j) of this thread -- the same eight channels each time.  inv = rstd * gamma[label], c0 = fma(-mean, inv, beta[label])
+// per channel sit in an LDS table built once per workgroup (a tile lies inside ONE image); the arithmetic and the 16-bit rounding are
+// bn.hip's apply pass (fma(x, inv, c0), ReLU, round to nearest even), so the convolution sees bit for bit what it would have read
+// from the written-out tensor.  Halo slots (zero padding of the NORMALISED tensor) are never touched.
+__device__ __forceinline__ void h8_bn_table(const MfmaConvArgs& a, float* tab /* [2][Cin] in LDS */, unsigned n_img, int tid) {
+  const int lab = a.bn_labels ? a.bn_labels[n_img] : 0, seg = (int)n_img / a.bn_seg_samples;
+  for (int c = tid; c < a.Cin; c += 512) {
+    const float inv = a.bn_rstd[seg * a.Cin + c] * a.bn_gamma[lab * a.Cin + c];
+    tab[c] = inv;
+    tab[a.Cin + c] = __fmaf_rn(-a.bn_mean[seg * a.Cin + c], inv, a.bn_beta[lab * a.Cin + c]);
+  }
+}
+// `keep`: per lane, false = a halo slot -- the zeros it holds are written back as they are (no branch: the straight-line form lets the
+// compiler schedule this work between the MFMAs of the segment it sits in)
+__device__ __forceinline__ void h8_bn_slot(unsigned char* slot, const float* tab, int cin, int ch0, float relu_floor, bool keep = true) {
+  const float4 i0 = *(const float4*)(tab + ch0), i1 = *(const float4*)(tab + ch0 + 4);
+  const float4 c0 = *(const float4*)(tab + cin + ch0), c1 = *(const float4*)(tab + cin + ch0 + 4);
+  const float inv8[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w}, c08[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  uint4 v = *(uint4*)slot;
+  uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lo = __fmaf_rn(h16_lo(w4[q]), inv8[2 * q], c08[2 * q]);
+    float hi = __fmaf_rn(h16_hi(w4[q]), inv8[2 * q + 1], c08[2 * q + 1]);
+    lo = fmaxf(lo, relu_floor); hi = fmaxf(hi, relu_floor);
+    w4[q] = keep ? pack_h16x2(lo, hi) : w4[q];
+  }
+  *(uint4*)slot = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+}
+
+// One straight-line segment = NPC transformed pieces + 16 MFMAs: the LDS reads first, then the vector ALU work dealt between the MFMAs
+// (which the compiler otherwise issues as one block behind it), the stores last.
+template <int NPC> __device__ __forceinline__ void h8_bn_interleave() {
+  __builtin_amdgcn_sched_group_barrier(0x100, 5 * NPC, 0);       // DS reads (table + slot)
+  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x002, 4 * NPC, 0);     // VALU
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
+  }
+  __builtin_amdgcn_sched_group_barrier(0x200, NPC, 0);           // DS writes
+}
+
 // PHM: the sub-pixel form of a 3x3 convolution behind the nearest 2x upsample (MfmaConvArgs::wph, conv_mfma8.hip): a tile is 256
 // pixels of ONE phase (ph, pw) over the LOW-resolution grid (W = its width), the reduction runs over the 2 x 2 taps (a, b) that read
 // low-resolution pixel (i + a - 1 + ph, j + b - 1 + pw) with the phase's summed filters -- patch rows / columns (a + ph, b + pw), so the
 // one (TR + 2) x (W + 2) patch serves every phase; the epilogue scatters the rows to output pixel (2 i + ph, 2 j + pw).  Four K-tiles per
 // chunk instead of nine: the patch pieces go out behind the filter bursts of the chunk's first two taps.
-template <int LW, bool RELU, bool PHM>
+template <int LW, bool RELU, bool PHM, bool BNIN = false>
 __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W = 1 << LW, TR = 256 >> LW;        // (low-resolution) image width, image rows per tile
   constexpr int NT = PHM ? 4 : 9;                   // taps = K-tiles per 64-channel chunk
-  constexpr int NTI = PHM ? 2 : 6;                  // ... of which the first NTI carry patch pieces (landed two K-tiles later: NTI <= NT - 2)
+  // ... of which the first NTI carry patch pieces (landed two K-tiles later: NTI <= NT - 2).  BNIN's sub-pixel form sends them all behind
+  // the first tap: the pieces are transformed under the MFMAs of the taps that follow their landing, and there are only two of those
+  constexpr int NTI = PHM ? (BNIN ? 1 : 2) : 6;
   constexpr int PC = W + H8_PC_EXTRA, PR = TR + 2;  // patch columns / rows
   constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;      // patch pixels, padded rows, DMA pieces (8 rows each)
   constexpr int PATCH = NROWS * 128;
@@ -188,6 +236,33 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // BNIN: the table behind the patches; the eight channels (of a chunk) this thread's deposits hold; its landed pieces of a patch
+  float* const bn_tab = (float*)(smem + P1OFF + PATCH);
+  const float bn_floor = a.bn_act == RCGAN_ACT_RELU ? 0.f : -INFINITY;
+  if (BNIN) {
+    h8_bn_table(a, bn_tab, n_img, tid);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (all eight wavefronts: the two groups are not yet a barrier apart)
+  }
+  auto bn_piece = [&](int j, int cnext) __attribute__((always_inline)) {
+    // (the thread's channel offset is recomputed from an opaque copy of the lane id where it is used: a loop-invariant of its own would be
+    // one more live register in a kernel that sits at its 256-register budget -- a spill's scratch load shares vmcnt with the LDS-DMA)
+    int ln;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+    const int bn_ch = ((ln & 7) ^ ((wave & 1) * 4 + (ln >> 4))) << 3;
+    if (poff[j] != ~0u) h8_bn_slot(smem + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024 + ln * 16, bn_tab, a.Cin, cnext * 64 + bn_ch, bn_floor);
+  };
+  // ... inside an MFMA segment: without a branch where every wavefront's piece j lies inside the patch (8 j + 7 < NP); a piece that was
+  // never fetched (all halo) holds zeros and keeps them
+  auto bn_piece_seg = [&](int j, int cnext) __attribute__((always_inline)) {
+    if (8 * j + 7 < NP) {
+      int ln;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+      const int bn_ch = ((ln & 7) ^ ((wave & 1) * 4 + (ln >> 4))) << 3;
+      h8_bn_slot(smem + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024 + ln * 16, bn_tab, a.Cin, cnext * 64 + bn_ch, bn_floor, poff[j] != ~0u);
+    } else if ((pmask >> j) & 1) {
+      bn_piece(j, cnext);
+    }
+  };
   auto issue_patch = [&](int j, int cnext) __attribute__((always_inline)) {      // piece j of this wavefront, patch of chunk cnext
     const bf16_t* base = a.in + cnext * 64;
     const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
@@ -243,9 +318,9 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) wfc[h][ks][g] = __builtin_bit_cast(bf16x8_t, lds_read16(ks ? wad1 : wad, h * H8_HALF + g * 16 * 128));
   };
-  auto mma = [&](int ph, int ch) __attribute__((always_inline)) {
+  auto mma = [&](int ph, int ch, bool prio = true) __attribute__((always_inline)) {
     if (H8_ABLATE & 16) return;
-    __builtin_amdgcn_s_setprio(1);
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -253,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
           acc[ch * 2 + g][ph * 4 + f] = mfma16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f]);
-    __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
   stamp(1);        // (scripts/exp_p8_timeline.py: segment 0 = patch sources, filter sources, fragment addresses)
@@ -265,6 +340,11 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   issue_w(0, 0, 0); issue_w(1, 0, 0);
   issue_w(0, 0, 1); issue_w(1, 0, 1);
   wait_vm<4>();
+  if (BNIN) {                                       // the first chunk's patch: all of this thread's pieces, now
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j)
+      if ((pmask >> j) & 1) bn_piece(j, 0);
+  }
   if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
   wg_barrier();
   stamp(2);
@@ -297,7 +377,17 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();                                 // a_1
-      mma(0, 0);
+      if (BNIN && PHM && tap == 3) {   // (see phase 4: the second half of the next chunk's pieces)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 3; j < MAXP; ++j) bn_piece_seg(j, c + 1);
+        mma(0, 0, false);
+        h8_bn_interleave<MAXP - 3>();
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        mma(0, 0);
+      }
       raw_barrier();                                 // b_1
       // phase 2: (P0, C1)
       load_w(1);
@@ -328,7 +418,23 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       else if (more1) wait_vm<2>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      mma(1, 0);
+      // BNIN: everything issued before C0 of the next tile has landed (the wait above) -- the next chunk's pieces that went out two taps
+      // ago.  They are transformed HERE, in the segment whose 16 MFMAs give the vector ALU work and the LDS round trips something to hide
+      // under (in front of the barrier the same work stalled all eight wavefronts: +11 % / +23 % on the plain / sub-pixel launches),
+      // complete (lgkmcnt) in front of the segment's closing barrier and first read a chunk -- at least six barriers -- later.  Plain
+      // form: the piece of tap - 2; sub-pixel form (all pieces behind tap 0): three here at tap 2, the rest under tap 3's first segment.
+      const bool bn_here = BNIN && (PHM ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
+      if (bn_here) {              // (also in the last chunk, on the dead patch buffer: no branch in the segment)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = PHM ? 0 : tap - 2; j < (PHM ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
+        mma(1, 0, false);
+        h8_bn_interleave<PHM ? 3 : 1>();
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        mma(1, 0);
+      }
       raw_barrier();
       wad ^= WBUF;                                  // the other filter buffer
     }
@@ -369,12 +475,12 @@ constexpr int H8N_WTILE = 128 * 128;                 // one filter K-tile
 constexpr int h8n_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8N_WTILE; }
 }  // namespace
 
-template <int LW, bool RELU, bool PHM>
+template <int LW, bool RELU, bool PHM, bool BNIN = false>
 __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W = 1 << LW, TR = 256 >> LW;
   constexpr int NT = PHM ? 4 : 9;
-  constexpr int NTI = PHM ? 2 : 6;                  // taps of a chunk that carry patch pieces (<= NT - 2)
+  constexpr int NTI = PHM ? (BNIN ? 1 : 2) : 6;     // taps of a chunk that carry patch pieces (<= NT - 2; BNIN: as in conv_mfma_h8_kernel)
   constexpr int PC = W + H8_PC_EXTRA, PR = TR + 2;
   constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;
   constexpr int PATCH = NROWS * 128;
@@ -432,6 +538,22 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  float* const bn_tab = (float*)(smem + P1OFF + PATCH);            // BNIN: as in conv_mfma_h8_kernel
+  const int bn_ch = (pos ^ ((wave & 1) * 4 + (lrow >> 1))) << 3;
+  const float bn_floor = a.bn_act == RCGAN_ACT_RELU ? 0.f : -INFINITY;
+  if (BNIN) {
+    h8_bn_table(a, bn_tab, n_img, tid);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  auto bn_piece = [&](int j, int cnext) __attribute__((always_inline)) {
+    if (poff[j] != ~0u) h8_bn_slot(smem + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024 + lane * 16, bn_tab, a.Cin, cnext * 64 + bn_ch, bn_floor);
+  };
+  auto bn_piece_seg = [&](int j, int cnext) __attribute__((always_inline)) {      // inside an MFMA segment (conv_mfma_h8_kernel)
+    if (8 * j + 7 < NP)
+      h8_bn_slot(smem + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024 + lane * 16, bn_tab, a.Cin, cnext * 64 + bn_ch, bn_floor, poff[j] != ~0u);
+    else if ((pmask >> j) & 1)
+      bn_piece(j, cnext);
+  };
   auto issue_patch = [&](int j, int cnext) __attribute__((always_inline)) {
     const bf16_t* base = a.in + cnext * 64;
     const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
@@ -475,13 +597,13 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) wf[g] = __builtin_bit_cast(bf16x8_t, lds_read16(ad, g * 16 * 128));
   };
-  auto mma = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(1);
+  auto mma = [&](bool prio = true) __attribute__((always_inline)) {
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[g][f] = mfma16(wf[g], xf[f], acc[g][f]);
-    __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
@@ -492,6 +614,11 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   issue_w(0, 0);
   issue_w(0, 1);
   wait_vm<2>();                                     // the patch and K-tile 0
+  if (BNIN) {
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j)
+      if ((pmask >> j) & 1) bn_piece(j, 0);
+  }
   if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
   wg_barrier();
 
@@ -518,7 +645,17 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       load_w(wcur, 0);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      mma();
+      if (BNIN && PHM && tap == 3) {   // (see phase B: the second half of the next chunk's pieces)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 3; j < MAXP; ++j) bn_piece_seg(j, c + 1);
+        mma(false);
+        h8_bn_interleave<MAXP - 3>();
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        mma();
+      }
       raw_barrier();
       // phase B: the second 32; the filters of K-tile t + 2 (its slot was last read in K-tile t - 2) and one patch piece behind them
       load_x(kh, kw, 1);
@@ -534,7 +671,20 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       else if (more1) wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      mma();
+      // BNIN: the next chunk's pieces that went out two taps ago have landed (the wait above): transformed under this segment's MFMAs
+      // (conv_mfma_h8_kernel, phase 4)
+      const bool bn_here = BNIN && (PHM ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
+      if (bn_here) {              // (also in the last chunk, on the dead patch buffer: no branch in the segment)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = PHM ? 0 : tap - 2; j < (PHM ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
+        mma(false);
+        h8_bn_interleave<PHM ? 3 : 1>();
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        mma();
+      }
       raw_barrier();
       slot = (slot + 1) & 3;
     }
@@ -559,18 +709,19 @@ bool mfma_conv8_halo_takes(const MfmaConvArgs& a) {
   return false;
 }
 
-template <int LW, bool RELU, bool PHM>
+#define H8_BN_MAX_CIN 1024       /* the batch-norm table [2][Cin] fp32 sits behind the patches: 150 KiB + 8 KiB <= 160 KiB */
+template <int LW, bool RELU, bool PHM, bool BNIN = false>
 static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  const size_t lds = h8_lds_bytes(LW);
+  const size_t lds = h8_lds_bytes(LW) + (BNIN ? 2 * H8_BN_MAX_CIN * sizeof(float) : 0);
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8_kernel<LW, RELU, PHM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8_kernel<LW, RELU, PHM, BNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU, PHM>), grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU, PHM, BNIN>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -579,6 +730,12 @@ static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   MfmaConvArgs b = a;
   b.stamps = (unsigned long long*)ctx->dbg_stamps;
+  if (a.bn_mean) {        // batch norm + activation on the staged patch (its own activation: no input-ReLU flavour)
+    if (a.relu_in || a.Cin > H8_BN_MAX_CIN || (a.bn_act != RCGAN_ACT_NONE && a.bn_act != RCGAN_ACT_RELU))
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "batch norm on the staged patch: no input ReLU, Cin <= %d, activation none / ReLU", H8_BN_MAX_CIN);
+    if (a.phase == 1) return a.lw == 6 ? launch8h<5, false, true, true>(ctx, b) : launch8h<4, false, true, true>(ctx, b);
+    return a.lw == 5 ? launch8h<5, false, false, true>(ctx, b) : launch8h<4, false, false, true>(ctx, b);
+  }
   if (a.phase == 1) {
     if (a.lw == 6) return a.relu_in ? launch8h<5, true, true>(ctx, b) : launch8h<5, false, true>(ctx, b);
     return a.relu_in ? launch8h<4, true, true>(ctx, b) : launch8h<4, false, true>(ctx, b);
@@ -596,24 +753,30 @@ bool mfma_conv8n_halo_takes(const MfmaConvArgs& a) {
   return false;
 }
 
-template <int LW, bool RELU, bool PHM>
+template <int LW, bool RELU, bool PHM, bool BNIN = false>
 static int launch8hn(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
-  const size_t lds = h8n_lds_bytes(LW);
+  const size_t lds = h8n_lds_bytes(LW) + (BNIN ? 2 * H8_BN_MAX_CIN * sizeof(float) : 0);
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8n_kernel<LW, RELU, PHM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, 256), a.Cout / 128);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM>), grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
 
 int mfma_conv8n_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
+  if (a.bn_mean) {
+    if (a.relu_in || a.Cin > H8_BN_MAX_CIN || (a.bn_act != RCGAN_ACT_NONE && a.bn_act != RCGAN_ACT_RELU))
+      RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "batch norm on the staged patch: no input ReLU, Cin <= %d, activation none / ReLU", H8_BN_MAX_CIN);
+    if (a.phase == 1) return a.lw == 6 ? launch8hn<5, false, true, true>(ctx, a) : launch8hn<4, false, true, true>(ctx, a);
+    return a.lw == 5 ? launch8hn<5, false, false, true>(ctx, a) : launch8hn<4, false, false, true>(ctx, a);
+  }
   if (a.phase == 1) {
     if (a.lw == 6) return a.relu_in ? launch8hn<5, true, true>(ctx, a) : launch8hn<5, false, true>(ctx, a);
     return a.relu_in ? launch8hn<4, true, true>(ctx, a) : launch8hn<4, false, true>(ctx, a);

@@ -261,12 +261,19 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
         pend = x
         n, hs, ws_, cin = pend.shape
         cout = weight.param.shape[-1]
-        bdesc = L.ConvDesc(n, hs, ws_, cin, cout, k, k, stride, pend.dtype, 0)
-        if (not in_up and not in_relu and accumulate_into is None and residual is None and not force_direct and not ctx.recording
-                and pend.act in (L.ACT_NONE, L.ACT_RELU) and ctx.lib.rcgan_conv_bn_in_ok(C.byref(bdesc))):
-            y = ctx.empty((n, hs, ws_, cout), pend.dtype)
-            ctx.check(ctx.lib.rcgan_conv2d_fwd_bn(ctx.h, C.byref(bdesc), _p(pend.x), _p(weight.prepared(bdesc)), _p(bias), _p(y), pend.segments,
-                                                  _p(pend.labels), _p(pend.gamma), _p(pend.beta), _p(pend.mean), _p(pend.rstd), pend.act))
+        # the convolution as the plain path below would pose it (upsample folded into the load, half-resolution residual in the epilogue)
+        bh, bw = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
+        bflags = (L.CONV_IN_UPSAMPLE2X if in_up else 0) | (L.CONV_RESID_UPSAMPLE2X if (residual is not None and residual_up) else 0)
+        bdesc = L.ConvDesc(n, bh, bw, cin, cout, k, k, stride, pend.dtype, bflags)
+        if (not in_relu and accumulate_into is None and not force_direct and not ctx.recording and stride == 1
+                and pend.act in (L.ACT_NONE, L.ACT_RELU) and ctx.lib.rcgan_conv_bn_in_ok(C.byref(bdesc))
+                and (residual is None or (residual.shape == ((n, bh // 2, bw // 2, cout) if residual_up else (n, bh, bw, cout))
+                                          and (not residual_up or ctx.lib.rcgan_conv_resid_up_ok(C.byref(bdesc)))))):
+            y = ctx.empty((n, bh, bw, cout), pend.dtype)
+            pdesc = L.ConvDesc(n, bh, bw, cin, cout, k, k, stride, pend.dtype, L.CONV_IN_UPSAMPLE2X if in_up else 0)
+            ctx.check(ctx.lib.rcgan_conv2d_fwd_bn_residual(ctx.h, C.byref(bdesc), _p(pend.x), _p(weight.prepared(pdesc)), _p(bias), _p(residual), _p(y),
+                                                           pend.segments, _p(pend.labels), _p(pend.gamma), _p(pend.beta), _p(pend.mean),
+                                                           _p(pend.rstd), pend.act))
             return y
         x = pend.materialize()
     n, hs, ws_, cin = x.shape

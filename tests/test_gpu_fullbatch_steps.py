@@ -127,14 +127,14 @@ def _grad_rows(tag, got, ref, tol, cos_min, B, special=None):
     return rows, bad
 
 
-def _torch_grads(P, U, cfg, batch, which, hinge_mask=None, delta=0.05, f64=False, storage=None):
+def _torch_grads(P, U, cfg, batch, which, hinge_mask=None, delta=0.05, f64=False, storage=None, grad_scale=1.0):
     """Gradients of disc_cost / gen_cost at (P, U) by the PyTorch-CPU restatement in fp32.  hinge_mask: the DEVICE's hinge
     activity pattern {term: bool array}, imposed on the oracle's hinge terms; a sample whose own pattern differs must sit within
     ``delta`` of the hinge in the oracle too (16-bit rounding of a logit), anything else is a real disagreement.  Returns the
     number of such flipped samples as well."""
     import torch
     from oracle.torch_port import CifarTorch
-    net = CifarTorch(P, U, torch.float64 if f64 else torch.float32, storage=storage)
+    net = CifarTorch(P, U, torch.float64 if f64 else torch.float32, storage=storage, grad_scale=grad_scale)
     net.hinge_mask = hinge_mask
     flips = 0
     if which == "D":
@@ -217,6 +217,8 @@ def _cifar_production_iteration(alg, perm, perm_type, B, dtype, d_tol, g_tol, g_
     sh = _Shadow(m)
     lr = 2e-4
     tag0 = "%s B=%d %s" % (alg, B, dtype)
+    # the loss scale the product's stored gradients carry (fp16 build; 1 otherwise): the storage-matched oracle rounds at that scale
+    gscale = (m.loss_scale_state()["scale"] if m.dynamic_ls else m.loss_scale) if dtype == "f16" else 1.0
     try:
         for it in range(iterations):
             # ---------------------------------------------------------------- N_CRITIC critic steps
@@ -251,7 +253,7 @@ def _cifar_production_iteration(alg, perm, perm_type, B, dtype, d_tol, g_tol, g_
                 _report(tag, dict(loss=(d_loss, cost), adam_max_abs=worst, hinge_flips=flips, grads=rows))
                 assert not bad, "\n".join(bad)
                 if stored is not None:
-                    cost_q, ref_q, _, flips_q = _torch_grads(P, Uo, cfg, batch, "D", pattern, delta, storage=dtype)
+                    cost_q, ref_q, _, flips_q = _torch_grads(P, Uo, cfg, batch, "D", pattern, delta, storage=dtype, grad_scale=gscale)
                     rows_q, bad_q = _grad_rows(tag + " (storage-matched)", got, ref_q, stored[0], stored[2], B)
                     _report(tag + " storage-matched", dict(loss=(d_loss, cost_q), hinge_flips=flips_q, grads=rows_q))
                     assert abs(d_loss - cost_q) <= loss_tol * max(1.0, abs(cost_q)), (tag, d_loss, cost_q)
@@ -282,7 +284,7 @@ def _cifar_production_iteration(alg, perm, perm_type, B, dtype, d_tol, g_tol, g_
             _report(tag, dict(loss=(g_loss, cost), adam_max_abs=worst, grads=rows))
             assert not bad, "\n".join(bad)
             if stored is not None:
-                cost_q, ref_q, _, _ = _torch_grads(P, Uo, cfg, dict(z=z_G, **gb), "G", storage=dtype)
+                cost_q, ref_q, _, _ = _torch_grads(P, Uo, cfg, dict(z=z_G, **gb), "G", storage=dtype, grad_scale=gscale)
                 rows_q, bad_q = _grad_rows(tag + " (storage-matched)", got, ref_q, stored[1], stored[2], 2 * B)
                 _report(tag + " storage-matched", dict(loss=(g_loss, cost_q), grads=rows_q))
                 assert abs(g_loss - cost_q) <= loss_tol * max(1.0, abs(cost_q)), (tag, g_loss, cost_q)
@@ -293,6 +295,14 @@ def _cifar_production_iteration(alg, perm, perm_type, B, dtype, d_tol, g_tol, g_
         assert "d_fakes" in m._graphs and "g" in m._graphs and "gf" in m._graphs
     finally:
         m.ctx.close()
+
+
+# (round 5) the storage-matched second comparison at configs[3] and configs[4] too: (critic bound, generator bound, cosine), ONE bound for
+# every tensor of a step, G.Input/W included
+# measured (profiles/r05_parity_report.jsonl): cfg4 critic steps <= 7.5e-3, generator step 5.6e-2 (G.Input/W; cosine 0.9984);
+# cfg5 (fp16, stored gradients rounded at the loss scale 1024) critic steps <= 1.1e-3, generator step 1.7e-2 (G.Input/W; cosine 0.99985)
+STORED_CFG4 = (1.2e-2, 8e-2, 0.997)
+STORED_CFG5 = (2.5e-3, 2.5e-2, 0.9996)
 
 
 def test_cfg3_rcgan_b64_bf16_production_iteration():
@@ -314,12 +324,14 @@ def test_cfg3_rcgan_b64_fp32_production_iteration():
 def test_cfg4_rcganu_b64_bf16_production_iteration():
     """BASELINE configs[3], one rank's shard: RCGAN-U (learned confusion matrix, permutation regulariser, confuse_init as
     run_rcganu.sh), per-GPU batch 64, bf16."""
-    _cifar_production_iteration("rcgan-u", True, "linear", 64, "bf16", d_tol=3e-2, g_tol=1.4e-1, g_in_tol=1.9e-1, loss_tol=5e-3)
+    _cifar_production_iteration("rcgan-u", True, "linear", 64, "bf16", d_tol=3e-2, g_tol=1.4e-1, g_in_tol=1.9e-1, loss_tol=5e-3,
+                                stored=STORED_CFG4)
 
 
 def test_cfg5_rcgan_b512_f16_production_iteration():
     """BASELINE configs[4], one rank's shard: per-GPU batch 512, fp16 activations (loss scale 1024)."""
-    _cifar_production_iteration("rcgan", False, "linear", 512, "f16", d_tol=6e-3, g_tol=2e-2, g_in_tol=6e-2, loss_tol=1e-3, delta=0.02)
+    _cifar_production_iteration("rcgan", False, "linear", 512, "f16", d_tol=6e-3, g_tol=2e-2, g_in_tol=6e-2, loss_tol=1e-3, delta=0.02,
+                                stored=STORED_CFG5)
 
 
 @pytest.mark.parametrize("alg", ["biased", "unbiased"])

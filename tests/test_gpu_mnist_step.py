@@ -27,8 +27,9 @@ KINK_EPS = 4e-6      # |rectifier input| <= this x the tensor's scale: the branc
 def _misfits(got, grads, grads32):
     """Tensors of the device's gradient that are not the oracle's: norm-relative error > 1e-2 (or 4x the float32 oracle's own
     distance from float64), largest entry off by > 1e-1 of the tensor's scale, or -- for tensors that are not noise-floor small --
-    a projection <got, ref> / <ref, ref> more than 1.5e-2 from 1 (a dropped or mis-scaled term).  -> [(name, message)]"""
-    bad = []
+    a projection <got, ref> / <ref, ref> more than 1.5e-2 from 1 (a dropped or mis-scaled term).  -> ([(name, message)], score):
+    score = the worst tensor's largest ratio measured / bound (<= 1: everything fits)."""
+    bad, score = [], 0.0
     gmax = max(float(np.abs(g).max()) for g in grads.values())
     for k, gref in grads.items():
         a = got[k]
@@ -39,9 +40,11 @@ def _misfits(got, grads, grads32):
         own = float(np.linalg.norm(grads32[k] - gref)) / max(float(np.linalg.norm(gref)), scale)
         rr = float((gref.astype(np.float64) ** 2).sum())
         proj = float((a.astype(np.float64) * gref).sum()) / rr if rr > 0 and float(np.abs(gref).max()) >= 1e-3 * gmax else 1.0
-        if not (nrm <= max(1e-2, 4 * own) and err <= 1e-1 and abs(proj - 1.0) <= max(1.5e-2, 4 * own)):
+        sc = max(nrm / max(1e-2, 4 * own), err / 1e-1, abs(proj - 1.0) / max(1.5e-2, 4 * own))
+        score = max(score, sc)
+        if sc > 1.0:
             bad.append((k, "%s: norm-rel %.3e max %.3e of scale %.3e, projection %.4f (fp32 oracle norm-rel %.3e)" % (k, nrm, err, scale, proj, own)))
-    return bad
+    return bad, score
 
 
 def _cmp(tag, got, oracle, grads32):
@@ -50,22 +53,26 @@ def _cmp(tag, got, oracle, grads32):
     oracle's, and at B = 8 ONE such unit moves whole tensors by a few per cent (round 4: "unbiased", second generator run, 3.1e-2
     on g_h0_lin / g_h1_lin with the split-reduction GEMMs on AND off).  Instead of a wider bound for every tensor (round 4 accepted
     6e-2 anywhere), the oracle lists its undecidable units (|input| <= KINK_EPS of the tensor's scale) and the device's gradient has to
-    be the oracle's for SOME assignment of them -- every tensor of the run at the strict bound under ONE assignment, found greedily."""
+    be the oracle's for SOME assignment of them -- every tensor of the run at the strict bounds under ONE assignment, found greedily
+    (smallest |input| first, a flip is kept when it lowers the worst measured / bound ratio; two passes)."""
     from oracle.tape import Kinks
     try:
         Kinks.reset(eps=KINK_EPS)
-        bad = _misfits(got, oracle(), grads32)
+        bad, score = _misfits(got, oracle(), grads32)
         found = list(Kinks.found)
         flips = []
         if bad:
-            assert 0 < len(found) <= 12, "%s: %s and %d undecidable rectifier inputs" % (tag, bad[0][1], len(found))
-            for i in range(len(found)):
-                Kinks.reset(eps=KINK_EPS, flip=flips + [i])
-                trial = _misfits(got, oracle(), grads32)
-                if len(trial) < len(bad):
-                    flips, bad = flips + [i], trial
-                if not bad:
-                    break
+            assert 0 < len(found) <= 16, "%s: %s and %d undecidable rectifier inputs" % (tag, bad[0][1], len(found))
+            order = sorted(range(len(found)), key=lambda i: abs(found[i][2]))
+            for _ in range(2):
+                for i in order:
+                    if not bad:
+                        break
+                    trial_flips = [f for f in flips if f != i] if i in flips else flips + [i]
+                    Kinks.reset(eps=KINK_EPS, flip=trial_flips)
+                    trial, tscore = _misfits(got, oracle(), grads32)
+                    if tscore < score:
+                        flips, bad, score = trial_flips, trial, tscore
         assert not bad, "%s (undecidable units %s, flipped %s): %s" % (tag, found, flips, "; ".join(m for _, m in bad))
         return flips
     finally:

@@ -644,6 +644,59 @@ def test_batch_norm_inside_the_image_end_convolution(dev, n, segments, hw):
     assert np.array_equal(outs[0], outs[1])
 
 
+# (n, h, w of the convolution's OUTPUT, cin, cout, upsample-folded, residual: 0 none / 1 same grid / 2 half resolution, segments, act)
+BN_PATCH_CASES = [
+    (60, 32, 32, 256, 256, False, 2, 5, "relu"),     # G.Block.3.Conv2's form: plain 3x3, 240 tiles of the 256 x 256 kernel, four chunks, half-resolution residual, 5 segments
+    (52, 32, 32, 128, 256, True, 0, 1, "relu"),      # G.Block.3.Conv1's: sub-pixel form over 16 x 16 low-resolution images, two chunks, one image per tile
+    (100, 16, 16, 256, 256, False, 1, 5, "relu"),    # G.Block.2.Conv2's: the 256 x 128 kernel, four chunks, full-resolution residual
+    (50, 32, 32, 64, 128, False, 0, 2, "none"),      # one chunk (the whole patch transformed in the prologue), no activation, Cout = 128
+    (13, 64, 64, 128, 128, True, 0, 1, "relu"),      # the 256 x 128 kernel's sub-pixel form over 32-wide low-resolution images
+]
+
+
+@pytest.mark.parametrize("case", BN_PATCH_CASES)
+def test_batch_norm_inside_the_patch_convolution(dev, case):
+    """conv(act(cond_batch_norm(x))) with the norm's affine + activation applied to the halo-patch kernels' staged input
+    (rcgan_conv2d_fwd_bn_residual; forward-only passes: the critic steps' generator forwards, normalization.py:47-57 +
+    gan_resnet.py:304-326): bit-identical to the written-out norm followed by the plain convolution."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("the halo-patch kernels run on 16-bit activations")
+    n, h, w, cin, cout, up, resid, segments, actname = case
+    act = L.ACT_RELU if actname == "relu" else L.ACT_NONE
+    rs = np.random.RandomState(n + cin + segments)
+    nl = 10
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = _prep(rs.randn(n, hs, ws, cin) * 1.5 + 0.3, mode)
+    gamma = (1.0 + 0.2 * rs.randn(nl, cin)).astype(np.float32); beta = (0.2 * rs.randn(nl, cin)).astype(np.float32)
+    lab = rs.randint(nl, size=n).astype(np.int32)
+    wv = (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32); bv = (0.1 * rs.randn(cout)).astype(np.float32)
+    r = None
+    if resid:
+        r = _prep(rs.randn(n, h // 2, w // 2, cout) if resid == 2 else rs.randn(n, h, w, cout), mode)
+    outs = []
+    for defer in (True, False):
+        ctx.new_step()
+        rec, ctx.recording = ctx.recording, False
+        try:
+            xd = ctx.upload(x)
+            pg, pb2, pw, pbias = FakeParam(ctx, gamma), FakeParam(ctx, beta), FakeParam(ctx, wv), FakeParam(ctx, bv)
+            W = O.Weight(ctx, pw.t, None)
+            hh = O.batch_norm_act(ctx, xd, pg.t, pb2.t, act=act, labels=ctx.upload(lab), n_labels=nl, segments=segments, defer_apply=defer)
+            assert isinstance(hh, O.BnPending) == defer
+            if defer:       # the fused route is the one under test
+                bflags = (L.CONV_IN_UPSAMPLE2X if up else 0) | (L.CONV_RESID_UPSAMPLE2X if resid == 2 else 0)
+                assert ctx.lib.rcgan_conv_bn_in_ok(C.byref(L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, xd.dtype, bflags)))
+            y = O.conv2d(ctx, hh, W, pbias.t, 3, in_up=up, residual=ctx.upload(r) if resid else None, residual_up=resid == 2)
+            outs.append(ctx.download(y).copy())
+        finally:
+            ctx.recording = rec
+    assert outs[0].shape == (n, h, w, cout) and np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("m,k,n", [(128, 128, 16384), (40, 64, 1024)])
 def test_wide_dense_layer_on_the_matrix_cores(dev, m, k, n, monkeypatch):
     """ops.linear routes a wide dense layer on 16-bit activations (G.Input: 128 -> 16384) through the 1x1-convolution kernels with its
