@@ -475,12 +475,29 @@ constexpr int H8N_WTILE = 128 * 128;                 // one filter K-tile
 constexpr int h8n_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8N_WTILE; }
 }  // namespace
 
-template <int LW, bool RELU, bool PHM, bool BNIN = false>
+// NPASS = 2 (sub-pixel form, Cin <= 128: both chunks' patches stay resident): one workgroup walks the phases (ph, 0) and (ph, 1) of its
+// 256 low-resolution pixels back to back on the SAME staged patches -- a second K loop with the other phase's filters and window offset
+// behind the first one's epilogue; its filters are prefetched through the ring as if the two loops were one.  Half the workgroups, one
+// prologue and one patch fetch per pair: D.Block.1.Conv2's pooled data gradient (8 K-tiles per phase) was 2 rounds of 512 workgroups
+// whose prologue + epilogue outweighed their K loop.
+// GATHER (MfmaConvArgs::phase == 2): the stride-2 16-tap forms -- ConvMeanPool forward (one 4x4 stride-2 convolution with summed filters)
+// and the data gradient of the upsample-3x3 sub-pixel form -- over their output's LOW-resolution grid.  Output pixel (i, j) reads
+// full-resolution pixels (2i + u - 1, 2j + v - 1), u, v = 0..3: split by the parity (pa, pb) of the source pixel these are four 2x2
+// convolutions over the four PARITY PLANES of the input (plane pixel (r, q) = full-resolution pixel (2r + pa, 2q + pb); tap u = 2a + 1 - pa
+// reads plane row i + a - pa), each exactly the sub-pixel form's geometry with (ph, pw) = (1 - pa, 1 - pb) -- all four accumulate into the
+// same tile.  So: the chunk sequence runs over (plane, 64 channels), a patch is the plane's (TR + 2) x (W + 2) window fetched with pixel
+// stride 2, the fragment bases move with the plane, and a K-tile's filter columns are (u * 4 + v) * Cin + c * 64 of the gather layout.
+// The tile-per-tap kernel these ran on re-fetched the pixel tile for each of the 16 taps (D.Block.1.Conv2 forward: 20 % MFMA busy on 64 x 64
+// tiles; G.Block.3.Conv1's data gradient: 35 %).
+template <int LW, bool RELU, bool PHM, bool BNIN = false, int NPASS = 1, bool GATHER = false>
 __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
+  static_assert(NPASS == 1 || (NPASS == 2 && PHM && !BNIN), "two passes: the sub-pixel form without a batch norm on the patch");
+  static_assert(!GATHER || (!PHM && !BNIN && NPASS == 1), "the gather form is its own mode");
+  constexpr bool SUBP = PHM || GATHER;              // 2 x 2 taps per chunk, (low-resolution / plane) grid of W x HI pixels per image
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W = 1 << LW, TR = 256 >> LW;
-  constexpr int NT = PHM ? 4 : 9;
-  constexpr int NTI = PHM ? (BNIN ? 1 : 2) : 6;     // taps of a chunk that carry patch pieces (<= NT - 2; BNIN: as in conv_mfma_h8_kernel)
+  constexpr int NT = SUBP ? 4 : 9;
+  constexpr int NTI = SUBP ? (BNIN ? 1 : 2) : 6;    // taps of a chunk that carry patch pieces (<= NT - 2; BNIN: as in conv_mfma_h8_kernel)
   constexpr int PC = W + H8_PC_EXTRA, PR = TR + 2;
   constexpr int NPX = PR * PC, NROWS = h8_patch_rows(LW), NP = NROWS / 8;
   constexpr int PATCH = NROWS * 128;
@@ -496,16 +513,17 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD
   unsigned mt = blockIdx.x;
   if ((gridDim.x & 7) == 0) mt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const long m0 = (long)mt * 256;
   const int co0 = blockIdx.y * 128;
-  const int K = NT * a.Cin;
+  const int K = (GATHER ? 16 : NT) * a.Cin;
   const int lrow = lane >> 3, pos = lane & 7;
-  const int HI = PHM ? (a.H >> 1) : a.H, lhi = PHM ? a.lh - 1 : a.lh;
+  const int HI = SUBP ? (a.H >> 1) : a.H, lhi = SUBP ? a.lh - 1 : a.lh;
   const long Mph = a.M >> 2;
-  const int tph = PHM ? (int)(m0 / Mph) : 0, ph = tph >> 1, pw = tph & 1;
-  const long mbase = PHM ? (long)tph * Mph : 0;
-  const unsigned ms0 = (unsigned)(m0 - mbase);
-  const bf16_t* const wbase = PHM ? a.wph + (long)tph * a.Cout * K : a.wt;
+  // one pass: tile mt = 256 pixels of phase tph; two passes: tile mt = 256 low-resolution pixels of row phase ph, column phases 0 then 1
+  const unsigned tiles_ph = (unsigned)(Mph >> 8);
+  const int tph0 = !PHM ? 0 : (NPASS == 2 ? 2 * (int)(mt / tiles_ph) : (int)(((long)mt * 256) / Mph));
+  const int ph = tph0 >> 1;
+  const unsigned ms0 = !PHM ? mt * 256u : (NPASS == 2 ? (mt % tiles_ph) * 256u : (unsigned)((long)mt * 256 - (long)tph0 * Mph));
+  auto wbase_of = [&](int pp) __attribute__((always_inline)) -> const bf16_t* { return PHM ? a.wph + (long)(tph0 + pp) * a.Cout * K : (GATHER ? a.wph : a.wt); };
 
   // ---- patch sources (as in conv_mfma_h8_kernel)
   const unsigned n_img = ms0 >> (LW + lhi);
@@ -518,7 +536,10 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
     const int pr = q / PC, pc = q - pr * PC;
     const int ih = oh0 - 1 + pr, iw = pc - 1;
     const bool ok = piece < NP && q < NPX && ih >= 0 && ih < HI && iw >= 0 && iw < W;
-    poff[j] = ok ? 2u * (((n_img * (unsigned)HI + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8)) : ~0u;
+    // (GATHER: plane pixel (ih, iw) of plane (0, 0) = full-resolution pixel (2 ih, 2 iw); the other planes are a uniform offset: issue_patch)
+    poff[j] = !ok ? ~0u : GATHER
+      ? 2u * (((n_img * (unsigned)a.H + 2u * (unsigned)ih) * (unsigned)a.W + 2u * (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8))
+      : 2u * (((n_img * (unsigned)HI + (unsigned)ih) * (unsigned)W + (unsigned)iw) * (unsigned)a.Cin + (unsigned)((pos ^ ((q >> 1) & 7)) * 8));
     if (!ok && piece < NP) {
       *(uint4*)(smem + P0OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
       *(uint4*)(smem + P1OFF + piece * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
@@ -554,14 +575,26 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
     else if ((pmask >> j) & 1)
       bn_piece(j, cnext);
   };
+  const int nchunks = a.Cin >> 6;                   // 64-channel chunks; GATHER: the chunk loop runs over 4 planes x nchunks
+  // (GATHER: chunk index -> (plane, channel chunk) by shifts: the plane-patch form takes power-of-two channel-chunk counts only -- a
+  // division by a run-time count is ~40 vector-ALU instructions, per patch piece and per filter burst)
+  const int lnc = GATHER ? 31 - __builtin_clz((unsigned)nchunks) : 0;
   auto issue_patch = [&](int j, int cnext) __attribute__((always_inline)) {
-    const bf16_t* base = a.in + cnext * 64;
+    const int plane = GATHER ? cnext >> lnc : 0, cc = GATHER ? cnext & (nchunks - 1) : cnext;
+    const bf16_t* base = a.in + cc * 64 + (GATHER ? ((plane >> 1) * a.W + (plane & 1)) * a.Cin : 0);
     const unsigned dst = lds0 + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024;
     if (poff[j] != ~0u) glds16_sbase(base, poff[j], dst);
   };
-  auto issue_w = [&](int c, int tap) __attribute__((always_inline)) {      // K-tile t = NT c + tap -> ring slot t & 3
-    const bf16_t* base = wbase + (tap * a.Cin + c * 64);
-    const unsigned dst = lds0 + WOFF + ((NT * c + tap) & 3) * H8N_WTILE + wave * 1024;
+  const int nvc = GATHER ? 4 * nchunks : nchunks;   // chunks the K loop walks
+  auto issue_w = [&](int pp, int c, int tap) __attribute__((always_inline)) {      // K-tile t = NT (pp nvc + c) + tap -> ring slot t & 3
+    int col = tap * a.Cin + c * 64;
+    if (GATHER) {       // plane (pa, pb), tap (a, b) -> filter tap (u, v) = (2a + 1 - pa, 2b + 1 - pb)
+      const int plane = c >> lnc, cc = c & (nchunks - 1);
+      const int u = 2 * (tap >> 1) + 1 - (plane >> 1), v = 2 * (tap & 1) + 1 - (plane & 1);
+      col = (u * 4 + v) * a.Cin + cc * 64;
+    }
+    const bf16_t* base = wbase_of(pp) + col;
+    const unsigned dst = lds0 + WOFF + ((NT * (pp * nvc + c) + tap) & 3) * H8N_WTILE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16_sbase(base, woff[j], dst + j * 8192);
   };
@@ -575,10 +608,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   const int frow = lane & 15, kc = lane >> 4;
   if (lds0 != 0) __builtin_trap();
   const int wad = WOFF + wn * 64 * 128 + frow * 128 + ((kc ^ ((frow >> 1) & 7)) * 16);      // + ring slot * H8N_WTILE
-  const int pw0 = ((wm * 64) >> LW) * PC + frow + (PHM ? ph * PC + pw : 0);
   int AD[16];
-#pragma unroll
-  for (int sx = 0; sx < 16; ++sx) AD[sx] = P0OFF + pw0 * 128 + ((kc ^ (((pw0 + sx) & 15) >> 1)) << 4);
 
   bf16x8_t xf[4], wf[4];
   auto load_x = [&](int kh, int kw, int ks) __attribute__((always_inline)) {
@@ -607,12 +637,11 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   };
 
   // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
-  const int nchunks = a.Cin >> 6;
 #pragma unroll
   for (int j = 0; j < MAXP; ++j)
     if ((pmask >> j) & 1) issue_patch(j, 0);
-  issue_w(0, 0);
-  issue_w(0, 1);
+  issue_w(0, 0, 0);
+  issue_w(0, 0, 1);
   wait_vm<2>();                                     // the patch and K-tile 0
   if (BNIN) {
 #pragma unroll
@@ -623,9 +652,21 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   wg_barrier();
 
   int slot = 0;                                     // ring slot of the current K-tile (wave-uniform)
-  for (int c = 0; c < nchunks; ++c) {
-    const bool next_chunk = c + 1 < nchunks;
-    const unsigned pmask_c = next_chunk ? pmask : 0u;
+#pragma unroll 1
+  for (int pp = 0; pp < NPASS; ++pp) {
+  const int pw = PHM ? ((tph0 + pp) & 1) : 0;
+  auto set_window = [&](int dph, int dpw, int buf) __attribute__((always_inline)) {      // fragment bases: window offset (dph, dpw) into patch `buf`
+    const int pw0 = ((wm * 64) >> LW) * PC + frow + dph * PC + dpw;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) AD[sx] = (buf ? P1OFF : P0OFF) + pw0 * 128 + ((kc ^ (((pw0 + sx) & 15) >> 1)) << 4);
+  };
+  // this pass's window into patch 0 (the chunk loop below toggles the bases and may leave them on patch 1)
+  if (!GATHER) set_window(PHM ? ph : 0, PHM ? pw : 0, 0);
+  const bool next_pass = pp + 1 < NPASS;
+  for (int c = 0; c < nvc; ++c) {
+    const bool next_chunk = c + 1 < nvc;
+    if (GATHER) { const int plane = c >> lnc; set_window(1 - (plane >> 1), 1 - (plane & 1), c & 1); }      // the plane's window, this chunk's patch
+    const unsigned pmask_c = (next_chunk && pp == 0) ? pmask : 0u;      // (a second pass finds every chunk's patch where the first left it)
     auto pieces_at = [&](int tp) __attribute__((always_inline)) -> int {
       int n = 0;
       if (tp >= 0 && tp < NTI) {
@@ -636,16 +677,17 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
     };
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      const int kh = PHM ? (tap >> 1) : tap / 3, kw = PHM ? (tap & 1) : tap - 3 * (tap / 3);
-      const bool more1 = tap < NT - 1 || next_chunk, more2 = tap < NT - 2 || next_chunk;
-      const int c2 = tap < NT - 2 ? c : c + 1, tap2 = tap < NT - 2 ? tap + 2 : tap + 2 - NT;
+      const int kh = SUBP ? (tap >> 1) : tap / 3, kw = SUBP ? (tap & 1) : tap - 3 * (tap / 3);
+      const bool more1 = tap < NT - 1 || next_chunk || next_pass, more2 = tap < NT - 2 || next_chunk || next_pass;
+      const int tap2 = tap < NT - 2 ? tap + 2 : tap + 2 - NT;
+      const int c2 = tap < NT - 2 ? c : (next_chunk ? c + 1 : 0), pp2 = (tap < NT - 2 || next_chunk) ? pp : pp + 1;
       const int wcur = wad + slot * H8N_WTILE;
       // phase A: the first 32 reduction elements
       load_x(kh, kw, 0);
       load_w(wcur, 0);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      if (BNIN && PHM && tap == 3) {   // (see phase B: the second half of the next chunk's pieces)
+      if (BNIN && SUBP && tap == 3) {  // (see phase B: the second half of the next chunk's pieces)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 3; j < MAXP; ++j) bn_piece_seg(j, c + 1);
@@ -660,7 +702,7 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       // phase B: the second 32; the filters of K-tile t + 2 (its slot was last read in K-tile t - 2) and one patch piece behind them
       load_x(kh, kw, 1);
       load_w(wcur, 1);
-      if (more2) issue_w(c2, tap2);
+      if (more2) issue_w(pp2, c2, tap2);
       if (tap < NTI) {
 #pragma unroll
         for (int j = tap; j < MAXP; j += NTI)
@@ -673,13 +715,13 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       raw_barrier();
       // BNIN: the next chunk's pieces that went out two taps ago have landed (the wait above): transformed under this segment's MFMAs
       // (conv_mfma_h8_kernel, phase 4)
-      const bool bn_here = BNIN && (PHM ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
+      const bool bn_here = BNIN && (SUBP ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
       if (bn_here) {              // (also in the last chunk, on the dead patch buffer: no branch in the segment)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = PHM ? 0 : tap - 2; j < (PHM ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
+        for (int j = SUBP ? 0 : tap - 2; j < (SUBP ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
         mma(false);
-        h8_bn_interleave<PHM ? 3 : 1>();
+        h8_bn_interleave<SUBP ? 3 : 1>();
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else {
@@ -688,14 +730,28 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       raw_barrier();
       slot = (slot + 1) & 3;
     }
-    const int pdelta = (c & 1) ? -PATCH : PATCH;
+    if (!GATHER) {
+      const int pdelta = (c & 1) ? -PATCH : PATCH;
 #pragma unroll
-    for (int sx = 0; sx < 16; ++sx) AD[sx] += pdelta;
+      for (int sx = 0; sx < 16; ++sx) AD[sx] += pdelta;
+    }
   }
+  // the end of a pass: group 0 waits for group 1's last barrier -- both run the epilogue side by side (a barrier apart they would take
+  // turns: each group's next barrier needs the other one past its epilogue); group 1 falls behind again in front of the next pass
   if (!grp) wg_barrier();
-
-  conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, m0 + wm * 64, co0 + wn * 64, lane,
-                RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+  {
+    const long mbase = PHM ? (long)(tph0 + pp) * Mph : 0;
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, mbase + ms0 + wm * 64, co0 + wn * 64, lane,
+                  RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+  }
+  if (next_pass) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (grp) wg_barrier();
+  }
+  }
 }
 
 // plain 3x3 stride-1 SAME convolution (forward, or the data gradient with the rotated filters) on 16- or 32-pixel-wide power-of-two
@@ -747,24 +803,29 @@ int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
 // the 256 x 128 sibling: the same shapes at Cout % 128 == 0
 bool mfma_conv8n_halo_takes(const MfmaConvArgs& a) {
   if (a.KH != 3 || a.KW != 3 || a.stats || a.lw < 0 || a.lh < 0 || a.M % 256 || a.Cin % 64 || a.Cout % 128) return false;
-  if ((long)a.N * a.H * a.W * a.Cin >= (1L << 31) || (long)a.Cout * 9 * a.Cin >= (1L << 31)) return false;
+  if ((long)a.N * a.H * a.W * a.Cin >= (1L << 31) || (long)a.Cout * 16 * a.Cin >= (1L << 31)) return false;
+  // the stride-2 16-tap forms over their low-resolution output grid (a.H, a.W = the full-resolution source grid, a.M = output pixels)
+  if (a.phase == 2) return !a.up && a.wph != nullptr && !a.bn_mean && (a.lw == 5 || a.lw == 6) && a.lh >= 1 && ((a.H >> 1) << (a.lw - 1)) % 256 == 0 &&
+                           ((a.Cin >> 6) & ((a.Cin >> 6) - 1)) == 0;      // (power-of-two channel-chunk count: the chunk -> plane map is a shift)
   if (a.phase == 0) return a.PT == 1 && a.PL == 1 && !a.up && (a.lw == 4 || a.lw == 5) && (a.H << a.lw) % 256 == 0;
   if (a.phase == 1) return a.up && a.wph != nullptr && (a.lw == 5 || a.lw == 6) && a.lh >= 1 && ((a.H >> 1) << (a.lw - 1)) % 256 == 0 && (a.M >> 2) % 256 == 0;
   return false;
 }
 
-template <int LW, bool RELU, bool PHM, bool BNIN = false>
+template <int LW, bool RELU, bool PHM, bool BNIN = false, int NPASS = 1, bool GATHER = false>
 static int launch8hn(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   static bool attr_set = false;
   const size_t lds = h8n_lds_bytes(LW) + (BNIN ? 2 * H8_BN_MAX_CIN * sizeof(float) : 0);
   if (!attr_set) {
-    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP(ctx, hipFuncSetAttribute((const void*)conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN, NPASS, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid(cdiv(a.M, 256), a.Cout / 128);
+  dim3 grid(cdiv(a.M, 256 * NPASS), a.Cout / 128);
   {
-    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
-    hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN>), grid, dim3(512), lds, ctx->stream, a);
+    // (GATHER: a.M counts low-resolution pixels; the reference's formulation is the 3x3 layer over the full-resolution grid)
+    ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * (GATHER ? 36 : 9) * a.Cin * a.Cout,
+                 2.0 * (double)a.M * (GATHER ? 16 : PHM ? 4 : 9) * a.Cin * a.Cout);
+    hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN, NPASS, GATHER>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
@@ -777,7 +838,19 @@ int mfma_conv8n_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a) {
     if (a.phase == 1) return a.lw == 6 ? launch8hn<5, false, true, true>(ctx, a) : launch8hn<4, false, true, true>(ctx, a);
     return a.lw == 5 ? launch8hn<5, false, false, true>(ctx, a) : launch8hn<4, false, false, true>(ctx, a);
   }
+  if (a.phase == 2) {
+    if (a.lw == 6) return a.relu_in ? launch8hn<5, true, false, false, 1, true>(ctx, a) : launch8hn<5, false, false, false, 1, true>(ctx, a);
+    return a.relu_in ? launch8hn<4, true, false, false, 1, true>(ctx, a) : launch8hn<4, false, false, false, 1, true>(ctx, a);
+  }
   if (a.phase == 1) {
+    // both column phases of a row phase in one workgroup where both chunks' patches fit (Cin <= 128) and halving the grid still fills the
+    // chip's 256 CUs; RCGAN_H8N_TWO_PASS=0 keeps one phase per workgroup
+    static int two = -1;
+    if (two < 0) { const char* e = getenv("RCGAN_H8N_TWO_PASS"); two = e ? atoi(e) : 1; }
+    if (two && a.Cin <= 128 && (a.M / 512) * (a.Cout / 128) >= 190) {
+      if (a.lw == 6) return a.relu_in ? launch8hn<5, true, true, false, 2>(ctx, a) : launch8hn<5, false, true, false, 2>(ctx, a);
+      return a.relu_in ? launch8hn<4, true, true, false, 2>(ctx, a) : launch8hn<4, false, true, false, 2>(ctx, a);
+    }
     if (a.lw == 6) return a.relu_in ? launch8hn<5, true, true>(ctx, a) : launch8hn<5, false, true>(ctx, a);
     return a.relu_in ? launch8hn<4, true, true>(ctx, a) : launch8hn<4, false, true>(ctx, a);
   }

@@ -73,6 +73,8 @@ CONV_CASES = [
     (50, 32, 32, 128, 128, 3, 1, False, True),  # ... 32-wide, Cout = 128, input ReLU, two chunks, both directions
     (48, 32, 32, 128, 128, 3, 1, True, True),   # ... sub-pixel form over 16 x 16 low-resolution images (the shape of D.Block.1.Conv2's pooled data gradient)
     (13, 64, 64, 64, 128, 3, 1, True, False),   # ... over 32-wide low-resolution images, one chunk
+    (64, 32, 32, 256, 256, 3, 1, True, False),  # ... its parity-plane (stride-2 16-tap) form for the DATA GRADIENT of an upsample-3x3 layer: G.Block.3.Conv1's shape, 16 plane chunks
+    (30, 64, 64, 128, 128, 3, 1, True, True),   # ... the same over 32-wide planes (data gradient), and the two-phases-per-workgroup sub-pixel forward on 32-wide images
     # the nine-tap filter gradient (conv_wgrad9.hip; the 16- and 32-wide cases above take it too): 8-pixel-wide images (four image rows per K-step),
     (6, 8, 8, 64, 128, 3, 1, False, True),
     (3, 16, 8, 128, 128, 3, 1, False, False),   # ... H != W
@@ -345,7 +347,8 @@ def test_conv_persistent_tiles(dev, case):
 @pytest.mark.parametrize("case", [(4, 32, 32, 128, 128, True, True),      # 64 x 64 kernel both ways, accumulating into a shortcut
                                   (8, 16, 16, 64, 64, False, False),
                                   (128, 32, 32, 128, 128, True, False),    # D.Block.1.Conv2 at the bench batch: 256 x 128 kernel for dx
-                                  (128, 16, 16, 128, 128, True, True)])    # D.Block.2.Conv2
+                                  (128, 16, 16, 128, 128, True, True),     # D.Block.2.Conv2
+                                  (32, 64, 64, 64, 128, True, False)])     # 32-wide parity planes, one channel chunk (the gather form of the 256 x 128 halo kernel)
 @pytest.mark.parametrize("force9", [False, True])      # True: the filter gradient on the nine-tap kernel's pooled form whatever the size
 def test_conv2d_meanpool(dev, case, force9, monkeypatch):
     """ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution with summed filters forward, the
