@@ -1723,7 +1723,8 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
     // (round 5) the parity-plane patch form of the 256 x 128 halo kernel where its tiles fill the chip: G.Block.3.Conv1's data gradient
     // (128 x 2 tiles) 78 -> 61 us.  Measured and left to the 64 x 64 kernel: D.Block.1.Conv2's forward (128 tiles = half the CUs) 33 -> 37 us
     // (RCGAN_H8N_GATHER_MINBLK=120 takes it too; 100000 switches the form off)
-    static const int gather_min = env_int("RCGAN_H8N_GATHER_MINBLK", 190), halo_n2 = env_int("RCGAN_P8N_HALO", 1);
+    static const int halo_n2 = env_int("RCGAN_P8N_HALO", 1);
+    const int gather_min = env_int("RCGAN_H8N_GATHER_MINBLK", 190);        // (read per call: the tests force the form on smaller grids)
     if (halo_n2 && a.M % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= gather_min && mfma_conv8n_halo_takes(a))
       return mfma_conv8n_halo_launch(ctx, a);
     if (a.M % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min2 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);

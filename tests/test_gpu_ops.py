@@ -127,6 +127,21 @@ def test_conv2d_fwd_bwd_nine_tap_forced(dev, case, grouped, monkeypatch):
         ctx.group_wgrads = keep
 
 
+# the parity-plane (stride-2 16-tap) form of the 256 x 128 halo kernel takes a layer only when its tiles fill the chip (190 workgroups): forced
+# here on the data gradients of the upsample-3x3 cases -- 16- and 32-wide planes, one / two / four channel chunks, with and without input ReLU
+GATHER_CASES = [c for c in CONV_CASES if c[7] and c[5] == 3 and c[3] % 128 == 0 and c[4] % 64 == 0 and (c[0] * c[1] * c[2] // 4) % 256 == 0 and c[2] in (32, 64)]
+assert len(GATHER_CASES) >= 4
+
+
+@pytest.mark.parametrize("case", GATHER_CASES)
+def test_conv2d_fwd_bwd_plane_gather_forced(dev, case, monkeypatch):
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("a 16-bit matrix-core kernel")
+    monkeypatch.setenv("RCGAN_H8N_GATHER_MINBLK", "1")
+    test_conv2d_fwd_bwd(dev, case)
+
+
 @pytest.mark.parametrize("case", CONV_CASES + _random_conv_cases())
 def test_conv2d_fwd_bwd(dev, case):
     from rcgan_amd import _lib as L
@@ -349,7 +364,7 @@ def test_conv_persistent_tiles(dev, case):
                                   (128, 32, 32, 128, 128, True, False),    # D.Block.1.Conv2 at the bench batch: 256 x 128 kernel for dx
                                   (128, 16, 16, 128, 128, True, True),     # D.Block.2.Conv2
                                   (32, 64, 64, 64, 128, True, False)])     # 32-wide parity planes, one channel chunk (the gather form of the 256 x 128 halo kernel)
-@pytest.mark.parametrize("force9", [False, True])      # True: the filter gradient on the nine-tap kernel's pooled form whatever the size
+@pytest.mark.parametrize("force9", [False, True])      # True: the filter gradient on the nine-tap kernel's pooled form whatever the size (and the forward on the 256 x 128 halo kernel's parity-plane form)
 def test_conv2d_meanpool(dev, case, force9, monkeypatch):
     """ConvMeanPool with the pool folded into the convolution (one 4x4 stride-2 convolution with summed filters forward, the
     sub-pixel form for the data gradient, the ordinary grouped filter gradient on the spread dy) against conv -> mean pool."""
@@ -361,6 +376,7 @@ def test_conv2d_meanpool(dev, case, force9, monkeypatch):
     if force9:
         monkeypatch.setenv("RCGAN_WGRAD9_MINWORK", "0")
         monkeypatch.setenv("RCGAN_WGRAD9_GROUP_MINWORK", "0")
+        monkeypatch.setenv("RCGAN_H8N_GATHER_MINBLK", "1")
     n, h, w, cin, cout, relu, acc = case
     rs = np.random.RandomState(n * 7 + cin)
     x = _prep(rs.randn(n, h, w, cin).astype(np.float32), mode)
