@@ -136,17 +136,25 @@ __device__ __forceinline__ void h8_bn_slot(unsigned char* slot, const float* tab
   *(uint4*)slot = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 }
 
-// One straight-line segment = NPC transformed pieces + 16 MFMAs: the LDS reads first, then the vector ALU work dealt between the MFMAs
-// (which the compiler otherwise issues as one block behind it), the stores last.
-template <int NPC> __device__ __forceinline__ void h8_bn_interleave() {
-  __builtin_amdgcn_sched_group_barrier(0x100, 5 * NPC, 0);       // DS reads (table + slot)
-  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
-#pragma unroll
-  for (int i = 0; i < 14; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x002, 4 * NPC, 0);     // VALU
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
-  }
-  __builtin_amdgcn_sched_group_barrier(0x200, NPC, 0);           // DS writes
+// The transform dealt between the four groups of four MFMAs of a segment (h8_bn_stage): word q of a slot (two channels' pair of
+// 16-bit values) needs table entries 2q, 2q + 1.  The stages are pinned between the MFMA groups with sched_barrier(0): left to itself the
+// compiler issues a piece's ~45 vector-ALU instructions as one block behind the 15th MFMA (a sched_group_barrier pipeline is not honoured
+// across the LDS-read dependency), which made the segment ~200 cycles longer; pinned, a stage's ~10 instructions issue while the four
+// MFMAs in front of it occupy the matrix pipe.
+struct H8BnTab { float4 i0, i1, c0, c1; };
+__device__ __forceinline__ H8BnTab h8_bn_tab_load(const float* tab, int cin, int ch0) {
+  return H8BnTab{*(const float4*)(tab + ch0), *(const float4*)(tab + ch0 + 4), *(const float4*)(tab + cin + ch0), *(const float4*)(tab + cin + ch0 + 4)};
+}
+__device__ __forceinline__ uint32_t h8_bn_word(uint32_t w, float ia, float ib, float ca, float cb, float relu_floor, bool keep) {
+  float lo = __fmaf_rn(h16_lo(w), ia, ca), hi = __fmaf_rn(h16_hi(w), ib, cb);
+  lo = fmaxf(lo, relu_floor); hi = fmaxf(hi, relu_floor);
+  return keep ? pack_h16x2(lo, hi) : w;
+}
+__device__ __forceinline__ void h8_bn_stage(int q, uint4& v, const H8BnTab& t, float relu_floor, bool keep) {
+  if (q == 0) v.x = h8_bn_word(v.x, t.i0.x, t.i0.y, t.c0.x, t.c0.y, relu_floor, keep);
+  if (q == 1) v.y = h8_bn_word(v.y, t.i0.z, t.i0.w, t.c0.z, t.c0.w, relu_floor, keep);
+  if (q == 2) v.z = h8_bn_word(v.z, t.i1.x, t.i1.y, t.c1.x, t.c1.y, relu_floor, keep);
+  if (q == 3) v.w = h8_bn_word(v.w, t.i1.z, t.i1.w, t.c1.z, t.c1.w, relu_floor, keep);
 }
 
 // PHM: the sub-pixel form of a 3x3 convolution behind the nearest 2x upsample (MfmaConvArgs::wph, conv_mfma8.hip): a tile is 256
@@ -239,10 +247,6 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
   // BNIN: the table behind the patches; the eight channels (of a chunk) this thread's deposits hold; its landed pieces of a patch
   float* const bn_tab = (float*)(smem + P1OFF + PATCH);
   const float bn_floor = a.bn_act == RCGAN_ACT_RELU ? 0.f : -INFINITY;
-  if (BNIN) {
-    h8_bn_table(a, bn_tab, n_img, tid);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (all eight wavefronts: the two groups are not yet a barrier apart)
-  }
   auto bn_piece = [&](int j, int cnext) __attribute__((always_inline)) {
     // (the thread's channel offset is recomputed from an opaque copy of the lane id where it is used: a loop-invariant of its own would be
     // one more live register in a kernel that sits at its 256-register budget -- a spill's scratch load shares vmcnt with the LDS-DMA)
@@ -318,9 +322,9 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) wfc[h][ks][g] = __builtin_bit_cast(bf16x8_t, lds_read16(ks ? wad1 : wad, h * H8_HALF + g * 16 * 128));
   };
-  auto mma = [&](int ph, int ch, bool prio = true) __attribute__((always_inline)) {
+  auto mma = [&](int ph, int ch) __attribute__((always_inline)) {
     if (H8_ABLATE & 16) return;
-    if (prio) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -328,7 +332,40 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
           acc[ch * 2 + g][ph * 4 + f] = mfma16(wfc[ch][ks][g], xf[ks][f], acc[ch * 2 + g][ph * 4 + f]);
-    if (prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the same 16 MFMAs with the batch-norm transform of this thread's pieces [j0, j1) of chunk cnext's patch dealt between their four
+  // groups (BNIN).  A piece that may lie behind the patch's end for some wavefronts (8 j + 7 >= NP: the last one) takes the branching form
+  // in front of the MFMAs.
+  auto mma_bn = [&](int ph, int ch, int j0, int j1, int cnext) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+    int ln;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));      // (an opaque copy of the lane id: see bn_piece)
+    unsigned char* const pbase = smem + ((cnext & 1) ? P1OFF : P0OFF) + wave * 1024 + ln * 16;
+    const H8BnTab t = h8_bn_tab_load(bn_tab, a.Cin, cnext * 64 + (((ln & 7) ^ ((wave & 1) * 4 + (ln >> 4))) << 3));
+    uint4 v[3];
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      if (8 * j + 7 < NP) v[j - j0] = *(uint4*)(pbase + j * 8192);
+      else if ((pmask >> j) & 1) bn_piece(j, cnext);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[ch * 2 + (q & 1)][ph * 4 + f] = mfma16(wfc[ch][q >> 1][q & 1], xf[q >> 1][f], acc[ch * 2 + (q & 1)][ph * 4 + f]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = j0; j < j1; ++j)
+        if (8 * j + 7 < NP) h8_bn_stage(q, v[j - j0], t, bn_floor, poff[j] != ~0u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = j0; j < j1; ++j)
+      if (8 * j + 7 < NP) *(uint4*)(pbase + j * 8192) = v[j - j0];
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
   stamp(1);        // (scripts/exp_p8_timeline.py: segment 0 = patch sources, filter sources, fragment addresses)
@@ -339,11 +376,31 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
     if ((pmask >> j) & 1) issue_patch(j, 0);
   issue_w(0, 0, 0); issue_w(1, 0, 0);
   issue_w(0, 0, 1); issue_w(1, 0, 1);
+  // BNIN: the table's global loads go out BEHIND the bursts and land under them (the compiler's own wait for them also covers every
+  // older burst: loads retire in order)
+  if (BNIN) h8_bn_table(a, bn_tab, n_img, tid);
   wait_vm<4>();
-  if (BNIN) {                                       // the first chunk's patch: all of this thread's pieces, now
+  if (BNIN) {                                       // the first chunk's patch: all of this thread's pieces, now, as one straight-line batch
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the table is complete; all eight wavefronts: the two groups are not yet a barrier apart)
+    int ln;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+    unsigned char* const pbase = smem + P0OFF + wave * 1024 + ln * 16;
+    const H8BnTab t = h8_bn_tab_load(bn_tab, a.Cin, ((ln & 7) ^ ((wave & 1) * 4 + (ln >> 4))) << 3);
+    uint4 v[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      if (8 * j + 7 < NP) v[j] = *(uint4*)(pbase + j * 8192);
+      else if ((pmask >> j) & 1) bn_piece(j, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j)
+        if (8 * j + 7 < NP) h8_bn_stage(q, v[j], t, bn_floor, poff[j] != ~0u);
 #pragma unroll
     for (int j = 0; j < MAXP; ++j)
-      if ((pmask >> j) & 1) bn_piece(j, 0);
+      if (8 * j + 7 < NP) *(uint4*)(pbase + j * 8192) = v[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
   wg_barrier();
@@ -377,30 +434,23 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();                                 // a_1
-      if (BNIN && PHM && tap == 3) {   // (see phase 4: the second half of the next chunk's pieces)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 3; j < MAXP; ++j) bn_piece_seg(j, c + 1);
-        mma(0, 0, false);
-        h8_bn_interleave<MAXP - 3>();
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      } else {
-        mma(0, 0);
-      }
+      if (BNIN && PHM && tap == 3) mma_bn(0, 0, 2, 4, c + 1);      // (see phase 4: the next chunk's pieces 2, 3; 4 and 5 follow below)
+      else mma(0, 0);
       raw_barrier();                                 // b_1
       // phase 2: (P0, C1)
       load_w(1);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      mma(0, 1);
+      if (BNIN && PHM && tap == 3 && MAXP > 4) mma_bn(0, 1, 4, 5, c + 1);
+      else mma(0, 1);
       raw_barrier();
       // phase 3: (P1, C1); C0 of tile t + 2 (its slot was last read in phase 1)
       if (!(H8_ABLATE & 8) || (c == 0 && tap == 0)) load_x(kh, kw, 1);
       if (more2 && !(H8_ABLATE & 4)) issue_w(0, c2, tap2);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      mma(1, 1);
+      if (BNIN && PHM && tap == 3 && MAXP > 5) mma_bn(1, 1, 5, MAXP, c + 1);      // (complete in front of b_3: first read behind b_4)
+      else mma(1, 1);
       raw_barrier();
       // phase 4: (P1, C0) -- both operands are still in registers; C1 of tile t + 2 (slot last read in phase 2)
       if (more2 && !(H8_ABLATE & 4)) issue_w(1, c2, tap2);
@@ -421,20 +471,12 @@ __global__ __launch_bounds__(512) void conv_mfma_h8_kernel(MfmaConvArgs a) {
       // BNIN: everything issued before C0 of the next tile has landed (the wait above) -- the next chunk's pieces that went out two taps
       // ago.  They are transformed HERE, in the segment whose 16 MFMAs give the vector ALU work and the LDS round trips something to hide
       // under (in front of the barrier the same work stalled all eight wavefronts: +11 % / +23 % on the plain / sub-pixel launches),
-      // complete (lgkmcnt) in front of the segment's closing barrier and first read a chunk -- at least six barriers -- later.  Plain
-      // form: the piece of tap - 2; sub-pixel form (all pieces behind tap 0): three here at tap 2, the rest under tap 3's first segment.
+      // complete (lgkmcnt) in front of the segment's closing barrier and first read a chunk -- at least two barriers -- later.  Plain
+      // form: the piece of tap - 2; sub-pixel form (all pieces behind tap 0): pieces 0, 1 here at tap 2, then 2, 3 / 4 / 5 under the first
+      // three segments of tap 3.  (Also in the last chunk, on the dead patch buffer: no branch in the segment.)
       const bool bn_here = BNIN && (PHM ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
-      if (bn_here) {              // (also in the last chunk, on the dead patch buffer: no branch in the segment)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = PHM ? 0 : tap - 2; j < (PHM ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
-        mma(1, 0, false);
-        h8_bn_interleave<PHM ? 3 : 1>();
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      } else {
-        mma(1, 0);
-      }
+      if (bn_here) mma_bn(1, 0, PHM ? 0 : tap - 2, PHM ? 2 : tap - 1, c + 1);
+      else mma(1, 0);
       raw_barrier();
       wad ^= WBUF;                                  // the other filter buffer
     }
@@ -562,10 +604,6 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   float* const bn_tab = (float*)(smem + P1OFF + PATCH);            // BNIN: as in conv_mfma_h8_kernel
   const int bn_ch = (pos ^ ((wave & 1) * 4 + (lrow >> 1))) << 3;
   const float bn_floor = a.bn_act == RCGAN_ACT_RELU ? 0.f : -INFINITY;
-  if (BNIN) {
-    h8_bn_table(a, bn_tab, n_img, tid);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
   auto bn_piece = [&](int j, int cnext) __attribute__((always_inline)) {
     if (poff[j] != ~0u) h8_bn_slot(smem + ((cnext & 1) ? P1OFF : P0OFF) + (wave + 8 * j) * 1024 + lane * 16, bn_tab, a.Cin, cnext * 64 + bn_ch, bn_floor);
   };
@@ -627,13 +665,40 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) wf[g] = __builtin_bit_cast(bf16x8_t, lds_read16(ad, g * 16 * 128));
   };
-  auto mma = [&](bool prio = true) __attribute__((always_inline)) {
-    if (prio) __builtin_amdgcn_s_setprio(1);
+  auto mma = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[g][f] = mfma16(wf[g], xf[f], acc[g][f]);
-    if (prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_bn = [&](int j0, int j1, int cnext) __attribute__((always_inline)) {      // (conv_mfma_h8_kernel's mma_bn)
+    __builtin_amdgcn_s_setprio(1);
+    unsigned char* const pbase = smem + ((cnext & 1) ? P1OFF : P0OFF) + wave * 1024 + lane * 16;
+    const H8BnTab t = h8_bn_tab_load(bn_tab, a.Cin, cnext * 64 + bn_ch);
+    uint4 v[3];
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      if (8 * j + 7 < NP) v[j - j0] = *(uint4*)(pbase + j * 8192);
+      else if ((pmask >> j) & 1) bn_piece(j, cnext);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[g][f] = mfma16(wf[g], xf[f], acc[g][f]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = j0; j < j1; ++j)
+        if (8 * j + 7 < NP) h8_bn_stage(g, v[j - j0], t, bn_floor, poff[j] != ~0u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = j0; j < j1; ++j)
+      if (8 * j + 7 < NP) *(uint4*)(pbase + j * 8192) = v[j - j0];
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
   // ---- prologue: the first chunk's patch, the filters of K-tiles 0 and 1
@@ -642,11 +707,27 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
     if ((pmask >> j) & 1) issue_patch(j, 0);
   issue_w(0, 0, 0);
   issue_w(0, 0, 1);
+  if (BNIN) h8_bn_table(a, bn_tab, n_img, tid);      // (behind the bursts: conv_mfma_h8_kernel)
   wait_vm<2>();                                     // the patch and K-tile 0
   if (BNIN) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    unsigned char* const pbase = smem + P0OFF + wave * 1024 + lane * 16;
+    const H8BnTab t = h8_bn_tab_load(bn_tab, a.Cin, bn_ch);
+    uint4 v[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      if (8 * j + 7 < NP) v[j] = *(uint4*)(pbase + j * 8192);
+      else if ((pmask >> j) & 1) bn_piece(j, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j)
+        if (8 * j + 7 < NP) h8_bn_stage(q, v[j], t, bn_floor, poff[j] != ~0u);
 #pragma unroll
     for (int j = 0; j < MAXP; ++j)
-      if ((pmask >> j) & 1) bn_piece(j, 0);
+      if (8 * j + 7 < NP) *(uint4*)(pbase + j * 8192) = v[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if (grp) wg_barrier();                            // group 1 runs one barrier behind group 0 from here on
   wg_barrier();
@@ -687,17 +768,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       load_w(wcur, 0);
       __builtin_amdgcn_sched_barrier(0);
       raw_barrier();
-      if (BNIN && SUBP && tap == 3) {  // (see phase B: the second half of the next chunk's pieces)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 3; j < MAXP; ++j) bn_piece_seg(j, c + 1);
-        mma(false);
-        h8_bn_interleave<MAXP - 3>();
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      } else {
-        mma();
-      }
+      if (BNIN && SUBP && tap == 3) mma_bn(3, MAXP, c + 1);      // (see phase B: the second half of the next chunk's pieces; complete in front of b_A, first read behind b_B)
+      else mma();
       raw_barrier();
       // phase B: the second 32; the filters of K-tile t + 2 (its slot was last read in K-tile t - 2) and one patch piece behind them
       load_x(kh, kw, 1);
@@ -716,17 +788,8 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
       // BNIN: the next chunk's pieces that went out two taps ago have landed (the wait above): transformed under this segment's MFMAs
       // (conv_mfma_h8_kernel, phase 4)
       const bool bn_here = BNIN && (SUBP ? tap == 2 : (tap >= 2 && tap - 2 < NTI));
-      if (bn_here) {              // (also in the last chunk, on the dead patch buffer: no branch in the segment)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = SUBP ? 0 : tap - 2; j < (SUBP ? 3 : tap - 1); ++j) bn_piece_seg(j, c + 1);
-        mma(false);
-        h8_bn_interleave<SUBP ? 3 : 1>();
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      } else {
-        mma();
-      }
+      if (bn_here) mma_bn(SUBP ? 0 : tap - 2, SUBP ? 3 : tap - 1, c + 1);      // (also in the last chunk, on the dead patch buffer: no branch in the segment)
+      else mma();
       raw_barrier();
       slot = (slot + 1) & 3;
     }

@@ -41,6 +41,30 @@ cd "$ROOT"
 # `make_profiles.sh <tag> pmc`: the bench line, the kernel trace and the counter passes only (a source change that does not touch what the
 # micro-benchmarks below measure still changes the source hash the committed counters are attached by)
 [ "${2:-all}" = pmc ] && { ls -la "$OUT"; exit 0; }
+if [ "${2:-all}" = lean ]; then
+  # `make_profiles.sh <tag> lean` (round 5): the above + per-layer / per-graph micro-benchmarks, the other BASELINE configurations, and this
+  # round's switches one at a time (no ablation builds, no re-run of earlier rounds' switches)
+  python3 scripts/bench_conv.py > "$OUT/microbench_conv.txt" 2>&1
+  python3 scripts/bench_bn.py 128 > "$OUT/microbench_bn.txt" 2>&1
+  python3 scripts/step_times.py > "$OUT/step_times.txt" 2>&1
+  python3 scripts/bench_mnist.py 256 f32 > "$OUT/bench_mnist.txt" 2>&1
+  python3 scripts/bench_wgrad_group.py > "$OUT/wgrad_group.txt" 2>&1
+  python3 bench.py --no-cpu-baseline --dtype f32 --steps 20 > "$OUT/bench_f32.json" 2> /dev/null
+  python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512.json" 2> /dev/null
+  python3 bench.py --no-cpu-baseline --dtype f16 > "$OUT/bench_f16.json" 2> /dev/null
+  python3 bench.py --no-cpu-baseline --algorithm rcgan-u > "$OUT/bench_rcganu.json" 2> /dev/null
+  python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 > "$OUT/bench_dpstub8_model_f32.json" 2> /dev/null
+  python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 --bucket-dtype bf16 > "$OUT/bench_dpstub8_model_bf16.json" 2> /dev/null
+  for rep in 1 2; do
+    python3 bench.py --no-cpu-baseline > "$OUT/bench_default_rep$rep.json" 2> /dev/null
+    RCGAN_P8N_HALO=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_p8n_halo_rep$rep.json" 2> /dev/null
+    RCGAN_H8N_TWO_PASS=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_two_pass_rep$rep.json" 2> /dev/null
+    RCGAN_H8N_GATHER_MINBLK=100000 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_gather_rep$rep.json" 2> /dev/null
+    RCGAN_BN_INTO_PATCH=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_bn_into_patch_rep$rep.json" 2> /dev/null
+    RCGAN_GRAPH_ADAM=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_graph_adam_rep$rep.json" 2> /dev/null
+  done
+  ls -la "$OUT"; exit 0
+fi
 python3 scripts/bench_conv.py > "$OUT/microbench_conv.txt" 2>&1
 python3 scripts/bench_bn.py 128 > "$OUT/microbench_bn.txt" 2>&1
 python3 scripts/bench_trunk.py 128 > "$OUT/microbench_trunk.txt" 2>&1
