@@ -169,6 +169,10 @@ def kernel_roofline(m, pool, default_workload=True):
             # algorithmic = the reference's formulation; the upsample-3x3 layers run in their sub-pixel form (four 2x2
             # convolutions with summed filters): the matrix cores execute 4/9 of those layers' multiply-adds
             "executed_tflops": round(fx.value / (ms.value * 1e-3) / 1e12, 2), "executed_frac": round(fx.value / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            # (round 5) in the forward-only generator pass the kernel also applies the conditional batch norm + ReLU in front of the
+            # convolution to its staged input (two of its five launches): their time includes that work, the FLOP count does not --
+            # RCGAN_BN_INTO_PATCH=0 gives the plain launches back (and three batch-norm apply launches with them)
+            "launches_with_batch_norm_on_the_staged_input": (2 if os.environ.get("RCGAN_BN_INTO_PATCH", "1") != "0" and default_workload else 0),
             **busy_extra}
 
 

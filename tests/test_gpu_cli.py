@@ -52,6 +52,25 @@ def test_train_cli_layout_and_restore(tmp_path, caplog):
     assert int(sd2["_opt/Discriminator/step"][0]) == 2 * int(sd["_opt/Discriminator/step"][0])
 
 
+def test_train_cli_on_class_pattern_images_scores_with_the_stand_in_classifier(tmp_path, caplog):
+    """--synthetic --synthetic_kind templates: the class-pattern stand-in data set through the CLI, generated-label accuracy by
+    eval_cifar.TemplateClassifier (not the CIFAR ResNet, whose verdict on these images would mean nothing) at
+    --generated_label_accuracy_freq and at the end of training (gan_resnet.py:995-1005, 1021-1035)."""
+    import logging
+    import re
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.train_cifar import main
+    parent = str(tmp_path)
+    argv = ["--algorithm", "rcgan", "--alpha", "0.6", "--log_file", os.path.join(parent, "log.txt"), "--parent_dir", parent, "--expt_dir", "t1",
+            "--ngpus", "1", "--multi_gpu_multi_batch", "--niters", "4", "--batch_size", "8", "--synthetic", "--synthetic_kind", "templates",
+            "--sample_freq", "0", "--inception_freq", "0", "--generated_label_accuracy_freq", "2", "--early_checkpoint_every", "4"]
+    with caplog.at_level(logging.INFO):
+        d = main(argv)
+    accs = [float(x) for x in re.findall(r"generated label accuracy: ([0-9.]+)", caplog.text)]
+    assert len(accs) == 3 and all(0.0 <= a <= 1.0 for a in accs)        # iterations 1, 3 and the final evaluation
+    assert glob.glob(os.path.join(d, "gen_label_acc.jpg"))
+
+
 def test_mnist_cli_layout_restore_and_presets(tmp_path, capsys):
     """mnist/main.py's flag surface (run_rcganu.sh preset + an ignored unknown flag), console lines, output tree
     (script/, samples/train_EE_IIII.png, samples_<epoch>.npy, mnist_<B>_28_28/DCGAN.model-<step>), restore without
