@@ -44,3 +44,29 @@ def generated_label_accuracy(dataset, samples, predict_fn):
     if num_sum == 0:
         raise ValueError("fewer than %d samples per class: nothing to score" % NUM_TEST)   # (the reference divides by zero here)
     return acc_sum / num_sum
+
+
+class TemplateClassifier:
+    """Stand-in for the missing frozen MNIST classifier on the "templates" synthetic digits (data_mnist.synthetic(kind="templates")):
+    the nearest class pattern in the pre-sigmoid domain.  ``TemplateClassifier()`` is a predict_fn for generated_label_accuracy
+    (float [n,28,28,1] in the sampler's [0, 1] range -> n class indices); as ``--label_classifier_fn
+    rcgan_amd.eval_mnist:template_predict`` it serves the training CLI.  Host numpy: evaluation of a synthetic stand-in."""
+
+    def __init__(self):
+        from . import data_mnist as DM
+        self.t = (DM.TEMPLATE_GAIN * DM.class_templates()).reshape(10, -1)
+
+    def __call__(self, images):
+        x = np.clip(np.asarray(images, np.float64).reshape(len(images), -1), 1e-3, 1 - 1e-3)
+        a = np.log(x) - np.log1p(-x)
+        d = (a * a).sum(1, keepdims=True) - 2.0 * a.dot(self.t.T) + (self.t * self.t).sum(1)[None]
+        return d.argmin(1)
+
+
+def template_predict(images):
+    global _TEMPLATE
+    try:
+        clf = _TEMPLATE
+    except NameError:
+        clf = _TEMPLATE = TemplateClassifier()
+    return clf(images)

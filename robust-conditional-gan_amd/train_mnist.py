@@ -75,6 +75,8 @@ def define_flags():
     f.DEFINE_string("dtype", 'f32', "activation dtype [f32, bf16]")
     f.DEFINE_boolean("synthetic", False, "train on SURVEY 8(d) synthetic digits instead of <data_dir>/mnist")
     f.DEFINE_integer("synthetic_size", 7000, "number of synthetic samples")
+    f.DEFINE_string("synthetic_kind", 'uniform', "with --synthetic: [uniform] label-free noise digits, [templates] class-pattern digits "
+                    "(data_mnist.template_images; score them with --label_classifier_fn rcgan_amd.eval_mnist:template_predict)")
     f.DEFINE_integer("seed", 0, "variable-initialisation seed")
     f.DEFINE_integer("save_every", 700, "checkpoint / sample-grid period in updates (the reference hard-codes 700)")
     f.DEFINE_string("label_classifier_fn", None, "package.module:callable -- the MNIST classifier of the generated-label accuracy "
@@ -130,7 +132,7 @@ def main(argv=None):
 
     # ---- data (DCGAN.__init__ -> load_mnist, model.py:83-89) ----------------------------------------------
     if FLAGS.synthetic:
-        X, y = DM.synthetic(FLAGS.synthetic_size, 1234)
+        X, y = DM.synthetic(FLAGS.synthetic_size, 1234, FLAGS.synthetic_kind)
         data = DM.corrupt(X, y, FLAGS.alpha, FLAGS.confusion_class_depend, FLAGS.real_match)
     else:
         data = DM.load_mnist(FLAGS.data_dir, FLAGS.alpha, FLAGS.confusion_class_depend, FLAGS.real_match)

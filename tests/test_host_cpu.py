@@ -285,3 +285,22 @@ def _rs_after_labels(seed, n):
     rs = np.random.RandomState(seed)
     rs.randint(10, size=n)
     return rs
+
+
+def test_mnist_class_pattern_digits_and_their_stand_in_classifier():
+    """data_mnist.synthetic(kind="templates") + eval_mnist.TemplateClassifier: the stand-in for MNIST and for the missing frozen
+    classifier (mnist/utils.py:276) in the MNIST training runs; through the reference's own bookkeeping (utils.py:292-305)."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd import data_mnist as DM
+    from rcgan_amd.eval_mnist import TemplateClassifier, generated_label_accuracy, template_predict
+    X, y = DM.synthetic(3000, 5, "templates")
+    assert X.shape == (3000, 28, 28, 1) and 0 <= X.min() and X.max() <= 255
+    clf = TemplateClassifier()
+    assert (clf(X / 255.) == y).mean() >= 0.995
+    Xu, yu = DM.synthetic(3000, 5)
+    assert 0.05 <= (clf(Xu / 255.) == yu).mean() <= 0.15
+    # [draws, 100, 28, 28, 1] on ten labels per class in class order: accuracy 1 on real images of those classes
+    byc = [X[y == c][:20] / 255. for c in range(10)]
+    samples = np.stack([np.concatenate([byc[c][10 * d:10 * d + 10] for c in range(10)]) for d in range(2)])
+    samples = np.concatenate([samples] * 5)                      # 10 draws -> one batch of 100 per class
+    assert generated_label_accuracy("mnist", samples, template_predict) >= 0.99
