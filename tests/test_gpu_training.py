@@ -13,16 +13,18 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 
 def test_generator_learns_the_conditional_distribution_in_bf16():
-    """3000 iterations (1 G + 5 D updates each) of rcgan at alpha = 1 (clean labels: the conditional GAN itself), bf16: the
-    generated-label accuracy leaves chance (0.1; the committed seeds reach 0.62-0.72 here and 0.9 by 4500 iterations), every
-    loss stays finite, and the critic's cost stays in the hinge's range.  ~20 s."""
+    """3000 iterations (1 G + 5 D updates each) of rcgan-u with the reference's run_rcganu.sh flags (learned confusion matrix,
+    permutation regulariser, confuse_init) at the CIFAR preset's 40 % label noise, bf16, production path: the generated-label
+    accuracy is far above chance (>= 0.6; the committed seeds read 1.00 / 0.78 / 1.00 at 3000 iterations and 1.00 from 4000 on), the learned
+    confusion matrix's diagonal has moved from its start (0.2) towards the true 0.6, every loss stays finite.  ~25 s."""
     import train_synthetic as TS
-    res = TS.run(algorithm="rcgan", dtype="bf16", iters=3000, eval_every=1000, alpha=1.0, batch=64, seed=0)
+    res = TS.run(algorithm="rcgan-u", dtype="bf16", iters=3000, eval_every=1000, alpha=0.6, batch=64, seed=0, perm_classifier=True, confuse_init=True)
     assert res["losses_finite"]
     accs = [c["gen_label_acc"] for c in res["curve"]]
-    assert accs[-1] >= 0.25, accs
-    assert accs[-1] > accs[0], accs
-    assert all(0.0 <= c["d_cost"] <= 2.5 for c in res["curve"]), res["curve"]
+    assert accs[-1] >= 0.6 and accs[-1] > accs[0], accs
+    diag = [c["confusion_diag_mean"] for c in res["curve"]]
+    assert 0.25 <= diag[-1] <= 0.7 and diag[-1] > 0.22, diag
+    assert all(0.0 <= c["d_cost"] <= 3.0 for c in res["curve"]), res["curve"]
 
 
 def test_noisy_labels_first_steps_are_finite_and_move_the_losses():
