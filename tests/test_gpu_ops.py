@@ -716,6 +716,32 @@ def test_batch_norm_inside_the_patch_convolution(dev, case):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_batch_norm_on_the_staged_input_refuses_what_no_kernel_takes(dev):
+    """rcgan_conv_bn_in_ok / rcgan_conv2d_fwd_bn_residual: a convolution whose routing does not end on a halo-patch (or image-end) kernel is
+    refused with RCGAN_EUNSUPPORTED_SHAPE and a message -- never run on a kernel that would ignore the norm."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("16-bit kernels")
+    n, h, w, cin, cout = 4, 8, 8, 64, 64                   # 64 x 64-tile kernel territory
+    d = L.ConvDesc(n, h, w, cin, cout, 3, 3, 1, ctx.act_dtype, 0)
+    assert not ctx.lib.rcgan_conv_bn_in_ok(C.byref(d))
+    assert not ctx.lib.rcgan_conv_bn_in_ok(C.byref(L.ConvDesc(60, 32, 32, 256, 256, 3, 3, 1, ctx.act_dtype, L.CONV_IN_RELU)))      # the norm's own activation only
+    assert ctx.lib.rcgan_conv_bn_in_ok(C.byref(L.ConvDesc(60, 32, 32, 256, 256, 3, 3, 1, ctx.act_dtype, 0)))
+    rs = np.random.RandomState(0)
+    ctx.new_step()
+    x = ctx.upload(_prep(rs.randn(n, h, w, cin), mode))
+    pw = FakeParam(ctx, (rs.randn(3, 3, cin, cout) * 0.05).astype(np.float32))
+    W = O.Weight(ctx, pw.t, None)
+    y = ctx.empty((n, h, w, cout), x.dtype)
+    one = ctx.upload(np.ones((1, cin), np.float32), L.F32)
+    rc = ctx.lib.rcgan_conv2d_fwd_bn_residual(ctx.h, C.byref(d), C.c_void_p(x.ptr), C.c_void_p(W.prepared(d).ptr), None, None, C.c_void_p(y.ptr), 1, None,
+                                             C.c_void_p(one.ptr), C.c_void_p(one.ptr), C.c_void_p(one.ptr), C.c_void_p(one.ptr), L.ACT_RELU)
+    assert rc == -2      # RCGAN_EUNSUPPORTED_SHAPE
+    assert b"rcgan_conv_bn_in_ok" in ctx.lib.rcgan_last_error(ctx.h)
+
+
 @pytest.mark.parametrize("m,k,n", [(128, 128, 16384), (40, 64, 1024)])
 def test_wide_dense_layer_on_the_matrix_cores(dev, m, k, n, monkeypatch):
     """ops.linear routes a wide dense layer on 16-bit activations (G.Input: 128 -> 16384) through the 1x1-convolution kernels with its
