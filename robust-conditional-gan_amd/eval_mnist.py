@@ -63,10 +63,12 @@ class TemplateClassifier:
         return d.argmin(1)
 
 
+_TEMPLATE = None
+
+
 def template_predict(images):
+    """``--label_classifier_fn rcgan_amd.eval_mnist:template_predict``: one shared TemplateClassifier."""
     global _TEMPLATE
-    try:
-        clf = _TEMPLATE
-    except NameError:
-        clf = _TEMPLATE = TemplateClassifier()
-    return clf(images)
+    if _TEMPLATE is None:
+        _TEMPLATE = TemplateClassifier()
+    return _TEMPLATE(images)
