@@ -758,7 +758,7 @@ static void mfma_fwd_args(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* 
   if (mfma_phase_filters(d) && (d->flags & RCGAN_CONV_IN_UPSAMPLE2X)) a.wph = (const bf16_t*)prepared + 2 * (size_t)d->kh * d->kw * d->cin * d->cout;
   a.resid = (const bf16_t*)residual;
   a.resid_up = (residual != nullptr && (d->flags & RCGAN_CONV_RESID_UPSAMPLE2X)) ? 1 : 0;
-  a.zero = ctx ? (const bf16_t*)ctx->zero_page : (const bf16_t*)d;       // (routing queries without a context: any non-null value)
+  a.zero = ctx ? (const bf16_t*)ctx->zero_page : (const bf16_t*)prepared;      // (routing queries without a context: any non-null value)
   a.Cin = d->cin; a.Cout = d->cout;
   a.up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) ? 1 : 0;
   a.relu_in = (d->flags & RCGAN_CONV_IN_RELU) ? 1 : 0;
@@ -775,8 +775,10 @@ static int mfma_bn_in_route(const rcgan_conv_desc* d) {
   static const int on = [] { const char* e = getenv("RCGAN_BN_INTO_PATCH"); return e ? atoi(e) : 1; }();
   if (!on) return 0;
   MfmaConvArgs a;
-  // (the summed sub-pixel filters exist whenever mfma_phase_filters(d): a non-null stand-in is enough for the routing question)
-  mfma_fwd_args(nullptr, d, nullptr, d, nullptr, nullptr, nullptr, a);
+  // (the summed sub-pixel filters exist whenever mfma_phase_filters(d): a non-null stand-in is enough for the routing question -- nothing
+  // is read through it)
+  static const bf16_t stand_in[8] = {0};
+  mfma_fwd_args(nullptr, d, nullptr, stand_in, nullptr, nullptr, nullptr, a);
   return mfma_conv_bn_route(a);
 }
 
