@@ -804,8 +804,10 @@ __global__ __launch_bounds__(512) void conv_mfma_h8n_kernel(MfmaConvArgs a) {
   if (!grp) wg_barrier();
   {
     const long mbase = PHM ? (long)(tph0 + pp) * Mph : 0;
-    conv_epilogue<4, 4, RowPhase, false, true>(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, mbase + ms0 + wm * 64, co0 + wn * 64, lane,
-                                               RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
+    // (measured and dropped: requesting ALL pixel rows' ReLU-mask operands in front of the first store instead of one row ahead -- D.Block.1.Conv2's
+    // pooled data gradient 31.1 -> 32.9 us: the launch is throughput-, not latency-bound on its 75 MB)
+    conv_epilogue(acc, a.bias, a.mask, a.resid, a.out, a.accumulate, a.M, a.Cout, mbase + ms0 + wm * 64, co0 + wn * 64, lane,
+                  RowPhase{PHM ? 1 : 0, PHM ? a.lw - 1 : a.lw, PHM ? a.lh - 1 : a.lh, ph, pw, mbase}, a.resid_up ? a.lw : -1, a.lh);
   }
   if (next_pass) {
 #pragma unroll

@@ -130,10 +130,7 @@ struct RowPhase {
 // STATS: also accumulate, per lane, the column sums of the STORED values (after the 16-bit rounding) and of their squares over
 // the wavefront's pixel rows -- st[p][e] / st[p][8 + e] for channel co_wave + (2p + (row & 1)) * 16 + (row >> 1) * 8 + e, row =
 // lane >> 4 -- from which the producing kernel builds per-tile batch-norm statistics (conv_mfma8.hip).
-// MASK_AHEAD (kernels with registers to spare: the 256 x 128 halo kernel): ALL pixel rows' ReLU-mask operands are requested before the first
-// row is stored -- one memory round trip per tile instead of one per pixel row.  With eight K-tiles per phase (D.Block.1.Conv2's pooled data
-// gradient) the four dependent round trips of the rolling scheme were as long as the K loop.
-template <int NI, int NJ, typename Map = RowIdent, bool STATS = false, bool MASK_AHEAD = false>
+template <int NI, int NJ, typename Map = RowIdent, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const float* __restrict__ bias, const bf16_t* mask,
                                               const bf16_t* resid, bf16_t* out, int accumulate, long M, int Cout,
                                               long m_wave /* first pixel of the wavefront's rows */,
@@ -154,20 +151,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const floa
   auto valid = [&](int j) __attribute__((always_inline)) -> bool { return m_wave + j * 16 + (lane & 15) < M; };
   const bool extras = mask != nullptr || resid != nullptr || accumulate != 0;
   uint4 e_mask[NP], e_acc[NP], e_res[NP];
-  uint4 a_mask[MASK_AHEAD ? NJ : 1][NP];
-  if (MASK_AHEAD && mask) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        a_mask[j][p] = valid(j) ? *(const uint4*)(mask + offs(j, p)) : make_uint4(0u, 0u, 0u, 0u);
-  }
   auto fetch = [&](int j) __attribute__((always_inline)) {
     if (!valid(j)) return;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const long o = offs(j, p);
-      if (mask && !MASK_AHEAD) e_mask[p] = *(const uint4*)(mask + o);
+      if (mask) e_mask[p] = *(const uint4*)(mask + o);
       if (accumulate) e_acc[p] = *(const uint4*)(out + o);
       if (resid) {
         long ro = o;
@@ -187,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[NI][NJ], const floa
     uint4 c_mask[NP], c_acc[NP], c_res[NP];
     if (extras) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) { c_mask[p] = MASK_AHEAD ? a_mask[j][p] : e_mask[p]; c_acc[p] = e_acc[p]; c_res[p] = e_res[p]; }
+      for (int p = 0; p < NP; ++p) { c_mask[p] = e_mask[p]; c_acc[p] = e_acc[p]; c_res[p] = e_res[p]; }
       if (j + 1 < NJ) fetch(j + 1);            // requested before row j is stored (see above)
     }
     const bool ok = valid(j);
