@@ -743,8 +743,12 @@ __device__ __forceinline__ void wgrad_glds_body(const MfmaWgradArgs& a, const un
     const int row = (wave * 2 + i) * 4 + lrow;
     r_off[i] = (pos ^ ((row & 7) << 1)) * 8;     // source-side swizzle (channel offset)
   }
+  // (the geometry pinned in scalar registers: see wgrad3_body)
   const bf16_t* xbase = a.x + ci0;
   const bf16_t* ybase = a.dy + co0;
+  const bf16_t* azero = a.zero;
+  int aH = a.H, aW = a.W, aCin = a.Cin, aCout = a.Cout, alw = a.lw, alh = a.lh, aup = a.up;
+  asm volatile("" : "+s"(xbase), "+s"(ybase), "+s"(azero), "+s"(aH), "+s"(aW), "+s"(aCin), "+s"(aCout), "+s"(alw), "+s"(alh), "+s"(aup));
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   long i_p0 = mb;
   auto issue = [&](int buf) {
@@ -752,17 +756,17 @@ __device__ __forceinline__ void wgrad_glds_body(const MfmaWgradArgs& a, const un
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long m = i_p0 + (wave * 2 + i) * 4 + lrow;
-      const bf16_t* px = a.zero;
-      const bf16_t* py = a.zero;
+      const bf16_t* px = azero;
+      const bf16_t* py = azero;
       if (m < me) {
         int ow, oh, n;
-        decode_pix(m, a.H, a.W, a.lh, a.lw, n, oh, ow);
+        decode_pix(m, aH, aW, alh, alw, n, oh, ow);
         int ih = oh + dh, iw = ow + dw;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-          if (a.up) { ih >>= 1; iw >>= 1; }
-          px = xbase + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + r_off[i]);
+        if (ih >= 0 && ih < aH && iw >= 0 && iw < aW) {
+          if (aup) { ih >>= 1; iw >>= 1; }
+          px = xbase + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * aCin + r_off[i]);
         }
-        py = ybase + (unsigned)((unsigned)m * a.Cout + r_off[i]);
+        py = ybase + (unsigned)((unsigned)m * aCout + r_off[i]);
       }
       glds16_asm(px, stage + (wave * 2 + i) * 1024);
       glds16_asm(py, stage + TILE + (wave * 2 + i) * 1024);
@@ -862,11 +866,14 @@ __device__ __forceinline__ void wgrad_bias_block(const MfmaWgradArgs& a, unsigne
   const int y_c1 = co0 + ((lane & 15) ^ ((y_row1 & 7) << 1)) * 8;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   long i_p0 = mb;
+  const bf16_t* ady = a.dy; const bf16_t* azero = a.zero;
+  int aCout = a.Cout;
+  asm volatile("" : "+s"(ady), "+s"(azero), "+s"(aCout));        // (pinned in scalar registers: see wgrad3_body)
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * YT;
     const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
-    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)((unsigned)m0 * a.Cout + y_c0) : a.zero;
-    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)((unsigned)m1 * a.Cout + y_c1) : a.zero;
+    const bf16_t* py0 = m0 < me ? ady + (unsigned)((unsigned)m0 * aCout + y_c0) : azero;
+    const bf16_t* py1 = m1 < me ? ady + (unsigned)((unsigned)m1 * aCout + y_c1) : azero;
     glds16_asm(py0, stage + (wave * 2) * 1024);
     glds16_asm(py1, stage + (wave * 2 + 1) * 1024);
     i_p0 += 32;
@@ -940,7 +947,15 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const int cit = b % nci; b /= nci;
   const int kh = b;
   const int ci0 = cit * 64, co0 = cot * 128;
-  const int Hs = a.up ? (a.H >> 1) : a.H, Ws = a.up ? (a.W >> 1) : a.W;
+  // The problem's geometry, PINNED in scalar registers (round 5).  `a` lives in the kernel-argument segment (a grouped launch indexes it with
+  // the problem number) and the compiler re-read its fields there on every use: 17 s_load + 9 s_waitcnt lgkmcnt(0) in the address
+  // arithmetic of EVERY K-step, each a scalar-cache round trip in front of the LDS-DMA issue.  An empty asm makes the copies opaque
+  // (scripts/bench_wgrad_group.py: the critic's 32x32 layer alone 78.7 -> 70.9 us, the critic step's set 166 -> 155 us).
+  const bf16_t* ax = a.x; const bf16_t* ady = a.dy; const bf16_t* azero = a.zero;
+  int aH = a.H, aW = a.W, aCin = a.Cin, aCout = a.Cout, alw = a.lw, alh = a.lh, aup = a.up;
+  long aM = a.M;
+  asm volatile("" : "+s"(ax), "+s"(ady), "+s"(azero), "+s"(aH), "+s"(aW), "+s"(aCin), "+s"(aCout), "+s"(alw), "+s"(alh), "+s"(aup), "+s"(aM));
+  const int Hs = aup ? (aH >> 1) : aH, Ws = aup ? (aW >> 1) : aW;
   const int pa = kh >> 2, pb = (kh >> 1) & 1, srow = kh & 1;                 // sub-pixel form only
   const int dh = !SUB ? kh - a.PT : (sub == 3 ? 0 : (sub == 1 ? srow - 1 + pa : srow - pa));
   // first column tap: dw = tap - 1 for the three taps, or dw in {-1, 0} / {0, +1} by the column parity (1x1: dw = 0, second tap idle)
@@ -961,17 +976,17 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   auto x_src = [&](long m, int coff) -> const bf16_t* {
-    const bf16_t* p = a.zero;
-    if (m >= 0 && m < a.M) {
+    const bf16_t* p = azero;
+    if (m >= 0 && m < aM) {
       const unsigned mm = (unsigned)m;
-      const int ow = (int)(mm & (unsigned)(a.W - 1));
-      const int oh = (int)((mm >> a.lw) & (unsigned)(a.H - 1));
-      const int n = (int)(mm >> (a.lw + a.lh));
+      const int ow = (int)(mm & (unsigned)(aW - 1));
+      const int oh = (int)((mm >> alw) & (unsigned)(aH - 1));
+      const int n = (int)(mm >> (alw + alh));
       int ih = oh + dh, iw = ow;
-      if (ih >= 0 && ih < a.H) {
-        if (a.up) { ih >>= 1; iw >>= 1; }
-        if (sub == 2) p = a.x + (unsigned)((((unsigned)n * 2 * a.H + 2 * ih + pa) * 2 * a.W + 2 * iw + pb) * a.Cin + coff);
-        else p = a.x + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * a.Cin + coff);
+      if (ih >= 0 && ih < aH) {
+        if (aup) { ih >>= 1; iw >>= 1; }
+        if (sub == 2) p = ax + (unsigned)((((unsigned)n * 2 * aH + 2 * ih + pa) * 2 * aW + 2 * iw + pb) * aCin + coff);
+        else p = ax + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * aCin + coff);
       }
     }
     return p;
@@ -980,15 +995,15 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   auto y_pix = [&](long m) -> unsigned {
     const unsigned mm = (unsigned)m;
     if (sub != 1) return mm;
-    const unsigned ow = mm & (unsigned)(a.W - 1), oh = (mm >> a.lw) & (unsigned)(a.H - 1), n = mm >> (a.lw + a.lh);
-    return ((n * 2 * a.H + 2 * oh + pa) * 2 * a.W + 2 * ow + pb);
+    const unsigned ow = mm & (unsigned)(aW - 1), oh = (mm >> alw) & (unsigned)(aH - 1), n = mm >> (alw + alh);
+    return ((n * 2 * aH + 2 * oh + pa) * 2 * aW + 2 * ow + pb);
   };
   long i_p0 = mb;
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * STAGE;
     const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
-    const bf16_t* py0 = m0 < me ? a.dy + (unsigned)(y_pix(m0) * a.Cout + y_c0) : a.zero;
-    const bf16_t* py1 = m1 < me ? a.dy + (unsigned)(y_pix(m1) * a.Cout + y_c1) : a.zero;
+    const bf16_t* py0 = m0 < me ? ady + (unsigned)(y_pix(m0) * aCout + y_c0) : azero;
+    const bf16_t* py1 = m1 < me ? ady + (unsigned)(y_pix(m1) * aCout + y_c1) : azero;
     glds16_asm(py0, stage + XT + (wave * 2) * 1024);
     glds16_asm(py1, stage + XT + (wave * 2 + 1) * 1024);
     glds16_asm(x_src(i_p0 - 4 + x_rowa, x_ca), stage + wave * 1024);
