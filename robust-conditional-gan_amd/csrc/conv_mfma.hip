@@ -975,9 +975,11 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const int x_cb = ci0 + ((lane & 7) ^ (((x_rowb >> 1) & 3) << 1)) * 8;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  auto x_src = [&](long m, int coff) -> const bf16_t* {
+  // (pixel indices are 32-bit in the loop -- mfma_wgrad_eligible bounds M -- : half the vector ALU work of the 64-bit compares and adds)
+  const int M32 = (int)aM, me32 = (int)me;
+  auto x_src = [&](int m, int coff) -> const bf16_t* {
     const bf16_t* p = azero;
-    if (m >= 0 && m < aM) {
+    if ((unsigned)m < (unsigned)M32) {
       const unsigned mm = (unsigned)m;
       const int ow = (int)(mm & (unsigned)(aW - 1));
       const int oh = (int)((mm >> alw) & (unsigned)(aH - 1));
@@ -992,18 +994,18 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
     return p;
   };
   // dy row of reduction pixel m: itself, or (sub 1) pixel (2i + pa, 2j + pb) of the full-resolution grid
-  auto y_pix = [&](long m) -> unsigned {
+  auto y_pix = [&](int m) -> unsigned {
     const unsigned mm = (unsigned)m;
     if (sub != 1) return mm;
     const unsigned ow = mm & (unsigned)(aW - 1), oh = (mm >> alw) & (unsigned)(aH - 1), n = mm >> (alw + alh);
     return ((n * 2 * aH + 2 * oh + pa) * 2 * aW + 2 * ow + pb);
   };
-  long i_p0 = mb;
+  int i_p0 = (int)mb;
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * STAGE;
-    const long m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
-    const bf16_t* py0 = m0 < me ? ady + (unsigned)(y_pix(m0) * aCout + y_c0) : azero;
-    const bf16_t* py1 = m1 < me ? ady + (unsigned)(y_pix(m1) * aCout + y_c1) : azero;
+    const int m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
+    const bf16_t* py0 = m0 < me32 ? ady + (unsigned)(y_pix(m0) * aCout + y_c0) : azero;
+    const bf16_t* py1 = m1 < me32 ? ady + (unsigned)(y_pix(m1) * aCout + y_c1) : azero;
     glds16_asm(py0, stage + XT + (wave * 2) * 1024);
     glds16_asm(py1, stage + XT + (wave * 2 + 1) * 1024);
     glds16_asm(x_src(i_p0 - 4 + x_rowa, x_ca), stage + wave * 1024);
@@ -1085,8 +1087,10 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
             uint4 v = __builtin_bit_cast(uint4, tr_pair(sb + offx[t][j], 16 * 128));
             if (!(WG3_ABLATE & 8)) {
             if (SUB ? relu_on : RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
-            if (t == 0) { v.x &= maskl[0]; v.y &= maskl[1]; v.z &= maskl[2]; v.w &= maskl[3]; }
-            if (t == NT - 1) { v.x &= maskr[0]; v.y &= maskr[1]; v.z &= maskr[2]; v.w &= maskr[3]; }
+            // (column 0 can only be fragment element 0 or 4, column W-1 only element 3 or 7 -- W divides the 4-pixel runs a lane holds:
+            // the left mask lives in words 0 and 2, the right one in words 1 and 3)
+            if (t == 0) { v.x &= maskl[0]; v.z &= maskl[2]; }
+            if (t == NT - 1) { v.y &= maskr[1]; v.w &= maskr[3]; }
             }
             xf[j] = __builtin_bit_cast(bf16x8_t, v);
           }
