@@ -952,10 +952,9 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   // arithmetic of EVERY K-step, each a scalar-cache round trip in front of the LDS-DMA issue.  An empty asm makes the copies opaque
   // (scripts/bench_wgrad_group.py: the critic's 32x32 layer alone 78.7 -> 70.9 us, the critic step's set 166 -> 155 us).
   const bf16_t* ax = a.x; const bf16_t* ady = a.dy; const bf16_t* azero = a.zero;
-  int aH = a.H, aW = a.W, aCin = a.Cin, aCout = a.Cout, alw = a.lw, alh = a.lh, aup = a.up;
+  int aH = a.H, aW = a.W, aCin = a.Cin, aCout = a.Cout, alw = a.lw, alh = a.lh;
   long aM = a.M;
-  asm volatile("" : "+s"(ax), "+s"(ady), "+s"(azero), "+s"(aH), "+s"(aW), "+s"(aCin), "+s"(aCout), "+s"(alw), "+s"(alh), "+s"(aup), "+s"(aM));
-  const int Hs = aup ? (aH >> 1) : aH, Ws = aup ? (aW >> 1) : aW;
+  asm volatile("" : "+s"(ax), "+s"(ady), "+s"(azero), "+s"(aH), "+s"(aW), "+s"(aCin), "+s"(aCout), "+s"(alw), "+s"(alh), "+s"(aM));
   const int pa = kh >> 2, pb = (kh >> 1) & 1, srow = kh & 1;                 // sub-pixel form only
   const int dh = !SUB ? kh - a.PT : (sub == 3 ? 0 : (sub == 1 ? srow - 1 + pa : srow - pa));
   // first column tap: dw = tap - 1 for the three taps, or dw in {-1, 0} / {0, +1} by the column parity (1x1: dw = 0, second tap idle)
@@ -971,45 +970,46 @@ __device__ __forceinline__ void wgrad3_body(const MfmaWgradArgs& a, const unsign
   const int y_c1 = co0 + ((lane & 15) ^ ((y_row1 & 7) << 1)) * 8;
   // X: deposit q = wave (and q = 4 from wave 0); lane -> row q*8 + lane/8, 16-B slot lane%8
   const int x_rowa = wave * 8 + (lane >> 3), x_rowb = 32 + (lane >> 3);
-  const int x_ca = ci0 + ((lane & 7) ^ (((x_rowa >> 1) & 3) << 1)) * 8;
-  const int x_cb = ci0 + ((lane & 7) ^ (((x_rowb >> 1) & 3) << 1)) * 8;
+  const int x_ca = ci0 + ((lane & 7) ^ (((x_rowa >> 1) & 3) << 1)) * 8;        // (rows 32 + r share row r's swizzle key)
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  // (pixel indices are 32-bit in the loop -- mfma_wgrad_eligible bounds M -- : half the vector ALU work of the 64-bit compares and adds)
-  const int M32 = (int)aM, me32 = (int)me;
-  auto x_src = [&](int m, int coff) -> const bf16_t* {
-    const bf16_t* p = azero;
-    if ((unsigned)m < (unsigned)M32) {
-      const unsigned mm = (unsigned)m;
-      const int ow = (int)(mm & (unsigned)(aW - 1));
-      const int oh = (int)((mm >> alw) & (unsigned)(aH - 1));
-      const int n = (int)(mm >> (alw + alh));
-      int ih = oh + dh, iw = ow;
-      if (ih >= 0 && ih < aH) {
-        if (aup) { ih >>= 1; iw >>= 1; }
-        if (sub == 2) p = ax + (unsigned)((((unsigned)n * 2 * aH + 2 * ih + pa) * 2 * aW + 2 * iw + pb) * aCin + coff);
-        else p = ax + (unsigned)((((unsigned)n * Hs + ih) * Ws + iw) * aCin + coff);
-      }
-    }
-    return p;
-  };
-  // dy row of reduction pixel m: itself, or (sub 1) pixel (2i + pa, 2j + pb) of the full-resolution grid
-  auto y_pix = [&](int m) -> unsigned {
-    const unsigned mm = (unsigned)m;
-    if (sub != 1) return mm;
-    const unsigned ow = mm & (unsigned)(aW - 1), oh = (mm >> alw) & (unsigned)(aH - 1), n = mm >> (alw + alh);
-    return ((n * 2 * aH + 2 * oh + pa) * 2 * aW + 2 * ow + pb);
-  };
+  // (pixel indices are 32-bit in the loop -- the element counts are bounded by the host -- : half the vector ALU work of 64-bit compares and adds)
+  const int M32 = (int)aM;
   int i_p0 = (int)mb;
+  // Linear addressing (round 5; the nearest-upsampled input, whose source row is floor(row / 2), goes to the per-tap kernel or, by default,
+  // to the sub-pixel form sub = 1).  A K-step advances the reduction index by 32 pixels = whole grid
+  // rows (W divides 32), so every lane's source address advances by the SAME amount per step, also in the strided sub-pixel forms (4 W elements
+  // per grid row of the full-resolution tensor): dy is fetched through a scalar base that steps + a constant per-lane offset -- no vector ALU
+  // work at all (chunks are whole K-steps: mfma_wgrad3_takes) --, x through a per-lane offset that steps, with the in-image test (halo rows
+  // read the zero page) as two compares and a select instead of the pixel's decomposition, three multiplies and two divergent branches.
+  auto y_lin = [&](int row) -> unsigned {        // element offset of pixel (step base + row), step base = a multiple of 32
+    if (sub != 1) return (unsigned)(row * aCout);
+    return (unsigned)((4 * aW * (row >> alw) + 2 * (row & (aW - 1)) + pa * 2 * aW + pb) * aCout);
+  };
+  auto x_lin = [&](int m, int coff) -> unsigned {      // element offset of the pixel tap row dh of reduction pixel m reads (m < 0: the same line, continued)
+    if (sub == 2) return (unsigned)((4 * aW * (m >> alw) + 2 * (m & (aW - 1)) + (2 * dh + pa) * 2 * aW + pb) * aCin + coff);
+    return (unsigned)((m + dh * aW) * aCin + coff);
+  };
+  const unsigned yv0 = 2u * (y_lin(y_row0) + (unsigned)y_c0), yv1 = 2u * (y_lin(y_row1) + (unsigned)y_c1);
+  const bf16_t* ybase = ady + (sub == 1 ? 4L : 1L) * mb * aCout;
+  const long ystep = (sub == 1 ? 128L : 32L) * aCout;
+  // (wave 0's second x deposit, rows 32..39 of the stage, reads what its first one reads a K-step later: same lane pattern, same swizzle key)
+  unsigned xoa = x_lin((int)mb - 4 + x_rowa, x_ca);
+  const unsigned xstep = (sub == 2 ? 128u : 32u) * (unsigned)aCin;
+  auto x_ptr = [&](int rowc, unsigned xo) -> const bf16_t* {
+    const int m = i_p0 + rowc;
+    const int ih = (int)__builtin_amdgcn_ubfe((unsigned)m, (unsigned)alw, (unsigned)alh) + dh;
+    const bool ok = (unsigned)m < (unsigned)M32 && (unsigned)ih < (unsigned)aH;
+    return ok ? ax + xo : azero;
+  };
   auto issue = [&](int buf) {
     const unsigned stage = lds0 + buf * STAGE;
-    const int m0 = i_p0 + y_row0, m1 = i_p0 + y_row1;
-    const bf16_t* py0 = m0 < me32 ? ady + (unsigned)(y_pix(m0) * aCout + y_c0) : azero;
-    const bf16_t* py1 = m1 < me32 ? ady + (unsigned)(y_pix(m1) * aCout + y_c1) : azero;
-    glds16_asm(py0, stage + XT + (wave * 2) * 1024);
-    glds16_asm(py1, stage + XT + (wave * 2 + 1) * 1024);
-    glds16_asm(x_src(i_p0 - 4 + x_rowa, x_ca), stage + wave * 1024);
-    if (wave == 0) glds16_asm(x_src(i_p0 - 4 + x_rowb, x_cb), stage + 4 * 1024);
+    glds16_sbase(ybase, yv0, stage + XT + (wave * 2) * 1024);
+    glds16_sbase(ybase, yv1, stage + XT + (wave * 2 + 1) * 1024);
+    ybase += ystep;
+    glds16_asm(x_ptr(x_rowa - 4, xoa), stage + wave * 1024);
+    xoa += xstep;
+    if (wave == 0) glds16_asm(x_ptr(x_rowb - 4, xoa), stage + 4 * 1024);
     i_p0 += 32;
   };
 
@@ -1775,6 +1775,7 @@ static bool wgrad3_shape(int kh, int kw, int h, int w) {
 }
 
 static bool wgrad3_geom(const MfmaWgradArgs& a) {     // (sub-pixel and 1x1 forms: the grid of the reduction index decides)
+  if (a.M % 32 != 0 || a.up) return false;       // whole K-steps: the dy stream of the linear addressing has no tail test; no floor(row / 2) sources
   return a.sub ? wgrad3_shape(3, 3, a.H, a.W) : (wgrad3_shape(a.KH, a.KW, a.H, a.W) && a.PL == 1);
 }
 
@@ -1820,12 +1821,14 @@ int mfma_wgrad_sub_kind(const rcgan_conv_desc* d, int use_tr) {
     // one keeps the per-tap kernel's 128 x 128 tiles (a staged pixel feeds one tap's MFMAs here: a third of the arithmetic intensity)
     static const double max_gflop = env_int("RCGAN_WGRAD_1X1_GROUP_MAXMFLOP", 600) * 1e6;
     const double fl = 2.0 * d->n * d->h * d->w * (double)d->cin * d->cout;
-    return fl <= max_gflop && !(d->flags & (RCGAN_CONV_OUT_MEANPOOL2 | RCGAN_CONV_IN_UPSAMPLE2X)) && wgrad3_shape(3, 3, d->h, d->w) ? 3 : 0;
+    // (the reduction index runs in whole 32-pixel K-steps: wgrad3_geom)
+    return fl <= max_gflop && !(d->flags & (RCGAN_CONV_OUT_MEANPOOL2 | RCGAN_CONV_IN_UPSAMPLE2X)) && wgrad3_shape(3, 3, d->h, d->w) &&
+           ((long)d->n * d->h * d->w) % 32 == 0 ? 3 : 0;
   }
   if (!on || d->kh != 3 || d->kw != 3) return 0;
   const bool up = (d->flags & RCGAN_CONV_IN_UPSAMPLE2X) != 0, pool = (d->flags & RCGAN_CONV_OUT_MEANPOOL2) != 0;
   if (up == pool || (d->h & 1) || (d->w & 1)) return 0;
-  if (!wgrad3_shape(3, 3, d->h / 2, d->w / 2)) return 0;
+  if (!wgrad3_shape(3, 3, d->h / 2, d->w / 2) || ((long)d->n * (d->h / 2) * (d->w / 2)) % 32 != 0) return 0;
   return up ? 1 : 2;
 }
 

@@ -77,14 +77,7 @@ constexpr int h8_lds_bytes(int lw) { return 2 * h8_patch_rows(lw) * 128 + 4 * H8
 
 }  // namespace
 
-// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the address of a burst needs no vector ALU
-// work in the loop (the tile-per-tap kernels add a 64-bit per-lane pointer per burst) -- every VALU instruction a "loading"
-// wavefront issues comes out of the matrix pipe's time of the wavefront it shares the SIMD with.
-__device__ __forceinline__ void glds16_sbase(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_byte_addr /* wave-uniform */) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
+// (glds16_sbase -- LDS-DMA with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset -- lives in mfma_util.h)
 
 // 16 bytes from an absolute LDS byte address + a compile-time offset (the ds_read immediate): no `smem +` pointer arithmetic, which
 // costs a vector add per read (the dynamic-LDS base is a relocation the compiler does not fold)

@@ -56,6 +56,15 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, unsigned lds_byte_a
                : "=&s"(keep) : "v"(gptr), "s"(lds_byte_addr) : "memory");
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the address of a burst needs no vector ALU work in the
+// loop -- a stream whose lanes keep their offsets advances with one scalar add per step (glds16_asm's callers add a 64-bit per-lane pointer
+// per burst); every VALU instruction a "loading" wavefront issues comes out of the matrix pipe's time of the wavefront it shares the SIMD with.
+__device__ __forceinline__ void glds16_sbase(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_byte_addr /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
