@@ -1143,7 +1143,7 @@ int rcgan_conv2d_bwd_weight_group(rcgan_ctx* ctx, int n, const rcgan_conv_desc* 
     if (any_group && img.n < IMG_GROUP_MAX && img_side(d) && (d->cin <= 3 ? d->cout : d->cin) == 128) {
       ImgWArgs ia;
       int cb = 0, nwg = 0;
-      static const int img_wgs = [] { const char* e = getenv("RCGAN_WGRAD_IMG_WGS"); return e ? atoi(e) : 96; }();       // (with 384 three-tap workgroups: 6.64 -> 6.62 ms)
+      static const int img_wgs = [] { const char* e = getenv("RCGAN_WGRAD_IMG_WGS"); return e ? atoi(e) : 128; }();       // (with 384 three-tap workgroups: 6.64 -> 6.62 ms with 96; round 5, the three-tap workgroups a quarter faster: 96 5.36 ms, 128 5.34, 160 5.40, 256 5.36)
       int rc = img_wgrad_plan(ctx, d, xs[i], dys[i], img_wgs, &ia, &cb, &nwg);
       if (rc) return rc;
       const long per = 32L * cb + 32;
