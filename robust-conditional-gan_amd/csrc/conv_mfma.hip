@@ -1748,6 +1748,8 @@ int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
       return mfma_conv8n_halo_launch(ctx, a);
     if (a.M % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min2 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);
     if (a.M % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= p8n_min2) return mfma_conv8_launch(ctx, a, false);
+    // (measured in round 5 and not kept: 128 x 128 tiles of this kernel for D.Block.1.Conv2's forward -- 256 tiles, one per CU, against 1024 of
+    // 64 x 64 -- same-box 5.20 -> 5.25 ms; for every 16-tap layer 5.40)
     if ((a.M / 64) * (a.Cout / 64) <= ks2_max2) return launch_conv_glds_phase<64, 64, 2, 2, 2>(ctx, a);
     return launch_conv_glds_phase<64, 64, 2, 1, 2>(ctx, a);
   }
