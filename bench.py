@@ -130,6 +130,8 @@ def kernel_roofline(m, pool, default_workload=True):
     ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(fl)))
     fx = C.c_double(0)
     ctx.check(ctx.lib.rcgan_prof_executed_flops(ctx.h, C.byref(fx)))
+    nbn = C.c_int(0)
+    ctx.check(ctx.lib.rcgan_prof_bn_in_launches(ctx.h, C.byref(nbn)))
     m.use_graphs = saved
     if n.value == 0 or ms.value <= 0:
         return None
@@ -172,7 +174,8 @@ def kernel_roofline(m, pool, default_workload=True):
             # (round 5) in the forward-only generator pass the kernel also applies the conditional batch norm + ReLU in front of the
             # convolution to its staged input (two of its five launches): their time includes that work, the FLOP count does not --
             # RCGAN_BN_INTO_PATCH=0 gives the plain launches back (and three batch-norm apply launches with them)
-            "launches_with_batch_norm_on_the_staged_input": (2 if os.environ.get("RCGAN_BN_INTO_PATCH", "1") != "0" and default_workload else 0),
+            # (counted by the runtime in this very section: rcgan_prof_bn_in_launches)
+            "bn_in_patch_launches": nbn.value,
             **busy_extra}
 
 

@@ -90,6 +90,9 @@ int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* tota
 /* Flops the kernels of the last rcgan_prof_begin .. rcgan_prof_end section EXECUTED: equal to the algorithmic count except for
  * the sub-pixel form of the upsample-3x3 convolutions (four 2x2 convolutions with summed filters: 4/9 of the multiply-adds). */
 int rcgan_prof_executed_flops(rcgan_ctx* ctx, double* executed_flops);
+/* How many launches of that section also applied the batch norm in front of the convolution to their staged input
+ * (rcgan_conv2d_fwd_bn_residual on a halo-patch kernel): their time includes that work, their FLOP count does not. */
+int rcgan_prof_bn_in_launches(rcgan_ctx* ctx, int* launches);
 /* Diagnostics: while `stamps` is non-null, every workgroup of the 256 x 256 convolution kernel writes 8 x uint64 to
  * stamps[workgroup * 8 ..]: s_memtime at {start, tap table built, first K-tile landed, K loop done, stores issued,
  * stores complete}, HW_ID, XCC_ID (scripts/exp_p8_timeline.py).  Pass null to switch it off. */

@@ -18,6 +18,7 @@ LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_CE_ONES, LOSS_CE_ZEROS = 0
 QUERY_TR_READ = 0
 
 RCGAN_EHIP, RCGAN_ERCCL = -4, -5
+EUNSUPPORTED_SHAPE = -2
 ERRORS = {-1: "RCGAN_EINVALID_ARG", -2: "RCGAN_EUNSUPPORTED_SHAPE", -3: "RCGAN_EWORKSPACE_TOO_SMALL",
           -4: "RCGAN_EHIP", -5: "RCGAN_ERCCL"}
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "rcgan_prof_begin": (I, [P, I]),
     "rcgan_prof_end": (I, [P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rcgan_prof_executed_flops": (I, [P, C.POINTER(C.c_double)]),
+    "rcgan_prof_bn_in_launches": (I, [P, C.POINTER(I)]),
     "rcgan_graph_begin": (I, [P]),
     "rcgan_reserve_scratch": (I, [P, C.c_size_t]),
     "rcgan_scratch_bytes": (I, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -459,6 +459,7 @@ int rcgan_reserve_scratch(rcgan_ctx* ctx, size_t bytes) {
 }
 
 int rcgan_scratch_bytes(rcgan_ctx* ctx, size_t* split_reduction_bytes, size_t* narrow_bytes) {
+  if (!ctx) return RCGAN_EINVALID_ARG;
   if (split_reduction_bytes) *split_reduction_bytes = ctx->splitr_ws_bytes;
   if (narrow_bytes) *narrow_bytes = ctx->narrow_ws_bytes;
   return RCGAN_OK;
@@ -516,6 +517,7 @@ int rcgan_prof_begin(rcgan_ctx* ctx, int which) {
   ctx->prof_ev.clear();
   ctx->prof_flops = 0.0;
   ctx->prof_flops_exec = 0.0;
+  ctx->prof_bn_in = 0;
   ctx->prof_which = which;
   return RCGAN_OK;
 }
@@ -541,6 +543,12 @@ int rcgan_prof_end(rcgan_ctx* ctx, int* launches, double* total_ms, double* tota
 int rcgan_prof_executed_flops(rcgan_ctx* ctx, double* executed_flops) {
   RC_REQUIRE(ctx, executed_flops != nullptr, "null argument");
   *executed_flops = ctx->prof_flops_exec;
+  return RCGAN_OK;
+}
+
+int rcgan_prof_bn_in_launches(rcgan_ctx* ctx, int* launches) {
+  if (!ctx || !launches) return RCGAN_EINVALID_ARG;
+  *launches = ctx->prof_bn_in;
   return RCGAN_OK;
 }
 

@@ -24,6 +24,7 @@ struct rcgan_ctx {
   int prof_which;
   std::vector<hipEvent_t> prof_ev;
   double prof_flops, prof_flops_exec;      // algorithmic (the reference's formulation) / executed by the kernels
+  int prof_bn_in = 0;                      // launches of the section that also applied a batch norm to their staged input
   // fork/join onto a second stream (rcgan_side_begin/end/join): lets an independent kernel pair -- a layer's filter
   // gradient and its data gradient -- share the chip when neither fills it.  Capturable (event fork/join).
   hipStream_t main_stream, side_stream;

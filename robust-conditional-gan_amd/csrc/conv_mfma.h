@@ -123,7 +123,7 @@ int img_fwd_bn(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const vo
 int img_wgrad_plan(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int target_wgs, ImgWArgs* a, int* cb, int* nwg);
 int img_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
               void* ws, size_t ws_bytes);
-int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts
+int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide, bool halo_patch);      // conv_mfma8.hip: 256 x 256 / 256 x 128 tiles, 8 wavefronts (halo_patch: conv_mfma8h.hip)
 bool mfma_conv8_halo_takes(const MfmaConvArgs& a);                             // conv_mfma8h.hip: 256 x 256 tile, pixel operand as an LDS patch
 int mfma_conv8_halo_launch(rcgan_ctx* ctx, const MfmaConvArgs& a);
 bool mfma_conv8n_halo_takes(const MfmaConvArgs& a);                            // ... its 256 x 128-tile sibling (Cout % 128 == 0)

@@ -1695,80 +1695,96 @@ static int launch_conv_mfma(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   return RCGAN_OK;
 }
 
-// an ordinary (phase 0 on entry) forward / data-gradient launch that mfma_conv_launch routes to the 256 x 256 eight-wave kernel
-bool mfma_conv_is_p8(const MfmaConvArgs& a) {
-  if (a.phase != 0 || a.Cin % 64 || a.Cout % 256 || a.zero == nullptr) return false;
-  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);
-  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);
-  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
-  return off32 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
+// THE routing decision of a forward / data-gradient launch (round 6: one function instead of three hand-kept mirrors).  It is the only
+// place that reads the routing thresholds; mfma_conv_launch launches what it returns, and the questions the host asks before it builds a
+// fused call (mfma_conv_is_p8: tile statistics; mfma_conv_bn_route: batch norm on the staged input) read the same answer.
+enum ConvRoute {
+  CR_H8,            // 256 x 256 halo-patch kernel (conv_mfma8h.hip)
+  CR_P8,            // 256 x 256 tile-per-tap kernel (conv_mfma8.hip)
+  CR_H8N,           // 256 x 128 halo-patch kernel; on a phase-2 launch: its parity-plane gather form
+  CR_P8N,           // 256 x 128 tile-per-tap kernel
+  CR_PHASE_KS2,     // 64 x 64 sub-pixel forms, two K-groups
+  CR_PHASE,         // 64 x 64 sub-pixel forms
+  CR_T256, CR_T256N, CR_T128, CR_64
+};
+
+static ConvRoute mfma_conv_route(const MfmaConvArgs& a) {
+  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);          // 256 x 256 eight-wave kernels
+  static const int p8n_min = env_int("RCGAN_P8N_MINBLK", 190);        // 256 x 128 eight-wave kernels
+  static const int ks2_max = env_int("RCGAN_KS2_MAXBLK", 576);
+  static const int halo = env_int("RCGAN_P8_HALO", 1), halo_n = env_int("RCGAN_P8N_HALO", 1);
+  static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
+  static const int t256_min = env_int("RCGAN_T256_MINBLK", 1 << 30);     // experiment: 256-pixel tiles (1 wave/SIMD)
+  if (a.phase == 1 || a.phase == 2) {
+    // forced sub-pixel forms.  1: the data gradient of a ConvMeanPool (a.wt is not a usable fallback); 2: the data gradient of the sub-pixel
+    // form (the caller checked mfma_phase_dgrad_ok).  256-pixel tiles where the grid fills the chip, else the 64 x 64 kernel
+    const bool whole = a.phase == 1 ? ((a.M >> 2) % 256 == 0) : (a.M % 256 == 0);
+    const long b8 = (a.M / 256) * (a.Cout / 256), b8n = (a.M / 256) * (a.Cout / 128);
+    if (a.phase == 2) {
+      // (round 5) the parity-plane patch form of the 256 x 128 halo kernel where its tiles fill the chip: G.Block.3.Conv1's data gradient
+      // (128 x 2 tiles) 78 -> 61 us.  Measured and left to the 64 x 64 kernel: D.Block.1.Conv2's forward (128 tiles = half the CUs) 33 -> 37 us
+      // (RCGAN_H8N_GATHER_MINBLK=120 takes it too; 100000 switches the form off -- since round 6 really off: the 256 x 128 tile-per-tap
+      // kernel gets the launch, not the gather form by the back door of mfma_conv8_launch)
+      const int gather_min = env_int("RCGAN_H8N_GATHER_MINBLK", 190);        // (read per call: the tests force the form on smaller grids)
+      if (halo_n && whole && a.Cout % 128 == 0 && b8n >= gather_min && mfma_conv8n_halo_takes(a)) return CR_H8N;
+    }
+    if (whole && a.Cout % 256 == 0 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256)
+      return (halo && !a.stats && mfma_conv8_halo_takes(a)) ? CR_H8 : CR_P8;
+    if (whole && a.Cout % 128 == 0 && b8n >= p8n_min)
+      return (a.phase == 1 && halo_n && mfma_conv8n_halo_takes(a)) ? CR_H8N : CR_P8N;
+    // (measured in round 5 and not kept: 128 x 128 tiles of the 64 x 64 kernel for D.Block.1.Conv2's forward -- 256 tiles, one per CU, against
+    // 1024 of 64 x 64 -- same-box 5.20 -> 5.25 ms; for every 16-tap layer 5.40)
+    return (a.M / 64) * (a.Cout / 64) <= ks2_max ? CR_PHASE_KS2 : CR_PHASE;
+  }
+  MfmaConvArgs b = a;
+  b.phase = mfma_conv8_phase_form(a) ? 1 : 0;                         // what mfma_conv8_launch will run it as
+  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);      // the tap-source table holds 32-bit element offsets
+  // one 256 x 256 workgroup per CU: a grid of 320 runs two rounds for 1.25 rounds of work -- such grids go to the
+  // 256 x 128 kernel (twice the workgroups, finer rounds) when less than 3/4 of the last round would be busy
+  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256), b8n = (long)cdiv(a.M, 256) * (a.Cout / 128);
+  const bool fit8 = 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
+  if (a.Cout % 256 == 0 && a.zero != nullptr && off32 && b8 >= p8_min && fit8) return (halo && !a.stats && mfma_conv8_halo_takes(b)) ? CR_H8 : CR_P8;
+  if (a.Cout % 128 == 0 && a.zero != nullptr && b8n >= p8n_min) return (halo_n && mfma_conv8n_halo_takes(b)) ? CR_H8N : CR_P8N;
+  if (a.Cout % 256 == 0 && b8 >= t256_min && a.zero != nullptr) return CR_T256;
+  if (a.Cout % 128 == 0 && b8n >= t256_min && a.zero != nullptr) return CR_T256N;
+  if (a.Cout % 128 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 128) >= t128_min) return CR_T128;
+  return CR_64;
 }
 
-// Would mfma_conv_launch run this (phase 0 on entry) forward launch on one of the halo-patch kernels -- the ones that can apply a
-// batch norm to their staged input (MfmaConvArgs::bn_*)?  1: 256 x 256 tile, 2: 256 x 128 tile, 0: no.  Mirrors the routing below.
+// an ordinary (phase 0 on entry) forward / data-gradient launch that runs on a 256 x 256 eight-wave kernel
+bool mfma_conv_is_p8(const MfmaConvArgs& a) {
+  if (a.phase != 0 || a.Cin % 64 || a.Cout % 64) return false;
+  const ConvRoute r = mfma_conv_route(a);
+  return r == CR_H8 || r == CR_P8;
+}
+
+// Does this (phase 0 on entry) forward launch run on one of the halo-patch kernels -- the ones that can apply a batch norm to their
+// staged input (MfmaConvArgs::bn_*)?  1: 256 x 256 tile, 2: 256 x 128 tile, 0: no.
 int mfma_conv_bn_route(const MfmaConvArgs& a) {
-  if (a.phase != 0 || a.Cin % 64 || a.zero == nullptr || a.stats || a.relu_in || a.Cin > 1024) return 0;
-  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200), p8n_min = env_int("RCGAN_P8N_MINBLK", 190);
-  static const int halo = env_int("RCGAN_P8_HALO", 1), halo_n = env_int("RCGAN_P8N_HALO", 1);
-  MfmaConvArgs b = a;
-  b.phase = mfma_conv8_phase_form(a) ? 1 : 0;
-  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);
-  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
-  if (a.Cout % 256 == 0 && off32 && b8 >= p8_min && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return (halo && mfma_conv8_halo_takes(b)) ? 1 : 0;
-  if (a.Cout % 128 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 128) >= p8n_min) return (halo_n && mfma_conv8n_halo_takes(b)) ? 2 : 0;
-  return 0;
+  if (a.phase != 0 || a.Cin % 64 || a.Cout % 64 || a.zero == nullptr || a.stats || a.relu_in || a.Cin > 1024) return 0;
+  const ConvRoute r = mfma_conv_route(a);
+  return r == CR_H8 ? 1 : r == CR_H8N ? 2 : 0;
 }
 
 int mfma_conv_launch(rcgan_ctx* ctx, const MfmaConvArgs& a_in) {
   MfmaConvArgs a = a_in;
   a.stamps = (unsigned long long*)ctx->dbg_stamps;       // diagnostics (rcgan_debug_stamps), normally null
   if (a.Cin % 64 || a.Cout % 64) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "channels %d -> %d", a.Cin, a.Cout);
-  if (a.bn_mean && !mfma_conv_bn_route(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "batch norm on the staged input needs a halo-patch kernel (rcgan_conv_bn_in_ok)");
-  if (a.stats && !mfma_conv_is_p8(a)) RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel (rcgan_conv_stats_ok)");
-  if (a.phase == 1) {
-    // forced sub-pixel form (the data gradient of a ConvMeanPool: a.wt is not a usable fallback): same routing as below
-    static const int p8_min1 = env_int("RCGAN_P8_MINBLK", 200), p8n_min1 = env_int("RCGAN_P8N_MINBLK", 190), ks2_max1 = env_int("RCGAN_KS2_MAXBLK", 576);
-    const long b8 = (a.M / 256) * (a.Cout / 256);
-    if ((a.M >> 2) % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min1 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);
-    if ((a.M >> 2) % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= p8n_min1) return mfma_conv8_launch(ctx, a, false);
-    if ((a.M / 64) * (a.Cout / 64) <= ks2_max1) return launch_conv_glds_phase<64, 64, 2, 2, 1>(ctx, a);
-    return launch_conv_glds_phase<64, 64, 2, 1, 1>(ctx, a);
+  const ConvRoute r = mfma_conv_route(a);
+  if (a.bn_mean && !(a.phase == 0 && !a.stats && !a.relu_in && a.Cin <= 1024 && a.zero != nullptr && (r == CR_H8 || r == CR_H8N)))
+    RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "batch norm on the staged input needs a halo-patch kernel (rcgan_conv_bn_in_ok)");
+  if (a.stats && !(a.phase == 0 && a.zero != nullptr && (r == CR_H8 || r == CR_P8)))
+    RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "tile statistics need the 256 x 256 kernel (rcgan_conv_stats_ok)");
+  switch (r) {
+    case CR_H8: case CR_P8: return mfma_conv8_launch(ctx, a, true, r == CR_H8);
+    case CR_H8N: case CR_P8N: return mfma_conv8_launch(ctx, a, false, r == CR_H8N);
+    case CR_PHASE_KS2: return a.phase == 1 ? launch_conv_glds_phase<64, 64, 2, 2, 1>(ctx, a) : launch_conv_glds_phase<64, 64, 2, 2, 2>(ctx, a);
+    case CR_PHASE: return a.phase == 1 ? launch_conv_glds_phase<64, 64, 2, 1, 1>(ctx, a) : launch_conv_glds_phase<64, 64, 2, 1, 2>(ctx, a);
+    case CR_T256: return launch_conv_glds<256, 256, 2>(ctx, a);
+    case CR_T256N: return launch_conv_glds<256, 128, 2>(ctx, a);
+    case CR_T128: return launch_conv_mfma<128, 128>(ctx, a);
+    default: return launch_conv_mfma<64, 64>(ctx, a);
   }
-  if (a.phase == 2) {
-    // data gradient of the sub-pixel form (the caller checked mfma_phase_dgrad_ok): 256-pixel tiles where the grid fills
-    // the chip, else the 64 x 64 kernel
-    static const int p8_min2 = env_int("RCGAN_P8_MINBLK", 200), p8n_min2 = env_int("RCGAN_P8N_MINBLK", 190), ks2_max2 = env_int("RCGAN_KS2_MAXBLK", 576);
-    const long b8 = (a.M / 256) * (a.Cout / 256);
-    // (round 5) the parity-plane patch form of the 256 x 128 halo kernel where its tiles fill the chip: G.Block.3.Conv1's data gradient
-    // (128 x 2 tiles) 78 -> 61 us.  Measured and left to the 64 x 64 kernel: D.Block.1.Conv2's forward (128 tiles = half the CUs) 33 -> 37 us
-    // (RCGAN_H8N_GATHER_MINBLK=120 takes it too; 100000 switches the form off)
-    static const int halo_n2 = env_int("RCGAN_P8N_HALO", 1);
-    const int gather_min = env_int("RCGAN_H8N_GATHER_MINBLK", 190);        // (read per call: the tests force the form on smaller grids)
-    if (halo_n2 && a.M % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= gather_min && mfma_conv8n_halo_takes(a))
-      return mfma_conv8n_halo_launch(ctx, a);
-    if (a.M % 256 == 0 && a.Cout % 256 == 0 && b8 >= p8_min2 && 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256) return mfma_conv8_launch(ctx, a, true);
-    if (a.M % 256 == 0 && a.Cout % 128 == 0 && (a.M / 256) * (a.Cout / 128) >= p8n_min2) return mfma_conv8_launch(ctx, a, false);
-    // (measured in round 5 and not kept: 128 x 128 tiles of this kernel for D.Block.1.Conv2's forward -- 256 tiles, one per CU, against 1024 of
-    // 64 x 64 -- same-box 5.20 -> 5.25 ms; for every 16-tap layer 5.40)
-    if ((a.M / 64) * (a.Cout / 64) <= ks2_max2) return launch_conv_glds_phase<64, 64, 2, 2, 2>(ctx, a);
-    return launch_conv_glds_phase<64, 64, 2, 1, 2>(ctx, a);
-  }
-  long blocks128 = (long)cdiv(a.M, 128) * (a.Cout / 128);
-  static const int t128_min = env_int("RCGAN_T128_MINBLK", 384);
-  static const int p8_min = env_int("RCGAN_P8_MINBLK", 200);         // 256 x 256 four-phase kernel (conv_mfma8.hip)
-  const bool off32 = (long)a.N * a.H * a.W * a.Cin < (1L << 32);      // its tap-source table holds 32-bit element offsets
-  // one 256 x 256 workgroup per CU: a grid of 320 runs two rounds for 1.25 rounds of work -- such grids go to the
-  // 256 x 128 kernel (twice the workgroups, finer rounds) when less than 3/4 of the last round would be busy
-  const long b8 = (long)cdiv(a.M, 256) * (a.Cout / 256);
-  const bool fit8 = 4 * b8 >= 3 * (long)cdiv(b8, 256) * 256;
-  if (a.Cout % 256 == 0 && a.zero != nullptr && off32 && b8 >= p8_min && fit8) return mfma_conv8_launch(ctx, a, true);
-  static const int p8n_min = env_int("RCGAN_P8N_MINBLK", 190);
-  if (a.Cout % 128 == 0 && a.zero != nullptr && (long)cdiv(a.M, 256) * (a.Cout / 128) >= p8n_min) return mfma_conv8_launch(ctx, a, false);
-  static const int t256_min = env_int("RCGAN_T256_MINBLK", 1 << 30);     // experiment: 256-pixel tiles (1 wave/SIMD)
-  if (a.Cout % 256 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 256) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 256, 2>(ctx, a);
-  if (a.Cout % 128 == 0 && (long)cdiv(a.M, 256) * (a.Cout / 128) >= t256_min && a.zero != nullptr) return launch_conv_glds<256, 128, 2>(ctx, a);
-  if (a.Cout % 128 == 0 && blocks128 >= t128_min) return launch_conv_mfma<128, 128>(ctx, a);
-  return launch_conv_mfma<64, 64>(ctx, a);
 }
 
 static bool wgrad3_shape(int kh, int kw, int h, int w) {

@@ -841,8 +841,9 @@ bool mfma_conv8_phase_form(const MfmaConvArgs& a) {
   return up_phase_enabled() && a.up && a.KH == 3 && a.KW == 3 && a.wph != nullptr && a.lw >= 1 && a.lh >= 1 && ((a.M >> 2) % 256) == 0;
 }
 
-// wide = 256 output channels per workgroup (Cout % 256 == 0), else 128
-int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
+// wide = 256 output channels per workgroup (Cout % 256 == 0), else 128; halo_patch = the halo-patch kernel of that width (conv_mfma8h.hip).
+// Both are mfma_conv_route's decision (conv_mfma.hip) -- nothing here re-derives the routing.
+int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide, bool halo_patch) {
   static int swz = -1, cm = -1;
   if (swz < 0) { const char* e = getenv("RCGAN_P8_XCD"); swz = e ? atoi(e) : 1; }
   if (cm < 0) { const char* e = getenv("RCGAN_P8_CM"); cm = e ? atoi(e) : 1; }
@@ -856,9 +857,7 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
     b.cm = (cm && a.KH * a.KW > 1) ? 1 : 0;
     // plain 3x3 layers on 16- / 32-wide images: the pixel operand as a zero-padded patch in LDS, fetched once per 64-channel chunk
     // instead of once per tap (conv_mfma8h.hip); RCGAN_P8_HALO=0 keeps the tile-per-tap kernel
-    static int halo = -1;
-    if (halo < 0) { const char* e = getenv("RCGAN_P8_HALO"); halo = e ? atoi(e) : 1; }
-    if (halo && !b.stats && mfma_conv8_halo_takes(b)) return mfma_conv8_halo_launch(ctx, b);
+    if (halo_patch) return mfma_conv8_halo_launch(ctx, b);
     // the persistent form needs >= 2 K-tiles per tile (table hand-over) and 3x3 / 1x1 filters (two 9-tap tables in LDS)
     if (persist && !b.phase && a.KH * a.KW * a.Cin >= 128 && a.KH * a.KW <= 9)
       return b.relu_in ? launch8p<true>(ctx, b, swz) : launch8p<false>(ctx, b, swz);
@@ -877,9 +876,7 @@ int mfma_conv8_launch(rcgan_ctx* ctx, const MfmaConvArgs& a, bool wide) {
   b.phase = a.phase ? a.phase : (phase ? 1 : 0);
   // plain 3x3 layers / their sub-pixel forms on 16- / 32-wide (low-resolution) images: the patch kernel's 256 x 128 sibling
   // (conv_mfma8h.hip); RCGAN_P8N_HALO=0 keeps the tile-per-tap kernel
-  static int halo_n = -1;
-  if (halo_n < 0) { const char* e = getenv("RCGAN_P8N_HALO"); halo_n = e ? atoi(e) : 1; }
-  if (halo_n && mfma_conv8n_halo_takes(b)) {
+  if (halo_patch) {
     b.stamps = (unsigned long long*)ctx->dbg_stamps;
     return mfma_conv8n_halo_launch(ctx, b);
   }

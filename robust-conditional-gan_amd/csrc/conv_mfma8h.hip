@@ -835,6 +835,7 @@ static int launch8h(rcgan_ctx* ctx, const MfmaConvArgs& a) {
   dim3 grid(cdiv(a.M, 256), a.Cout / 256);
   {
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8, 2.0 * (double)a.M * 9 * a.Cin * a.Cout, 2.0 * (double)a.M * (PHM ? 4 : 9) * a.Cin * a.Cout);
+    if (BNIN && ps.on) ctx->prof_bn_in++;
     hipLaunchKernelGGL((conv_mfma_h8_kernel<LW, RELU, PHM, BNIN>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);
@@ -883,6 +884,7 @@ static int launch8hn(rcgan_ctx* ctx, const MfmaConvArgs& a) {
     // (GATHER: a.M counts low-resolution pixels; the reference's formulation is the 3x3 layer over the full-resolution grid)
     ProfScope ps(ctx, RCGAN_PROF_CONV_P8N, 2.0 * (double)a.M * (GATHER ? 36 : 9) * a.Cin * a.Cout,
                  2.0 * (double)a.M * (GATHER ? 16 : PHM ? 4 : 9) * a.Cin * a.Cout);
+    if (BNIN && ps.on) ctx->prof_bn_in++;
     hipLaunchKernelGGL((conv_mfma_h8n_kernel<LW, RELU, PHM, BNIN, NPASS, GATHER>), grid, dim3(512), lds, ctx->stream, a);
   }
   RC_LAUNCH_CHECK(ctx);

@@ -468,6 +468,13 @@ class MnistRCGAN:
             ctx.graph_begin()
             try:
                 body()
+            except L.RcganError:
+                # a layer shape this bound does not cover wanted more hidden scratch than was reserved (hipErrorStreamCaptureUnsupported:
+                # nothing of the capture has run): drop the capture, run the body eagerly -- which grows the scratch -- as THIS step, and
+                # capture on the next call.  A genuine error raises again from the eager run.
+                ctx.graph_abort()
+                body()
+                return
             except BaseException:
                 ctx.graph_abort()
                 raise

@@ -261,6 +261,7 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
         pend = x
         n, hs, ws_, cin = pend.shape
         cout = weight.param.shape[-1]
+        assert weight.param.shape == (k, k, cin, cout), (weight.param.shape, (k, k, cin, cout))
         # the convolution as the plain path below would pose it (upsample folded into the load, half-resolution residual in the epilogue)
         bh, bw = (hs * 2, ws_ * 2) if in_up else (hs, ws_)
         bflags = (L.CONV_IN_UPSAMPLE2X if in_up else 0) | (L.CONV_RESID_UPSAMPLE2X if (residual is not None and residual_up) else 0)
@@ -271,10 +272,13 @@ def conv2d(ctx, x, weight, bias, k, stride=1, in_up=False, in_relu=False, accumu
                                           and (not residual_up or ctx.lib.rcgan_conv_resid_up_ok(C.byref(bdesc)))))):
             y = ctx.empty((n, bh, bw, cout), pend.dtype)
             pdesc = L.ConvDesc(n, bh, bw, cin, cout, k, k, stride, pend.dtype, L.CONV_IN_UPSAMPLE2X if in_up else 0)
-            ctx.check(ctx.lib.rcgan_conv2d_fwd_bn_residual(ctx.h, C.byref(bdesc), _p(pend.x), _p(weight.prepared(pdesc)), _p(bias), _p(residual), _p(y),
-                                                           pend.segments, _p(pend.labels), _p(pend.gamma), _p(pend.beta), _p(pend.mean),
-                                                           _p(pend.rstd), pend.act))
-            return y
+            rc = ctx.lib.rcgan_conv2d_fwd_bn_residual(ctx.h, C.byref(bdesc), _p(pend.x), _p(weight.prepared(pdesc)), _p(bias), _p(residual), _p(y),
+                                                      pend.segments, _p(pend.labels), _p(pend.gamma), _p(pend.beta), _p(pend.mean),
+                                                      _p(pend.rstd), pend.act)
+            if rc == 0:
+                return y
+            if rc != L.EUNSUPPORTED_SHAPE:      # (the library declined the fused form after all: write the normalised tensor and go on)
+                ctx.check(rc)
         x = pend.materialize()
     n, hs, ws_, cin = x.shape
     h, w = (hs * 2, ws_ * 2) if in_up else (hs, ws_)

@@ -69,7 +69,9 @@ def main():
         import rcgan_amd  # noqa: F401
         from rcgan_amd import _lib
         sha = _lib.source_hash()
-        if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        if len(sys.argv) > 4:
+            if not os.path.exists(sys.argv[4]):      # no record of what the run measured: never stamp it with the tree's hash
+                raise SystemExit("pmc_busy_table.py: %s is missing -- the run directory does not say which sources it measured: not published" % sys.argv[4])
             measured = open(sys.argv[4]).read().strip()
             if measured != sha:
                 raise SystemExit("pmc_busy_table.py: the counters were measured on sources %s, the tree is %s: not published" % (measured, sha))

@@ -50,7 +50,9 @@ def main():
     alg_avg = sum(fetch[g][0] * alg[g] for g in fetch) / n
     import rcgan_amd  # noqa: F401
     from rcgan_amd import _lib
-    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    if len(sys.argv) > 4:
+        if not os.path.exists(sys.argv[4]):      # no record of what the run measured: never stamp it with the tree's hash
+            raise SystemExit("pmc_traffic_json.py: %s is missing -- the run directory does not say which sources it measured: not published" % sys.argv[4])
         measured = open(sys.argv[4]).read().strip()
         if measured != _lib.source_hash():
             raise SystemExit("pmc_traffic_json.py: the counters were measured on sources %s, the tree is %s: not published" % (measured, _lib.source_hash()))
