@@ -347,6 +347,14 @@ int rcgan_pad_channels(rcgan_ctx* ctx, size_t rows, int c, int before, int after
 int rcgan_concat_channels_fwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* x,
                               const float* yb, void* y);
 int rcgan_concat_channels_bwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* dy, void* dx);
+/* The batch repeated `reps` times back to back, y[r][i] = x[i] (count elements per copy), and its adjoint dx[i] (+)= sum_r dy[r][i]:
+ * the reference's ten discriminator() calls on the same images, one per label (mnist/model.py:152-163 `unbiased`, :187-197
+ * `estimate_confuse`), as ONE pass over 10 x batch samples for the discriminators whose convolutions see the label
+ * (disc_type=vanilla, --concat_y).  rcgan_transpose_f32: y[c][r] (+)= x[r][c] -- that pass's [labels][samples] logits as the
+ * [samples][labels] matrix of tf.concat(D_logits_all, 1) (:165,199), and the adjoint. */
+int rcgan_tile_rows_fwd(rcgan_ctx* ctx, size_t count, int reps, int dtype, const void* x, void* y);
+int rcgan_tile_rows_bwd(rcgan_ctx* ctx, size_t count, int reps, int dtype, const void* dy, void* dx, int accumulate);
+int rcgan_transpose_f32(rcgan_ctx* ctx, int rows, int cols, const float* x, float* y, int accumulate);
 /* uint8-as-int32 CHW [n][3][32][32] + dequantisation noise (fp32, CHW order) -> NHWC in [-1,1):
  * 2*(x/256-.5)+noise (gan_resnet.py:548-551). */
 int rcgan_preprocess_cifar(rcgan_ctx* ctx, int n, const int32_t* images_chw, const float* noise_chw,

@@ -164,6 +164,9 @@ SIGNATURES = {
     "rcgan_pad_channels": (I, [P, SZ, I, I, I, I, P, P]),
     "rcgan_concat_channels_fwd": (I, [P, I, I, I, I, I, P, P, P]),
     "rcgan_concat_channels_bwd": (I, [P, I, I, I, I, I, P, P]),
+    "rcgan_tile_rows_fwd": (I, [P, SZ, I, I, P, P]),
+    "rcgan_tile_rows_bwd": (I, [P, SZ, I, I, P, P, I]),
+    "rcgan_transpose_f32": (I, [P, I, I, P, P, I]),
     "rcgan_preprocess_cifar": (I, [P, I, P, P, I, P]),
     "rcgan_rng_fill": (I, [P, SZ, I, I, F, F, C.c_uint64, P, P]),
     "rcgan_act_meanhw_fwd": (I, [P, I, I, I, I, I, P, P]),

@@ -216,6 +216,36 @@ __global__ void concat_channels_bwd_kernel(int n, int hw, int c1, int c2, const 
   }
 }
 
+// The batch repeated `reps` times back to back, y[r][i] = x[i] -- one discriminator pass over every label instead of the reference's
+// ten discriminator() calls on the same images (mnist/model.py:152-163,187-197) -- and its adjoint dx[i] (+)= sum_r dy[r][i]
+// (fp32 sum, rounded once).
+template <typename T>
+__global__ void tile_rows_fwd_kernel(size_t count, int reps, const T* x, T* y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const T v = x[i];
+    for (int r = 0; r < reps; ++r) y[(size_t)r * count + i] = v;
+  }
+}
+
+template <typename T>
+__global__ void tile_rows_bwd_kernel(size_t count, int reps, const T* dy, T* dx, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? Elem<T>::ld(dx + i) : 0.f;
+    for (int r = 0; r < reps; ++r) s += Elem<T>::ld(dy + (size_t)r * count + i);
+    Elem<T>::st(dx + i, s);
+  }
+}
+
+// y[c][r] (+)= x[r][c], fp32: the [labels][samples] logits of that pass as the [samples][labels] matrix the weighted loss terms take
+__global__ void transpose_f32_kernel(int rows, int cols, const float* x, float* y, int accumulate) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const size_t o = (size_t)c * rows + r;
+    y[o] = accumulate ? y[o] + x[i] : x[i];
+  }
+}
+
 // gan_resnet.py:548-551
 template <typename T>
 __global__ void preprocess_cifar_kernel(int n, const int32_t* img, const float* noise, T* y) {
@@ -406,6 +436,27 @@ int rcgan_concat_channels_fwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int
 int rcgan_concat_channels_bwd(rcgan_ctx* ctx, int n, int hw, int c1, int c2, int dtype, const void* dy, void* dx) {
   size_t cnt = (size_t)n * hw * c1;
   RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(concat_channels_bwd_kernel<T>, dim3(ew_grid(cnt)), dim3(EW_BLOCK), 0, ctx->stream, n, hw, c1, c2, (const T*)dy, (T*)dx));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_tile_rows_fwd(rcgan_ctx* ctx, size_t count, int reps, int dtype, const void* x, void* y) {
+  RC_REQUIRE(ctx, reps >= 1 && x && y, "bad arguments");
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(tile_rows_fwd_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, reps, (const T*)x, (T*)y));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_tile_rows_bwd(rcgan_ctx* ctx, size_t count, int reps, int dtype, const void* dy, void* dx, int accumulate) {
+  RC_REQUIRE(ctx, reps >= 1 && dy && dx, "bad arguments");
+  RC_DISPATCH_DTYPE(ctx, dtype, hipLaunchKernelGGL(tile_rows_bwd_kernel<T>, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, ctx->stream, count, reps, (const T*)dy, (T*)dx, accumulate));
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_transpose_f32(rcgan_ctx* ctx, int rows, int cols, const float* x, float* y, int accumulate) {
+  RC_REQUIRE(ctx, rows >= 1 && cols >= 1 && x && y, "bad arguments");
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(EW_BLOCK), 0, ctx->stream, rows, cols, x, y, accumulate);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }

@@ -132,6 +132,10 @@ class MnistRCGAN:
         self.inp.update(x_all=P((2 * B, 28, 28, 1), act, fill=0.0), y_all_fake=P((2 * B, Y_DIM), f32, fill=0.0), y_all_gen=P((2 * B, Y_DIM), f32, fill=0.0))
         self.merge_critic = os.environ.get("RCGAN_MNIST_MERGE_CRITIC", "1") == "1"
         ctx.view(self.inp["eye"]).copy_(torch.eye(Y_DIM))
+        if (self.alg == "unbiased" or self.est) and (self.disc_type != "projection" or self.layers):
+            # one-hot(l) for every sample of copy l of the batch: the label rows of discriminator_all_labels' single pass
+            self.inp["y_all_labels"] = P((Y_DIM * B, Y_DIM), f32, fill=0.0)
+            ctx.view(self.inp["y_all_labels"]).copy_(torch.eye(Y_DIM).repeat_interleave(B, dim=0))
         if confusion_matrix is None:
             confusion_matrix = ((1 - alpha) / 9.0) * np.ones((10, 10)) + (alpha - (1 - alpha) / 9.0) * np.eye(10)
         self.confusion_matrix_actual = np.asarray(confusion_matrix)
@@ -196,9 +200,9 @@ class MnistRCGAN:
             x = conv_cond_concat(image, y)
             h0 = lrelu(conv2d(x, 1 + Y_DIM, name='d_h0_conv'))
             h0 = conv_cond_concat(h0, y)
-            h1 = self.d_bn1(conv2d(h0, DF_DIM + Y_DIM, name='d_h1_conv'), _act=L.ACT_LRELU)
+            h1 = self.d_bn1(conv2d(h0, DF_DIM + Y_DIM, name='d_h1_conv'), _act=L.ACT_LRELU, _segments=segments)
             h1 = O.concat_channels(ctx, O.reshape(ctx, h1, (B, -1)), y)
-            h3 = self.d_bn2(linear(h1, DFC_DIM, 'd_h3_lin'), _act=L.ACT_LRELU)
+            h3 = self.d_bn2(linear(h1, DFC_DIM, 'd_h3_lin'), _act=L.ACT_LRELU, _segments=segments)
             h3 = O.concat_channels(ctx, h3, y)
             return O.cast(ctx, O.reshape(ctx, linear(h3, 1, 'd_h4_lin'), (-1,)), L.F32)
 
@@ -212,7 +216,14 @@ class MnistRCGAN:
                 h3, h4 = self._features(image, None)
                 E = linear(self.inp["eye"], DF_DIM, 'd_h5_y_lin', max_norm=self.max_norm)
                 return O.proj_logit_all(ctx, h3, h4, E)
-        raise NotImplementedError("per-label discriminator passes for label-concatenating discriminators")
+        # A discriminator whose convolutions see the label (disc_type=vanilla, --concat_y): the reference's ten discriminator() calls
+        # (model.py:152-163 `unbiased`, :187-197 `estimate_confuse`) as ONE pass over 10 x B samples, label-major -- copy l of the batch
+        # carries one-hot(l) -- with the batch norms taking their statistics and moving-average updates per copy, in label order,
+        # as the ten consecutive calls do; the [10][B] logits come back as tf.concat(D_logits_all, 1) = [B][10].
+        B = image.shape[0]
+        x10 = O.tile_rows(ctx, image, Y_DIM)
+        logits = self.discriminator(x10, self.inp["y_all_labels"], segments=Y_DIM)
+        return O.transpose2d(ctx, O.reshape(ctx, logits, (Y_DIM, B)))
 
     def classifier(self, x):
         ctx = self.ctx

@@ -873,6 +873,37 @@ def concat_channels(ctx, x, yb):
     return y
 
 
+def tile_rows(ctx, x, reps):
+    """[n, ...] -> [reps * n, ...]: the batch `reps` times back to back (one discriminator pass over every label on the same
+    images, mnist/model.py:152-163,187-197); the adjoint sums the copies' gradients."""
+    y = ctx.empty((reps * x.shape[0],) + tuple(x.shape[1:]), x.dtype)
+    ctx.check(ctx.lib.rcgan_tile_rows_fwd(ctx.h, x.size, reps, x.dtype, _p(x), _p(y)))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_tile_rows_bwd(ctx.h, x.size, reps, x.dtype, _p(y.grad), _p(dx), acc))
+        ctx.record(bw)
+    return y
+
+
+def transpose2d(ctx, x):
+    """fp32 [r, c] -> [c, r] (tf.concat(D_logits_all, 1) of per-label passes laid out label-major, mnist/model.py:165,199)."""
+    assert x.dtype == L.F32 and len(x.shape) == 2, (x.dtype, x.shape)
+    r, c = x.shape
+    y = ctx.empty((c, r), L.F32)
+    ctx.check(ctx.lib.rcgan_transpose_f32(ctx.h, r, c, _p(x), _p(y), 0))
+    if _track(ctx, y, x):
+        def bw():
+            if y.grad is None:
+                return
+            dx, acc = grad_of(ctx, x)
+            ctx.check(ctx.lib.rcgan_transpose_f32(ctx.h, c, r, _p(y.grad), _p(dx), acc))
+        ctx.record(bw)
+    return y
+
+
 def reshape(ctx, x, shape):
     y = x.reshape(shape)
     y.req = x.req

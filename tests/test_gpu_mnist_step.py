@@ -81,7 +81,12 @@ def _cmp(tag, got, oracle, grads32):
 
 CASES = [("rcgan", "projection", False, "hinge", False), ("rcgan", "projection", True, "hinge", False),
          ("unbiased", "projection", False, "hinge", False), ("biased", "vanilla", False, "ce", False),
-         ("rcgan", "projection", False, "hinge", True)]
+         ("rcgan", "projection", False, "hinge", True),
+         # (round 6) the flag combinations outside the run_*.sh presets: per-label passes (unbiased, estimate_confuse) through a
+         # discriminator whose convolutions see the label -- ONE 10 x B pass here, ten discriminator() calls in the oracle as in the
+         # reference (model.py:152-163,187-197)
+         ("unbiased", "vanilla", False, "ce", False), ("rcgan", "vanilla", True, "hinge", False),
+         ("rcgan", "projection", True, "hinge", True), ("unbiased", "projection", False, "hinge", True)]
 
 
 @pytest.mark.parametrize("alg,disc,est,loss,concat", CASES)
