@@ -124,14 +124,23 @@ def kernel_roofline(m, pool, default_workload=True):
     ctx = m.ctx
     saved = m.use_graphs
     m.use_graphs = False
-    ctx.check(ctx.lib.rcgan_prof_begin(ctx.h, 4))       # RCGAN_PROF_CONV_P8
+    # (round 6) the critic steps' generator forwards run on a second context (CifarRCGAN.overlap_gf): the kernel's launches are
+    # counted on both, each bracketed by events on the stream it is launched on
+    ctxs = [ctx] + ([m.ctx2] if getattr(m, "ctx2", None) is not None else [])
+    for c in ctxs:
+        c.check(c.lib.rcgan_prof_begin(c.h, 4))       # RCGAN_PROF_CONV_P8
     iteration(m, pool, 1, [0])
-    n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
-    ctx.check(ctx.lib.rcgan_prof_end(ctx.h, C.byref(n), C.byref(ms), C.byref(fl)))
-    fx = C.c_double(0)
-    ctx.check(ctx.lib.rcgan_prof_executed_flops(ctx.h, C.byref(fx)))
-    nbn = C.c_int(0)
-    ctx.check(ctx.lib.rcgan_prof_bn_in_launches(ctx.h, C.byref(nbn)))
+    n, ms, fl, fx, nbn = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+    for c in ctxs:
+        n1, ms1, fl1, fx1, nb1 = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        c.check(c.lib.rcgan_prof_end(c.h, C.byref(n1), C.byref(ms1), C.byref(fl1)))
+        c.check(c.lib.rcgan_prof_executed_flops(c.h, C.byref(fx1)))
+        c.check(c.lib.rcgan_prof_bn_in_launches(c.h, C.byref(nb1)))
+        n.value += n1.value
+        ms.value += ms1.value
+        fl.value += fl1.value
+        fx.value += fx1.value
+        nbn.value += nb1.value
     m.use_graphs = saved
     if n.value == 0 or ms.value <= 0:
         return None

@@ -503,6 +503,30 @@ class CifarRCGAN:
         self.loss_d = self.PD.scalar(0)
         self.loss_g = self.PG.scalar(0)
         self.rng_state = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+        # (round 6) The critic steps' generator forwards on a SECOND stream.  The generator does not change during the N_CRITIC critic
+        # updates of an iteration (gan_resnet.py:928-947), so step k + 1's Generator() call can run while critic step k does: a critic
+        # step is a chain of ~26 small-grid launches that leaves half the chip idle most of the time, the generator forward is the
+        # big-grid work that fills it.  prepare_critic_fakes() then enqueues N_CRITIC per-step passes (B samples each, the reference's
+        # own call shape) on the second context's stream and every d_step() waits for its slice's event; a second context = its own
+        # stream, arena, workspace, arrival counters and random-stream position, so nothing is shared but the (read-only) generator
+        # parameters, their prepared filters and the step inputs.
+        # MEASURED AND LEFT OFF (RCGAN_OVERLAP_GF=1 turns it on; tests/test_gpu_cifar_step.py runs both forms): same box, B = 64,
+        # 5.26 ms per iteration with the one batched pass on the step stream against 5.47 ms overlapped.  The premise does not hold on
+        # this chip (scripts/exp_overlap_streams.py, two engines with NO dependency between them): 5 critic steps 2.08 ms + the
+        # batched generator pass 1.11 ms = 3.23 ms one after the other, 2.91 ms side by side -- only 0.3 ms of the 1.1 hides -- and
+        # the per-step passes the dependency needs cost 1.72 ms instead of 1.11 (half-empty grids at n = 64): 3.11 ms pipelined.
+        self.overlap_gf = os.environ.get("RCGAN_OVERLAP_GF", "0") == "1"
+        self.ctx2 = None
+        if self.overlap_gf:
+            self.ctx2 = Context(device, dtype, arena_bytes=int(2.5e6 * self.B * (4 if dtype == "f32" else 2)) + (256 << 20), ws_bytes=256 << 20)
+            ctx.also_close = [self.ctx2]
+            ctx.check(self.ctx2.lib.rcgan_set_grad_scale(self.ctx2.h, 1.0, None))
+            self.graph2 = Graph(self.ctx2, [ParamGroup.alias(self.ctx2, self.PG)], {})
+            self.graph2.persist = self.graph.persist        # the generator's prepared filters (refresh_persistent on the step stream)
+            self.rng_state_gf = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+            self._gf_done = [torch.cuda.Event() for _ in range(N_CRITIC)]
+            self._gf_pending = [False] * N_CRITIC
+            torch.cuda.set_device(ctx.device)
         self.slice_ctr = torch.zeros(4, dtype=torch.int32, device=ctx.device)     # which slice of fakes_all the next critic step takes
         self._slice_mirror = 0
         self.seed = seed
@@ -784,8 +808,8 @@ class CifarRCGAN:
             O.loss_term(ctx, L.LOSS_NEG_MEAN, disc_fake, 1.0, self.loss_g)                           # :773
 
     # ---------------------------------------------------------------------------------- stepping
-    def _run(self, key, body):
-        ctx = self.ctx
+    def _run(self, key, body, ctx=None):
+        ctx = ctx or self.ctx
         if not self.use_graphs:
             body()
             return
@@ -876,6 +900,44 @@ class CifarRCGAN:
         finally:
             ctx.recording = rec
 
+    def _gf_chunk_body(self, k):
+        """Generator() of critic step k (gan_resnet.py:540-546) on the second context: its own z, labels and batch-norm statistics."""
+        ctx2, g2, B, inp = self.ctx2, self.graph2, self.B, self.inp
+        ctx2.new_step()
+        g2.begin_step(set())
+        rec, ctx2.recording = ctx2.recording, False
+        try:
+            z = inp["z_all"].rows(k * B, (k + 1) * B)
+            if self.device_rng:
+                # (a random stream of its own: the step stream draws the dequantisation noise from rng_state at the same time)
+                ctx2.check(ctx2.lib.rcgan_rng_fill(ctx2.h, z.size, z.dtype, 1, 0.0, 1.0, self.seed * 1000003 + self.rank + 500009,
+                                                   C.c_void_p(self.rng_state_gf.data_ptr()), C.c_void_p(z.ptr)))
+            Generator(B, inp["labels_random_all"].rows(k * B, (k + 1) * B), z, out=self.fakes_all.rows(k * B, (k + 1) * B))
+        finally:
+            ctx2.recording = rec
+
+    def _join_gf(self):
+        """The step stream waits for every generator-forward pass still in flight: in front of anything that WRITES what they read
+        (the generator's update, a checkpoint load)."""
+        if self.overlap_gf:
+            for k in range(N_CRITIC):
+                if self._gf_pending[k]:
+                    self.ctx.stream.wait_event(self._gf_done[k])
+                    self._gf_pending[k] = False
+
+    def _prepare_critic_fakes_overlapped(self):
+        s1, s2 = self.ctx.stream, self.ctx2.stream
+        self._refresh_generator_filters()
+        # everything the passes read is final on the step stream here: the generator's parameters and prepared filters (the last
+        # g_step), the "gf" feed; and the critic steps that read the previous fakes have been enqueued in front of this point
+        ev = torch.cuda.Event()
+        ev.record(s1)
+        s2.wait_event(ev)
+        for k in range(N_CRITIC):
+            self._run("gf%d" % k, lambda k=k: self._gf_chunk_body(k), ctx=self.ctx2)
+            self._gf_done[k].record(s2)
+            self._gf_pending[k] = True
+
     def prepare_critic_fakes(self):
         """The generator does not change during the N_CRITIC critic updates of an iteration (gan_resnet.py:928-947), so their
         N_CRITIC Generator() calls (:540-546, one fresh z and label draw each) are evaluated here as ONE pass over
@@ -883,7 +945,10 @@ class CifarRCGAN:
         statistics per step's batch (segments) -- and the next N_CRITIC d_step() calls consume one slice each.
         Inputs: labels_random_all [N_CRITIC*B] (feed "gf"; slice k must equal step k's labels_random), z_all (drawn on the
         device unless device_rng=False)."""
-        self._run("gf", self._gf_body)
+        if self.overlap_gf:
+            self._prepare_critic_fakes_overlapped()
+        else:
+            self._run("gf", self._gf_body)
         self._fakes_left = N_CRITIC
         if self._slice_mirror != 0:          # the previous batch was not used up: the device's slice counter goes back to 0
             with torch.cuda.stream(self.ctx.stream):
@@ -900,6 +965,9 @@ class CifarRCGAN:
             k = N_CRITIC - self._fakes_left
             self._fakes_left -= 1
             ctx = self.ctx
+            if self.overlap_gf and self._gf_pending[k]:
+                ctx.stream.wait_event(self._gf_done[k])      # slice k of fakes_all is written by the generator-forward stream
+                self._gf_pending[k] = False
             if self._rides_inputs():
                 # the step's launch fetches slice slice_ctr (a device counter it moves on itself); the host mirrors it
                 assert self._slice_mirror == k, (self._slice_mirror, k)
@@ -917,6 +985,7 @@ class CifarRCGAN:
         (gan_resnet.py:806-817)."""
         it = self.iteration if iteration is None else iteration
         self._fakes_left = 0                 # images prepared by prepare_critic_fakes belong to the generator before this update
+        self._join_gf()
         self._refresh_generator_filters()
         steps = [(self.PG, self.lr * lr_decay(it))]
         if self.PC is not None:
@@ -1040,6 +1109,9 @@ class CifarRCGAN:
 
     def load_state_dict(self, sd):
         self._fakes_left = 0
+        if self.overlap_gf:
+            self.ctx2.sync()                 # (host-side writes to the parameters follow)
+            self._gf_pending = [False] * N_CRITIC
         for gname, grp in zip(("Generator", "Discriminator", "confusion"), self.groups):
             for n in grp.names:
                 if n not in sd:

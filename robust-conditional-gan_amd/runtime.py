@@ -149,6 +149,9 @@ class Context:
             raise L.RcganError(rc, self.lib.rcgan_last_error(self.h).decode())
 
     def close(self):
+        for c in getattr(self, "also_close", []):       # (contexts that exist only beside this one: the generator-forward stream)
+            c.close()
+        self.also_close = []
         if self.h is not None:
             self.lib.rcgan_destroy(self.h)
             self.h = None
@@ -325,6 +328,15 @@ class ParamGroup:
             host[o:o + a.size] = a
         self.value.copy_(torch.from_numpy(host))
         torch.cuda.synchronize()
+
+    @classmethod
+    def alias(cls, ctx, other):
+        """The same slabs seen from another context (another stream / arena): parameter lookups only -- the optimiser, the
+        zero-fills and the version counter stay with the owning group."""
+        g = cls.__new__(cls)
+        g.__dict__.update(other.__dict__)
+        g.ctx = ctx
+        return g
 
     def _on_stream(self):
         return torch.cuda.stream(self.ctx.stream)

@@ -202,14 +202,18 @@ def test_segmented_generator_forward_equals_separate_calls(dtype, tol):
         m.ctx.close()
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
 @pytest.mark.parametrize("alg,dtype,tol", [("rcgan", "f32", 3e-3), ("rcgan", "bf16", 3e-2), ("rcgan-u", "f32", 3e-3)])
-def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
+def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol, overlap, monkeypatch):
     """prepare_critic_fakes() + N_CRITIC d_step() == N_CRITIC plain d_step() (the generator forward inside every critic
     step, as the reference runs it) on the same z / labels / real batches: discriminator weights after the five Adam
     updates and the last critic loss agree.  (Adam moves a weight whose gradient is ~0 by up to lr per step whatever the
     gradient's size, so in fp32 single elements may differ by up to 5 * 2 * lr = 2e-3 ABSOLUTE -- that is the element bound -- while
     the norm-relative error, the criterion that matters, stays <= 2e-4.)"""
     from rcgan_amd.cifar import N_CRITIC
+    # overlap "1" (round 6, the default): prepare_critic_fakes() = N_CRITIC per-step passes on the generator-forward stream, every
+    # d_step() waiting for its slice; "0": the one batched pass on the step stream
+    monkeypatch.setenv("RCGAN_OVERLAP_GF", overlap)
     rs = np.random.RandomState(41)
     B = 4
     steps = []
@@ -219,6 +223,7 @@ def test_batched_critic_fakes_equal_per_step_generator(alg, dtype, tol):
     outs = []
     for batched in (False, True):
         m, P, Uo = _make(alg, alg == "rcgan-u", B, dtype)
+        assert m.overlap_gf == (overlap == "1")
         try:
             if batched:
                 m.set_inputs(labels_random_all=np.concatenate([r["labels_random"] for r in steps]),
