@@ -325,6 +325,21 @@ typedef struct rcgan_sn_bwd_item {
 } rcgan_sn_bwd_item;
 /* dW from dW_bar, differentiating THROUGH the power iteration (no stop_gradient in the reference). */
 int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items);
+/* The same two launches with the optimiser of a SINGLE-RANK step in the second (round 6): after dW is formed for a chunk of
+ * rows, TF ApplyAdam (tf.train.AdamOptimizer, gan_resnet.py:802-808; the arithmetic of rcgan_adam_tf) updates those rows of the
+ * optimiser group's slabs w / m / v in place; rider workgroups do the same for the slab's other parameters (`ranges`: host array
+ * of n_ranges {lo, hi} float offsets).  Items and ranges must tile [0, count) exactly, every item's w / dw must point into w / g at
+ * the same offset.  hyper: DEVICE {lr, t} with t = the number of updates applied so far: the call advances it by one (in its first
+ * launch) and uses the advanced value for the bias correction -- a captured step replays with a fresh count, the host rewrites the
+ * pair only when lr changes.  dW is still written to g.  Not for data-parallel steps (the all-reduce sits between the gradient
+ * and the update) nor for a dynamic loss scale (the overflow verdict does). */
+typedef struct rcgan_sn_adam {
+  float* w; float* g; float* m; float* v; size_t count;
+  float* hyper;
+  float beta1, beta2, eps, clip, grad_scale;
+  int n_ranges; const size_t* ranges;
+} rcgan_sn_adam;
+int rcgan_sn_bwd_adam(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items, const rcgan_sn_adam* opt);
 
 /* ---- elementwise / resampling -------------------------------------------------------------------- */
 int rcgan_act_fwd(rcgan_ctx* ctx, size_t count, int dtype, int act, const void* x, void* y);

@@ -85,6 +85,12 @@ class SnBwdItem(C.Structure):
                 ("k", C.c_int), ("c", C.c_int), ("accumulate", C.c_int)]
 
 
+class SnAdam(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("count", C.c_size_t),
+                ("hyper", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("clip", C.c_float),
+                ("grad_scale", C.c_float), ("n_ranges", C.c_int), ("ranges", C.POINTER(C.c_size_t))]
+
+
 P, I, F, SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 DP = C.POINTER(ConvDesc)
 
@@ -152,6 +158,7 @@ SIGNATURES = {
     "rcgan_sn_save_floats": (SZ, [I, I]),
     "rcgan_sn_power_iter": (I, [P, C.POINTER(SnItem), I]),
     "rcgan_sn_bwd": (I, [P, C.POINTER(SnBwdItem), I]),
+    "rcgan_sn_bwd_adam": (I, [P, C.POINTER(SnBwdItem), I, C.POINTER(SnAdam)]),
     "rcgan_act_fwd": (I, [P, SZ, I, I, P, P]),
     "rcgan_act_bwd": (I, [P, SZ, I, I, P, P, P, I]),
     "rcgan_add": (I, [P, SZ, I, P, P, P]),

@@ -467,6 +467,14 @@ class CifarRCGAN:
         # against 5.55 / 5.56 / 5.55 captured.  RCGAN_GRAPH_ADAM=1 turns it on.
         self.graph_adam = self.dp_adam_in_graph or (not self.dp_active and not self.dynamic_ls and
                                                     os.environ.get("RCGAN_GRAPH_ADAM", "0") == "1")
+        # (round 6) single rank, static loss scale: the critic step's optimiser inside the second launch of the spectral-norm backward
+        # (rcgan_sn_bwd_adam: TF-Adam on the rows of dW a workgroup has just formed, rider workgroups for the biases / embeddings
+        # between them) -- the step's last launch updates the discriminator; no optimiser launch, no {lr, t} launch (the step count
+        # lives on the device and moves on inside the call; the host rewrites {lr, t} only when lr changes: once per iteration).
+        # RCGAN_SN_ADAM=0 restores the separate launch.
+        self.fused_tail = (not self.dp_active and not self.dynamic_ls and not self.graph_adam
+                           and os.environ.get("RCGAN_SN_ADAM", "1") == "1")
+        self._tail_fused = {}
         B = self.B
         f32, i32, act = L.F32, "i32", ctx.act_dtype
         P = ctx.persistent
@@ -684,6 +692,8 @@ class CifarRCGAN:
         self._refresh_generator_filters()       # no-op unless the generator changed behind d_step/g_step's back
         ctx.new_step()
         g.begin_step({1})
+        ctx.sn_adam = (dict(group=self.PD, beta1=0.0, beta2=0.9, grad_scale=1.0 / (self.world * self.loss_scale))
+                       if (self.fused_tail and ctx.recording and self.PD.hyper is not None) else None)
         # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
         # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
         # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
@@ -759,6 +769,8 @@ class CifarRCGAN:
             logits = perm_classifier(real, self.perm_type)                               # :692
             O.bce_onehot_term(ctx, logits, inp["labels"], 1.0, self.loss_d)                          # :693-695
         ctx.backward()
+        self._tail_fused[bool(fakes_ready)] = bool(ctx.sn_adam and ctx.sn_adam.get("done"))
+        ctx.sn_adam = None
         self._dp_finish([self.PD])
 
     # ---------------------------------------------------------------------------------- G step
@@ -769,6 +781,7 @@ class CifarRCGAN:
         self._refresh_generator_filters()
         ctx.new_step()
         g.begin_step({0, 2} if self.PC is not None else {0})
+        ctx.sn_adam = None
         self.PG.zero_grad()
         if self.PC is not None:
             self.PC.zero_grad()
@@ -881,6 +894,11 @@ class CifarRCGAN:
 
     def _pre_step(self, steps):
         """In front of a step's launch: {lr, t} of the optimiser launches the step's graph contains."""
+        if self.fused_tail:
+            for grp, lr in steps:
+                if grp is self.PD and (grp.hyper is None or getattr(grp, "_dev_hyper", None) != (float(lr), grp.t)):
+                    grp.set_hyper_device(lr, grp.t)          # t = updates applied so far; the step's launches advance it themselves
+                    grp._dev_hyper = (float(lr), grp.t)
         if self.graph_adam:
             for grp, lr in steps:
                 grp.t += 1
@@ -976,8 +994,17 @@ class CifarRCGAN:
                 with torch.cuda.stream(ctx.stream):
                     ctx.view(self.x_all.rows(self.B, 2 * self.B)).copy_(ctx.view(self.fakes_all.rows(k * self.B, (k + 1) * self.B)), non_blocking=True)
             self._run("d_fakes", lambda: self._d_body(True))
+            fused = self._tail_fused.get(True, False)
         else:
             self._run("d", self._d_body)
+            fused = self._tail_fused.get(False, False)
+        if fused:
+            # the step's last launch applied the update (rcgan_sn_bwd_adam): host-side bookkeeping only
+            lr = steps[0][1]
+            self.PD.t += 1
+            self.PD._dev_hyper = (float(lr), self.PD.t)
+            self.PD.version += 1
+            return
         self._optimise_or_publish(steps)
 
     def g_step(self, iteration=None):

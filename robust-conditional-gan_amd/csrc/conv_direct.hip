@@ -5,6 +5,8 @@
 // the fp32 parity runs), the MNIST 5x5 stride-2 convs and transposed convs, and all dense layers.  Same math as
 // tf.nn.conv2d / conv2d_backprop_input / conv2d_backprop_filter with SAME padding (reference call sites:
 // mnist/ops.py:62,78; cifar10/common/ops/conv2d.py:181-187).
+#include <algorithm>
+
 #include "common.h"
 #include <type_traits>
 
@@ -1025,6 +1027,21 @@ static int wgrad_splits(long K, long Cout, long M) {
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
+  // (round 6) whole rounds: such a grid runs two 512-thread workgroups per CU (launch_gemm: two K-slices, 74 KB of LDS each), 512 at
+  // a time on 256 CUs.  tiles x splits just above a multiple of 512 -- the MNIST generator's 5x5 transposed convolution: 150 tiles
+  // x 7 splits = 1050 -- pays a whole extra round for a few workgroups; one split less (900: two rounds of 17 % longer workgroups)
+  // is the shorter launch.  RCGAN_GG_WGRAD_FIT=0: the plain ceil(1024 / tiles).
+  static const int fit = gg_env_int("RCGAN_GG_WGRAD_FIT", 1);
+  if (fit && want > 1 && tiles * want >= 512) {
+    const long over = (tiles * want) % 512;
+    if (over != 0 && over * 4 < 512) {               // the last round less than a quarter full
+      long w2 = want;
+      while (w2 > 1 && (tiles * w2) % 512 != 0 && ((tiles * w2) % 512) * 4 < 512 && tiles * w2 > 512) --w2;
+      // accept when the rounds saved outweigh the longer workgroups: rounds(w2) / w2 < rounds(want) / want
+      const long r1 = (tiles * want + 511) / 512, r2 = (tiles * w2 + 511) / 512;
+      if (r2 * want < r1 * w2) want = w2;
+    }
+  }
   return (int)want;
 }
 
@@ -1352,6 +1369,10 @@ int direct_dgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* dy, const fl
           tab.cls[ncls++] = c;
         }
       if (ncls == 0) return RCGAN_OK;
+      // (round 6) longest class first: grid.z is the slowest dispatch index, and with a 5x5 filter the classes reduce over 4, 6, 6 and 9
+      // taps -- in (ph, pw) order the 9-tap workgroups started last and the launch ended on them alone.  RCGAN_S2_LPT=0: (ph, pw) order.
+      static const int lpt = gg_env_int("RCGAN_S2_LPT", 1);
+      if (lpt) std::stable_sort(tab.cls, tab.cls + ncls, [](const S2Cls& a, const S2Cls& b) { return a.R * a.M > b.R * b.M; });
       for (int q = ncls; q < 4; ++q) tab.cls[q] = tab.cls[0];
       // launch-shape fields (the kernel re-selects per class)
       op.M = maxM; op.R = maxR; op.r_chunk = maxR;

@@ -4,6 +4,10 @@
 //   the reference puts no stop_gradient on v / u', so the backward differentiates the iteration.
 // In the reference each weight costs ~20 tiny dependent TF ops per D instantiation (pure latency);
 // here every SN weight of the discriminator is handled by the same 2 (forward) / 3 (backward) launches.
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 #define SN_MAX_K 4096
@@ -155,9 +159,41 @@ __global__ __launch_bounds__(SN_NT) void sn_fwd_finish_kernel(SnBatch batch) {
   sn_fwd_finish<false>(batch.it[blockIdx.x], red);
 }
 
-// backward 1/3: the chunk's share of <dW_bar, W>
-__global__ __launch_bounds__(SN_NT) void sn_bwd_gw_kernel(SnBwdBatch batch) {
+// ---- backward (round 6: two launches instead of three, optionally with the optimiser in the second) ----------------------------
+// dW = dW_bar / sigma + v (x) db + da (x) u_in, with  dsigma = -<dW_bar, W> / sigma^2,  db = dsigma * q,
+//   q = u2 + b / (nb + eps) - b * |b|^2 / (nb (nb + eps)^2)            (a c-vector of FORWARD quantities only),
+//   dv = W db = dsigma * p,  p = W q,   <dv, a> = dsigma * <p, a>,   da = dv / (na + eps) - a <dv, a> / (na (na + eps)^2).
+// Rounds 1-5 ran <dW_bar, W> | dv = W db | dW as three launches because db needs dsigma.  But db is dsigma TIMES a vector that does
+// not depend on the gradient: p = W q and <p, a> come out of the SAME pass over W that forms <dW_bar, W>, and dsigma multiplies
+// them afterwards.  Pass 1: per 32-row chunk <dW_bar, W>, p and <p, a>.  Pass 2: the scalars, da, dW -- and, for a single-rank
+// step with a static loss scale (rcgan_sn_bwd_adam), TF-Adam on the rows just produced, with rider workgroups for the
+// slab's other parameters: the critic step's optimiser launch and the 8 us in front of it are gone.
+#define SN_MAX_RANGES 48
+struct SnAdam {
+  float *w_base, *m_base, *v_base, *g_base;      // the optimiser group's slabs; an item's w / dw point into w_base / g_base at the same offset
+  const float* hyper;                            // device {lr, t}: t was advanced by pass 1 of the same call
+  float beta1, beta2, eps, clip, grad_scale;
+  int riders;                                    // this launch carries the rider row (the last batch of a call)
+  int n_ranges;
+  unsigned lo[SN_MAX_RANGES], hi[SN_MAX_RANGES]; // float offsets [lo, hi) of the slab NOT covered by the items
+};
+
+__device__ __forceinline__ void sn_adam_elem(float g, float& m, float& v, float& w, float alpha, float omb1, float omb2, float eps, float clip,
+                                             float grad_scale) {
+  // (the operation sequence of adam_tf_kernel, api.hip)
+  const float gi = g * grad_scale;
+  m = m + (gi - m) * omb1;
+  v = v + (gi * gi - v) * omb2;
+  w = w - (m * alpha) / (sqrtf(v) + eps);
+  if (clip > 0.f) w = fminf(fmaxf(w, -clip), clip);
+}
+
+// pass 1/2: q (every workgroup recomputes the c-vector), and for the chunk's rows <dW_bar, W>, p = W q, <p, a>
+__global__ __launch_bounds__(SN_NT) void sn_bwd_p1_kernel(SnBwdBatch batch, float* hyper_inc) {
+  __shared__ float q_s[SN_MAX_C];
   __shared__ float red[SN_NW];
+  // the optimiser's step count moves on HERE, one launch in front of the one that reads it (rcgan_sn_bwd_adam)
+  if (hyper_inc != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hyper_inc[1] += 1.f;
   const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
   const int k = it.k, c = it.c;
   const int r0 = blockIdx.x * SN_RB;
@@ -166,62 +202,55 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_gw_kernel(SnBwdBatch batch) {
   const SnLayout L = sn_layout(it.save, k, c);
   const float* w = it.w + (long)r0 * c;
   const float* g = it.dwbar + (long)r0 * c;
-  const long total = (long)rows * c;
-  const int tid = threadIdx.x;
-  float gw = 0.f;
-  if ((c & 3) == 0) {
-    const float4* g4 = (const float4*)g;
-    const float4* w4 = (const float4*)w;
-    for (long i = tid; i < total / 4; i += SN_NT) {
-      float4 a = g4[i], b = w4[i];
-      gw += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-    }
-  } else {
-    for (long i = tid; i < total; i += SN_NT) gw += g[i] * w[i];
-  }
-  gw = block_sum_nt(gw, red);
-  if (tid == 0) L.pgw[blockIdx.x] = gw;
-}
-
-// backward 2/3: dsigma -> db (every workgroup recomputes the c-vector), dv = W db for the chunk's rows
-__global__ __launch_bounds__(SN_NT) void sn_bwd_dv_kernel(SnBwdBatch batch) {
-  __shared__ float db_s[SN_MAX_C];
-  __shared__ float red[SN_NW];
-  const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
-  const int k = it.k, c = it.c;
-  const int r0 = blockIdx.x * SN_RB;
-  if (r0 >= k) return;
-  const int rows = min(SN_RB, k - r0);
-  const SnLayout L = sn_layout(it.save, k, c);
-  const float* w = it.w + (long)r0 * c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float na = L.s[0], nb = L.s[1], sigma = L.s[2];
-  (void)na;
-  float gw = 0.f;
-  for (int q = tid; q < L.chunks; q += SN_NT) gw += L.pgw[q];
-  gw = block_sum_nt(gw, red);
-  const float dsigma = -gw / (sigma * sigma);
-  // sigma = b.u2, u2 = b/(nb+eps)
-  float dot = 0.f;
-  for (int j = tid; j < c; j += SN_NT) { float b = L.b[j]; dot += dsigma * b * b; }
-  dot = block_sum_nt(dot, red);
+  // c <= 128 (every weight of these critics): the wavefront's rows of W and dW_bar are requested HERE, in front of the q chain (two
+  // block reductions and a barrier), and wait in registers -- one memory round trip less on the launch's critical path
+  constexpr int NR = SN_RB / SN_NW;
+  const bool small_c = c <= 128;
+  float wr[NR][2], gr[NR][2];
+  if (small_c) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = wave + i * SN_NW;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = lane + 64 * e;
+        const bool ok = r < rows && j < c;
+        wr[i][e] = ok ? w[(long)r * c + j] : 0.f;
+        gr[i][e] = ok ? g[(long)r * c + j] : 0.f;
+      }
+    }
+  }
+  const float nb = L.s[1];
+  float s2 = 0.f;
+  for (int j = tid; j < c; j += SN_NT) { const float b = L.b[j]; s2 += b * b; }
+  s2 = block_sum_nt(s2, red);
   const float inv_nb = 1.f / (nb + SN_EPS);
-  const float coef_b = dot / (nb * (nb + SN_EPS) * (nb + SN_EPS));
+  const float coef_q = s2 / (nb * (nb + SN_EPS) * (nb + SN_EPS));
   for (int j = tid; j < c; j += SN_NT) {
-    float b = L.b[j];
-    float d = dsigma * L.u2[j] + dsigma * b * inv_nb - b * coef_b;
-    db_s[j] = d;
-    if (blockIdx.x == 0) L.db[j] = d;
+    const float b = L.b[j];
+    const float q = L.u2[j] + b * inv_nb - b * coef_q;
+    q_s[j] = q;
+    if (blockIdx.x == 0) L.db[j] = q;
   }
   __syncthreads();
-  float dva = 0.f;
+  float gw = 0.f, pa = 0.f;
   float part[SN_RB / SN_NW], av[SN_RB / SN_NW];
 #pragma unroll
   for (int i = 0; i < SN_RB / SN_NW; ++i) {          // every row of the wavefront requested before the first reduction
     const int r = wave + i * SN_NW;
     float s = 0.f;
-    if (r < rows)
-      for (int j = lane; j < c; j += 64) s += w[(long)r * c + j] * db_s[j];
+    if (small_c) {
+      const float q0 = lane < c ? q_s[lane] : 0.f, q1 = lane + 64 < c ? q_s[lane + 64] : 0.f;
+      s = wr[i][0] * q0 + wr[i][1] * q1;
+      gw += gr[i][0] * wr[i][0] + gr[i][1] * wr[i][1];
+    } else if (r < rows) {
+      for (int j = lane; j < c; j += 64) {
+        const float wv = w[(long)r * c + j];
+        s += wv * q_s[j];
+        gw += g[(long)r * c + j] * wv;
+      }
+    }
     part[i] = s;
     av[i] = (lane == 0 && r < rows) ? L.a[r0 + r] : 0.f;
   }
@@ -229,17 +258,37 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_dv_kernel(SnBwdBatch batch) {
   for (int i = 0; i < SN_RB / SN_NW; ++i) {
     const int r = wave + i * SN_NW;
     const float s = wave_sum(part[i]);
-    if (lane == 0 && r < rows) { L.dv[r0 + r] = s; dva += s * av[i]; }
+    if (lane == 0 && r < rows) { L.dv[r0 + r] = s; pa += s * av[i]; }      // (the dv slot holds p = W q)
   }
-  dva = block_sum_nt(lane == 0 ? dva : 0.f, red);
-  if (tid == 0) L.pdva[blockIdx.x] = dva;
+  gw = block_sum_nt(gw, red);
+  pa = block_sum_nt(lane == 0 ? pa : 0.f, red);
+  if (tid == 0) { L.pgw[blockIdx.x] = gw; L.pdva[blockIdx.x] = pa; }
 }
 
-// backward 3/3: da for the chunk's rows, dW = dW_bar/sigma + v (x) db + da (x) u_in
-__global__ __launch_bounds__(SN_NT) void sn_bwd_dw_kernel(SnBwdBatch batch) {
+// pass 2/2: dsigma, da for the chunk's rows, dW = dW_bar/sigma + (dsigma v) (x) q + da (x) u_in; ADAM: the update of those rows, and
+// the rider row (blockIdx.y == number of items) for the parameters between the spectrally normalised ones
+template <bool ADAM>
+__global__ __launch_bounds__(SN_NT) void sn_bwd_p2_kernel(SnBwdBatch batch, int n_items, SnAdam ad) {
   __shared__ float da_s[SN_RB];
   __shared__ float v_s[SN_RB];
   __shared__ float red[SN_NW];
+  const int tid = threadIdx.x;
+  float alpha = 0.f, omb1 = 0.f, omb2 = 0.f;
+  if (ADAM) {
+    const float lr = ad.hyper[0], t = ad.hyper[1];
+    alpha = lr * sqrtf(1.f - powf(ad.beta2, t)) / (1.f - powf(ad.beta1, t));
+    omb1 = 1.f - ad.beta1;
+    omb2 = 1.f - ad.beta2;
+    if ((int)blockIdx.y >= n_items) {               // riders: biases, embeddings, the slab's alignment holes (zeros stay zeros)
+      for (int rg = 0; rg < ad.n_ranges; ++rg)
+        for (unsigned o = ad.lo[rg] + blockIdx.x * SN_NT + tid; o < ad.hi[rg]; o += gridDim.x * SN_NT) {
+          float m = ad.m_base[o], v = ad.v_base[o], wv = ad.w_base[o];
+          sn_adam_elem(ad.g_base[o], m, v, wv, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+          ad.m_base[o] = m; ad.v_base[o] = v; ad.w_base[o] = wv;
+        }
+      return;
+    }
+  }
   const rcgan_sn_bwd_item it = batch.it[blockIdx.y];
   const int k = it.k, c = it.c;
   const int r0 = blockIdx.x * SN_RB;
@@ -248,28 +297,31 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_dw_kernel(SnBwdBatch batch) {
   const SnLayout L = sn_layout(it.save, k, c);
   const float* g = it.dwbar + (long)r0 * c;
   float* dw = it.dw + (long)r0 * c;
-  const int tid = threadIdx.x;
   const float na = L.s[0], sigma = L.s[2];
-  float dva = 0.f;
-  for (int q = tid; q < L.chunks; q += SN_NT) dva += L.pdva[q];
-  dva = block_sum_nt(dva, red);
+  float gw = 0.f, pa = 0.f;
+  for (int q = tid; q < L.chunks; q += SN_NT) { gw += L.pgw[q]; pa += L.pdva[q]; }
+  gw = block_sum_nt(gw, red);
+  pa = block_sum_nt(pa, red);
+  const float dsigma = -gw / (sigma * sigma);
+  const float dva = dsigma * pa;
   const float inv_na = 1.f / (na + SN_EPS);
   const float coef_a = dva / (na * (na + SN_EPS) * (na + SN_EPS));
   if (tid < rows) {
-    da_s[tid] = L.dv[r0 + tid] * inv_na - L.a[r0 + tid] * coef_a;
-    v_s[tid] = L.v[r0 + tid];
+    da_s[tid] = dsigma * L.dv[r0 + tid] * inv_na - L.a[r0 + tid] * coef_a;
+    v_s[tid] = dsigma * L.v[r0 + tid];
   }
   __syncthreads();
   const float inv_sigma = 1.f / sigma;
+  const long aoff = ADAM ? (long)(dw - ad.g_base) : 0;       // this chunk's offset inside the group's slabs
   if ((c & 3) == 0) {
     const int c4 = c >> 2;
     const float4* g4 = (const float4*)g;
     float4* dw4 = (float4*)dw;
-    const float4* db4 = (const float4*)L.db;
+    const float4* q4 = (const float4*)L.db;
     const float4* u4 = (const float4*)L.uin;
     for (int i = tid; i < rows * c4; i += SN_NT) {
       const int r = i / c4, j = i - r * c4;
-      const float4 gv = g4[i], d = db4[j], u = u4[j];
+      const float4 gv = g4[i], d = q4[j], u = u4[j];
       const float vr = v_s[r], ar = da_s[r];
       float4 o;
       o.x = gv.x * inv_sigma + vr * d.x + ar * u.x;
@@ -278,6 +330,17 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_dw_kernel(SnBwdBatch batch) {
       o.w = gv.w * inv_sigma + vr * d.w + ar * u.w;
       if (it.accumulate) { float4 p = dw4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
       dw4[i] = o;
+      if (ADAM) {
+        float4* m4 = (float4*)(ad.m_base + aoff) + i;
+        float4* vv4 = (float4*)(ad.v_base + aoff) + i;
+        float4* w4 = (float4*)(ad.w_base + aoff) + i;
+        float4 m = *m4, v = *vv4, wv = *w4;
+        sn_adam_elem(o.x, m.x, v.x, wv.x, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.y, m.y, v.y, wv.y, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.z, m.z, v.z, wv.z, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.w, m.w, v.w, wv.w, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        *m4 = m; *vv4 = v; *w4 = wv;
+      }
     }
   } else {
     for (int i = tid; i < rows * c; i += SN_NT) {
@@ -285,6 +348,11 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_dw_kernel(SnBwdBatch batch) {
       float o = g[i] * inv_sigma + v_s[r] * L.db[j] + da_s[r] * L.uin[j];
       if (it.accumulate) o += dw[i];
       dw[i] = o;
+      if (ADAM) {
+        float m = ad.m_base[aoff + i], v = ad.v_base[aoff + i], wv = ad.w_base[aoff + i];
+        sn_adam_elem(o, m, v, wv, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        ad.m_base[aoff + i] = m; ad.v_base[aoff + i] = v; ad.w_base[aoff + i] = wv;
+      }
     }
   }
 }
@@ -321,7 +389,7 @@ int rcgan_sn_power_iter(rcgan_ctx* ctx, const rcgan_sn_item* items, int n_items)
   return RCGAN_OK;
 }
 
-int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items) {
+static int sn_bwd_launch(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items, const rcgan_sn_adam* opt) {
   for (int base = 0; base < n_items; base += SN_BATCH) {
     SnBwdBatch b;
     int n = n_items - base < SN_BATCH ? n_items - base : SN_BATCH;
@@ -333,14 +401,53 @@ int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items) {
       if (b.it[i].k > maxk) maxk = b.it[i].k;
     }
     const dim3 grid(sn_chunks(maxk), n);
-    hipLaunchKernelGGL(sn_bwd_gw_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
+    // (the step count moves on once per call: in the first batch's first launch)
+    hipLaunchKernelGGL(sn_bwd_p1_kernel, grid, dim3(SN_NT), 0, ctx->stream, b, (opt && base == 0) ? opt->hyper : (float*)nullptr);
     RC_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sn_bwd_dv_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
-    RC_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sn_bwd_dw_kernel, grid, dim3(SN_NT), 0, ctx->stream, b);
+    SnAdam ad = {};
+    if (opt) {
+      const bool last = base + n >= n_items;
+      ad.w_base = opt->w; ad.m_base = opt->m; ad.v_base = opt->v; ad.g_base = opt->g; ad.hyper = opt->hyper;
+      ad.beta1 = opt->beta1; ad.beta2 = opt->beta2; ad.eps = opt->eps; ad.clip = opt->clip; ad.grad_scale = opt->grad_scale;
+      ad.riders = last ? 1 : 0;
+      ad.n_ranges = last ? opt->n_ranges : 0;
+      for (int r = 0; r < ad.n_ranges; ++r) { ad.lo[r] = (unsigned)opt->ranges[2 * r]; ad.hi[r] = (unsigned)opt->ranges[2 * r + 1]; }
+      hipLaunchKernelGGL(sn_bwd_p2_kernel<true>, dim3(grid.x, n + (last ? 1 : 0)), dim3(SN_NT), 0, ctx->stream, b, n, ad);
+    } else {
+      hipLaunchKernelGGL(sn_bwd_p2_kernel<false>, grid, dim3(SN_NT), 0, ctx->stream, b, n, ad);
+    }
     RC_LAUNCH_CHECK(ctx);
   }
   return RCGAN_OK;
+}
+
+int rcgan_sn_bwd(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items) { return sn_bwd_launch(ctx, items, n_items, nullptr); }
+
+int rcgan_sn_bwd_adam(rcgan_ctx* ctx, const rcgan_sn_bwd_item* items, int n_items, const rcgan_sn_adam* opt) {
+  RC_REQUIRE(ctx, items && n_items >= 1 && opt && opt->w && opt->g && opt->m && opt->v && opt->hyper, "null argument");
+  RC_REQUIRE(ctx, opt->count < (1ull << 32) && opt->n_ranges >= 0 && opt->n_ranges <= SN_MAX_RANGES && (opt->n_ranges == 0 || opt->ranges),
+             "%zu parameters, %d ranges (at most %d)", opt->count, opt->n_ranges, SN_MAX_RANGES);
+  // every item inside the slabs at the same offset in w and g, items and ranges disjoint and together covering [0, count)
+  std::vector<std::pair<size_t, size_t>> iv;
+  for (int i = 0; i < n_items; ++i) {
+    const size_t sz = (size_t)items[i].k * items[i].c;
+    RC_REQUIRE(ctx, items[i].w >= opt->w && items[i].w + sz <= opt->w + opt->count, "item %d: w outside the slab", i);
+    RC_REQUIRE(ctx, items[i].dw - opt->g == items[i].w - opt->w, "item %d: dw and w at different slab offsets", i);
+    iv.push_back({(size_t)(items[i].w - opt->w), (size_t)(items[i].w - opt->w) + sz});
+  }
+  for (int r = 0; r < opt->n_ranges; ++r) {
+    RC_REQUIRE(ctx, opt->ranges[2 * r] <= opt->ranges[2 * r + 1] && opt->ranges[2 * r + 1] <= opt->count, "range %d outside the slab", r);
+    iv.push_back({opt->ranges[2 * r], opt->ranges[2 * r + 1]});
+  }
+  std::sort(iv.begin(), iv.end());
+  size_t at = 0;
+  for (auto& p : iv) {
+    if (p.first == p.second) continue;
+    RC_REQUIRE(ctx, p.first == at, "items and ranges must tile the slab: gap or overlap at float offset %zu (next piece starts at %zu)", at, p.first);
+    at = p.second;
+  }
+  RC_REQUIRE(ctx, at == opt->count, "items and ranges cover %zu of %zu parameters", at, opt->count);
+  return sn_bwd_launch(ctx, items, n_items, opt);
 }
 
 }  // extern "C"

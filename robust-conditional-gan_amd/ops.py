@@ -229,6 +229,27 @@ def spectral_norm_batch(ctx, entries):
         for j, (i, w, (save, k, c)) in enumerate(todo):
             bi[j] = L.SnBwdItem(w.param.ptr, w.dwbar.ptr, w.param.grad.ptr, save.ptr, k, c, 1)
             done.add(i)
+        fa = getattr(ctx, "sn_adam", None)
+        if fa is not None and not fa.get("done") and len(todo) == len(weights) and all(w.param.group is fa["group"] for _, w, _ in todo):
+            # (round 6) a single-rank step whose optimiser group is exactly this call's weights + the parameters between them: the
+            # second launch also applies TF-Adam -- to the rows it has just produced, and through rider workgroups to the rest of
+            # the slab (rcgan_sn_bwd_adam).  This closure is the LAST gradient work of the step (recorded first, it runs last), so
+            # every other gradient of the group is final here.
+            grp = fa["group"]
+            cover = sorted((grp.offsets[w.param.name], grp.offsets[w.param.name] + w.param.size) for _, w, _ in todo)
+            ranges, at = [], 0
+            for lo, hi in cover:
+                if lo > at:
+                    ranges += [at, lo]
+                at = hi
+            if at < grp.count:
+                ranges += [at, grp.count]
+            ra = (C.c_size_t * max(len(ranges), 1))(*ranges)
+            opt = L.SnAdam(grp.value.data_ptr(), grp.grad.data_ptr(), grp.m.data_ptr(), grp.v.data_ptr(), grp.count, grp.hyper.data_ptr(),
+                           fa["beta1"], fa["beta2"], fa.get("eps", 1e-8), fa.get("clip", 0.0), fa["grad_scale"], len(ranges) // 2, ra)
+            ctx.check(ctx.lib.rcgan_sn_bwd_adam(ctx.h, bi, len(todo), C.byref(opt)))
+            fa["done"] = True
+            return
         ctx.check(ctx.lib.rcgan_sn_bwd(ctx.h, bi, len(todo)))
     if any(p.req for p, _, _ in entries):
         ctx.record(bw)

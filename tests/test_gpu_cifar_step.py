@@ -480,3 +480,45 @@ def test_grad_finite_check_finds_any_non_finite_value():
             assert float(ls[2]) == want, (pos, val, ls)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("alg,perm,dtype,use_graphs", [("rcgan", False, "bf16", True), ("rcgan-u", True, "bf16", False), ("rcgan", False, "f32", True)])
+def test_optimiser_inside_the_spectral_norm_backward(alg, perm, dtype, use_graphs, monkeypatch):
+    """(round 6) rcgan_sn_bwd_adam: the critic step whose last launch applies TF-Adam (the rows of dW a workgroup has just formed;
+    rider workgroups for the biases / embeddings between the spectrally normalised weights; the step count on the device) against
+    the separate optimiser launch (RCGAN_SN_ADAM=0) on the same weights and batches.  After the first step: gradients identical,
+    parameters and both Adam slots equal to 2 ulp (same operation sequence, compiled into two kernels).  After four steps (a new
+    learning rate each, graph replays from the second on): the host's step count, and the parameters within what Adam with
+    beta1 = 0 allows two runs 2 ulp apart (a weight whose gradient is ~0 moves by lr * sign(noise): 2 * lr per step)."""
+    rs = np.random.RandomState(5)
+    B = 4
+    steps = [_batches(rs, B)[1] for _ in range(4)]
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("RCGAN_SN_ADAM", fused)
+        m, P, Uo = _make(alg, perm, B, dtype, use_graphs=use_graphs)
+        try:
+            assert m.fused_tail == (fused == "1")
+            first = None
+            for it, raw in enumerate(steps):
+                m.set_inputs(labels_all=_labels_all(alg, raw), **raw)
+                m.d_step(iteration=it * 7000)            # (a different learning rate every step: lr_decay)
+                if it == 0:
+                    m.ctx.sync()
+                    first = (m.get_grads(m.PD), {w: {n: m.PD.get(n, w) for n in m.PD.names} for w in ("value", "m", "v")})
+            assert m._tail_fused.get(False, False) == (fused == "1")
+            assert m.PD.t == len(steps)
+            m.ctx.sync()
+            outs.append((first, {n: m.PD.get(n, "value") for n in m.PD.names}))
+        finally:
+            m.ctx.close()
+    ((ga, sa), fa), ((gb, sb), fb) = outs
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), "gradient %s" % k
+    for w in ("value", "m", "v"):
+        for n in sa[w]:
+            a, b = sa[w][n].astype(np.float64), sb[w][n].astype(np.float64)
+            tol = 2 * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+            assert np.all(np.abs(a - b) <= tol), "%s of %s: max diff %.3e" % (w, n, float(np.abs(a - b).max()))
+    for n in fa:
+        assert np.isfinite(fa[n]).all() and float(np.abs(fa[n].astype(np.float64) - fb[n]).max()) <= 2 * 2e-4 * len(steps) + 1e-6, n
