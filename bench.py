@@ -485,7 +485,9 @@ def main():
                           "gradient_exchange": ("none (single rank)" if m.world == 1 else
                                                 "in-ABI %s all-reduce(sum) of the gradient slabs inside the step's graph, %s, optimiser %s"
                                                 % ("RCCL" if m.comm_kind == "rccl" else "TEST-DOUBLE (--dp-stub %d: schedule only, no traffic)" % args.dp_stub,
-                                                   "1 whole-slab %s bucket per optimiser group and step" % m.grad_bucket_dtype,
+                                                   ("2 buckets per optimiser group and step, the last layers' leaving on the communication stream "
+                                                    "during the backward pass (RCGAN_DP_OVERLAP=1)" if getattr(m, "dp_overlap", False) else
+                                                    "1 whole-slab %s bucket per optimiser group and step" % m.grad_bucket_dtype),
                                                    "in the graph" if m.dp_adam_in_graph else "after the graph")),
                           "critic_generator_forwards": ("one pass over N_CRITIC x B samples, batch-norm statistics per critic step"
                                                         if BATCH_CRITIC_FAKES else "inside every critic step"),

@@ -248,6 +248,8 @@ def Generator(n_samples, labels, noise, out=None, segments=1):
         output = Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = O.reshape(ctx, output, (-1, 4, 4, DIM_G * 8))
         output = G_ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', labels, segments)
+        if Graph.current.early_g is not None and output.req:
+            ctx.record(Graph.current.early_g)       # backward: G.Block.2 .. G.Output are done here -> their bucket leaves early
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', labels, segments)
         output = G_ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', labels, segments)
         with variable_scope('G.OutputNorm'):
@@ -302,6 +304,8 @@ def Discriminator(inputs, labels, update_collection=None, _head=True):
             h = Conv2D(x, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv1', _in_relu=True, **kw)
             t = Conv2D(h, DIM_D, DIM_D, 3, 1, 'D.Block.2.Conv2', _in_relu=True, _accumulate_into=t, **kw)
             x = O.meanpool2(ctx, t)
+        if Graph.current.early_d is not None and x.req:
+            ctx.record(Graph.current.early_d)       # backward: D.Block.3 .. the head are done here -> their bucket leaves early
         if FUSED_TRUNK and O.d_trunk_ok(ctx, x):
             # D.Block.3 .. D.Block.6 (identity shortcuts, 8 x 8 pixels): one launch for the eight convolutions (ops.d_trunk)
             g, blocks = Graph.current, []
@@ -459,6 +463,14 @@ class CifarRCGAN:
         # the test double it cost 0.6-0.73 ms per iteration of extra launches (second filter-gradient group, second spectral-norm
         # backward, fork / join) with nothing to hide, and under the link model of `bench.py --dp-stub 8 --dp-stub-gbps 200
         # --dp-stub-lat-us 40` it still lost: 6.94 ms against 6.70 ms (fp32 buckets) and 6.42 ms (bf16 buckets) -- DESIGN 5.
+        # (round 6) ... and is back behind a switch, so that the first 8-GPU box can A/B the two schedules instead of trusting the link
+        # model: RCGAN_DP_OVERLAP=1 = two buckets per step, the layers whose backward finishes first (D.Block.3 .. head | G.Block.2 ..
+        # G.Output) leave on the communication stream while the rest of the backward pass runs, the remainder follows on the step's stream
+        # (reverse-layer-order buckets overlapped with backward).  fp32 buckets only.
+        self.dp_overlap = self.dp_active and self.grad_bucket_dtype == "f32" and os.environ.get("RCGAN_DP_OVERLAP", "0") == "1"
+        # first parameter of the early bucket of each group (everything from there to the end of the slab)
+        self._early_lo = {id(self.PD): self.PD.offsets["Discriminator/D.Block.3.Conv1/Filters"],
+                          id(self.PG): self.PG.offsets["Generator/G.Block.2.Shortcut/Filters"]}
         self.dp_adam_in_graph = self.dp_active and not self.dynamic_ls and os.environ.get("RCGAN_DP_GRAPH_ADAM", "1") == "1"
         # (round 5, measured and left off) single rank: the optimiser launch at the end of the step's captured graph too ({lr, t} from
         # device memory, the rcgan_adam_tf launch the data-parallel steps capture).  As an eager launch BEHIND the graph it starts ~8 us
@@ -694,6 +706,7 @@ class CifarRCGAN:
         g.begin_step({1})
         ctx.sn_adam = (dict(group=self.PD, beta1=0.0, beta2=0.9, grad_scale=1.0 / (self.world * self.loss_scale))
                        if (self.fused_tail and ctx.recording and self.PD.hyper is not None) else None)
+        g.early_d = self._dp_early(self.PD) if (self.dp_overlap and ctx.recording) else None
         # With the fakes ready and the noise drawn on the device, everything at the head of the step that depends on its inputs
         # only -- noise, preprocessing, the image pool of D.Block.1's shortcut, the zero-fill -- rides in the filter-preparation
         # launch (rcgan_conv_prepare_batch_riders) instead of five launches in front of the first convolution.
@@ -782,6 +795,7 @@ class CifarRCGAN:
         ctx.new_step()
         g.begin_step({0, 2} if self.PC is not None else {0})
         ctx.sn_adam = None
+        g.early_g = self._dp_early(self.PG) if (self.dp_overlap and ctx.recording) else None
         self.PG.zero_grad()
         if self.PC is not None:
             self.PC.zero_grad()
@@ -852,9 +866,24 @@ class CifarRCGAN:
         ctx.graph_launch(self._graphs[key])
 
     # ---------------------------------------------------------------------------------- data parallel
+    def _dp_early(self, grp):
+        """Tape closure for the point of the backward pass where the group's LAST layers are done (RCGAN_DP_OVERLAP=1): flush their
+        filter gradients, run their spectral-norm backward, and start the all-reduce of slab[lo:] on the communication stream."""
+        ctx, lo = self.ctx, self._early_lo[id(grp)]
+        state = {"sent": False}
+        grp._dp_early_state = state
+
+        def fire():
+            ctx.flush_wgrads()
+            for bw in ctx.sn_partial:
+                bw(lambda name: name in grp.offsets and grp.offsets[name] >= lo)
+            ctx.check(ctx.lib.rcgan_allreduce_sum_async(ctx.h, C.c_void_p(grp.grad.data_ptr() + 4 * lo), grp.count - lo))
+            state["sent"] = True
+        return fire
+
     def _dp_finish(self, groups):
-        """End of a step's backward pass: all-reduce the gradient slabs of the step's optimiser groups (ONE RCCL group) and -- static
-        loss scale -- run the optimiser inside the same captured graph."""
+        """End of a step's backward pass: all-reduce the gradient slabs of the step's optimiser groups (ONE RCCL group; what an early
+        bucket has not taken yet) and -- static loss scale -- run the optimiser inside the same captured graph."""
         ctx = self.ctx
         if not ctx.recording:                         # (forward-only evaluations -- eval_d_cost -- exchange and update nothing)
             return
@@ -865,8 +894,12 @@ class CifarRCGAN:
             return
         ptrs, counts = [], []
         for grp in groups:
-            ptrs.append(grp.grad.data_ptr())
-            counts.append(grp.count)
+            st = getattr(grp, "_dp_early_state", None)
+            hi = self._early_lo[id(grp)] if (st is not None and st["sent"]) else grp.count
+            grp._dp_early_state = None
+            if hi > 0:
+                ptrs.append(grp.grad.data_ptr())
+                counts.append(hi)
         n = len(ptrs)
         if self.grad_bucket_dtype == "bf16":
             cnt = (C.c_size_t * n)(*counts)
@@ -880,6 +913,8 @@ class CifarRCGAN:
                                                                self._bucket16.numel()))
         else:
             ctx.check(ctx.lib.rcgan_allreduce_sum_buckets(ctx.h, n, (C.c_void_p * n)(*ptrs), (C.c_size_t * n)(*counts)))
+        if self.dp_overlap:
+            ctx.check(ctx.lib.rcgan_allreduce_join(ctx.h))      # the step's stream waits for the early buckets
         if self.dp_adam_in_graph:
             for grp in groups:
                 grp.adam_captured(0.0, 0.9, grad_scale=1.0 / (self.world * self.loss_scale))

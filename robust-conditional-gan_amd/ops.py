@@ -218,11 +218,12 @@ def spectral_norm_batch(ctx, entries):
 
     done = set()
 
-    def bw():
-        """dW_bar -> dW through the power iteration for every weight not handled yet."""
+    def bw(only=None):
+        """dW_bar -> dW through the power iteration for every weight not handled yet (only: predicate on the parameter name -- the
+        overlapped data-parallel schedule finishes the gradients of its first bucket early, Context.sn_partial)."""
         ctx.flush_wgrads()          # the deferred filter gradients write the dW_bar this closure consumes
         todo = [(i, w, s) for i, (w, s) in enumerate(zip(weights, saves))
-                if i not in done and w.dwbar is not None and w.param.req]
+                if i not in done and w.dwbar is not None and w.param.req and (only is None or only(w.param.name))]
         if not todo:
             return
         bi = (L.SnBwdItem * len(todo))()
@@ -253,6 +254,7 @@ def spectral_norm_batch(ctx, entries):
         ctx.check(ctx.lib.rcgan_sn_bwd(ctx.h, bi, len(todo)))
     if any(p.req for p, _, _ in entries):
         ctx.record(bw)
+        ctx.sn_partial.append(bw)
     return weights
 
 

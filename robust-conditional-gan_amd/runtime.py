@@ -135,6 +135,7 @@ class Context:
         self.ws2 = torch.empty(int(ws_bytes), dtype=torch.uint8, device=self.device) if self.overlap else None
         self.ws2_ptr = self.ws2.data_ptr() if self.overlap else 0
         self.tape = []
+        self.sn_partial = []        # spectral-norm backward closures of this step that take a parameter-name predicate (RCGAN_DP_OVERLAP)
         self.pending_wgrads = []
         self.group_wgrads = os.environ.get("RCGAN_GROUP_WGRAD", "1") == "1"     # see defer_wgrad
         self.recording = True
@@ -250,6 +251,7 @@ class Context:
     def new_step(self):
         self.check(self.lib.rcgan_head_flush(self.h))      # (a head whose backward pass never ran: its buffers are still valid here)
         self.tape = []
+        self.sn_partial = []
         self.pending_wgrads = []
         self.arena.reset()
         self.epoch += 1

@@ -54,6 +54,11 @@ class Graph:
         self.image_pool = None
         self.head_E = None
         self.trunk_frag = None
+        # overlapped data-parallel schedule (RCGAN_DP_OVERLAP=1): closures the model functions record on the tape where the LAST layers'
+        # gradients are complete in the backward pass (Discriminator: in front of D.Block.3; Generator: in front of G.Block.2) -- they
+        # finish that bucket and hand it to the all-reduce while the earlier layers' backward still runs (CifarRCGAN._dp_early)
+        self.early_d = None
+        self.early_g = None
         Graph.current = self
 
     def param(self, name):

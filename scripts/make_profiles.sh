@@ -55,14 +55,30 @@ if [ "${2:-all}" = lean ]; then
   python3 bench.py --no-cpu-baseline --algorithm rcgan-u > "$OUT/bench_rcganu.json" 2> /dev/null
   python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 > "$OUT/bench_dpstub8_model_f32.json" 2> /dev/null
   python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 --bucket-dtype bf16 > "$OUT/bench_dpstub8_model_bf16.json" 2> /dev/null
+  # BASELINE configs[4]'s single-GPU leg: per-GPU batch 512, fp16 activations (round 6)
+  python3 bench.py --no-cpu-baseline --dtype f16 --batch 512 --steps 8 > "$OUT/bench_f16_b512.json" 2> /dev/null
+  # MNIST cfg2 under the profiler: per-kernel summary (55 iterations) and launches per iteration
+  ( cd /tmp && rocprofv3 --kernel-trace -d "$OUT/prof_mnist" -o kt -- python3 "$ROOT/scripts/bench_mnist.py" 256 f32 > /dev/null 2>&1 )
+  DBM=$(find "$OUT/prof_mnist" -name "*.db" | head -1)
+  python3 scripts/prof_summary.py "$DBM" 55 --csv "$OUT/mnist_b256_f32_kernel_stats.csv" > "$OUT/mnist_b256_f32_kernel_stats.txt"
+  python3 scripts/prof_summary.py "$DBM" 55 --by-grid > "$OUT/mnist_b256_f32_kernel_stats_by_grid.txt"
+  rm -rf "$OUT/prof_mnist"
+  { RCGAN_GG_WGRAD_FIT=0 RCGAN_S2_LPT=0 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/no_fit no_lpt : /"
+    RCGAN_GG_WGRAD_FIT=1 RCGAN_S2_LPT=0 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/fit    no_lpt : /"
+    RCGAN_GG_WGRAD_FIT=0 RCGAN_S2_LPT=1 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/no_fit lpt    : /"; } > "$OUT/bench_mnist_switches.txt"
   for rep in 1 2; do
     python3 bench.py --no-cpu-baseline > "$OUT/bench_default_rep$rep.json" 2> /dev/null
-    RCGAN_P8N_HALO=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_p8n_halo_rep$rep.json" 2> /dev/null
-    RCGAN_H8N_TWO_PASS=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_two_pass_rep$rep.json" 2> /dev/null
+    # this round's switches, one at a time (the gather form's switch really switches it off since round 6: ADVICE r05)
     RCGAN_H8N_GATHER_MINBLK=100000 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_gather_rep$rep.json" 2> /dev/null
+    RCGAN_SN_ADAM=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_sn_adam_rep$rep.json" 2> /dev/null
+    RCGAN_OVERLAP_GF=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_overlap_gf_rep$rep.json" 2> /dev/null
     RCGAN_BN_INTO_PATCH=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_bn_into_patch_rep$rep.json" 2> /dev/null
-    RCGAN_GRAPH_ADAM=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_graph_adam_rep$rep.json" 2> /dev/null
   done
+  # the two data-parallel schedules under the same link model (ASSUMPTIONS: 40 us + 2(N-1)/N * bytes / 200 GB/s per all-reduce group)
+  RCGAN_DP_OVERLAP=1 python3 bench.py --no-cpu-baseline --dp-stub 8 --dp-stub-gbps 200 --dp-stub-lat-us 40 > "$OUT/bench_dpstub8_model_f32_overlap.json" 2> /dev/null
+  # the gather form where it could pay: per-GPU batch 512
+  python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512_rep2.json" 2> /dev/null
+  RCGAN_H8N_GATHER_MINBLK=100000 python3 bench.py --no-cpu-baseline --batch 512 --steps 8 > "$OUT/bench_b512_no_gather.json" 2> /dev/null
   ls -la "$OUT"; exit 0
 fi
 python3 scripts/bench_conv.py > "$OUT/microbench_conv.txt" 2>&1

@@ -26,6 +26,10 @@ fi
 for N in 1 2 4 8; do
   if [ "$N" -le "$NG" ]; then
     timeout 900 python bench.py --gpus $N --steps $STEPS --warmup 5 --no-cpu-baseline 2> "$OUT/bench_n$N.err" | tail -1 > "$OUT/bench_n$N.json"
+    # (round 6) the two-bucket schedule overlapped with the backward pass, the SAME node: the A/B the link model cannot give
+    if [ "$N" -gt 1 ]; then
+      RCGAN_DP_OVERLAP=1 timeout 900 python bench.py --gpus $N --steps $STEPS --warmup 5 --no-cpu-baseline 2> "$OUT/bench_overlap_n$N.err" | tail -1 > "$OUT/bench_overlap_n$N.json"
+    fi
   fi
   if [ "$N" -gt 1 ]; then
     timeout 600 python bench.py --gpus 1 --steps $STEPS --warmup 5 --no-cpu-baseline --dp-stub $N --dp-stub-gbps 200 --dp-stub-lat-us 40 \
@@ -42,7 +46,7 @@ def load(name):
     except Exception:
         return None
 base = load("bench_n1.json")
-print("%-3s %10s %12s %8s %10s %16s %16s %18s" % ("N", "ms/iter", "images/s", "eff", "weights==", "allreduce ms", "model ms/iter", "model allreduce ms"))
+print("%-3s %10s %12s %8s %10s %16s %16s %18s %18s" % ("N", "ms/iter", "images/s", "eff", "weights==", "allreduce ms", "model ms/iter", "model allreduce ms", "overlapped ms/iter"))
 for n in (1, 2, 4, 8):
     b, mo = load("bench_n%d.json" % n), load("model_n%d.json" % n)
     row = ["%-3d" % n]
@@ -55,5 +59,9 @@ for n in (1, 2, 4, 8):
         row += ["%10s" % "-", "%12s" % "-", "%8s" % "-", "%10s" % "-", "%16s" % "-"]
     if mo:
         row += ["%16.3f" % mo["ms_per_step"], "%18s" % mo["config"].get("allreduce_ms_per_iteration", "-")]
+    else:
+        row += ["%16s" % "-", "%18s" % "-"]
+    ov = load("bench_overlap_n%d.json" % n)
+    row += ["%18.3f" % ov["ms_per_step"] if ov else "%18s" % "-"]
     print(" ".join(row))
 PY
