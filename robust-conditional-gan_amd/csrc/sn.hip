@@ -297,6 +297,29 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_p2_kernel(SnBwdBatch batch, int 
   const SnLayout L = sn_layout(it.save, k, c);
   const float* g = it.dwbar + (long)r0 * c;
   float* dw = it.dw + (long)r0 * c;
+  // c <= 128 and a multiple of 4 (every weight of these critics): the chunk's dW_bar, the accumulate target and the optimiser's three
+  // slabs are requested HERE, in front of the scalar chain (two block reductions and a barrier) -- up to four 16-byte pieces per
+  // thread and tensor wait in registers
+  constexpr int PF = SN_RB * 128 / 4 / SN_NT;       // 4
+  const bool pf = (c & 3) == 0 && c <= 128;
+  const long aoff = ADAM ? (long)(dw - ad.g_base) : 0;       // this chunk's offset inside the group's slabs
+  float4 pg[PF], pd[PF], pm[PF], pv[PF], pw[PF];
+  if (pf) {
+    const int n4 = rows * (c >> 2);
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      const int i = tid + e * SN_NT;
+      const bool ok = i < n4;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      pg[e] = ok ? ((const float4*)g)[i] : z4;
+      pd[e] = (ok && it.accumulate) ? ((const float4*)dw)[i] : z4;
+      if (ADAM) {
+        pm[e] = ok ? ((const float4*)(ad.m_base + aoff))[i] : z4;
+        pv[e] = ok ? ((const float4*)(ad.v_base + aoff))[i] : z4;
+        pw[e] = ok ? ((const float4*)(ad.w_base + aoff))[i] : z4;
+      }
+    }
+  }
   const float na = L.s[0], sigma = L.s[2];
   float gw = 0.f, pa = 0.f;
   for (int q = tid; q < L.chunks; q += SN_NT) { gw += L.pgw[q]; pa += L.pdva[q]; }
@@ -312,8 +335,37 @@ __global__ __launch_bounds__(SN_NT) void sn_bwd_p2_kernel(SnBwdBatch batch, int 
   }
   __syncthreads();
   const float inv_sigma = 1.f / sigma;
-  const long aoff = ADAM ? (long)(dw - ad.g_base) : 0;       // this chunk's offset inside the group's slabs
-  if ((c & 3) == 0) {
+  if (pf) {
+    const int c4 = c >> 2, n4 = rows * c4;
+    float4* dw4 = (float4*)dw;
+    const float4* q4 = (const float4*)L.db;
+    const float4* u4 = (const float4*)L.uin;
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      const int i = tid + e * SN_NT;
+      if (i >= n4) break;
+      const int r = i / c4, j = i - r * c4;
+      const float4 gv = pg[e], d = q4[j], u = u4[j];
+      const float vr = v_s[r], ar = da_s[r];
+      float4 o;
+      o.x = gv.x * inv_sigma + vr * d.x + ar * u.x;
+      o.y = gv.y * inv_sigma + vr * d.y + ar * u.y;
+      o.z = gv.z * inv_sigma + vr * d.z + ar * u.z;
+      o.w = gv.w * inv_sigma + vr * d.w + ar * u.w;
+      if (it.accumulate) { o.x += pd[e].x; o.y += pd[e].y; o.z += pd[e].z; o.w += pd[e].w; }
+      dw4[i] = o;
+      if (ADAM) {
+        float4 m = pm[e], v = pv[e], wv = pw[e];
+        sn_adam_elem(o.x, m.x, v.x, wv.x, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.y, m.y, v.y, wv.y, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.z, m.z, v.z, wv.z, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        sn_adam_elem(o.w, m.w, v.w, wv.w, alpha, omb1, omb2, ad.eps, ad.clip, ad.grad_scale);
+        ((float4*)(ad.m_base + aoff))[i] = m;
+        ((float4*)(ad.v_base + aoff))[i] = v;
+        ((float4*)(ad.w_base + aoff))[i] = wv;
+      }
+    }
+  } else if ((c & 3) == 0) {
     const int c4 = c >> 2;
     const float4* g4 = (const float4*)g;
     float4* dw4 = (float4*)dw;
