@@ -518,6 +518,9 @@ int rcgan_adam_tf(rcgan_ctx* ctx, size_t count, float* w, const float* g, float*
 int rcgan_adam_tf_host(rcgan_ctx* ctx, size_t count, float* w, const float* g, float* m, float* v,
                        float lr, float t, float beta1, float beta2, float eps, float clip, float grad_scale);
 int rcgan_fill_f32(rcgan_ctx* ctx, size_t count, float* p, float value);
+/* dst[i] = src[i] for `count` 4-byte words (both DEVICE-accessible), as a kernel on the context's stream: the hand-over of a step's
+ * packed input batch (the feed_dict of gan_resnet.py:931,938) into the static input slab the captured step reads. */
+int rcgan_copy_words(rcgan_ctx* ctx, size_t count, const void* src, void* dst);
 
 /* ---- batch statistics out of the producing convolution (tf.nn.moments of normalization.py:47 fused into conv2d.py:181-216) ----------------
  * For the convolutions the 256 x 256 eight-wave kernel takes (rcgan_conv_stats_ok: 16-bit activations, Cout = 256, whole 256-pixel tiles,

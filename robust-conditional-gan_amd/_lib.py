@@ -203,6 +203,7 @@ SIGNATURES = {
     "rcgan_adam_tf": (I, [P, SZ, P, P, P, P, P, F, F, F, F, F]),
     "rcgan_adam_tf_host": (I, [P, SZ, P, P, P, P, F, F, F, F, F, F, F]),
     "rcgan_fill_f32": (I, [P, SZ, P, F]),
+    "rcgan_copy_words": (I, [P, SZ, P, P]),
     "rcgan_conv_stats_ok": (I, [DP]),
     "rcgan_conv_stats_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd_stats": (I, [P, DP, P, P, P, P, P, P]),

@@ -191,6 +191,9 @@ def C_ALPHA(alpha):
     return ((1 - alpha) / 9.0) * np.ones((10, 10)) + (alpha - (1 - alpha) / 9.0) * np.eye(10)
 
 
+FEED_COPY_KERNEL = os.environ.get("RCGAN_FEED_COPY_KERNEL", "1") == "1"
+
+
 def lr_decay(iteration):
     """gan_resnet.py:700-705."""
     return max(0., 1. - iteration / 100000.) if iteration < 50000 else 0.5
@@ -612,6 +615,12 @@ class CifarRCGAN:
         """One copy of a packed batch (numpy int32 array or device / pinned int32 tensor) into the D-step ("d") or G-step
         ("g") inputs."""
         src = blob if isinstance(blob, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blob, dtype=np.int32))
+        if src.is_cuda and src.dtype == torch.int32 and src.is_contiguous() and FEED_COPY_KERNEL:
+            # (round 6) a device-resident batch: an ordinary kernel on the step's stream instead of the runtime's device-to-device copy
+            ctx = self.ctx
+            assert src.numel() == self.feed[key].numel(), (src.numel(), self.feed[key].numel())
+            ctx.check(ctx.lib.rcgan_copy_words(ctx.h, src.numel(), C.c_void_p(src.data_ptr()), C.c_void_p(self.feed[key].data_ptr())))
+            return
         with torch.cuda.stream(self.ctx.stream):
             self.feed[key].copy_(src.reshape(-1), non_blocking=True)
 

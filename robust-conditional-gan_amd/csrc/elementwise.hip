@@ -246,6 +246,16 @@ __global__ void transpose_f32_kernel(int rows, int cols, const float* x, float* 
   }
 }
 
+// dst[i] = src[i], 4-byte words (16-byte pieces where both sides are 16-byte aligned): a step's packed input batch into the step's
+// static input slab (the feed_dict of one session.run, gan_resnet.py:931,938) as an ordinary kernel on the step's stream -- the
+// runtime's own device-to-device copy sits between two graph launches as a different kind of packet and costs a longer turnaround
+__global__ void copy_words_kernel(size_t count, const uint32_t* src, uint32_t* dst) {
+  const size_t n4 = ((((size_t)src | (size_t)dst) & 15) == 0) ? count / 4 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    ((uint4*)dst)[i] = ((const uint4*)src)[i];
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // gan_resnet.py:548-551
 template <typename T>
 __global__ void preprocess_cifar_kernel(int n, const int32_t* img, const float* noise, T* y) {
@@ -353,6 +363,14 @@ int rcgan_cast(rcgan_ctx* ctx, size_t count, int sd, const void* s, int dd, void
   else if (sd == RCGAN_F32 && dd == RCGAN_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, ctx->stream, count, (const float*)s, (float*)d);
   else if (sd == RCGAN_H16 && dd == RCGAN_H16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, ctx->stream, count, (const bf16_t*)s, (bf16_t*)d);
   else RC_FAIL(ctx, RCGAN_EINVALID_ARG, "bad dtypes %d %d", sd, dd);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+
+int rcgan_copy_words(rcgan_ctx* ctx, size_t count, const void* src, void* dst) {
+  RC_REQUIRE(ctx, src && dst, "null pointer");
+  if (count == 0) return RCGAN_OK;
+  hipLaunchKernelGGL(copy_words_kernel, dim3(ew_grid((count + 3) / 4)), dim3(EW_BLOCK), 0, ctx->stream, count, (const uint32_t*)src, (uint32_t*)dst);
   RC_LAUNCH_CHECK(ctx);
   return RCGAN_OK;
 }
