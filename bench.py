@@ -36,7 +36,7 @@ import torch  # noqa: E402
 
 N_CRITIC = 5
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 (= fp16) MFMA peak, MI355X_MICROARCH.md
-POOL = 32                     # synthetic batches resident on the device (2048 images at B = 64: the critic cannot memorise them in a bench run)
+POOL = 30                     # synthetic batches resident on the device (1920 images at B = 64: the critic cannot memorise them in a bench run); a multiple of N_CRITIC: an iteration's batches are consecutive pool slots
 BATCH_CRITIC_FAKES = os.environ.get("RCGAN_BATCH_CRITIC_FAKES", "1") == "1"
 
 
@@ -110,6 +110,13 @@ def iteration(m, pool, it, dcount):
         # batch-norm statistics each)
         m.set_feed("gf", pool["feed_gf"][dcount[0] % POOL])
         m.prepare_critic_fakes()
+    k0 = dcount[0] % POOL
+    if BATCH_CRITIC_FAKES and k0 + N_CRITIC <= POOL:
+        # the iteration's N_CRITIC packed batches handed over together; where the engine can, the five critic steps are ONE captured
+        # graph (CifarRCGAN.critic_steps: same launches, same order), else five d_step() calls
+        m.critic_steps(pool["feed_d"][k0:k0 + N_CRITIC], iteration=it)
+        dcount[0] += N_CRITIC
+        return
     for _ in range(N_CRITIC):
         feed_d(m, pool, dcount[0])
         dcount[0] += 1
@@ -491,6 +498,9 @@ def main():
                                                    "in the graph" if m.dp_adam_in_graph else "after the graph")),
                           "critic_generator_forwards": ("one pass over N_CRITIC x B samples, batch-norm statistics per critic step"
                                                         if BATCH_CRITIC_FAKES else "inside every critic step"),
+                          "critic_steps": ("one captured graph of the N_CRITIC steps, optimiser inside each step's last launch (rcgan_sn_bwd_adam)"
+                                           if (getattr(m, "critic_graph", False) and getattr(m, "fused_tail", False) and BATCH_CRITIC_FAKES and not args.no_graphs)
+                                           else "one graph per step" + (", optimiser inside the step's last launch" if getattr(m, "fused_tail", False) else "")),
                           "iteration_tflops_algorithmic": round(60.858 * args.batch * world / 1e3, 3),
                           "sustained_tflops": round(60.858 * args.batch * world / 1e3 / (dt / args.steps), 2),
                           "losses_finite": bool(ok), "d_loss": round(d_loss, 4), "g_loss": round(g_loss, 4)}}

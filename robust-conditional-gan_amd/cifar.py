@@ -512,6 +512,18 @@ class CifarRCGAN:
             for name, shp, dt in fields:
                 self.inp[name] = DT(slab.data_ptr() + 4 * off, shp, dt, slab, name)
                 off += int(np.prod(shp))
+        # (round 6) the N_CRITIC critic steps of an iteration as ONE captured graph (critic_steps): a slab of N_CRITIC "d" batches, and per
+        # slot the views the step body reads its inputs through while that slot's step is recorded
+        words_d = self.feed["d"].numel()
+        self.feed["d5"] = torch.zeros(N_CRITIC * words_d, dtype=torch.int32, device=ctx.device)
+        self._d_slot_views = []
+        for k in range(N_CRITIC):
+            off, views = k * words_d, {}
+            for name, shp, dt in self.feed_layout["d"]:
+                views[name] = DT(self.feed["d5"].data_ptr() + 4 * off, shp, dt, self.feed["d5"], name)
+                off += int(np.prod(shp))
+            self._d_slot_views.append(views)
+        self.critic_graph = os.environ.get("RCGAN_CRITIC_GRAPH", "1") == "1"
         self.inp.update(noise=P((B, OUTPUT_DIM), f32), z=P((B, Z_DIM), act), z_G=P((2 * B, Z_DIM), act),
                         z_all=P((N_CRITIC * B, Z_DIM), act),
                         arange=P((VOCAB_SIZE,), i32), C_const=P((VOCAB_SIZE, VOCAB_SIZE), f32))
@@ -586,6 +598,7 @@ class CifarRCGAN:
         """pack_feed + set_feed for a host-side loader: the batch is packed straight into a pinned staging slot (a ring of
         8 per feed, guarded by events) and handed over with ONE asynchronous copy -- no per-array conversions, pinned
         allocations or synchronous copies in the training loop."""
+        steps = arrays.pop("_steps", None)       # key "d5": a list of N_CRITIC "d" batches, packed slot by slot
         ring = self._feed_ring.setdefault(key, {"slots": [], "events": [], "next": 0})
         words = self.feed[key].numel()
         if not ring["slots"]:
@@ -597,14 +610,16 @@ class CifarRCGAN:
             ring["events"][i].synchronize()              # the copy that last read this slot has finished
         dst = ring["slots"][i].numpy()
         off = 0
-        for name, shp, dt in self.feed_layout[key]:
-            n = int(np.prod(shp))
-            a = np.asarray(arrays[name]).reshape(-1)
-            if dt == L.F32:
-                dst[off:off + n].view(np.float32)[:] = a
-            else:
-                dst[off:off + n] = a
-            off += n
+        for arrs in (steps if steps is not None else [arrays]):
+            for name, shp, dt in self.feed_layout["d" if steps is not None else key]:
+                n = int(np.prod(shp))
+                a = np.asarray(arrs[name]).reshape(-1)
+                if dt == L.F32:
+                    dst[off:off + n].view(np.float32)[:] = a
+                else:
+                    dst[off:off + n] = a
+                off += n
+        assert off == words, (off, words)
         with torch.cuda.stream(self.ctx.stream):
             self.feed[key].copy_(ring["slots"][i], non_blocking=True)
             ev = torch.cuda.Event()
@@ -1050,6 +1065,55 @@ class CifarRCGAN:
             self.PD.version += 1
             return
         self._optimise_or_publish(steps)
+
+    def _critic_graph_ok(self):
+        """The N_CRITIC critic steps can run as one graph: the optimiser lives in the step's last launch with its step count on the
+        device (fused_tail), the fakes of all steps are ready, and the step's launch fetches its own inputs (noise, fake slice)."""
+        return (self.critic_graph and self.fused_tail and self._fakes_left == N_CRITIC and self._rides_inputs() and self._slice_mirror == 0)
+
+    def critic_steps(self, batches, iteration=None):
+        """The N_CRITIC critic updates of one iteration (gan_resnet.py:928-947) after prepare_critic_fakes().  batches: N_CRITIC dicts
+        of host arrays (the "d" feed's fields), or a device int32 tensor [N_CRITIC, words] of packed batches (pack_feed).
+        Where _critic_graph_ok(): ONE hand-over of the five batches and ONE captured graph of the five steps -- the same launches in
+        the same order as five d_step() calls (tests: bit-identical weights), without the four graph-to-graph turnarounds (~9 us from
+        a graph's last kernel to the next packet) and the four feed copies between them.  Otherwise: five d_step() calls."""
+        it = self.iteration if iteration is None else iteration
+        packed = isinstance(batches, torch.Tensor)
+        assert (batches.shape[0] if packed else len(batches)) == N_CRITIC
+        if not self._critic_graph_ok():
+            for k in range(N_CRITIC):
+                if packed:
+                    self.set_feed("d", batches[k])
+                else:
+                    self.feed_host("d", **batches[k])
+                self.d_step(iteration=it)
+            return
+        ctx = self.ctx
+        if packed:
+            src = batches.reshape(-1)
+            assert src.is_cuda and src.dtype == torch.int32 and src.is_contiguous() and src.numel() == self.feed["d5"].numel()
+            ctx.check(ctx.lib.rcgan_copy_words(ctx.h, src.numel(), C.c_void_p(src.data_ptr()), C.c_void_p(self.feed["d5"].data_ptr())))
+        else:
+            self.feed_host("d5", _steps=batches)
+        self._refresh_generator_filters()
+        lr = self.lr * lr_decay(it)
+        self._pre_step([(self.PD, lr)])
+        self._join_gf()
+
+        def body():
+            for k in range(N_CRITIC):
+                saved = {n: self.inp[n] for n in self._d_slot_views[k]}
+                self.inp.update(self._d_slot_views[k])
+                try:
+                    self._d_body(True)
+                finally:
+                    self.inp.update(saved)
+        self._run("d5", body)
+        assert self._tail_fused.get(True, False), "critic_steps: the step's last launch did not apply the update"
+        self._fakes_left = 0                    # (the device's slice counter has walked all N_CRITIC slices and is back at 0)
+        self.PD.t += N_CRITIC
+        self.PD._dev_hyper = (float(lr), self.PD.t)
+        self.PD.version += 1
 
     def g_step(self, iteration=None):
         """One generator update (+ confusion-matrix update for rcgan-u): gen_train_op, confuse_train_op

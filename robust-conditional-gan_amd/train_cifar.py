@@ -144,10 +144,10 @@ def main(argv=None):
     fixed_noise = np.random.normal(size=(100, Z_DIM)).astype('float32')       # gan_resnet.py:822
     fixed_labels = np.array([k for k in range(10) for _ in range(10)], dtype='int32')
 
-    def feed_d(batch):
+    def d_feed(batch):
         images, labels, rnd, bia, inv = batch
         second = rnd if ALGORITHM in ("biased", "unbiased") else bia
-        m.feed_host("d", images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
+        return dict(images=sh(images), labels=sh(labels), labels_random=sh(rnd), labels_biased=sh(bia),
                     inv_weights=sh(inv), labels_all=np.concatenate([sh(labels), sh(second)]))
 
     # generated-label accuracy (gan_resnet.py:424-455, 847-861): 1000 samples, 100 per class, ONE classifier batch
@@ -214,9 +214,9 @@ def main(argv=None):
         batches = [next(gen) for _ in range(N_CRITIC)]
         m.feed_host("gf", labels_random_all=np.concatenate([sh(b[2]) for b in batches]))
         m.prepare_critic_fakes()
-        for batch in batches:
-            feed_d(batch)
-            m.d_step(iteration=iteration)
+        # the N_CRITIC critic updates (disc_train_op, gan_resnet.py:928-947): one hand-over of their batches, one captured graph where
+        # the engine can (CifarRCGAN.critic_steps), else batch by batch
+        m.critic_steps([d_feed(batch) for batch in batches], iteration=iteration)
         m.iteration = iteration + 1
         pending.append((iteration, m.enqueue_losses()))
         if timed:
@@ -244,7 +244,7 @@ def main(argv=None):
             logging.info('starting calculating dev cost.')
             dev_disc_costs = []
             for batch in dev_gen():
-                feed_d(batch)
+                m.feed_host("d", **d_feed(batch))
                 dev_disc_costs.append(m.eval_d_cost())
             if dev_disc_costs:
                 plot.plot('dev_cost', mean_over_ranks(np.mean(dev_disc_costs), m.ctx.device))

@@ -58,11 +58,12 @@ def run(algorithm="rcgan", dtype="bf16", iters=10000, eval_every=500, alpha=0.6,
         batches = [next(gen) for _ in range(N_CRITIC)]
         m.feed_host("gf", labels_random_all=np.concatenate([b[2] for b in batches]))
         m.prepare_critic_fakes()
+        feeds = []
         for images, labels, rnd, bia, inv in batches:
             second = rnd if algorithm in ("biased", "unbiased") else bia
-            m.feed_host("d", images=images, labels=labels, labels_random=rnd, labels_biased=bia, inv_weights=inv,
-                        labels_all=np.concatenate([labels, second]))
-            m.d_step(iteration=it)
+            feeds.append(dict(images=images, labels=labels, labels_random=rnd, labels_biased=bia, inv_weights=inv,
+                              labels_all=np.concatenate([labels, second])))
+        m.critic_steps(feeds, iteration=it)
         m.iteration = it + 1
         pending.append(m.enqueue_losses())
         if len(pending) >= 256 or (it + 1) % eval_every == 0 or it + 1 == iters:

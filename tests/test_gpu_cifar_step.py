@@ -522,3 +522,55 @@ def test_optimiser_inside_the_spectral_norm_backward(alg, perm, dtype, use_graph
             assert np.all(np.abs(a - b) <= tol), "%s of %s: max diff %.3e" % (w, n, float(np.abs(a - b).max()))
     for n in fa:
         assert np.isfinite(fa[n]).all() and float(np.abs(fa[n].astype(np.float64) - fb[n]).max()) <= 2 * 2e-4 * len(steps) + 1e-6, n
+
+
+@pytest.mark.parametrize("alg,perm,dtype", [("rcgan", False, "bf16"), ("rcgan-u", True, "bf16"), ("rcgan", False, "f32")])
+def test_critic_steps_as_one_graph_equal_single_steps(alg, perm, dtype, monkeypatch):
+    """(round 6) CifarRCGAN.critic_steps(): the N_CRITIC critic updates of an iteration as ONE captured graph (one hand-over of their
+    batches, the optimiser inside each step's last launch, the step count on the device) against prepare_critic_fakes() + N_CRITIC
+    d_step() calls: the same launches in the same order on the same random stream -- generator, discriminator and spectral-norm state
+    after three iterations (capture + replays, a generator step between them, a new learning rate every iteration) bit for bit."""
+    import rcgan_amd  # noqa: F401
+    from rcgan_amd.cifar import CifarRCGAN, N_CRITIC
+    rs = np.random.RandomState(23)
+    B = 8
+    its = []
+    for _ in range(3):
+        ds = []
+        for _ in range(N_CRITIC):
+            raw = _batches(rs, B)[1]
+            d = {k: raw[k] for k in ("images", "labels", "labels_random", "labels_biased", "inv_weights")}
+            d["labels_all"] = _labels_all(alg, raw)
+            ds.append(d)
+        its.append((ds, dict(labels_random_G=rs.randint(10, size=2 * B), labels_biased_G=rs.randint(10, size=2 * B))))
+    outs = []
+    for one_graph in ("1", "0"):
+        monkeypatch.setenv("RCGAN_CRITIC_GRAPH", one_graph)
+        m = CifarRCGAN(algorithm=alg, alpha=0.6, batch_size=B, dtype=dtype, seed=5, perm_classifier=perm, confuse_init=perm,
+                       use_graphs=True, device_rng=True, arena_bytes=2 << 30)
+        try:
+            for it, (ds, g) in enumerate(its):
+                if it > 0:
+                    m.feed_host("g", **g)
+                    m.g_step(iteration=it * 9000)
+                m.feed_host("gf", labels_random_all=np.concatenate([d["labels_random"] for d in ds]))
+                m.prepare_critic_fakes()
+                assert m._critic_graph_ok() == (one_graph == "1")
+                if one_graph == "1":
+                    m.critic_steps(ds, iteration=it * 9000)
+                else:
+                    for d in ds:
+                        m.feed_host("d", **d)
+                        m.d_step(iteration=it * 9000)
+            assert ("d5" in m._graphs) == (one_graph == "1")
+            assert m.PD.t == 3 * N_CRITIC and m._fakes_left == 0
+            m.ctx.sync()
+            outs.append((m.get_params(), m.get_state(), m.losses()))
+        finally:
+            m.ctx.close()
+    (pa, sa, la), (pb, sb, lb) = outs
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
