@@ -253,6 +253,15 @@ int rcgan_deconv2d_bwd_data(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void
 int rcgan_deconv2d_bwd_data_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* dy, const float* w, void* dx, int n_cols);
 int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy,
                               float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
+/* The same filter gradient for x = conv_cond_concat(t, yb) (mnist/ops.py:46-51; the generator's g_h2 / g_h3, model.py:722-731): the first
+ * n_cols channels of x are real, the other d.cout - n_cols (<= 16) are yb[n][:] (fp32 [n][d.cout - n_cols]) on every pixel.  The gather
+ * GEMM runs over the n_cols real columns only (for 128 + 10 channels: two 64-wide column tiles instead of three); the label columns are
+ * dW[kh][kw][c][n_cols + l] = sum_n yb[n][l] * (sum of dy[n] over the sub-grid of output pixels tap (kh, kw) reaches): one pass over dy, a
+ * small product, and one reduction that writes all d.cout columns.  Same values as rcgan_deconv2d_bwd_weight up to fp32 summation
+ * order.  Workspace: rcgan_deconv2d_bwd_weight_concat_bytes(d, n_cols). */
+size_t rcgan_deconv2d_bwd_weight_concat_bytes(const rcgan_conv_desc* d, int n_cols);
+int rcgan_deconv2d_bwd_weight_concat(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int n_cols, const float* yb,
+                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes);
 
 /* ---- dense ----------------------------------------------------------------------------------- */
 /* y[m,n] = x[m,k] @ w[k,n] (+bias).  w fp32 row-major, optionally divided by *sigma.

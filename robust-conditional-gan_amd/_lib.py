@@ -143,6 +143,8 @@ SIGNATURES = {
     "rcgan_deconv2d_bwd_data": (I, [P, DP, P, P, P]),
     "rcgan_deconv2d_bwd_data_cols": (I, [P, DP, P, P, P, I]),
     "rcgan_deconv2d_bwd_weight": (I, [P, DP, P, P, P, P, I, P, SZ]),
+    "rcgan_deconv2d_bwd_weight_concat_bytes": (SZ, [DP, I]),
+    "rcgan_deconv2d_bwd_weight_concat": (I, [P, DP, P, P, I, P, P, P, I, P, SZ]),
     "rcgan_linear_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
     "rcgan_linear_bwd_data": (I, [P, I, I, I, I, P, P, P, P, I]),
     "rcgan_linear_bwd_weight": (I, [P, I, I, I, I, P, P, P, P, I, P, SZ]),

@@ -10,6 +10,8 @@ size_t direct_wgrad_ws_bytes(const rcgan_conv_desc* d);
 template <typename T> int direct_fwd(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, T*, int n_cols = 0);
 template <typename T> int direct_dgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const float*, const float*, const float*, const T*, T*, int);
 template <typename T> int direct_wgrad(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, float*, float*, int, void*, size_t);
+template <typename T> int direct_wgrad_cols(rcgan_ctx*, const rcgan_conv_desc*, const T*, const T*, int, const float*, float*, int, void*, size_t);
+size_t direct_wgrad_cols_ws_bytes(const rcgan_conv_desc* d, int c1);
 template <typename T> int colsum_launch(rcgan_ctx*, const T*, long, int, float*, int, float*);
 template <typename T> int linear_fwd(rcgan_ctx*, long, long, long, const T*, const float*, const float*, const float*, T*);
 template <typename T> int linear_dgrad(rcgan_ctx*, long, long, long, const T*, const float*, const float*, T*, int);
@@ -1298,6 +1300,32 @@ int rcgan_deconv2d_bwd_weight(rcgan_ctx* ctx, const rcgan_conv_desc* d, const vo
     // partial column sums go to the tail of the workspace (the filter-gradient slabs sit at its head and are consumed)
     size_t need = ((size_t)(cdiv(rows, 2048) + 1024) * d->cin * sizeof(float) + 255) / 256 * 256;
     float* part = (ws != nullptr && ws_bytes >= direct_wgrad_ws_bytes(d) + need) ? (float*)((char*)ws + (ws_bytes - need) / 256 * 256) : nullptr;
+    RC_DISPATCH_DTYPE(ctx, d->dtype, rc = colsum_launch<T>(ctx, (const T*)dy, rows, d->cin, dbias, accumulate, part));
+    if (rc) return rc;
+  }
+  return RCGAN_OK;
+}
+
+size_t rcgan_deconv2d_bwd_weight_concat_bytes(const rcgan_conv_desc* d, int n_cols) {
+  if (!d || n_cols <= 0 || n_cols >= d->cout) return 0;
+  const long rows = (long)d->n * d->h * d->w;
+  return direct_wgrad_cols_ws_bytes(d, n_cols) + ((size_t)(cdiv(rows, 2048) + 1024) * d->cin * sizeof(float) + 255) / 256 * 256 + 256;
+}
+
+int rcgan_deconv2d_bwd_weight_concat(rcgan_ctx* ctx, const rcgan_conv_desc* d, const void* x, const void* dy, int n_cols, const float* yb,
+                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes) {
+  int rc = check_desc(ctx, d);
+  if (rc) return rc;
+  RC_REQUIRE(ctx, n_cols > 0 && n_cols < d->cout && yb != nullptr, "%d real columns of %d, yb %p", n_cols, d->cout, (const void*)yb);
+  const size_t need = rcgan_deconv2d_bwd_weight_concat_bytes(d, n_cols);
+  if (ws == nullptr || ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  // forward-conv input = deconv output gradient dy; forward-conv output gradient = deconv input x = [t ; yb]
+  RC_DISPATCH_DTYPE(ctx, d->dtype, rc = direct_wgrad_cols<T>(ctx, d, (const T*)dy, (const T*)x, n_cols, yb, dw, accumulate, ws, ws_bytes));
+  if (rc) return rc;
+  if (dbias) {
+    const long rows = (long)d->n * d->h * d->w;
+    const size_t tail = ((size_t)(cdiv(rows, 2048) + 1024) * d->cin * sizeof(float) + 255) / 256 * 256;
+    float* part = (float*)((char*)ws + (ws_bytes - tail) / 256 * 256);
     RC_DISPATCH_DTYPE(ctx, d->dtype, rc = colsum_launch<T>(ctx, (const T*)dy, rows, d->cin, dbias, accumulate, part));
     if (rc) return rc;
   }

@@ -1432,5 +1432,159 @@ int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* 
   }
   return RCGAN_OK;
 }
+// ---- filter gradient of a convolution whose OUTPUT-gradient rows end in label columns (round 6) -------------------------------------
+// dy = conv_cond_concat(t, yb) (mnist/ops.py:46-51) seen from the transposed convolution that consumes it (the MNIST generator's g_h2 / g_h3,
+// model.py:722-731: the layer's input is [t ; yb broadcast over the pixels]): columns j >= c1 of an output-gradient row are yb[n][j - c1],
+// the same for every pixel of sample n.  The gather GEMM over all Cout = c1 + c2 columns pays a whole 64-wide column tile for the c2 = 10
+// label columns (150 output tiles instead of 100 for the 5x5x128x138 filter).  Here the GEMM runs over the c1 real columns only and the
+// label columns come from what they are:
+//     dW[kh][kw][c][c1 + l] = sum_n yb[n][l] * D[n][kh][kw][c],     D[n][kh][kw][c] = sum over the output pixels (oh, ow) whose tap (kh, kw)
+//                                                                    lands inside the image of x[n][oh*S - PT + kh][ow*S - PL + kw][c]
+// -- D is a sum over a sub-grid of the image, separable in rows and columns: ONE pass over x (wgrad_label_sums_kernel), then a
+// [c2 x N] x [N x K] product in sample chunks (wgrad_label_cols_kernel), and one reduction that writes the c1 columns from the GEMM's
+// slabs and the c2 columns from the chunk partials with the filter's own row stride.
+#define WGRAD_LABEL_RG 4        /* row groups: a sample's image rows ih = rg, rg + 4, ... go to workgroup (n, rg) */
+// which image columns (rows) a tap column kw (row kh) reaches: bit iw of col[kw] is set iff (iw + PL - kw) is a multiple of S inside the
+// output grid -- computed on the host, so the kernel's inner loop is a mask test instead of two integer divisions per (pixel, tap)
+struct LabelMasks { unsigned col[5], row[5]; };
+template <typename T>
+__global__ __launch_bounds__(128) void wgrad_label_sums_kernel(ConvGeom g, LabelMasks mk, const T* x, float* D) {      // D[rg][n][KH*KW][Cin]; H, W <= 32
+  const int n = blockIdx.x, rg = blockIdx.y;
+  for (int c = threadIdx.x; c < g.Cin; c += blockDim.x) {
+    float d[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) d[t] = 0.f;
+    for (int ih = rg; ih < g.H; ih += WGRAD_LABEL_RG) {
+      const T* row = x + ((long)(n * g.H + ih) * g.W) * g.Cin + c;
+      float v[32];
+#pragma unroll
+      for (int iw = 0; iw < 32; ++iw) v[iw] = iw < g.W ? Elem<T>::ld(row + (long)iw * g.Cin) : 0.f;      // the whole row in flight at once
+      float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const unsigned m = mk.col[kw];
+#pragma unroll
+        for (int iw = 0; iw < 32; ++iw) cs[kw] += ((m >> iw) & 1u) ? v[iw] : 0.f;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        if ((mk.row[kh] >> ih) & 1u) {
+#pragma unroll
+          for (int kw = 0; kw < 5; ++kw) d[kh * 5 + kw] += cs[kw];
+        }
+      }
+    }
+    const long K = (long)g.KH * g.KW * g.Cin;
+    for (int kh = 0; kh < g.KH; ++kh)
+      for (int kw = 0; kw < g.KW; ++kw) D[((long)rg * g.N + n) * K + (long)(kh * g.KW + kw) * g.Cin + c] = d[kh * 5 + kw];
+  }
+}
+
+// partial[chunk][i][l] = sum over the chunk's samples (at most 8) of yb[n][l] * D[n][i]   (i = (kh, kw, c), K of them; c2 <= 16)
+// (D arrives as WGRAD_LABEL_RG row-group partials [rg][n][K], summed here in a fixed order; every load of the chunk in flight at once)
+#define WGRAD_LABEL_PER_CHUNK 8
+__global__ __launch_bounds__(128) void wgrad_label_cols_kernel(const float* D, const float* yb, int N, long K, int c2, float* partial) {
+  __shared__ float yb_s[WGRAD_LABEL_PER_CHUNK * 16];
+  const int n0 = blockIdx.y * WGRAD_LABEL_PER_CHUNK;
+  for (int e = threadIdx.x; e < WGRAD_LABEL_PER_CHUNK * c2; e += blockDim.x) {
+    const int q = e / c2, l = e - q * c2;
+    yb_s[q * 16 + l] = n0 + q < N ? yb[(long)(n0 + q) * c2 + l] : 0.f;
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  float dv[WGRAD_LABEL_PER_CHUNK][WGRAD_LABEL_RG];
+#pragma unroll
+  for (int q = 0; q < WGRAD_LABEL_PER_CHUNK; ++q)
+#pragma unroll
+    for (int rg = 0; rg < WGRAD_LABEL_RG; ++rg) dv[q][rg] = n0 + q < N ? D[((long)rg * N + n0 + q) * K + i] : 0.f;
+  float acc[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
+#pragma unroll
+  for (int q = 0; q < WGRAD_LABEL_PER_CHUNK; ++q) {
+    float d = 0.f;
+#pragma unroll
+    for (int rg = 0; rg < WGRAD_LABEL_RG; ++rg) d += dv[q][rg];
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+      if (l < c2) acc[l] += yb_s[q * 16 + l] * d;
+  }
+#pragma unroll
+  for (int l = 0; l < 16; ++l)
+    if (l < c2) partial[((long)blockIdx.y * K + i) * c2 + l] = acc[l];
+}
+
+// out[i][j] (= or +=)  j < c1: sum_z slab[z][i][j] (slabs [K][c1])   |   j >= c1: sum_q partial[q][i][j - c1]      (out rows of c1 + c2 floats)
+__global__ void slab_reduce_cols_kernel(const float* slab, int nz, const float* partial, int nq, float* out, long K, int c1, int c2, int accumulate) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ld = c1 + c2;
+  if (e >= K * ld) return;
+  const long i = e / ld;
+  const int j = (int)(e - i * ld);
+  float s = 0.f;
+  if (j < c1) {
+    for (int z = 0; z < nz; ++z) s += slab[((long)z * K + i) * c1 + j];
+  } else {
+    for (int q = 0; q < nq; ++q) s += partial[((long)q * K + i) * c2 + (j - c1)];
+  }
+  out[e] = accumulate ? out[e] + s : s;
+}
+
+size_t direct_wgrad_cols_ws_bytes(const rcgan_conv_desc* d, int c1) {
+  ConvGeom g = make_geom(d);
+  const long K = (long)g.KH * g.KW * g.Cin, M = (long)g.N * g.OH * g.OW;
+  const int c2 = g.Cout - c1;
+  const int nz = wgrad_splits(K, c1, M);
+  return ((size_t)nz * K * c1 + (size_t)WGRAD_LABEL_RG * g.N * K + (size_t)cdiv(g.N, WGRAD_LABEL_PER_CHUNK) * K * c2) * sizeof(float) + 1024;
+}
+
+// dy rows: [c1 real columns ; c2 = Cout - c1 label columns = yb[n][:]]  (yb: fp32 [N][c2], c2 <= 16; KH, KW <= 5)
+template <typename T>
+int direct_wgrad_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* dy, int c1, const float* yb, float* dw, int accumulate,
+                      void* ws, size_t ws_bytes) {
+  WgradOp<T> op;
+  op.g = make_geom(d); op.x = x; op.dy = dy; op.wscale = nullptr;
+  const int c2 = op.g.Cout - c1;
+  if (c1 <= 0 || c2 <= 0 || c2 > 16 || op.g.KH > 5 || op.g.KW > 5 || op.g.W > 32 || op.g.H > 32 || op.g.up || yb == nullptr)
+    RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "label-column filter gradient: %d + %d columns, %d x %d filter", c1, c2, op.g.KH, op.g.KW);
+  const long K = (long)op.g.KH * op.g.KW * op.g.Cin, M = (long)op.g.N * op.g.OH * op.g.OW;
+  int nz = wgrad_splits(K, c1, M);
+  const size_t need = direct_wgrad_cols_ws_bytes(d, c1);
+  if (ws_bytes < need) RC_FAIL(ctx, RCGAN_EWORKSPACE_TOO_SMALL, "need %zu have %zu", need, ws_bytes);
+  float* const slab = (float*)ws;
+  float* const Dn = slab + (size_t)nz * K * c1;
+  float* const partial = Dn + (size_t)WGRAD_LABEL_RG * op.g.N * K;
+  // the label columns' two small launches first (they only read x and yb), then the GEMM over the real columns
+  LabelMasks mk;
+  for (int t = 0; t < 5; ++t) {
+    mk.col[t] = 0; mk.row[t] = 0;
+    for (int p = 0; p < 32; ++p) {
+      const int qc = p + op.g.PL - t, qr = p + op.g.PT - t;
+      if (t < op.g.KW && p < op.g.W && qc >= 0 && qc % op.g.S == 0 && qc / op.g.S < op.g.OW) mk.col[t] |= 1u << p;
+      if (t < op.g.KH && p < op.g.H && qr >= 0 && qr % op.g.S == 0 && qr / op.g.S < op.g.OH) mk.row[t] |= 1u << p;
+    }
+  }
+  hipLaunchKernelGGL(wgrad_label_sums_kernel<T>, dim3(op.g.N, WGRAD_LABEL_RG), dim3(128), 0, ctx->stream, op.g, mk, x, Dn);
+  RC_LAUNCH_CHECK(ctx);
+  const int nq = cdiv(op.g.N, WGRAD_LABEL_PER_CHUNK);
+  hipLaunchKernelGGL(wgrad_label_cols_kernel, dim3(cdiv(K, 128), nq), dim3(128), 0, ctx->stream, (const float*)Dn, yb, op.g.N, K, c2, partial);
+  RC_LAUNCH_CHECK(ctx);
+  op.slab = slab;
+  op.M = K; op.N = c1; op.R = M;               // (the row stride of dy stays g.Cout: b4 reads columns j < N of a Cout-wide row)
+  op.avec = vec_of(x, op.g.Cin); op.bvec = vec_of(dy, op.g.Cout);
+  op.r_chunk = ((M + nz - 1) / nz + 15) / 16 * 16;
+  nz = cdiv(M, op.r_chunk);
+  int rc = launch_gemm(ctx, op, nz);
+  if (rc) return rc;
+  const long cnt = K * op.g.Cout;
+  hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)slab, nz, (const float*)partial, nq, dw, K, c1, c2,
+                     accumulate);
+  RC_LAUNCH_CHECK(ctx);
+  return RCGAN_OK;
+}
+template int direct_wgrad_cols<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, int, const float*, float*, int, void*, size_t);
+template int direct_wgrad_cols<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const bf16_t*, int, const float*, float*, int, void*, size_t);
+
 template int direct_wgrad<float>(rcgan_ctx*, const rcgan_conv_desc*, const float*, const float*, float*, float*, int, void*, size_t);
 template int direct_wgrad<bf16_t>(rcgan_ctx*, const rcgan_conv_desc*, const bf16_t*, const bf16_t*, float*, float*, int, void*, size_t);

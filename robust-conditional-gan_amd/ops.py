@@ -155,6 +155,7 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
 RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
 # the data gradient of a layer fed by conv_cond_concat(x, labels) computed for the x channels only, straight into x's gradient
 CONCAT_DIRECT = os.environ.get("RCGAN_CONCAT_DIRECT", "1") != "0"
+CONCAT_WGRAD = os.environ.get("RCGAN_CONCAT_WGRAD", "1") != "0"     # (round 6) ops.deconv2d: label columns of the filter gradient from per-sample sums
 LINEAR_MFMA = os.environ.get("RCGAN_LINEAR_MFMA", "1") != "0"
 
 
@@ -576,9 +577,16 @@ def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
                     ctx.check(ctx.lib.rcgan_deconv2d_bwd_data(ctx.h, C.byref(desc), _p(dy), _p(w), _p(tmp)))
                     ctx.check(ctx.lib.rcgan_axpby(ctx.h, x.size, x.dtype, 1.0, _p(tmp), 1.0, _p(dx)))
             if w.req:
-                ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(w.grad),
-                                                            _p(bias.grad) if (bias is not None and bias.req) else None, 1,
-                                                            C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                db = _p(bias.grad) if (bias is not None and bias.req) else None
+                yb = getattr(x, "concat_labels", None)
+                if (src is not None and yb is not None and CONCAT_WGRAD and 0 < cin - src[1] <= 16 and k <= 5 and src[1] >= 64 and cout >= 64 and ow <= 32
+                        and ctx.lib.rcgan_deconv2d_bwd_weight_concat_bytes(C.byref(desc), src[1]) <= ctx.ws_bytes):
+                    # (round 6) x = conv_cond_concat(xs, yb): the GEMM over the real channels only, the label columns from per-sample sums
+                    ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight_concat(ctx.h, C.byref(desc), _p(x), _p(dy), src[1], _p(yb), _p(w.grad), db, 1,
+                                                                       C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
+                else:
+                    ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight(ctx.h, C.byref(desc), _p(x), _p(dy), _p(w.grad), db, 1,
+                                                                C.c_void_p(ctx.ws_ptr), ctx.ws_bytes))
         ctx.record(bw)
     return y
 
@@ -881,6 +889,7 @@ def concat_channels(ctx, x, yb):
     y = ctx.empty(oshape, x.dtype)
     ctx.check(ctx.lib.rcgan_concat_channels_fwd(ctx.h, n, hw, c1, c2, x.dtype, _p(x), _p(yb), _p(y)))
     y.concat_src = (x, c1)       # a consumer whose data gradient can be limited to the x channels bypasses the split below
+    y.concat_labels = yb         # ... and one whose filter gradient knows the label columns are per-sample constants skips their column tile
     if _track(ctx, y, x):
         def bw():
             if y.grad is None:

@@ -31,7 +31,7 @@ def _np_dtype(code):
 
 class DT:
     """A device tensor: raw pointer + shape + dtype code.  ``base`` keeps the owning torch storage alive."""
-    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen", "group", "tile_stats", "pooled", "pool_grad", "concat_src")
+    __slots__ = ("ptr", "shape", "dtype", "base", "grad", "req", "name", "frozen", "group", "tile_stats", "pooled", "pool_grad", "concat_src", "concat_labels")
 
     def __init__(self, ptr, shape, dtype, base=None, name=None):
         self.ptr = int(ptr)
@@ -47,6 +47,7 @@ class DT:
         self.pooled = None         # (features, activation kind) the producer left beside the tensor (ops.d_trunk(pool=...))
         self.pool_grad = None      # gradient of those features, handed back by their consumer (ops.proj_head)
         self.concat_src = None     # (x, channels of x) when this tensor is conv_cond_concat(x, labels) (ops.concat_channels)
+        self.concat_labels = None  # ... and the label rows yb [n, c2] (fp32) it appended
 
     @property
     def size(self):
