@@ -65,13 +65,15 @@ if [ "${2:-all}" = lean ]; then
   rm -rf "$OUT/prof_mnist"
   { RCGAN_GG_WGRAD_FIT=0 RCGAN_S2_LPT=0 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/no_fit no_lpt : /"
     RCGAN_GG_WGRAD_FIT=1 RCGAN_S2_LPT=0 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/fit    no_lpt : /"
-    RCGAN_GG_WGRAD_FIT=0 RCGAN_S2_LPT=1 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/no_fit lpt    : /"; } > "$OUT/bench_mnist_switches.txt"
+    RCGAN_GG_WGRAD_FIT=0 RCGAN_S2_LPT=1 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/no_fit lpt    : /"
+    RCGAN_CONCAT_WGRAD=0 python3 scripts/bench_mnist.py 256 f32 2> /dev/null | sed "s/^/fit lpt, label columns inside the filter-gradient GEMM (RCGAN_CONCAT_WGRAD=0) : /"; } > "$OUT/bench_mnist_switches.txt"
   for rep in 1 2; do
     python3 bench.py --no-cpu-baseline > "$OUT/bench_default_rep$rep.json" 2> /dev/null
     # this round's switches, one at a time (the gather form's switch really switches it off since round 6: ADVICE r05)
     RCGAN_H8N_GATHER_MINBLK=100000 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_gather_rep$rep.json" 2> /dev/null
     RCGAN_SN_ADAM=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_sn_adam_rep$rep.json" 2> /dev/null
     RCGAN_OVERLAP_GF=1 python3 bench.py --no-cpu-baseline > "$OUT/bench_overlap_gf_rep$rep.json" 2> /dev/null
+    RCGAN_CRITIC_GRAPH=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_critic_graph_rep$rep.json" 2> /dev/null
     RCGAN_BN_INTO_PATCH=0 python3 bench.py --no-cpu-baseline > "$OUT/bench_no_bn_into_patch_rep$rep.json" 2> /dev/null
   done
   # the two data-parallel schedules under the same link model (ASSUMPTIONS: 40 us + 2(N-1)/N * bytes / 200 GB/s per all-reduce group)

@@ -33,12 +33,12 @@ echo "# scripts/bench_trunk.py 128  (the fused 8x8 stage, RCGAN_FUSED_TRUNK, aga
 echo "# STAMPS=1 scripts/bench_rf.py 128  (the register-filter convolution, rcgan_conv2d_rf, against the tile-per-tap kernels; per-workgroup s_memtime segments)" >> $F; g $R/microbench_rf.txt >> $F
 echo "# scripts/step_times.py  (HIP-graph replays, B = 64)" >> $F; g $R/step_times.txt >> $F
 echo "# scripts/bench_mnist.py 256 f32" >> $F; g $R/bench_mnist.txt >> $F
-[ -f $R/bench_mnist_switches.txt ] && { echo "# ... with round 6's two launch-policy switches off (RCGAN_GG_WGRAD_FIT: filter-gradient splits fitted to whole rounds; RCGAN_S2_LPT: stride-2 parity classes longest first)" >> $F; cat $R/bench_mnist_switches.txt >> $F; }
+[ -f $R/bench_mnist_switches.txt ] && { echo "# ... with round 6's switches off, one or two at a time (RCGAN_GG_WGRAD_FIT: filter-gradient splits fitted to whole rounds; RCGAN_S2_LPT: stride-2 parity classes longest first; RCGAN_CONCAT_WGRAD: the label columns of the transposed convolutions' filter gradient from per-sample sums)" >> $F; cat $R/bench_mnist_switches.txt >> $F; }
 echo "# scripts/bench_wgrad_group.py  (rcgan_conv2d_bwd_weight_group on the critic step's layer set as PLAIN 3x3 layers, n = 128; grouped launches + grouped reduction)" >> $F; g $R/wgrad_group.txt >> $F
 echo "# python bench.py --no-cpu-baseline --batch 512 --steps 8 | --dtype f16 | --algorithm rcgan-u   (ms per iteration, images/s, sustained TFLOP/s at the reference's FLOP count, dominant kernel: fraction of peak at the reference's count / executed)" >> $F
 for f in b512 f16 f16_b512 rcganu dpstub8 dpstub8_model_f32 dpstub8_model_bf16 dpstub8_model_f32_overlap no_wgrad9 wgrad9_everywhere fuse_bn_stats no_head_riders no_pool_in_trunk no_rf_conv no_fused_trunk no_bn_into_conv no_linear_mfma img_out_stages2 \
          default_rep1 default_rep2 no_p8n_halo_rep1 no_p8n_halo_rep2 no_two_pass_rep1 no_two_pass_rep2 no_gather_rep1 no_gather_rep2 no_bn_into_patch_rep1 no_bn_into_patch_rep2 graph_adam_rep1 graph_adam_rep2 \
-         no_sn_adam_rep1 no_sn_adam_rep2 overlap_gf_rep1 overlap_gf_rep2 b512_rep2 b512_no_gather; do [ -s $R/bench_$f.json ] && python3 -c "
+         no_sn_adam_rep1 no_sn_adam_rep2 no_critic_graph_rep1 no_critic_graph_rep2 overlap_gf_rep1 overlap_gf_rep2 b512_rep2 b512_no_gather; do [ -s $R/bench_$f.json ] && python3 -c "
 import json
 d=json.load(open('$R/bench_$f.json')); print('%-16s %8.3f ms %10.1f img/s %8.1f TFLOP/s   %.3f / %.3f' % ('$f', d['ms_per_step'], d['value'], d['config']['sustained_tflops'], d['roofline']['frac'], d['roofline']['executed_frac']))" >> $F; done
 echo "# scripts/exp_bench_data.py 60 32: d_loss / g_loss of the bench workload, smooth class-conditional images (default) vs uniform noise (rounds 1-2)" >> $F
