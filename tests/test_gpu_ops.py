@@ -1000,6 +1000,46 @@ def test_deconv(dev, hin, cin, cout):
     assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "deconv db")
 
 
+@pytest.mark.parametrize("n,hin,c1,c2,cout,k", [(5, 7, 128, 10, 128, 5), (3, 7, 64, 10, 64, 5), (9, 4, 128, 3, 64, 3), (2, 14, 64, 16, 128, 5), (11, 7, 192, 10, 128, 5)])
+def test_deconv_filter_gradient_with_label_columns(dev, n, hin, c1, c2, cout, k):
+    """(round 6) ops.deconv2d on x = conv_cond_concat(t, yb) (mnist/ops.py:46-51, model.py:722-731): rcgan_deconv2d_bwd_weight_concat --
+    the gather GEMM over the c1 real channels, the c2 label columns of dW from per-sample sub-grid sums of dy -- against the oracle's
+    filter gradient of the full (c1 + c2)-channel input, with DENSE label rows (not only one-hot), odd sample counts, 3x3 and 5x5
+    filters; the data gradient (first c1 channels) and the bias gradient ride along.  Tolerance of the plain filter-gradient path."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    rs = np.random.RandomState(n * 100 + hin + c1 + c2)
+    t = _prep(rs.randn(n, hin, hin, c1), mode)
+    yb = rs.rand(n, c2).astype(np.float32)
+    if c2 == 10:
+        yb = np.eye(10, dtype=np.float32)[rs.randint(10, size=n)]          # (the trainer's case: one-hot rows)
+    w = (rs.randn(k, k, cout, c1 + c2) * 0.05).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    ctx.new_step()
+    td = ctx.upload(t)
+    td.req = True
+    ybd = ctx.upload(yb.astype(np.float32), dtype=L.F32)
+    wp, bp = FakeParam(ctx, w), FakeParam(ctx, b)
+    x = O.concat_channels(ctx, td, ybd)
+    assert x.concat_labels is ybd and x.concat_src[1] == c1
+    oshape = (n, 2 * hin, 2 * hin, cout)
+    y = O.deconv2d(ctx, x, wp.t, bp.t, oshape, k=k)
+    xfull = np.concatenate([t.astype(np.float64), np.broadcast_to(yb[:, None, None, :].astype(np.float64), (n, hin, hin, c2))], axis=3)
+    ref = nn.conv2d_transpose_fwd(xfull, w.astype(np.float64), oshape, 2) + b
+    assert_close(ctx.download(y), ref, TOL[mode], "deconv fwd on the concatenated input")
+    dy = _prep(rs.randn(*oshape), mode)
+    y.grad = ctx.upload(dy)
+    ctx.backward()
+    dxf = nn.conv2d_transpose_bwd_input(dy.astype(np.float64), w.astype(np.float64), 2)
+    assert_close(ctx.download(td.grad), dxf[..., :c1], TOL[mode], "deconv dx (real channels)")
+    dwr = nn.conv2d_transpose_bwd_filter(xfull, dy.astype(np.float64), w.shape, 2)
+    got = wp.grad(ctx)
+    assert_close(got[..., :c1], dwr[..., :c1], 2e-4, "deconv dw, real columns")
+    assert_close(got[..., c1:], dwr[..., c1:], 2e-4, "deconv dw, label columns")
+    assert_close(bp.grad(ctx), dy.astype(np.float64).sum(axis=(0, 1, 2)), 2e-4, "deconv db")
+
+
 @pytest.mark.parametrize("m,k,n", [(5, 110, 1024), (64, 128, 16384), (7, 128, 1), (9, 300, 128), (4, 3072, 10)] + _random_cases("linear", 12, 12))
 def test_linear(dev, m, k, n):
     from rcgan_amd import _lib as L

@@ -304,3 +304,25 @@ def test_mnist_class_pattern_digits_and_their_stand_in_classifier():
     samples = np.stack([np.concatenate([byc[c][10 * d:10 * d + 10] for c in range(10)]) for d in range(2)])
     samples = np.concatenate([samples] * 5)                      # 10 draws -> one batch of 100 per class
     assert generated_label_accuracy("mnist", samples, template_predict) >= 0.99
+
+
+def test_precision_study_bookkeeping():
+    """scripts/precision_study.py: arm specifications, the tail-mean score and the paired differences (no GPU: the runs are child processes)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("precision_study", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "scripts", "precision_study.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    assert ps.parse_arm("bf16") == ("bf16", "bf16", {})
+    assert ps.parse_arm("plain=bf16:RCGAN_UP_PHASE=0:X=1") == ("plain", "bf16", {"RCGAN_UP_PHASE": "0", "X": "1"})
+    curve = [{"iteration": 250 * i, "gen_label_acc": i / 20.0} for i in range(1, 21)]
+    sc, n = ps.score(curve, 0.4)
+    assert n == 8 and abs(sc - np.mean([i / 20.0 for i in range(13, 21)])) < 1e-12
+    res = [{"arm": a, "seed": s, "losses_finite": True,
+            "curve": [{"iteration": 250 * i, "gen_label_acc": i / 20.0 + 0.01 * s + (0.1 + 0.02 * s if a == "f32" else 0.0)} for i in range(1, 21)]}
+           for a in ("bf16", "f32") for s in range(4)]
+    per_arm, paired = ps.summarise(res, [("bf16", "bf16", {}), ("f32", "f32", {})], "f32", 0.4)
+    assert per_arm["bf16"]["n_seeds"] == 4 and per_arm["f32"]["n_seeds"] == 4
+    d = paired["f32_minus_bf16"]
+    assert d["n_pairs"] == 4 and abs(d["mean"] - 0.13) < 1e-9 and d["se"] > 0 and abs(d["t"] - d["mean"] / d["se"]) < 1e-9
