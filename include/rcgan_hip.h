@@ -183,6 +183,15 @@ typedef struct rcgan_step_inputs_desc {
 } rcgan_step_inputs_desc;
 int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
                                     const rcgan_step_inputs_desc* si);
+/* (round 6) ... and the fragment-major filter copies the fused 8x8 stage and the register-filter kernel read (rcgan_dtrunk*,
+ * rcgan_conv2d_rf; the layout of rcgan_fragments_prepare), written by the SAME launch straight from the fp32 weights instead of by a
+ * launch of its own behind it: frags[i] names items[frags[i].item] (a 16-bit 3x3 stride-1 filter, channels % 64 == 0) and the two
+ * destinations -- forward rows / rotated data-gradient rows, 9*cin*cout elements each -- with ctn channel tiles of 16 rows per block and
+ * ss K-steps of 32 per slice (the 8x8 stage: 2, 36; the register-filter kernel: 4, 18).  Bit-identical to rcgan_conv_prepare +
+ * rcgan_fragments_prepare (the same fp32 product W / sigma rounded once).  At most 12 per call; e / si may be NULL. */
+typedef struct rcgan_frag_item { int item; int ctn, ss; void* fwd; void* bwd; } rcgan_frag_item;
+int rcgan_conv_prepare_batch_frags(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
+                                   const rcgan_step_inputs_desc* si, const rcgan_frag_item* frags, int n_frags);
 
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d);
 /* y = conv2d_SAME(x, w) (+bias).  Replaces tf.nn.conv2d + bias_add: mnist/ops.py:62-65,

@@ -54,6 +54,10 @@ class PrepareItem(C.Structure):
     _fields_ = [("desc", ConvDesc), ("w", C.c_void_p), ("sigma", C.c_void_p), ("prepared", C.c_void_p)]
 
 
+class FragItem(C.Structure):
+    _fields_ = [("item", C.c_int), ("ctn", C.c_int), ("ss", C.c_int), ("fwd", C.c_void_p), ("bwd", C.c_void_p)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("d", C.c_int), ("v", C.c_int), ("e_dim", C.c_int),
                 ("rows_a", C.c_int), ("kind_a", C.c_int), ("kind_b", C.c_int), ("weight", C.c_float),
@@ -126,6 +130,7 @@ SIGNATURES = {
     "rcgan_conv_prepare_batch": (I, [P, C.POINTER(PrepareItem), I]),
     "rcgan_conv_prepare_batch_embed": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc)]),
     "rcgan_conv_prepare_batch_riders": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc), C.POINTER(StepInputsDesc)]),
+    "rcgan_conv_prepare_batch_frags": (I, [P, C.POINTER(PrepareItem), I, C.POINTER(EmbedDesc), C.POINTER(StepInputsDesc), C.POINTER(FragItem), I]),
     "rcgan_conv_workspace_bytes": (SZ, [DP]),
     "rcgan_conv2d_fwd": (I, [P, DP, P, P, P, P]),
     "rcgan_conv_bn_in_ok": (I, [DP]),

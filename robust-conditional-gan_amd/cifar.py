@@ -689,21 +689,33 @@ class CifarRCGAN:
             _, _, table, w_e, b_e = _head_weights(head_update)
             E = self.ctx.empty((table.shape[0], w_e.param.shape[-1]), L.F32)
             embed = (table, w_e, b_e, E)
-        rode = g.prepare_convs(names, self.ctx.act_dtype, embed=embed, inputs=inputs)
-        if rode and embed is not None:
-            g.head_E = embed[3]
-        # every fragment-major filter copy of the critic in one launch: the 8x8 stage's (ops.d_trunk) and the register-filter
-        # layers' (ops.conv2d -> rcgan_conv2d_rf: D.Block.2.Conv1, 16 x 16 x 128)
+        # every fragment-major filter copy of the critic: the 8x8 stage's (ops.d_trunk) and the register-filter layers' (ops.conv2d ->
+        # rcgan_conv2d_rf: D.Block.2.Conv1, 16 x 16 x 128).  Round 6: written by the filter-preparation launch itself, straight from the
+        # fp32 weights (fragment rows of conv_prepare_batch_kernel) -- the launch of their own they used to be (rf_fragments_kernel, 5 us
+        # behind the preparation on every step's dependency chain) is gone; RCGAN_FRAG_IN_PREPARE=0 restores it.
         g.trunk_frag = None
+        trunk, rf = None, []
         if self.PD in which and self.ctx.act_dtype != L.F32 and (FUSED_TRUNK or O.RF_CONV):
             sn = lambda n: g.sn["Discriminator/%s/Filters" % n][0]
             trunk = [sn("D.Block.%d.%s" % (b, c)) for b in (3, 4, 5, 6) for c in ("Conv1", "Conv2")] if FUSED_TRUNK else None
-            rf = []
             if O.RF_CONV:
                 d = L.ConvDesc(1, 16, 16, DIM_D, DIM_D, 3, 3, 1, self.ctx.act_dtype, L.CONV_IN_RELU)
                 if self.ctx.lib.rcgan_conv_rf_ok(C.byref(d)):
                     rf.append((sn("D.Block.2.Conv1"), d))
-            g.trunk_frag = O.fragments_batch(self.ctx, trunk, rf)
+        if (trunk or rf) and O.FRAG_IN_PREPARE:
+            tf, reqs = O.fragment_requests(self.ctx, trunk, rf)
+            rode, written = g.prepare_convs(names, self.ctx.act_dtype, embed=embed, inputs=inputs, frags=reqs)
+            if len(written) == len(reqs):
+                g.trunk_frag = tf
+            else:
+                # (some of these filters were prepared earlier in the step: their row-major copies exist, the separate launch re-lays them)
+                g.trunk_frag = O.fragments_batch(self.ctx, trunk, rf)
+        else:
+            rode = g.prepare_convs(names, self.ctx.act_dtype, embed=embed, inputs=inputs)
+            if trunk or rf:
+                g.trunk_frag = O.fragments_batch(self.ctx, trunk, rf)
+        if rode and embed is not None:
+            g.head_E = embed[3]
         return rode
 
     def _refresh_generator_filters(self):

@@ -621,8 +621,21 @@ int rcgan_conv_prepare_batch_embed(rcgan_ctx* ctx, const rcgan_prepare_item* ite
 
 int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
                                     const rcgan_step_inputs_desc* si) {
-  if (e == nullptr && si == nullptr) return rcgan_conv_prepare_batch(ctx, items, n_items);
+  return rcgan_conv_prepare_batch_frags(ctx, items, n_items, e, si, nullptr, 0);
+}
+
+int rcgan_conv_prepare_batch_frags(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n_items, const rcgan_embed_desc* e,
+                                   const rcgan_step_inputs_desc* si, const rcgan_frag_item* frags, int n_frags) {
+  if (e == nullptr && si == nullptr && n_frags == 0) return rcgan_conv_prepare_batch(ctx, items, n_items);
   RC_REQUIRE(ctx, items != nullptr && n_items >= 1, "the riders need at least one filter to ride with");
+  RC_REQUIRE(ctx, n_frags >= 0 && n_frags <= 12 && (n_frags == 0 || frags != nullptr), "%d fragment copies (at most 12)", n_frags);
+  for (int f = 0; f < n_frags; ++f) {
+    RC_REQUIRE(ctx, frags[f].item >= 0 && frags[f].item < n_items && frags[f].fwd && frags[f].bwd, "fragment copy %d: bad item / null destination", f);
+    const rcgan_conv_desc& d = items[frags[f].item].desc;
+    RC_REQUIRE(ctx, mfma_eligible(&d) && d.kh == 3 && d.kw == 3 && frags[f].ctn >= 1 && frags[f].ss >= 1 && d.cout % (16 * frags[f].ctn) == 0 &&
+                        d.cin % (16 * frags[f].ctn) == 0 && (9 * d.cin / 32) % frags[f].ss == 0 && (9 * d.cout / 32) % frags[f].ss == 0,
+               "fragment copy %d: not a 16-bit 3x3 filter this layout divides (%d -> %d, %d tiles, %d steps)", f, d.cin, d.cout, frags[f].ctn, frags[f].ss);
+  }
   for (int i = 0; i < n_items; ++i) {
     int rc = check_desc(ctx, &items[i].desc);
     if (rc) return rc;
@@ -646,7 +659,7 @@ int rcgan_conv_prepare_batch_riders(rcgan_ctx* ctx, const rcgan_prepare_item* it
     RC_REQUIRE(ctx, si->fakes == nullptr || (si->fake_slice != nullptr && si->n_slices >= 1 && ((size_t)si->fakes & 15) == 0 && ((size_t)si->x & 15) == 0),
                "fake slices need a device counter and 16-byte aligned tensors");
   }
-  return conv_prepare_batch_launch(ctx, items, n_items, e ? &ge : nullptr, si ? &sa : nullptr);
+  return conv_prepare_batch_launch(ctx, items, n_items, e ? &ge : nullptr, si ? &sa : nullptr, frags, n_frags);
 }
 
 size_t rcgan_conv_workspace_bytes(const rcgan_conv_desc* d) {

@@ -132,4 +132,4 @@ int mfma_conv_bn_route(const MfmaConvArgs& a);                                 /
 struct SmallGemmArgs;
 struct StepInputsArgs;
 int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm = nullptr,
-                              const StepInputsArgs* inputs = nullptr);
+                              const StepInputsArgs* inputs = nullptr, const rcgan_frag_item* frags = nullptr, int n_frags = 0);

@@ -1317,7 +1317,50 @@ struct PrepItem { const float* w; const float* sigma; void* out; void* extra; in
 // rows = the n filters, then the phase filters; row r owns workgroups [start[r], start[r+1]) of the one-dimensional grid
 // ... and, last, an optional small-left GEMM (the label embeddings of the projection head: parameters only, see small_gemm.h)
 // ... and the critic step's input work (step_inputs.h): noise, preprocessing, image pool, zero-fill
-struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; int start[60]; int n, rows, gemm_row, inputs_row; SmallGemmArgs gemm; StepInputsArgs inputs; };
+// (round 6) fragment rows: the fragment-major copies the fused 8x8 stage and the register-filter kernel read (conv_trunk.hip, conv_rf.hip)
+// written by THIS launch straight from the fp32 weights -- they used to be a launch of their own behind this one (rf_fragments_kernel, 5 us on
+// every step's dependency chain) that re-read the 16-bit rows this launch had just written.  Same values: the same fp32 product rounded once.
+struct FragRow { int item; int ctn, ss; bf16_t* fwd; bf16_t* bwd; };
+struct PrepBatch { PrepItem it[48]; PhasePrepBatch::It ph[8]; FragRow fr[12]; int start[72]; int n, rows, frag_row0, nfrag, gemm_row, inputs_row; SmallGemmArgs gemm; StepInputsArgs inputs; };
+
+static_assert(sizeof(PrepBatch) <= 4096, "kernel arguments are limited to 4 KiB");
+
+// rows [R][K] -> fragment-major [block of 16*ctn rows][slice][step ss][tile ctn][lane 64][8] (rf_fragments_kernel's layout): the element index of (row, k)
+__device__ __forceinline__ long frag_index(int row, int k, int ctn, int ss, int nsl) {
+  const int blk = row / (16 * ctn), ct = (row - blk * 16 * ctn) >> 4, r = row & 15;
+  const int ks = k >> 5, sl = ks / ss, s = ks - sl * ss, kc = (k >> 3) & 3, e = k & 7;
+  return ((((long)(blk * nsl + sl) * ss + s) * ctn + ct) * 64 + kc * 16 + r) * 8 + e;
+}
+
+__device__ __forceinline__ void prepare_fragment_units(const PrepItem& it, const FragRow& fr, bf16_t (*tile)[66], int bid, int nb) {
+  const float inv = it.sigma ? 1.f / *it.sigma : 1.f;
+  const int nci = it.Cin / 64, nco = it.Cout / 64;
+  const int ntiles = it.T * nci * nco;
+  const int nsl_f = it.T * it.Cin / 32 / fr.ss, nsl_d = it.T * it.Cout / 32 / fr.ss;
+  const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int tl = bid; tl < ntiles; tl += nb) {
+    const int cot = tl % nco, cit = (tl / nco) % nci, t = tl / (nco * nci);
+    const int ci0 = cit * 64, co0 = cot * 64;
+    __syncthreads();
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = it.w[((long)t * it.Cin + ci0 + i * 4 + grp) * it.Cout + co0 + lane64];     // one round trip
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = i * 4 + grp;
+      const bf16_t h = f32_to_bf16(v[i] * inv);
+      // data-gradient rows: row = ci, reduction index (T - 1 - t) * Cout + co (the rotated filter): eight lanes = one 16-byte piece
+      fr.bwd[frag_index(ci0 + ci, (it.T - 1 - t) * it.Cout + co0 + lane64, fr.ctn, fr.ss, nsl_d)] = h;
+      tile[ci][lane64] = h;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int co = i * 4 + grp;
+      fr.fwd[frag_index(co0 + co, t * it.Cin + ci0 + lane64, fr.ctn, fr.ss, nsl_f)] = tile[lane64][co];
+    }
+  }
+}
 
 // One (64 ci x 64 co tile, tap class) unit of the summed filters of the sub-pixel forms (layouts and tap classes: see
 // conv_prepare_phase_kernel, whose values these are bit for bit -- same fp32 summation order).  The filter is read along co;
@@ -1391,6 +1434,11 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
     if (r < b.rows && (int)blockIdx.x >= b.start[r]) row = r;
   }
   const int bid = (int)blockIdx.x - b.start[row], nb = b.start[row + 1] - b.start[row];
+  if (row >= b.frag_row0 && row < b.frag_row0 + b.nfrag) {
+    const FragRow fr = b.fr[row - b.frag_row0];
+    prepare_fragment_units(b.it[fr.item], fr, tile, bid, nb);
+    return;
+  }
   if (row == b.gemm_row) { small_gemm_body(b.gemm, bid, lds_u, lds_u + SG_AS_FLOATS); return; }
   if (row == b.inputs_row) { step_inputs_body(b.inputs, bid, nb); return; }
   if (row >= b.n) { prepare_phase_units(b.ph[row - b.n], tile, bid, nb); return; }
@@ -1439,7 +1487,8 @@ __global__ __launch_bounds__(256) void conv_prepare_batch_kernel(PrepBatch b) {
 }
 
 static int env_int(const char* name, int dflt);
-int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm, const StepInputsArgs* inputs) {
+int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, int n, const SmallGemmArgs* gemm, const StepInputsArgs* inputs,
+                              const rcgan_frag_item* frags, int n_frags) {
   // the summed phase filters of the sub-pixel forms (upsample-3x3, ConvMeanPool): up to 8 of them ride as extra rows of the
   // first launch's grid, the rest (none in these networks) take the stand-alone kernel
   static const int ride = env_int("RCGAN_PREP_PHASE_RIDE", 1);
@@ -1486,7 +1535,20 @@ int conv_prepare_batch_launch(rcgan_ctx* ctx, const rcgan_prepare_item* items, i
       at += units > 1024 ? 1024 : (int)units;
     }
     b.rows = m + np;
-    b.start[m + np] = at;
+    // fragment rows: one workgroup per 64 x 64 tile of a tap, for the filters of THIS launch's items
+    b.frag_row0 = b.rows;
+    b.nfrag = 0;
+    for (int f = 0; f < n_frags; ++f) {
+      const int idx = frags[f].item - base;
+      if (idx < 0 || idx >= m) continue;
+      const rcgan_conv_desc& d = items[frags[f].item].desc;
+      b.fr[b.nfrag] = FragRow{idx, frags[f].ctn, frags[f].ss, (bf16_t*)frags[f].fwd, (bf16_t*)frags[f].bwd};
+      b.start[b.rows] = at;
+      at += d.kh * d.kw * (d.cin / 64) * (d.cout / 64);
+      ++b.nfrag;
+      ++b.rows;
+    }
+    b.start[b.rows] = at;
     b.gemm_row = -1;
     if (gemm && base == 0) {             // the riding product: cdiv(d, 16) workgroups behind everything else
       b.gemm = *gemm;

@@ -107,13 +107,17 @@ class Weight:
         return self.dwbar
 
 
-def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, inputs=None):
+def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, inputs=None, frags=None):
     """Prepare the filters of many convs in one launch.  weights_and_shapes: list of (Weight, k, stride, hw):
     hw = spatial size of the conv input (the image-end layouts depend on it), 8 if irrelevant.
     persistent: None -> per-step arena buffers, skipped when already prepared this step;
                 dict {param name: {key: DT}} -> (re)fill buffers that survive the step (filters that only change
-                with their optimiser step)."""
+                with their optimiser step).
+    frags: [(Weight, fwd ptr, bwd ptr, ctn, ss)] -- fragment-major copies (the fused 8x8 stage's, the register-filter kernel's) the
+           SAME launch writes for filters it prepares (rcgan_conv_prepare_batch_frags); returns (rode, set of Weights whose copies were written)
+           when frags is given."""
     todo = []
+    index = {}
     for w, k, stride, hw, *rest in weights_and_shapes:
         cin, cout = w.param.shape[-2:]          # HWIO filters, or a [k, n] matrix prepared as a 1x1 filter (ops.linear)
         # flags that change the prepared layout (CONV_IN_UPSAMPLE2X: the summed phase filters of the sub-pixel form ride along)
@@ -131,9 +135,24 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
                 slot[key] = DT(t.data_ptr(), (nbytes,), "u8", t)
             buf = slot[key]
         w._prepared[key] = buf
+        index[id(w)] = len(todo)
         todo.append(L.PrepareItem(desc, w.param.ptr, w.sigma.ptr if w.sigma is not None else None, buf.ptr))
+    fitems = [(index[id(w)], f, b, ctn, ss, w) for (w, f, b, ctn, ss) in (frags or []) if id(w) in index]
     if todo:
         arr = (L.PrepareItem * len(todo))(*todo)
+        if fitems and len(fitems) <= 12:
+            ed = si = None
+            if embed is not None:
+                table, w_e, b_e, E = embed
+                v, e_dim = table.shape
+                ed = L.EmbedDesc(v, e_dim, w_e.param.shape[-1], table.ptr, w_e.param.ptr, w_e.sigma.ptr if w_e.sigma is not None else None,
+                                 b_e.ptr if b_e is not None else None, E.ptr)
+            if inputs is not None:
+                si = inputs
+            fa = (L.FragItem * len(fitems))(*[L.FragItem(i, ctn, ss, f, b) for i, f, b, ctn, ss, _ in fitems])
+            ctx.check(ctx.lib.rcgan_conv_prepare_batch_frags(ctx.h, arr, len(todo), C.byref(ed) if ed is not None else None,
+                                                             C.byref(si) if si is not None else None, fa, len(fitems)))
+            return (embed is not None or inputs is not None), {id(w) for *_, w in fitems}
         if embed is not None or inputs is not None:
             ed = si = None
             if embed is not None:
@@ -147,9 +166,9 @@ def prepare_batch(ctx, weights_and_shapes, dtype, persistent=None, embed=None, i
                 si = inputs
             ctx.check(ctx.lib.rcgan_conv_prepare_batch_riders(ctx.h, arr, len(todo), C.byref(ed) if ed is not None else None,
                                                               C.byref(si) if si is not None else None))
-            return True
+            return True if frags is None else (True, set())
         ctx.check(ctx.lib.rcgan_conv_prepare_batch(ctx.h, arr, len(todo)))
-    return False
+    return False if frags is None else (False, set())
 
 
 RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
@@ -157,6 +176,26 @@ RF_CONV = os.environ.get("RCGAN_RF_CONV", "1") != "0"
 CONCAT_DIRECT = os.environ.get("RCGAN_CONCAT_DIRECT", "1") != "0"
 CONCAT_WGRAD = os.environ.get("RCGAN_CONCAT_WGRAD", "1") != "0"     # (round 6) ops.deconv2d: label columns of the filter gradient from per-sample sums
 LINEAR_MFMA = os.environ.get("RCGAN_LINEAR_MFMA", "1") != "0"
+
+
+FRAG_IN_PREPARE = os.environ.get("RCGAN_FRAG_IN_PREPARE", "1") != "0"
+
+
+def fragment_requests(ctx, trunk, rf):
+    """(round 6) The fragment-major copies of a step as riders of the filter-preparation launch (prepare_batch(frags=...)): allocates the
+    destinations and returns (trunk fragment buffer or None, [(Weight, fwd ptr, bwd ptr, ctn, ss)]); the rf Weights get .rf_frag."""
+    reqs, tf = [], None
+    if trunk:
+        nb = ctx.lib.rcgan_dtrunk_fragment_bytes()
+        tf = DT(ctx.arena.alloc(nb), (nb,), "u8", ctx.arena.buf)
+        elems2 = 9 * 128 * 128 * 2                     # bytes of one layer's fragments in one direction
+        for i, w in enumerate(trunk):                  # forward: layers first to last; backward: last to first (conv_trunk.hip)
+            reqs.append((w, tf.ptr + i * elems2, tf.ptr + (8 + (7 - i)) * elems2, 2, 36))
+    for w, d in rf:
+        nb = ctx.lib.rcgan_conv_rf_fragment_bytes(C.byref(d))
+        w.rf_frag = DT(ctx.arena.alloc(nb), (nb,), "u8", ctx.arena.buf)
+        reqs.append((w, w.rf_frag.ptr, w.rf_frag.ptr + nb // 2, 4, 18))
+    return tf, reqs
 
 
 def fragments_batch(ctx, trunk, rf):

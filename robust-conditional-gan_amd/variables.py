@@ -89,14 +89,15 @@ class Graph:
             raise ValueError("spectral norm of %s was prefetched with update=%s but used with update=%s" % (pname, upd, update))
         return w
 
-    def prepare_convs(self, names, dtype, embed=None, inputs=None):
+    def prepare_convs(self, names, dtype, embed=None, inputs=None, frags=None):
         """Batch-prepare the conv filters named in ``names`` ([(param name, k, stride, input hw)]): one launch.
-        embed: see ops.prepare_batch; returns whether it rode along."""
+        embed / inputs / frags: see ops.prepare_batch; returns whether the riders rode along (and, with frags, which Weights' fragment
+        copies the launch wrote)."""
         ws = []
         for pn, k, stride, hw, *rest in names:
             w = self.sn[pn][0] if pn in self.sn else self.weight(pn)
             ws.append((w, k, stride, hw, *rest))
-        return O.prepare_batch(self.ctx, ws, dtype, embed=embed, inputs=inputs)
+        return O.prepare_batch(self.ctx, ws, dtype, embed=embed, inputs=inputs, frags=frags)
 
     def refresh_persistent(self, names, dtype):
         """(Re)prepare the un-normalised filters in ``names`` into buffers that survive the step: called after their

@@ -559,6 +559,46 @@ def test_d_trunk_pooled_boundary(dev, n, kind_a, kind_b):
         assert rel_err(a[k], b[k]) < 1e-5, (k, rel_err(a[k], b[k]))
 
 
+def test_fragment_copies_written_by_the_preparation_launch(dev):
+    """(round 6) rcgan_conv_prepare_batch_frags: the fragment-major filter copies of the fused 8x8 stage (eight 3x3 128 -> 128 filters,
+    both directions) and of the register-filter layer, written by the filter-preparation launch straight from the fp32 weights, against
+    rcgan_conv_prepare_batch + rcgan_fragments_prepare (the launch of their own they used to be): bit for bit, the row-major copies too."""
+    from rcgan_amd import _lib as L
+    from rcgan_amd import ops as O
+    ctx, mode = dev
+    if mode == "f32":
+        pytest.skip("fragment-major copies exist for 16-bit filters only")
+    rs = np.random.RandomState(91)
+    ws = [(rs.randn(3, 3, 128, 128) / np.sqrt(9 * 128)).astype(np.float32) for _ in range(9)]
+    sig = [np.array([0.7 + 0.1 * i], np.float32) for i in range(9)]
+    tdesc = L.ConvDesc(1, 8, 8, 128, 128, 3, 3, 1, ctx.act_dtype, L.CONV_IN_RELU)
+    rdesc = L.ConvDesc(1, 16, 16, 128, 128, 3, 3, 1, ctx.act_dtype, L.CONV_IN_RELU)
+    out = {}
+    for fused in (True, False):
+        ctx.new_step()
+        W = [O.Weight(ctx, FakeParam(ctx, w).t, ctx.upload(s_, L.F32)) for w, s_ in zip(ws, sig)]
+        trunk, rf = W[:8], [(W[8], rdesc)]
+        shapes = [(w, 3, 1, 8) for w in W]
+        if fused:
+            tf, reqs = O.fragment_requests(ctx, trunk, rf)
+            rode, written = O.prepare_batch(ctx, shapes, ctx.act_dtype, frags=reqs)
+            assert not rode and len(written) == 9
+        else:
+            assert O.prepare_batch(ctx, shapes, ctx.act_dtype) is False
+            tf = O.fragments_batch(ctx, trunk, rf)
+        ctx.sync()
+
+        def raw(t):       # the buffer's bytes (the DTs are untyped "u8" blocks)
+            off = t.ptr - t.base.data_ptr()
+            return t.base.view(torch.uint8).reshape(-1)[off:off + t.nbytes].cpu().numpy().copy()
+        out[fused] = (raw(tf), raw(W[8].rf_frag), [raw(w.prepared(tdesc)) for w in W])
+    a, b = out[True], out[False]
+    assert np.array_equal(a[0], b[0]), "8x8 stage fragments: %d bytes differ" % int((a[0] != b[0]).sum())
+    assert np.array_equal(a[1], b[1]), "register-filter fragments: %d bytes differ" % int((a[1] != b[1]).sum())
+    for k in range(9):
+        assert np.array_equal(a[2][k], b[2][k]), "row-major copy %d" % k
+
+
 def test_register_filter_conv_admits_only_shapes_it_runs_well(dev):
     """rcgan_conv_rf_ok is the admission test of rcgan_conv2d_rf: 3x3 stride-1 128 -> 128 on 16x16 images, 16-bit.  8x8 images are
     refused (their data gradient ran 250x slower than the tile kernel in round 3; the fused stage serves those layers)."""
