@@ -690,9 +690,8 @@ class CifarRCGAN:
             E = self.ctx.empty((table.shape[0], w_e.param.shape[-1]), L.F32)
             embed = (table, w_e, b_e, E)
         # every fragment-major filter copy of the critic: the 8x8 stage's (ops.d_trunk) and the register-filter layers' (ops.conv2d ->
-        # rcgan_conv2d_rf: D.Block.2.Conv1, 16 x 16 x 128).  Round 6: written by the filter-preparation launch itself, straight from the
-        # fp32 weights (fragment rows of conv_prepare_batch_kernel) -- the launch of their own they used to be (rf_fragments_kernel, 5 us
-        # behind the preparation on every step's dependency chain) is gone; RCGAN_FRAG_IN_PREPARE=0 restores it.
+        # rcgan_conv2d_rf: D.Block.2.Conv1, 16 x 16 x 128) -- one launch behind the preparation (rf_fragments_kernel); or, measured slower
+        # and off by default (ops.FRAG_IN_PREPARE), fragment rows of the preparation launch itself.
         g.trunk_frag = None
         trunk, rf = None, []
         if self.PD in which and self.ctx.act_dtype != L.F32 and (FUSED_TRUNK or O.RF_CONV):

@@ -178,7 +178,12 @@ CONCAT_WGRAD = os.environ.get("RCGAN_CONCAT_WGRAD", "1") != "0"     # (round 6) 
 LINEAR_MFMA = os.environ.get("RCGAN_LINEAR_MFMA", "1") != "0"
 
 
-FRAG_IN_PREPARE = os.environ.get("RCGAN_FRAG_IN_PREPARE", "1") != "0"
+# (round 6) MEASURED AND LEFT OFF: the fragment-major copies written by the filter-preparation launch itself (fragment rows of
+# conv_prepare_batch_kernel, rcgan_conv_prepare_batch_frags; bit-identical, tests/test_gpu_ops.py) instead of by a launch of their own behind
+# it.  The launch it removes is 5.3 us on every step's chain, but the fragment layout scatters a tile's bytes into 16-byte pieces and the
+# preparation launch grows by more than that: same box 5.181 / 5.174 / 5.181 ms per iteration with the separate launch, 5.209 / 5.196 /
+# 5.208 with the rows.  RCGAN_FRAG_IN_PREPARE=1 turns them on.
+FRAG_IN_PREPARE = os.environ.get("RCGAN_FRAG_IN_PREPARE", "0") == "1"
 
 
 def fragment_requests(ctx, trunk, rf):

@@ -595,8 +595,9 @@ def test_fragment_copies_written_by_the_preparation_launch(dev):
     a, b = out[True], out[False]
     assert np.array_equal(a[0], b[0]), "8x8 stage fragments: %d bytes differ" % int((a[0] != b[0]).sum())
     assert np.array_equal(a[1], b[1]), "register-filter fragments: %d bytes differ" % int((a[1] != b[1]).sum())
+    nrow = 2 * 9 * 128 * 128 * 2          # forward rows + rotated data-gradient rows, 16-bit (the buffer is padded behind them)
     for k in range(9):
-        assert np.array_equal(a[2][k], b[2][k]), "row-major copy %d" % k
+        assert np.array_equal(a[2][k][:nrow], b[2][k][:nrow]), "row-major copy %d" % k
 
 
 def test_register_filter_conv_admits_only_shapes_it_runs_well(dev):
