@@ -1447,30 +1447,40 @@ int direct_wgrad(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, const T* 
 // which image columns (rows) a tap column kw (row kh) reaches: bit iw of col[kw] is set iff (iw + PL - kw) is a multiple of S inside the
 // output grid -- computed on the host, so the kernel's inner loop is a mask test instead of two integer divisions per (pixel, tap)
 struct LabelMasks { unsigned col[5], row[5]; };
-template <typename T>
-__global__ __launch_bounds__(128) void wgrad_label_sums_kernel(ConvGeom g, LabelMasks mk, const T* x, float* D) {      // D[rg][n][KH*KW][Cin]; H, W <= 32
+template <typename T, int WMAX>
+__global__ __launch_bounds__(128) void wgrad_label_sums_kernel(ConvGeom g, LabelMasks mk, const T* x, float* D) {      // D[rg][n][KH*KW][Cin]; H <= 32, W <= WMAX
   const int n = blockIdx.x, rg = blockIdx.y;
   for (int c = threadIdx.x; c < g.Cin; c += blockDim.x) {
     float d[25];
 #pragma unroll
     for (int t = 0; t < 25; ++t) d[t] = 0.f;
-    for (int ih = rg; ih < g.H; ih += WGRAD_LABEL_RG) {
-      const T* row = x + ((long)(n * g.H + ih) * g.W) * g.Cin + c;
-      float v[32];
+    // the workgroup's rows ih = rg, rg + 4, ... in batches of four: every load of a batch (4 x W) is in flight before the first sum
+    for (int ih0 = rg; ih0 < g.H; ih0 += 4 * WGRAD_LABEL_RG) {
+      float v[4][WMAX];
 #pragma unroll
-      for (int iw = 0; iw < 32; ++iw) v[iw] = iw < g.W ? Elem<T>::ld(row + (long)iw * g.Cin) : 0.f;      // the whole row in flight at once
-      float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 4; ++b) {
+        const int ih = ih0 + b * WGRAD_LABEL_RG;
+        const T* row = x + ((long)(n * g.H + (ih < g.H ? ih : 0)) * g.W) * g.Cin + c;
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
-        const unsigned m = mk.col[kw];
-#pragma unroll
-        for (int iw = 0; iw < 32; ++iw) cs[kw] += ((m >> iw) & 1u) ? v[iw] : 0.f;
+        for (int iw = 0; iw < WMAX; ++iw) v[b][iw] = (ih < g.H && iw < g.W) ? Elem<T>::ld(row + (long)iw * g.Cin) : 0.f;
       }
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh) {
-        if ((mk.row[kh] >> ih) & 1u) {
+      for (int b = 0; b < 4; ++b) {
+        const int ih = ih0 + b * WGRAD_LABEL_RG;
+        if (ih >= g.H) break;
+        float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kw = 0; kw < 5; ++kw) d[kh * 5 + kw] += cs[kw];
+        for (int kw = 0; kw < 5; ++kw) {
+          const unsigned m = mk.col[kw];
+#pragma unroll
+          for (int iw = 0; iw < WMAX; ++iw) cs[kw] += ((m >> iw) & 1u) ? v[b][iw] : 0.f;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+          if ((mk.row[kh] >> ih) & 1u) {
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) d[kh * 5 + kw] += cs[kw];
+          }
         }
       }
     }
@@ -1516,19 +1526,29 @@ __global__ __launch_bounds__(128) void wgrad_label_cols_kernel(const float* D, c
 }
 
 // out[i][j] (= or +=)  j < c1: sum_z slab[z][i][j] (slabs [K][c1])   |   j >= c1: sum_q partial[q][i][j - c1]      (out rows of c1 + c2 floats)
+// one thread per four real columns (16-byte slab loads; c1 % 4 == 0) or per label column
 __global__ void slab_reduce_cols_kernel(const float* slab, int nz, const float* partial, int nq, float* out, long K, int c1, int c2, int accumulate) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int ld = c1 + c2;
-  if (e >= K * ld) return;
-  const long i = e / ld;
-  const int j = (int)(e - i * ld);
-  float s = 0.f;
-  if (j < c1) {
-    for (int z = 0; z < nz; ++z) s += slab[((long)z * K + i) * c1 + j];
+  const int per_row = (c1 >> 2) + c2, ld = c1 + c2;
+  if (e >= K * per_row) return;
+  const long i = e / per_row;
+  const int q = (int)(e - i * per_row);
+  if (q < (c1 >> 2)) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nz; ++z) {
+      const float4 t = *(const float4*)(slab + ((long)z * K + i) * c1 + 4 * q);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float* o = out + i * ld + 4 * q;         // (rows of c1 + c2 floats: 8-byte aligned at best)
+    if (accumulate) { s.x += o[0]; s.y += o[1]; s.z += o[2]; s.w += o[3]; }
+    o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
   } else {
-    for (int q = 0; q < nq; ++q) s += partial[((long)q * K + i) * c2 + (j - c1)];
+    const int l = q - (c1 >> 2);
+    float s = 0.f;
+    for (int z = 0; z < nq; ++z) s += partial[((long)z * K + i) * c2 + l];
+    float* o = out + i * ld + c1 + l;
+    *o = accumulate ? *o + s : s;
   }
-  out[e] = accumulate ? out[e] + s : s;
 }
 
 size_t direct_wgrad_cols_ws_bytes(const rcgan_conv_desc* d, int c1) {
@@ -1546,7 +1566,7 @@ int direct_wgrad_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, cons
   WgradOp<T> op;
   op.g = make_geom(d); op.x = x; op.dy = dy; op.wscale = nullptr;
   const int c2 = op.g.Cout - c1;
-  if (c1 <= 0 || c2 <= 0 || c2 > 16 || op.g.KH > 5 || op.g.KW > 5 || op.g.W > 32 || op.g.H > 32 || op.g.up || yb == nullptr)
+  if (c1 <= 0 || (c1 & 3) || c2 <= 0 || c2 > 16 || op.g.KH > 5 || op.g.KW > 5 || op.g.W > 32 || op.g.H > 32 || op.g.up || yb == nullptr)
     RC_FAIL(ctx, RCGAN_EUNSUPPORTED_SHAPE, "label-column filter gradient: %d + %d columns, %d x %d filter", c1, c2, op.g.KH, op.g.KW);
   const long K = (long)op.g.KH * op.g.KW * op.g.Cin, M = (long)op.g.N * op.g.OH * op.g.OW;
   int nz = wgrad_splits(K, c1, M);
@@ -1565,7 +1585,8 @@ int direct_wgrad_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, cons
       if (t < op.g.KH && p < op.g.H && qr >= 0 && qr % op.g.S == 0 && qr / op.g.S < op.g.OH) mk.row[t] |= 1u << p;
     }
   }
-  hipLaunchKernelGGL(wgrad_label_sums_kernel<T>, dim3(op.g.N, WGRAD_LABEL_RG), dim3(128), 0, ctx->stream, op.g, mk, x, Dn);
+  if (op.g.W <= 16) hipLaunchKernelGGL((wgrad_label_sums_kernel<T, 16>), dim3(op.g.N, WGRAD_LABEL_RG), dim3(128), 0, ctx->stream, op.g, mk, x, Dn);
+  else hipLaunchKernelGGL((wgrad_label_sums_kernel<T, 32>), dim3(op.g.N, WGRAD_LABEL_RG), dim3(128), 0, ctx->stream, op.g, mk, x, Dn);
   RC_LAUNCH_CHECK(ctx);
   const int nq = cdiv(op.g.N, WGRAD_LABEL_PER_CHUNK);
   hipLaunchKernelGGL(wgrad_label_cols_kernel, dim3(cdiv(K, 128), nq), dim3(128), 0, ctx->stream, (const float*)Dn, yb, op.g.N, K, c2, partial);
@@ -1577,7 +1598,7 @@ int direct_wgrad_cols(rcgan_ctx* ctx, const rcgan_conv_desc* d, const T* x, cons
   nz = cdiv(M, op.r_chunk);
   int rc = launch_gemm(ctx, op, nz);
   if (rc) return rc;
-  const long cnt = K * op.g.Cout;
+  const long cnt = K * ((c1 >> 2) + c2);
   hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, (const float*)slab, nz, (const float*)partial, nq, dw, K, c1, c2,
                      accumulate);
   RC_LAUNCH_CHECK(ctx);

@@ -623,7 +623,7 @@ def deconv2d(ctx, x, w, bias, out_shape, k=5, stride=2):
             if w.req:
                 db = _p(bias.grad) if (bias is not None and bias.req) else None
                 yb = getattr(x, "concat_labels", None)
-                if (src is not None and yb is not None and CONCAT_WGRAD and 0 < cin - src[1] <= 16 and k <= 5 and src[1] >= 64 and cout >= 64 and ow <= 32
+                if (src is not None and yb is not None and CONCAT_WGRAD and 0 < cin - src[1] <= 16 and k <= 5 and src[1] >= 64 and src[1] % 4 == 0 and cout >= 64 and ow <= 32
                         and ctx.lib.rcgan_deconv2d_bwd_weight_concat_bytes(C.byref(desc), src[1]) <= ctx.ws_bytes):
                     # (round 6) x = conv_cond_concat(xs, yb): the GEMM over the real channels only, the label columns from per-sample sums
                     ctx.check(ctx.lib.rcgan_deconv2d_bwd_weight_concat(ctx.h, C.byref(desc), _p(x), _p(dy), src[1], _p(yb), _p(w.grad), db, 1,
